@@ -1,0 +1,125 @@
+/*
+ * wc_types.h — plain-old-data records that cross the C-ABI of the MI355X hot path.
+ *
+ * Every record is a flat run of doubles / ints so that it can live in HBM, in a numpy array, or
+ * in a C++ host struct without translation.  Each one names the reference type it stands for
+ * (paths relative to the reference checkout).
+ */
+#ifndef WC_TYPES_H_
+#define WC_TYPES_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Input point buffer.  The reference hands `std::vector<hilti_ros::Point>` (src/common/common.h:12-28,
+ * a 48-byte AoS record: float x,y,z,pad @0, float intensity @16, double time @24, uint16 ring @32) to
+ * BuildSurfels (src/odometry/surfel_extraction.cc:316).  The descriptor accepts that record in place
+ * (xyz = base, xyz_stride = 48, time = base + 24, time_stride = 48) or a packed SoA
+ * (xyz_stride = 12 or 16, time_stride = 8).  Pointers are DEVICE pointers for the wc_* entry points and
+ * host pointers for the oracle. */
+typedef struct wc_points {
+  const void *xyz;      /* first float of point 0 (x, y, z consecutive floats)            */
+  const void *time;     /* first double (timestamp of point 0), ascending                  */
+  uint32_t xyz_stride;  /* bytes between consecutive points' x                             */
+  uint32_t time_stride; /* bytes between consecutive points' timestamps                    */
+  uint64_t n;           /* number of points                                                */
+} wc_points;
+
+#define WC_HILTI_POINT_BYTES 48
+#define WC_HILTI_POINT_TIME_OFFSET 24
+
+/* One surfel as `BuildSurfels` emits it: reference `Surfel` ctor arguments
+ * (src/odometry/surfel.h:39-40, src/odometry/surfel_extraction.cc:62).  144 bytes.
+ * Right after extraction center/cov/normal are in the world frame; after the first pose update they are in
+ * the body frame (surfel.h:48-58). */
+typedef struct wc_surfel {
+  double t;          /* mean timestamp of the cluster                       */
+  double center[3];  /* mean point                                          */
+  double cov[9];     /* population covariance, row-major 3x3 (symmetric)    */
+  double normal[3];  /* eigenvector of the smallest eigenvalue, view-flipped */
+  double resolution; /* 4 * quarter_length of the emitting octree node      */
+  double sigma;      /* sqrt(lambda_min)                                    */
+} wc_surfel;
+
+/* Identity of the octree node + temporal cluster a surfel came from.  Not a reference type: the
+ * reference's emission order is hash-map order, so parity is checked by matching surfels
+ * on this id.  node = layer | o1 << 2 | o2 << 5 | cluster << 8, where o1/o2 are the octant codes
+ * 4*[x>cx] + 2*[y>cy] + [z>cz] (surfel_extraction.cc:147-158) of the layer-1 / layer-2 node and
+ * `cluster` is the ordinal of the temporal cluster inside the node (dropped clusters count). */
+typedef struct wc_surfel_id {
+  int32_t kx, ky, kz; /* root voxel index, floor(p / voxel_size)  (surfel_extraction.h:59-64) */
+  uint32_t node;
+} wc_surfel_id;
+
+/* Body->world pose attached to a surfel (surfel.h:114-115). quat = (w, x, y, z). 56 bytes. */
+typedef struct wc_pose {
+  double pos[3];
+  double quat[4];
+} wc_pose;
+
+/* Reference `ImuState` (src/odometry/surfel.h:25-33) flattened: 112 bytes. quat = (w, x, y, z). */
+typedef struct wc_imu_state {
+  double t;
+  double pos[3];
+  double quat[4];
+  double acc[3];
+  double gyr[3];
+} wc_imu_state;
+
+/* Index pair produced by the matcher: reference `SurfelCorrespondence{s1, s2}`
+ * (src/odometry/surfel.h:124-127) with s1 the older surfel (knn_surfel_matcher.cc:41-45).
+ * For the sliding-window matcher both are indices into the query/target set (the same set);
+ * for the fixed-window matcher `first` indexes the fixed-window (target) set and `second` the query set. */
+typedef struct wc_pair {
+  int32_t first;
+  int32_t second;
+} wc_pair;
+
+/* Hard-coded reference parameters of the path.  wc_params_default() fills the
+ * reference values; tests may override them to reach edge cases. */
+typedef struct wc_params {
+  /* extraction: src/odometry/surfel_extraction.cc:327 */
+  float voxel_size;          /* 0.8f  (float in the reference signature)               */
+  int32_t max_layer;         /* 2                                                     */
+  int32_t min_points;        /* node is tested when n > min_points (20)               */
+  float planer_threshold;    /* 0.01f                                                 */
+  double min_plane_likeness; /* 0.1                                                   */
+  double view_point[3];      /* (0,0,0)                                               */
+  double cluster_gap;        /* 0.05 s  (surfel_extraction.cc:24)                     */
+  int32_t cluster_min_points;/* clusters with fewer points are dropped (20, cc:33)    */
+  /* matcher: src/odometry/knn_surfel_matcher.h:37-41 */
+  double center_scale;       /* 1.0                                                   */
+  double angular_scale;      /* 5 deg in rad                                          */
+  double surfel_dist_max;    /* 0.1                                                   */
+  int32_t knn_k;             /* 10                                                    */
+  double time_diff_min;      /* 0.06                                                  */
+  /* factors / solver: src/odometry/lio_config.h:10-14,32-45, lidar_odometry.cc:270,551-560 */
+  double surfel_sigma0;      /* 0.05 / 6 (cost_functor.h:24)                          */
+  double cauchy_a;           /* 0.4                                                   */
+  double w_gyr, w_acc, w_bg, w_ba; /* IMU cost weights                                */
+  double imu_dt;             /* 1 / imu_rate = 0.005                                  */
+  int32_t max_iterations;    /* 100                                                   */
+  int32_t reference_quirks;  /* 1: reproduce Q1 (Jacobian overwrite) and Q3           */
+} wc_params;
+
+/* Solver summary (subset of ceres::Solver::Summary the reference logs, lidar_odometry.cc:562). */
+typedef struct wc_solve_summary {
+  double initial_cost;
+  double final_cost;
+  int32_t iterations;            /* LM iterations performed (iteration 0 excluded)   */
+  int32_t successful_steps;
+  int32_t unsuccessful_steps;
+  int32_t termination;           /* 0 = convergence, 1 = no convergence (max iters), 2 = failure */
+  int32_t n_linearizations;
+  int32_t n_cost_evaluations;
+  double first_step[16];         /* unused tail; first_step_norm kept in [0]          */
+} wc_solve_summary;
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WC_TYPES_H_ */

@@ -1,0 +1,216 @@
+"""ctypes binding of oracle/libwc_oracle.so — TEST INFRASTRUCTURE.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+"""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_PKG = os.path.join(os.path.dirname(_HERE), "wildcat-slam_amd", "python")
+if _PKG not in sys.path:
+    sys.path.insert(0, _PKG)
+from wildcat_slam_amd import records as R  # noqa: E402
+
+_LIB = None
+
+
+def build():
+    subprocess.run(["make", "-C", _HERE, "libwc_oracle.so"], check=True, stdout=subprocess.DEVNULL)
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(_HERE, "libwc_oracle.so")
+        if not os.path.exists(so):
+            build()
+        _LIB = C.CDLL(so)
+        _LIB.wco_window_create.restype = C.c_void_p
+        _LIB.wco_window_num_residuals.restype = C.c_uint64
+    return _LIB
+
+
+def default_params():
+    p = R.Params()
+    lib().wco_params_default(C.byref(p))
+    return p
+
+
+class ExtractStats(C.Structure):
+    _fields_ = [
+        ("root_voxels", C.c_uint64),
+        ("nodes_tested", C.c_uint64 * 4),
+        ("nodes_plane", C.c_uint64 * 4),
+        ("clusters_total", C.c_uint64),
+        ("clusters_rejected", C.c_uint64),
+        ("surfels", C.c_uint64),
+        ("min_gate_margin", C.c_double),
+    ]
+
+
+def _vec(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def so3_exp(w):
+    out = np.zeros(4)
+    lib().wco_so3_exp(R.ptr(_vec(w)), R.ptr(out))
+    return out
+
+
+def so3_log(q):
+    out = np.zeros(3)
+    lib().wco_so3_log(R.ptr(_vec(q)), R.ptr(out))
+    return out
+
+
+def _m3(fn, v):
+    out = np.zeros(9)
+    getattr(lib(), fn)(R.ptr(_vec(v)), R.ptr(out))
+    return out.reshape(3, 3)
+
+
+def so3_jl(v):
+    return _m3("wco_so3_jl", v)
+
+
+def so3_jl_inv(v):
+    return _m3("wco_so3_jl_inv", v)
+
+
+def so3_jr(v):
+    return _m3("wco_so3_jr", v)
+
+
+def so3_jr_inv(v):
+    return _m3("wco_so3_jr_inv", v)
+
+
+def eig3(a):
+    a = _vec(a).reshape(9)
+    ev, V = np.zeros(3), np.zeros(9)
+    lib().wco_eig3(R.ptr(a), R.ptr(ev), R.ptr(V))
+    return ev, V.reshape(3, 3)
+
+
+def voxel_keys(points, params=None):
+    params = params or default_params()
+    d = R.points_from_aos(points)
+    keys = np.zeros((len(points), 3), np.int32)
+    lib().wco_voxel_keys(C.byref(d), C.byref(params), R.ptr(keys))
+    return keys
+
+
+def extract_surfels(points, params=None, cap=None):
+    """-> (surfels[SURFEL], ids[SURFEL_ID], stats)"""
+    params = params or default_params()
+    d = R.points_from_aos(points)
+    cap = cap or max(1024, len(points) // 8)
+    out = np.zeros(cap, R.SURFEL)
+    ids = np.zeros(cap, R.SURFEL_ID)
+    n = C.c_uint64(0)
+    st = ExtractStats()
+    rc = lib().wco_extract_surfels(C.byref(d), C.byref(params), R.ptr(out), R.ptr(ids), C.c_uint64(cap), C.byref(n), C.byref(st))
+    if rc == 1:
+        return extract_surfels(points, params, cap=int(n.value))
+    assert rc == 0, rc
+    return out[: n.value].copy(), ids[: n.value].copy(), st
+
+
+def update_surfel_poses(imu, surf, pose, in_body):
+    rc = lib().wco_update_surfel_poses(R.ptr(imu), C.c_uint64(len(imu)), R.ptr(surf), R.ptr(pose), R.ptr(in_body), C.c_uint64(len(surf)))
+    return rc
+
+
+def knn6(cloud, query, k=10):
+    cloud = np.ascontiguousarray(cloud, np.float64)
+    query = np.ascontiguousarray(query, np.float64)
+    idx = np.zeros((len(query), k), np.int32)
+    d2 = np.zeros((len(query), k))
+    lib().wco_knn6(R.ptr(cloud), C.c_uint64(len(cloud)), R.ptr(query), C.c_uint64(len(query)), C.c_int(k), R.ptr(idx), R.ptr(d2))
+    return idx, d2
+
+
+def match(q_surf, q_pose, t_surf, t_pose, same_set, params=None):
+    params = params or default_params()
+    cap = len(q_surf)
+    pairs = np.zeros(max(cap, 1), R.PAIR)
+    n = C.c_uint64(0)
+    rc = lib().wco_match(C.byref(params), R.ptr(q_surf), R.ptr(q_pose), C.c_uint64(len(q_surf)), R.ptr(t_surf), R.ptr(t_pose),
+                         C.c_uint64(len(t_surf)), C.c_int(1 if same_set else 0), R.ptr(pairs), C.c_uint64(cap), C.byref(n))
+    assert rc == 0, rc
+    return pairs[: n.value].copy()
+
+
+class Window:
+    """wco_window wrapper (the ceres::Problem of lidar_odometry.cc:541-545)."""
+
+    def __init__(self, sample_times, grav, fix_first_pos, params=None):
+        self.params = params or default_params()
+        self.times = _vec(sample_times)
+        self.ns = len(self.times)
+        self._h = C.c_void_p(lib().wco_window_create(C.byref(self.params), R.ptr(self.times), C.c_uint64(self.ns), R.ptr(_vec(grav)), C.c_int(int(fix_first_pos))))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().wco_window_destroy(self._h)
+            self._h = None
+
+    def add_binary(self, surf, pose, pairs):
+        rc = lib().wco_window_add_binary(self._h, R.ptr(surf), R.ptr(pose), R.ptr(pairs), C.c_uint64(len(pairs)))
+        assert rc == 0, rc
+
+    def add_unary(self, fix_surf, fix_pose, sld_surf, sld_pose, pairs):
+        rc = lib().wco_window_add_unary(self._h, R.ptr(fix_surf), R.ptr(fix_pose), R.ptr(sld_surf), R.ptr(sld_pose), R.ptr(pairs), C.c_uint64(len(pairs)))
+        assert rc == 0, rc
+
+    def add_imu(self, imu):
+        rc = lib().wco_window_add_imu(self._h, R.ptr(imu), C.c_uint64(len(imu)))
+        assert rc == 0, rc
+
+    def counts(self):
+        c = (C.c_uint64 * 6)()
+        lib().wco_window_counts(self._h, c)
+        return list(c)
+
+    def num_residuals(self):
+        return int(lib().wco_window_num_residuals(self._h))
+
+    def evaluate(self, x, want_residuals=False):
+        x = _vec(x)
+        cost = C.c_double(0)
+        res = np.zeros(self.num_residuals()) if want_residuals else None
+        lib().wco_window_evaluate(self._h, R.ptr(x), C.byref(cost), R.ptr(res) if want_residuals else None)
+        return (cost.value, res) if want_residuals else cost.value
+
+    def linearize(self, x):
+        x = _vec(x)
+        n = 12 * self.ns
+        H, g = np.zeros((n, n)), np.zeros(n)
+        cost = C.c_double(0)
+        lib().wco_window_linearize(self._h, R.ptr(x), R.ptr(H), R.ptr(g), C.byref(cost))
+        return H, g, cost.value
+
+    def solve(self, x):
+        x = _vec(x).copy()
+        s = R.SolveSummary()
+        first = np.zeros(12 * self.ns)
+        lib().wco_window_solve(self._h, R.ptr(x), C.byref(s), R.ptr(first))
+        return x, s, first
+
+
+def bspline_fit_eval(timestamps, points, query_t):
+    timestamps, points, query_t = _vec(timestamps), _vec(points), _vec(query_t)
+    out = np.zeros((len(query_t), 3))
+    valid = np.zeros(len(query_t), np.uint8)
+    lib().wco_bspline_fit_eval(R.ptr(timestamps), R.ptr(points), C.c_uint64(len(timestamps)), R.ptr(query_t), C.c_uint64(len(query_t)), R.ptr(out), R.ptr(valid))
+    return out, valid.astype(bool)
+
+
+def update_imu_poses(sample_times, x, ba, bg, grav, imu):
+    rc = lib().wco_update_imu_poses(R.ptr(_vec(sample_times)), R.ptr(_vec(x)), C.c_uint64(len(sample_times)), R.ptr(_vec(ba)), R.ptr(_vec(bg)), R.ptr(_vec(grav)), R.ptr(imu), C.c_uint64(len(imu)))
+    return rc

@@ -1,0 +1,47 @@
+"""Shared comparison helpers for the parity tests."""
+import numpy as np
+
+
+def id_tuples(ids):
+    return [tuple(r) for r in np.stack([ids["kx"], ids["ky"], ids["kz"], ids["node"].astype(np.int64)], -1).tolist()]
+
+
+def match_by_id(ids_a, ids_b):
+    """permutation p such that b[p[i]] has the id of a[i]; asserts the id multisets are identical"""
+    ta, tb = id_tuples(ids_a), id_tuples(ids_b)
+    assert len(ta) == len(tb), (len(ta), len(tb))
+    pos = {t: i for i, t in enumerate(tb)}
+    assert len(pos) == len(tb), "duplicate surfel ids"
+    assert set(ta) == set(tb), "surfel id sets differ"
+    return np.array([pos[t] for t in ta], np.int64)
+
+
+def rel_err(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    denom = np.maximum(np.abs(b).max(), 1e-300)
+    return float(np.abs(a - b).max() / denom)
+
+
+def check_surfels(s_gpu, id_gpu, s_ref, id_ref, tol=1e-6, t_tol=None):
+    """counts and ids bit-exact; geometry within `tol` relative (north_star: 1e-6)."""
+    p = match_by_id(id_ref, id_gpu)
+    g = s_gpu[p]
+    n = len(s_ref)
+    if n == 0:
+        return dict(n=0)
+    # normals: unit vectors, compare absolutely
+    dn = np.abs(g["normal"] - s_ref["normal"]).max()
+    scale_c = np.maximum(np.abs(s_ref["center"]).max(), 1.0)
+    dc = np.abs(g["center"] - s_ref["center"]).max() / scale_c
+    cov_scale = np.abs(s_ref["cov"]).max(axis=1, keepdims=True)
+    dcov = (np.abs(g["cov"] - s_ref["cov"]) / cov_scale).max()
+    dsig = np.abs(g["sigma"] - s_ref["sigma"]).max() / np.abs(s_ref["sigma"]).max()
+    assert np.array_equal(g["resolution"], s_ref["resolution"])
+    assert dn <= tol and dc <= tol and dcov <= tol and dsig <= tol, (dn, dc, dcov, dsig)
+    dt = np.abs(g["t"] - s_ref["t"]).max()
+    if t_tol is not None:
+        assert dt <= t_tol, dt
+    # the GPU output must itself be sorted by timestamp (surfel_extraction.cc:334)
+    assert np.all(np.diff(s_gpu["t"]) >= 0)
+    bit_exact = all(np.array_equal(g[f], s_ref[f]) for f in ("t", "center", "cov", "normal", "sigma"))
+    return dict(n=n, dn=dn, dc=dc, dcov=dcov, dsig=dsig, dt=dt, bit_exact=bit_exact)

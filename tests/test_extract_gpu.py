@@ -1,0 +1,102 @@
+"""GPU parity of wc_extract_surfels against the CPU oracle (BuildSurfels, surfel_extraction.cc:316-337).
+Bar (north_star): voxel indices and surfel counts bit-exact, normals within 1e-6 relative."""
+import numpy as np
+import pytest
+
+import helpers
+from wildcat_slam_amd import records as R
+from wildcat_slam_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(gpu, oracle, pts, **kw):
+    s_ref, id_ref, st = oracle.extract_surfels(pts)
+    s_gpu, id_gpu = gpu.extract_surfels(pts, **kw)
+    assert len(s_gpu) == len(s_ref) == st.surfels
+    info = helpers.check_surfels(s_gpu, id_gpu, s_ref, id_ref, tol=1e-6, t_tol=1e-5)
+    return info, st
+
+
+def test_voxel_keys_bit_exact(gpu, oracle):
+    pts = synth.g1_room(50_000)
+    assert np.array_equal(gpu.voxel_keys(pts), oracle.voxel_keys(pts))
+    pts, _ = synth.g2_lattice(300, m=32)
+    assert np.array_equal(gpu.voxel_keys(pts), oracle.voxel_keys(pts))
+
+
+def test_g2_lattice_small(gpu, oracle):
+    pts, info = synth.g2_lattice(400, m=32)
+    res, st = _run(gpu, oracle, pts)
+    assert res["n"] == 8 * 400
+    print(res)
+
+
+def test_g2_sparse_overlap_q4(gpu, oracle):
+    # one patch per root: the root is a plane AND is force-split, so root (0.8 m) and child (0.4 m) surfels overlap (Q4)
+    pts, info = synth.g2_lattice(500, m=48, patches_per_root=1)
+    res, st = _run(gpu, oracle, pts)
+    assert st.nodes_plane[0] > 0 and st.nodes_plane[1] > 0
+    print(res)
+
+
+def test_g1_room_multires(gpu, oracle):
+    pts = synth.g1_room(300_000)
+    res, st = _run(gpu, oracle, pts)
+    assert res["n"] > 1000
+    print(res, list(st.nodes_plane))
+
+
+def test_g1_no_time_hint(gpu, oracle):
+    pts = synth.g1_room(100_000, seed=7)
+    _run(gpu, oracle, pts, hint=False)
+
+
+def test_small_timestamps_and_temporal_clusters(gpu, oracle):
+    # re-observe the same lattice twice, 0.2 s apart, inside one sweep: every node holds two temporal clusters
+    a, _ = synth.g2_lattice(200, m=32, t_start=0.0, duration=0.1)
+    b, _ = synth.g2_lattice(200, m=32, t_start=0.3, duration=0.1)
+    b["x"] += np.float32(0.001)
+    pts = synth.concat_points(a, b)
+    res, st = _run(gpu, oracle, pts)
+    assert res["n"] == 2 * 8 * 200
+    assert st.clusters_total > 2 * 8 * 200
+
+
+def test_empty_and_tiny_inputs(gpu, oracle):
+    s, i = gpu.extract_surfels(np.zeros(0, R.POINT))
+    assert len(s) == 0
+    pts, _ = synth.g2_lattice(1, m=5)  # 40 points in one root, no node reaches 21 points at layer 1
+    res, st = _run(gpu, oracle, pts)
+    pts, _ = synth.g2_lattice(3, m=2)  # 16 points per root: below the root threshold
+    s, i = gpu.extract_surfels(pts)
+    assert len(s) == 0
+
+
+def test_wide_extent_falls_back_to_wide_keys(gpu, oracle):
+    pts, _ = synth.g2_lattice(64, m=32, span=8)
+    far, _ = synth.g2_lattice(64, m=32, span=8, seed=5, t_start=synth.T0 + 0.6)
+    far["x"] += np.float32(2000.0)  # > 512 root voxels away from the first point
+    pts = synth.concat_points(pts, far)
+    _run(gpu, oracle, pts)
+
+
+def test_capacity_error(gpu):
+    from wildcat_slam_amd import lib
+
+    pts, _ = synth.g2_lattice(100, m=32)
+    with pytest.raises(lib.WildcatError) as e:
+        gpu.extract_surfels(pts, cap=10)
+    assert e.value.code == lib.WC_ERR_CAPACITY
+
+
+def test_c2_full_size_properties(gpu, oracle):
+    """BASELINE config C2 (999 936 points): count is known by construction (8 surfels per root), output sorted,
+    and a 1/16 sub-sample of roots agrees with the oracle."""
+    pts, info = synth.g2_lattice(3906, m=32)
+    s_gpu, id_gpu = gpu.extract_surfels(pts)
+    assert len(pts) == 999_936 and len(s_gpu) == 8 * 3906
+    assert np.all(np.diff(s_gpu["t"]) >= 0)
+    assert np.all(s_gpu["resolution"] == np.float64(np.float32(0.4)))
+    s_ref, id_ref, st = oracle.extract_surfels(pts)
+    helpers.check_surfels(s_gpu, id_gpu, s_ref, id_ref, tol=1e-6, t_tol=1e-5)

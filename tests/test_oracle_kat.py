@@ -1,0 +1,86 @@
+"""Pins the CPU oracle against every known-answer test the reference's own test-suite holds for this path
+ and against the golden vectors generated from the reference's numpy prototype."""
+import json
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def is_approx(a, b, prec=1e-12):
+    """Eigen's isApprox: ||a - b||^2 <= prec^2 * min(||a||^2, ||b||^2)"""
+    return np.sum((a - b) ** 2) <= prec**2 * min(np.sum(a**2), np.sum(b**2))
+
+
+def test_utils_jl_jl_inv(oracle):
+    # src/common/utils_test.cc:5-12
+    v = np.array([1.0, 2.0, 3.0])
+    assert is_approx(oracle.so3_jl_inv(v), np.linalg.inv(oracle.so3_jl(v)))
+
+
+def test_utils_jl_jr(oracle):
+    # src/common/utils_test.cc:14-21
+    v = np.array([1.0, 2.0, 3.0])
+    assert is_approx(oracle.so3_jl(v), oracle.so3_jr(-v))
+
+
+def test_so3_exp_log_roundtrip(oracle):
+    rng = np.random.default_rng(3)
+    for _ in range(200):
+        w = rng.normal(size=3) * rng.choice([1e-12, 1e-3, 1.0, 3.0])
+        if np.linalg.norm(w) > 3.1:
+            continue
+        q = oracle.so3_exp(w)
+        assert abs(np.linalg.norm(q) - 1) < 1e-14
+        assert np.allclose(oracle.so3_log(q), w, rtol=1e-10, atol=1e-15)
+
+
+def test_knn_self_query(oracle):
+    # src/odometry/knn_surfel_matcher_test.cc:19-43: 10 000 random 6-D vectors in [-1,1]^6, k = 10, self is nearest
+    rng = np.random.default_rng(12345)
+    cloud = rng.uniform(-1, 1, size=(10_000, 6))
+    idx, d2 = oracle.knn6(cloud, cloud, 10)
+    assert idx.shape == (10_000, 10)
+    assert np.array_equal(idx[:, 0], np.arange(10_000))
+    # and the whole neighbour list is the exact answer (brute force on a slice)
+    for i in range(0, 10_000, 997):
+        d = np.sum((cloud - cloud[i]) ** 2, axis=1)
+        ref = np.argsort(d, kind="stable")[:10]
+        assert np.array_equal(idx[i], ref)
+        assert np.allclose(d2[i], d[ref], rtol=1e-14)
+
+
+def test_bspline_knot_reproduction(oracle):
+    # src/odometry/spline_interpolation_test.cc:79-96
+    ts = np.array([0.3, 0.4, 0.5, 0.6, 0.7, 0.8, 0.9, 1.0])
+    p = np.array([1, 1, 1, 2, 3, 2, 4, 5, 5, 6, 6, 3, 5, 4, 1, 6, 7, 1, 9, 9, 8, 12, 15, 11], float).reshape(8, 3)
+    out, valid = oracle.bspline_fit_eval(ts, p, ts)
+    assert valid.all()
+    for i in range(8):
+        assert is_approx(out[i], p[i], 1e-6)
+    _, valid = oracle.bspline_fit_eval(ts, p, np.array([0.29, 1.01]))
+    assert not valid.any()  # Interp returns nullptr outside the knot range (spline_interpolation.h:52-54)
+
+
+def test_bspline_against_notebook_golden(oracle):
+    # golden vectors produced by executing the reference's scripts/CubicBSpline3D.ipynb (tests/golden/make_bspline_golden.py)
+    g = json.load(open(os.path.join(HERE, "golden", "bspline_notebook.json")))
+    p = np.array(g["p"], float)
+    f = np.array(g["index_f"])
+    ts = np.arange(8, dtype=float)  # index_f = t + 1 for these knots
+    out, valid = oracle.bspline_fit_eval(ts, p, f - 1.0)
+    assert valid.all()
+    assert np.abs(out - np.array(g["curve"])).max() < 1e-9
+
+
+def test_eig3_against_lapack(oracle):
+    rng = np.random.default_rng(1)
+    for _ in range(500):
+        a = rng.normal(size=(3, 3))
+        a = a @ a.T * 10 ** rng.uniform(-6, 2)
+        ev, v = oracle.eig3(a)
+        ev2 = np.linalg.eigvalsh(a)
+        assert np.abs(ev - ev2).max() <= 4e-15 * ev2.max()
+        assert np.abs(a @ v - v * ev).max() <= 1e-14 * ev2.max()
+        assert np.abs(v.T @ v - np.eye(3)).max() < 1e-14

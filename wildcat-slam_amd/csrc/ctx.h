@@ -1,0 +1,82 @@
+// ctx.h — internal definition of the opaque wc_ctx: one HIP stream, growable scratch buffers in HBM, pinned
+// host mailbox for the few words that travel back (counts, status flags), last-error text.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/wildcat_hip.h"
+
+struct wc_window_state;  // window.hip
+
+struct wc_buf {
+  void *p = nullptr;
+  size_t cap = 0;
+};
+
+struct wc_ctx {
+  int device = 0;
+  wc_params P;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  std::string err;
+  // scratch buffers (device), grown on demand and kept for the lifetime of the ctx
+  wc_buf b_keys[2], b_vals[2], b_sorttmp, b_slots, b_slot_ids, b_slot_keys[2], b_slot_idx[2], b_cand, b_cand_meta,
+      b_status, b_misc[8];
+  // pinned host mailbox
+  uint32_t *h_status = nullptr;  // [0] n_emitted, [1] flags, ...
+  double *h_mail = nullptr;      // small double mailbox (costs etc.)
+  // pending extraction (enqueue/finish split)
+  struct {
+    bool active = false;
+    wc_points pts;
+    double t_lo, t_hi;
+    wc_surfel *d_out;
+    wc_surfel_id *d_ids;
+    uint64_t cap;
+    bool wide;
+  } ex;
+  wc_window_state *win = nullptr;
+};
+
+inline int wc_fail(wc_ctx *ctx, int code, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  if (ctx) ctx->err = buf;
+  return code;
+}
+
+#define WC_HIP(ctx, call)                                                                                   \
+  do {                                                                                                      \
+    hipError_t e_ = (call);                                                                                 \
+    if (e_ != hipSuccess)                                                                                   \
+      return wc_fail(ctx, WC_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+
+// grow-only device buffer
+inline int wc_ensure(wc_ctx *ctx, wc_buf &b, size_t bytes) {
+  if (bytes <= b.cap) return WC_OK;
+  if (b.p) {
+    WC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    WC_HIP(ctx, hipFree(b.p));
+    b.p = nullptr;
+    b.cap = 0;
+  }
+  size_t want = bytes + bytes / 8 + 256;
+  WC_HIP(ctx, hipMalloc(&b.p, want));
+  b.cap = want;
+  return WC_OK;
+}
+#define WC_TRY(expr)            \
+  do {                          \
+    int rc_ = (expr);           \
+    if (rc_ != WC_OK) return rc_; \
+  } while (0)

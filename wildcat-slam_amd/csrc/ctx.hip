@@ -1,0 +1,168 @@
+// ctx.hip — context lifetime, default parameters, device-memory helpers and HIP-event timer of the C-ABI.
+#include "ctx.h"
+
+#include <cmath>
+#include <cstring>
+
+extern "C" const char *wc_version(void) { return "wildcat_hip 0.1 (gfx950)"; }
+
+extern "C" int wc_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+extern "C" void wc_params_default(wc_params *p) {
+  std::memset(p, 0, sizeof(*p));
+  // BuildVoxelMap(points, Vector3d::Zero(), 0.8, 2, {20,20,20,20}, 0.01, 0.1, ...)  surfel_extraction.cc:327
+  p->voxel_size = 0.8f;
+  p->max_layer = 2;
+  p->min_points = 20;
+  p->planer_threshold = 0.01f;
+  p->min_plane_likeness = 0.1;
+  p->cluster_gap = 0.05;       // surfel_extraction.cc:24
+  p->cluster_min_points = 20;  // surfel_extraction.cc:33
+  // knn_surfel_matcher.h:37-41
+  p->center_scale = 1.0;
+  p->angular_scale = 5.0 * M_PI / 180.0;
+  p->surfel_dist_max = 0.1;
+  p->knn_k = 10;
+  p->time_diff_min = 0.06;
+  p->surfel_sigma0 = 0.05 / 6;  // cost_functor.h:24
+  p->cauchy_a = 0.4;            // lidar_odometry.cc:270
+  // lio_config.h:10-14,32,42-45
+  const double gn = 0.00015198973532354657, an = 0.006308226052016165;
+  const double gw = 0.00011673723527962174, aw = 2.664506559330434e-06;
+  const double rate = 200, k = 0.01;
+  p->w_gyr = 1 / (gn * std::sqrt(rate)) * k;
+  p->w_acc = 1 / (an * std::sqrt(rate)) * k;
+  p->w_bg = 1 / (gw / std::sqrt(rate)) * k;
+  p->w_ba = 1 / (aw / std::sqrt(rate)) * k;
+  p->imu_dt = 1 / rate;
+  p->max_iterations = 100;
+  p->reference_quirks = 1;
+}
+
+static int check_params(wc_ctx *ctx, const wc_params *p) {
+  if (p->max_layer < 0 || p->max_layer > 2) return wc_fail(ctx, WC_ERR_ARG, "max_layer must be 0..2");
+  if (!(p->voxel_size > 0)) return wc_fail(ctx, WC_ERR_ARG, "voxel_size must be positive");
+  if (p->cluster_min_points < 1 || p->min_points < 0) return wc_fail(ctx, WC_ERR_ARG, "bad point thresholds");
+  if (p->knn_k < 1 || p->knn_k > 16) return wc_fail(ctx, WC_ERR_ARG, "knn_k must be 1..16");
+  return WC_OK;
+}
+
+extern "C" int wc_ctx_create(const wc_params *params, int device, wc_ctx **out) {
+  if (!out) return WC_ERR_ARG;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return WC_ERR_NOGPU;
+  wc_ctx *ctx = new wc_ctx;
+  ctx->device = device;
+  if (params)
+    ctx->P = *params;
+  else
+    wc_params_default(&ctx->P);
+  int rc = check_params(ctx, &ctx->P);
+  if (rc != WC_OK) {
+    delete ctx;
+    return rc;
+  }
+  if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess ||
+      hipHostMalloc((void **)&ctx->h_status, 64 * sizeof(uint32_t)) != hipSuccess ||
+      hipHostMalloc((void **)&ctx->h_mail, 64 * sizeof(double)) != hipSuccess) {
+    delete ctx;
+    return WC_ERR_HIP;
+  }
+  ctx->stream = ctx->own_stream;
+  *out = ctx;
+  return WC_OK;
+}
+
+void wc_window_free(wc_ctx *ctx);  // window.hip
+
+extern "C" void wc_ctx_destroy(wc_ctx *ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  wc_window_free(ctx);
+  wc_buf *all[] = {&ctx->b_keys[0],      &ctx->b_keys[1],     &ctx->b_vals[0],     &ctx->b_vals[1],      &ctx->b_sorttmp,
+                   &ctx->b_slots,        &ctx->b_slot_ids,    &ctx->b_slot_keys[0], &ctx->b_slot_keys[1], &ctx->b_slot_idx[0],
+                   &ctx->b_slot_idx[1],  &ctx->b_cand,        &ctx->b_cand_meta,   &ctx->b_status};
+  for (wc_buf *b : all)
+    if (b->p) (void)hipFree(b->p);
+  for (wc_buf &b : ctx->b_misc)
+    if (b.p) (void)hipFree(b.p);
+  if (ctx->h_status) (void)hipHostFree(ctx->h_status);
+  if (ctx->h_mail) (void)hipHostFree(ctx->h_mail);
+  if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+  if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+  if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+  delete ctx;
+}
+
+extern "C" const char *wc_last_error(const wc_ctx *ctx) { return ctx ? ctx->err.c_str() : "no context"; }
+
+extern "C" int wc_ctx_set_stream(wc_ctx *ctx, void *hip_stream) {
+  if (!ctx) return WC_ERR_ARG;
+  WC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+  return WC_OK;
+}
+
+extern "C" int wc_ctx_set_params(wc_ctx *ctx, const wc_params *params) {
+  if (!ctx || !params) return WC_ERR_ARG;
+  WC_TRY(check_params(ctx, params));
+  ctx->P = *params;
+  return WC_OK;
+}
+
+extern "C" int wc_dev_alloc(wc_ctx *ctx, size_t bytes, void **d_ptr) {
+  if (!ctx || !d_ptr) return WC_ERR_ARG;
+  WC_HIP(ctx, hipSetDevice(ctx->device));
+  WC_HIP(ctx, hipMalloc(d_ptr, bytes ? bytes : 1));
+  return WC_OK;
+}
+extern "C" int wc_dev_free(wc_ctx *ctx, void *d_ptr) {
+  if (!ctx) return WC_ERR_ARG;
+  WC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  WC_HIP(ctx, hipFree(d_ptr));
+  return WC_OK;
+}
+extern "C" int wc_h2d(wc_ctx *ctx, void *d_dst, const void *h_src, size_t bytes) {
+  if (!ctx) return WC_ERR_ARG;
+  if (!bytes) return WC_OK;
+  WC_HIP(ctx, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+  WC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return WC_OK;
+}
+extern "C" int wc_d2h(wc_ctx *ctx, void *h_dst, const void *d_src, size_t bytes) {
+  if (!ctx) return WC_ERR_ARG;
+  if (!bytes) return WC_OK;
+  WC_HIP(ctx, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  WC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return WC_OK;
+}
+extern "C" int wc_memset(wc_ctx *ctx, void *d_dst, int value, size_t bytes) {
+  if (!ctx) return WC_ERR_ARG;
+  if (!bytes) return WC_OK;
+  WC_HIP(ctx, hipMemsetAsync(d_dst, value, bytes, ctx->stream));
+  return WC_OK;
+}
+extern "C" int wc_sync(wc_ctx *ctx) {
+  if (!ctx) return WC_ERR_ARG;
+  WC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return WC_OK;
+}
+extern "C" int wc_timer_start(wc_ctx *ctx) {
+  if (!ctx) return WC_ERR_ARG;
+  WC_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  return WC_OK;
+}
+extern "C" int wc_timer_stop_ms(wc_ctx *ctx, float *h_ms) {
+  if (!ctx || !h_ms) return WC_ERR_ARG;
+  WC_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+  WC_HIP(ctx, hipEventSynchronize(ctx->ev1));
+  WC_HIP(ctx, hipEventElapsedTime(h_ms, ctx->ev0, ctx->ev1));
+  return WC_OK;
+}

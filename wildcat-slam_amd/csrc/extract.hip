@@ -1,0 +1,586 @@
+// extract.hip — surfel extraction on gfx950: root-voxel binning, 3-level octree planarity tests, temporal
+// clustering and per-cluster 3x3 PCA.  Replaces BuildSurfels (src/odometry/surfel_extraction.cc:316-337) and
+// everything beneath it (BuildVoxelMap :186-220, InitOctoTree :128-140, CutOctoTree :142-184, InitPlane :82-126,
+// ExtractSurfelInfo :304-314, ClusterSurfels :12-65).  Decision rules: SURVEY.md Appendix A.
+//
+// Pipeline (all on one stream, no host synchronisation until the count is read back):
+//   1. k_keygen      point -> root-voxel key relative to the voxel of point 0 (floor(p / (double)0.8f), true fp64
+//                    division), 10 bits per axis (21 in the wide fallback); value = point index
+//   2. radix sort    stable LSD sort of (key, index): points of one root voxel become one contiguous segment that is
+//                    still in time order (the input is time ordered) — the order ClusterSurfels relies on (cc:22-29)
+//   3. k_roots       one wavefront per segment.  Lanes are (level, moment) pairs: 3 octree levels x 11 running
+//                    moments {n, St, Sx, Sy, Sz, Sxx, Sxy, Sxz, Syy, Syz, Szz}.  Points are streamed in time order
+//                    through LDS-resident per-node accumulators, so every sum is formed in exactly the order the
+//                    reference forms it (bit-identical moments => bit-identical gate decisions).  Node totals feed
+//                    the planarity test, open-cluster sums are flushed to candidate slots when the gap rule fires.
+//                    At the end of the segment: node tests (3x3 Jacobi eigensolve per lane), then one lane per
+//                    candidate cluster does the cluster PCA, the gates, the view-point flip and writes the surfel.
+//   4. radix sort    of the surfel slots by timestamp (compacts and orders, surfel_extraction.cc:334)
+//   5. k_gather      slot -> caller's output buffer
+// The path is HBM/latency bound (20 B read per point, 144 B written per surfel); no MFMA.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <rocprim/rocprim.hpp>
+
+#include "ctx.h"
+#include "dmath.h"
+
+namespace {
+
+constexpr int kNodes = 73;  // 1 root + 8 layer-1 + 64 layer-2 nodes
+constexpr int kMom = 11;    // n, St, Sx, Sy, Sz, Sxx, Sxy, Sxz, Syy, Syz, Szz
+constexpr uint32_t kFlagKeyRange = 1u, kFlagSlotOverflow = 2u, kFlagTimeRange = 4u;
+
+struct ExParams {
+  double vs;           // (double)voxel_size
+  float vs_f;          // voxel_size as float
+  int max_layer;
+  int min_points;
+  double thr;          // (double)planer_threshold
+  double min_like;
+  double view[3];
+  double gap;
+  int cluster_min;
+  uint64_t t_lo_bits;  // ordered bits of the time hint lower bound
+};
+
+__device__ __forceinline__ uint64_t ordered_bits(double t) {
+  uint64_t u = (uint64_t)__double_as_longlong(t);
+  return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+inline uint64_t ordered_bits_host(double t) {
+  uint64_t u;
+  memcpy(&u, &t, 8);
+  return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+
+__device__ __forceinline__ void load_xyz(const wc_points &pts, uint64_t i, double &x, double &y, double &z) {
+  const float *f = (const float *)((const char *)pts.xyz + i * pts.xyz_stride);
+  x = (double)f[0];
+  y = (double)f[1];
+  z = (double)f[2];
+}
+__device__ __forceinline__ double load_t(const wc_points &pts, uint64_t i) {
+  return *(const double *)((const char *)pts.time + i * pts.time_stride);
+}
+// VoxelLoc (surfel_extraction.h:59-64): floor(pos / resolution) cast to int32, true fp64 division
+__device__ __forceinline__ int vox(double p, double vs) { return (int)floor(p / vs); }
+
+template <typename K>
+struct KeyTraits;
+template <>
+struct KeyTraits<uint32_t> {
+  static constexpr int bits = 10;
+};
+template <>
+struct KeyTraits<uint64_t> {
+  static constexpr int bits = 21;
+};
+
+template <typename K>
+__global__ void __launch_bounds__(256) k_keygen(wc_points pts, double vs, K *keys, uint32_t *vals, uint32_t *status) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= pts.n) return;
+  constexpr int B = KeyTraits<K>::bits;
+  constexpr int half = 1 << (B - 1);
+  double x0, y0, z0, x, y, z;
+  load_xyz(pts, 0, x0, y0, z0);
+  load_xyz(pts, i, x, y, z);
+  int rx = vox(x, vs) - vox(x0, vs) + half;
+  int ry = vox(y, vs) - vox(y0, vs) + half;
+  int rz = vox(z, vs) - vox(z0, vs) + half;
+  if ((unsigned)rx >= (unsigned)(2 * half) || (unsigned)ry >= (unsigned)(2 * half) || (unsigned)rz >= (unsigned)(2 * half)) {
+    atomicOr(&status[1], kFlagKeyRange);
+    rx = min(max(rx, 0), 2 * half - 1);
+    ry = min(max(ry, 0), 2 * half - 1);
+    rz = min(max(rz, 0), 2 * half - 1);
+  }
+  keys[i] = (K)rx | ((K)ry << B) | ((K)rz << (2 * B));
+  vals[i] = (uint32_t)i;
+}
+
+__global__ void __launch_bounds__(256) k_voxel_keys(wc_points pts, double vs, int32_t *out) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= pts.n) return;
+  double x, y, z;
+  load_xyz(pts, i, x, y, z);
+  out[3 * i + 0] = vox(x, vs);
+  out[3 * i + 1] = vox(y, vs);
+  out[3 * i + 2] = vox(z, vs);
+}
+
+struct Pca {
+  double c[3];
+  double cov[9];
+  double ev[3];
+  double nrm[3];  // eigenvector of the smallest eigenvalue (unflipped)
+  double tmean;
+  double like;
+};
+
+// moments -> mean, un-centred population covariance, eigen-decomposition
+// (surfel_extraction.cc:36-51 and :89-101)
+__device__ __forceinline__ void pca_from_moments(const double *m, Pca &r) {
+  const double n = m[0];
+  r.tmean = m[1] / n;
+  r.c[0] = m[2] / n, r.c[1] = m[3] / n, r.c[2] = m[4] / n;
+  const double sxx = m[5], sxy = m[6], sxz = m[7], syy = m[8], syz = m[9], szz = m[10];
+  wc::M3 C;
+  C.m[0][0] = sxx / n - r.c[0] * r.c[0];
+  C.m[0][1] = sxy / n - r.c[0] * r.c[1];
+  C.m[0][2] = sxz / n - r.c[0] * r.c[2];
+  C.m[1][0] = sxy / n - r.c[1] * r.c[0];
+  C.m[1][1] = syy / n - r.c[1] * r.c[1];
+  C.m[1][2] = syz / n - r.c[1] * r.c[2];
+  C.m[2][0] = sxz / n - r.c[2] * r.c[0];
+  C.m[2][1] = syz / n - r.c[2] * r.c[1];
+  C.m[2][2] = szz / n - r.c[2] * r.c[2];
+  wc::M3 V;
+  wc::eig3_sym(C, r.ev, V);
+  for (int i = 0; i < 3; ++i) {
+    r.nrm[i] = V.m[i][0];
+    for (int j = 0; j < 3; ++j) r.cov[3 * i + j] = C.m[i][j];
+  }
+  r.like = 2 * (r.ev[1] - r.ev[0]) / ((r.ev[0] + r.ev[1]) + r.ev[2]);
+}
+
+struct RootsArgs {
+  wc_points pts;
+  ExParams P;
+  uint64_t n;
+  const uint32_t *vals;   // sorted point indices
+  double *cand;           // [total_slots][11] candidate cluster moments
+  uint32_t *cand_meta;    // [total_slots] node | ordinal << 8
+  wc_surfel *slots;       // [total_slots]
+  wc_surfel_id *slot_ids; // [total_slots]
+  uint64_t *slot_keys;    // [total_slots] time sort keys (memset to ~0 = invalid)
+  uint32_t *slot_idx;     // [total_slots] iota
+  uint64_t total_slots;
+  uint32_t *status;       // [0] emitted count, [1] flags
+};
+
+template <typename K>
+__global__ void __launch_bounds__(64) k_roots(RootsArgs A, const K *__restrict__ keys) {
+  __shared__ double s_open[kNodes * kMom];
+  __shared__ double s_total[kNodes * kMom];
+  __shared__ double s_last[kNodes];
+  __shared__ uint32_t s_ord[kNodes];
+  __shared__ double s_stage[64 * 5];
+  __shared__ uint32_t s_code[64];
+  __shared__ uint32_t s_plane[kNodes];
+
+  const int lane = threadIdx.x;
+  const uint64_t tile = (uint64_t)blockIdx.x * 64;
+  const uint64_t mypos = tile + lane;
+  const ExParams &P = A.P;
+  constexpr int B = KeyTraits<K>::bits;
+
+  // segment heads inside this tile
+  bool is_head = false;
+  if (mypos < A.n) is_head = (mypos == 0) || (keys[mypos] != keys[mypos - 1]);
+  unsigned long long heads = __ballot(is_head);
+
+  // lane roles for the streaming phase
+  const bool act = lane < 3 * kMom;
+  const int L = lane / kMom;       // octree level handled by this lane (valid when act)
+  const int m = lane - L * kMom;   // moment handled by this lane
+  // moment m = stage[ia] * stage[ib] with stage = {1, t, x, y, z}
+  const int ia = (m <= 4) ? m : (m <= 7 ? 2 : (m <= 9 ? 3 : 4));
+  const int ib = (m <= 4) ? 0 : (m == 5 ? 2 : (m == 6 ? 3 : (m == 7 ? 4 : (m == 8 ? 3 : (m == 9 ? 4 : 4)))));
+
+  double x0, y0, z0;
+  load_xyz(A.pts, 0, x0, y0, z0);
+  const int k0x = vox(x0, P.vs), k0y = vox(y0, P.vs), k0z = vox(z0, P.vs);
+
+  while (heads) {
+    const int hb = __ffsll((long long)heads) - 1;
+    heads &= heads - 1;
+    const uint64_t head = tile + hb;
+    const K rootkey = keys[head];
+
+    // ---- first chunk: also decides the cheap exit for sparse roots (InitOctoTree, cc:129) ----
+    uint64_t pos = head + lane;
+    bool valid = pos < A.n && keys[pos] == rootkey;
+    unsigned long long vm = __ballot(valid);
+    int nvalid = __popcll(vm);  // valid lanes are a prefix (keys sorted)
+    if (nvalid < 64 && nvalid <= P.min_points) continue;
+
+    // absolute root voxel index and centre ((0.5 + k) * voxel_size, cc:208-210)
+    constexpr int half = 1 << (B - 1);
+    const int kx = (int)(rootkey & ((K(1) << B) - 1)) - half + k0x;
+    const int ky = (int)((rootkey >> B) & ((K(1) << B) - 1)) - half + k0y;
+    const int kz = (int)((rootkey >> (2 * B)) & ((K(1) << B) - 1)) - half + k0z;
+    const double cx = (0.5 + kx) * P.vs_f, cy = (0.5 + ky) * P.vs_f, cz = (0.5 + kz) * P.vs_f;
+    const float q0 = P.vs_f / 4;  // quarter_length_ of the root (cc:207)
+
+    for (int i = lane; i < kNodes * kMom; i += 64) {
+      s_open[i] = 0.0;
+      s_total[i] = 0.0;
+    }
+    for (int i = lane; i < kNodes; i += 64) {
+      s_last[i] = 0.0;
+      s_ord[i] = 0;
+      s_plane[i] = 0;
+    }
+    const uint64_t slot_base = (head * (uint64_t)(P.max_layer + 1)) / (uint64_t)P.cluster_min;
+    uint32_t ncand = 0;
+    __syncthreads();
+
+    uint64_t chunk_pos = head;
+    while (true) {
+      // ---- stage up to 64 points of this segment: {1, t, x, y, z} + octant code ----
+      if (valid) {
+        const uint32_t idx = A.vals[pos];
+        double x, y, z;
+        load_xyz(A.pts, idx, x, y, z);
+        const double t = load_t(A.pts, idx);
+        // octant = 4*[x>cx] + 2*[y>cy] + [z>cz]  (strict >, cc:147-158); child centre = centre +- quarter (cc:163-165)
+        const int bx = x > cx, by = y > cy, bz = z > cz;
+        const double c1x = cx + (double)((float)(2 * bx - 1) * q0);
+        const double c1y = cy + (double)((float)(2 * by - 1) * q0);
+        const double c1z = cz + (double)((float)(2 * bz - 1) * q0);
+        const int o1 = 4 * bx + 2 * by + bz;
+        const int o2 = 4 * (x > c1x) + 2 * (y > c1y) + (z > c1z);
+        s_stage[lane * 5 + 0] = 1.0;
+        s_stage[lane * 5 + 1] = t;
+        s_stage[lane * 5 + 2] = x;
+        s_stage[lane * 5 + 3] = y;
+        s_stage[lane * 5 + 4] = z;
+        s_code[lane] = (uint32_t)(o1 * 8 + o2);
+      }
+      __syncthreads();
+
+      // ---- stream the staged points in time order through the node accumulators ----
+      for (int j = 0; j < nvalid; ++j) {
+        int nu = 0;
+        double t = 0, cnt = 0;
+        bool close = false;
+        if (act) {
+          const uint32_t code = s_code[j];
+          nu = (L == 0) ? 0 : (L == 1 ? 1 + (int)(code >> 3) : 9 + (int)code);
+          t = s_stage[j * 5 + 1];
+          cnt = s_open[nu * kMom];
+          // new cluster when the gap to the previous point OF THIS NODE exceeds cluster_gap (cc:24)
+          close = cnt > 0.0 && (t - s_last[nu] > P.gap);
+        }
+        const unsigned long long cm = __ballot(close);
+        if (cm) {
+          for (int l = 0; l <= P.max_layer; ++l) {
+            if (!((cm >> (l * kMom)) & 1ull)) continue;
+            const double cnt_l = __shfl(cnt, l * kMom);
+            const bool mine = act && (L == l);
+            if (cnt_l >= (double)P.cluster_min) {  // clusters with fewer points are dropped (cc:33)
+              const uint64_t slot = slot_base + ncand;
+              if (slot < A.total_slots) {
+                if (mine) {
+                  A.cand[slot * kMom + m] = s_open[nu * kMom + m];
+                  if (m == 0) A.cand_meta[slot] = (uint32_t)nu | (s_ord[nu] << 8);
+                }
+              } else if (lane == 0) {
+                atomicOr(&A.status[1], kFlagSlotOverflow);
+              }
+              ++ncand;
+            }
+            if (mine) {
+              s_open[nu * kMom + m] = 0.0;
+              if (m == 0) s_ord[nu] += 1;
+            }
+          }
+        }
+        if (act && L <= P.max_layer) {
+          const double v = s_stage[j * 5 + ia] * s_stage[j * 5 + ib];
+          s_open[nu * kMom + m] += v;
+          s_total[nu * kMom + m] += v;
+          if (m == 0) s_last[nu] = t;
+        }
+      }
+      __syncthreads();
+      if (nvalid < 64) break;
+      chunk_pos += 64;
+      pos = chunk_pos + lane;
+      valid = pos < A.n && keys[pos] == rootkey;
+      vm = __ballot(valid);
+      nvalid = __popcll(vm);
+      if (nvalid == 0) break;
+    }
+
+    // ---- node tests: InitOctoTree / CutOctoTree gates (cc:129-138, :170-183) ----
+    const double n_root = s_total[0];
+    if (!(n_root > (double)P.min_points)) {
+      __syncthreads();
+      continue;
+    }
+    // flush the still-open clusters as candidates (end of ClusterSurfels' first loop)
+    for (int nu = 0; nu < kNodes; ++nu) {
+      const double cnt_n = s_open[nu * kMom];
+      if (cnt_n >= (double)P.cluster_min) {
+        const uint64_t slot = slot_base + ncand;
+        if (slot < A.total_slots) {
+          if (lane < kMom) A.cand[slot * kMom + lane] = s_open[nu * kMom + lane];
+          if (lane == 0) A.cand_meta[slot] = (uint32_t)nu | (s_ord[nu] << 8);
+        } else if (lane == 0) {
+          atomicOr(&A.status[1], kFlagSlotOverflow);
+        }
+        ++ncand;
+      }
+    }
+    // round 1: root + layer-1 nodes on lanes 0..8
+    bool plane = false, tested = false;
+    if (lane < 9) {
+      const double cnt_n = s_total[lane * kMom];
+      const bool exists = (lane == 0) || (P.max_layer >= 1);
+      if (exists && cnt_n > (double)P.min_points) {
+        tested = true;
+        double mom[kMom];
+        for (int i = 0; i < kMom; ++i) mom[i] = s_total[lane * kMom + i];
+        Pca r;
+        pca_from_moments(mom, r);
+        plane = (r.ev[0] < P.thr) && (r.like > P.min_like);  // cc:106-111
+      }
+      s_plane[lane] = plane ? 1u : 0u;
+    }
+    // a layer-1 node is split when it was tested and is not a plane (cc:175-182)
+    const unsigned long long split1 = __ballot(lane >= 1 && lane < 9 && tested && !plane && P.max_layer >= 2) >> 1;
+    {
+      const int o1 = lane >> 3;
+      bool p2 = false;
+      if ((split1 >> o1) & 1ull) {
+        const int nu = 9 + lane;
+        const double cnt_n = s_total[nu * kMom];
+        if (cnt_n > (double)P.min_points) {
+          double mom[kMom];
+          for (int i = 0; i < kMom; ++i) mom[i] = s_total[nu * kMom + i];
+          Pca r;
+          pca_from_moments(mom, r);
+          p2 = (r.ev[0] < P.thr) && (r.like > P.min_like);
+        }
+      }
+      s_plane[9 + lane] = p2 ? 1u : 0u;
+    }
+    __threadfence_block();
+    __syncthreads();
+
+    // ---- emission: ExtractSurfelInfo + ClusterSurfels second loop (cc:305-308, :32-64) ----
+    uint32_t emitted = 0;
+    const uint32_t ncap = (uint32_t)min((uint64_t)ncand, A.total_slots > slot_base ? A.total_slots - slot_base : 0);
+    for (uint32_t c0 = 0; c0 < ncap; c0 += 64) {
+      const uint32_t c = c0 + lane;
+      bool ok = false;
+      if (c < ncap) {
+        const uint64_t slot = slot_base + c;
+        const uint32_t meta = A.cand_meta[slot];
+        const int nu = (int)(meta & 0xFF);
+        const uint32_t ord = meta >> 8;
+        if (s_plane[nu]) {
+          double mom[kMom];
+          for (int i = 0; i < kMom; ++i) mom[i] = A.cand[slot * kMom + i];
+          Pca r;
+          pca_from_moments(mom, r);
+          if (!(r.ev[0] > P.thr || r.like < P.min_like)) {  // cc:54
+            double nx = r.nrm[0], ny = r.nrm[1], nz = r.nrm[2];
+            const double d = nx * (r.c[0] - P.view[0]) + ny * (r.c[1] - P.view[1]) + nz * (r.c[2] - P.view[2]);
+            if (d < 0) nx = -nx, ny = -ny, nz = -nz;  // cc:59-61
+            const int layer = nu == 0 ? 0 : (nu < 9 ? 1 : 2);
+            const float ql = layer == 0 ? q0 : (layer == 1 ? q0 / 2 : (q0 / 2) / 2);
+            wc_surfel s;
+            s.t = r.tmean;
+            s.center[0] = r.c[0], s.center[1] = r.c[1], s.center[2] = r.c[2];
+            for (int i = 0; i < 9; ++i) s.cov[i] = r.cov[i];
+            s.normal[0] = nx, s.normal[1] = ny, s.normal[2] = nz;
+            s.resolution = (double)(ql * 4);  // quarter_length_ * 4, float arithmetic (cc:307)
+            s.sigma = sqrt(r.ev[0]);
+            A.slots[slot] = s;
+            uint32_t node = (uint32_t)layer;
+            if (layer == 1) node |= (uint32_t)(nu - 1) << 2;
+            if (layer == 2) node |= ((uint32_t)((nu - 9) >> 3) << 2) | ((uint32_t)((nu - 9) & 7) << 5);
+            A.slot_ids[slot] = wc_surfel_id{kx, ky, kz, node | (ord << 8)};
+            const uint64_t ob = ordered_bits(r.tmean);
+            uint64_t key;
+            if (ob < P.t_lo_bits) {
+              atomicOr(&A.status[1], kFlagTimeRange);
+              key = 0;
+            } else {
+              key = ob - P.t_lo_bits;
+            }
+            A.slot_keys[slot] = key;
+            ok = true;
+          }
+        }
+      }
+      emitted += (uint32_t)__popcll(__ballot(ok));
+    }
+    if (lane == 0 && emitted) atomicAdd(&A.status[0], emitted);
+    __syncthreads();
+  }
+}
+
+__global__ void __launch_bounds__(256) k_iota(uint32_t *v, uint64_t n) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) v[i] = (uint32_t)i;
+}
+
+// slot -> output, 16 bytes per thread (a wc_surfel is 9 x 16 B, a wc_surfel_id 1 x 16 B)
+__global__ void __launch_bounds__(256) k_gather(const uint32_t *__restrict__ sorted_slot, const wc_surfel *__restrict__ slots,
+                                               const wc_surfel_id *__restrict__ slot_ids, const uint32_t *status,
+                                               wc_surfel *out, wc_surfel_id *out_ids, uint64_t cap) {
+  const uint64_t n = min((uint64_t)status[0], cap);
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t rec = i / 10, part = i - rec * 10;
+  if (rec >= n) return;
+  const uint32_t s = sorted_slot[rec];
+  if (part < 9) {
+    const double2 *src = (const double2 *)(slots + s);
+    double2 *dst = (double2 *)(out + rec);
+    dst[part] = src[part];
+  } else if (out_ids) {
+    const uint4 *src = (const uint4 *)(slot_ids + s);
+    uint4 *dst = (uint4 *)(out_ids + rec);
+    *dst = *src;
+  }
+}
+
+template <typename K>
+int sort_pairs(wc_ctx *ctx, K *kin, K *kout, uint32_t *vin, uint32_t *vout, size_t n, unsigned end_bit) {
+  size_t tmp = 0;
+  WC_HIP(ctx, rocprim::radix_sort_pairs(nullptr, tmp, kin, kout, vin, vout, n, 0u, end_bit, ctx->stream));
+  WC_TRY(wc_ensure(ctx, ctx->b_sorttmp, tmp));
+  tmp = ctx->b_sorttmp.cap;
+  WC_HIP(ctx, rocprim::radix_sort_pairs(ctx->b_sorttmp.p, tmp, kin, kout, vin, vout, n, 0u, end_bit, ctx->stream));
+  return WC_OK;
+}
+
+template <typename K>
+int run_pipeline(wc_ctx *ctx, const wc_points &pts, double t_lo, double t_hi, wc_surfel *d_out, wc_surfel_id *d_ids,
+                 uint64_t cap) {
+  const wc_params &P = ctx->P;
+  const uint64_t n = pts.n;
+  hipStream_t st = ctx->stream;
+  ExParams E;
+  E.vs = (double)P.voxel_size;
+  E.vs_f = P.voxel_size;
+  E.max_layer = P.max_layer;
+  E.min_points = P.min_points;
+  E.thr = (double)P.planer_threshold;
+  E.min_like = P.min_plane_likeness;
+  for (int i = 0; i < 3; ++i) E.view[i] = P.view_point[i];
+  E.gap = P.cluster_gap;
+  E.cluster_min = P.cluster_min_points;
+  E.t_lo_bits = ordered_bits_host(t_lo);
+  const uint64_t span = ordered_bits_host(t_hi) - E.t_lo_bits;
+  unsigned tbits = 1;
+  while (tbits < 64 && (span >> tbits)) ++tbits;
+  const unsigned slot_end_bit = tbits >= 63 ? 64 : tbits + 1;  // one extra bit so that ~0 (invalid) sorts last
+
+  const uint64_t total_slots = (n * (uint64_t)(P.max_layer + 1)) / (uint64_t)P.cluster_min_points + 1;
+  WC_TRY(wc_ensure(ctx, ctx->b_keys[0], n * sizeof(K)));
+  WC_TRY(wc_ensure(ctx, ctx->b_keys[1], n * sizeof(K)));
+  WC_TRY(wc_ensure(ctx, ctx->b_vals[0], n * 4));
+  WC_TRY(wc_ensure(ctx, ctx->b_vals[1], n * 4));
+  WC_TRY(wc_ensure(ctx, ctx->b_cand, total_slots * kMom * 8));
+  WC_TRY(wc_ensure(ctx, ctx->b_cand_meta, total_slots * 4));
+  WC_TRY(wc_ensure(ctx, ctx->b_slots, total_slots * sizeof(wc_surfel)));
+  WC_TRY(wc_ensure(ctx, ctx->b_slot_ids, total_slots * sizeof(wc_surfel_id)));
+  WC_TRY(wc_ensure(ctx, ctx->b_slot_keys[0], total_slots * 8));
+  WC_TRY(wc_ensure(ctx, ctx->b_slot_keys[1], total_slots * 8));
+  WC_TRY(wc_ensure(ctx, ctx->b_slot_idx[0], total_slots * 4));
+  WC_TRY(wc_ensure(ctx, ctx->b_slot_idx[1], total_slots * 4));
+  WC_TRY(wc_ensure(ctx, ctx->b_status, 64 * 4));
+  uint32_t *status = (uint32_t *)ctx->b_status.p;
+
+  WC_HIP(ctx, hipMemsetAsync(status, 0, 64 * 4, st));
+  WC_HIP(ctx, hipMemsetAsync(ctx->b_slot_keys[0].p, 0xFF, total_slots * 8, st));
+  const unsigned g256 = (unsigned)((n + 255) / 256);
+  k_keygen<K><<<g256, 256, 0, st>>>(pts, E.vs, (K *)ctx->b_keys[0].p, (uint32_t *)ctx->b_vals[0].p, status);
+  k_iota<<<(unsigned)((total_slots + 255) / 256), 256, 0, st>>>((uint32_t *)ctx->b_slot_idx[0].p, total_slots);
+  WC_TRY(sort_pairs<K>(ctx, (K *)ctx->b_keys[0].p, (K *)ctx->b_keys[1].p, (uint32_t *)ctx->b_vals[0].p,
+                       (uint32_t *)ctx->b_vals[1].p, n, 3 * KeyTraits<K>::bits));
+  RootsArgs A;
+  A.pts = pts;
+  A.P = E;
+  A.n = n;
+  A.vals = (const uint32_t *)ctx->b_vals[1].p;
+  A.cand = (double *)ctx->b_cand.p;
+  A.cand_meta = (uint32_t *)ctx->b_cand_meta.p;
+  A.slots = (wc_surfel *)ctx->b_slots.p;
+  A.slot_ids = (wc_surfel_id *)ctx->b_slot_ids.p;
+  A.slot_keys = (uint64_t *)ctx->b_slot_keys[0].p;
+  A.slot_idx = (uint32_t *)ctx->b_slot_idx[0].p;
+  A.total_slots = total_slots;
+  A.status = status;
+  k_roots<K><<<(unsigned)((n + 63) / 64), 64, 0, st>>>(A, (const K *)ctx->b_keys[1].p);
+  WC_TRY(sort_pairs<uint64_t>(ctx, (uint64_t *)ctx->b_slot_keys[0].p, (uint64_t *)ctx->b_slot_keys[1].p,
+                              (uint32_t *)ctx->b_slot_idx[0].p, (uint32_t *)ctx->b_slot_idx[1].p, total_slots,
+                              slot_end_bit));
+  const uint64_t gth = std::min<uint64_t>(total_slots, cap) * 10;
+  if (gth)
+    k_gather<<<(unsigned)((gth + 255) / 256), 256, 0, st>>>((const uint32_t *)ctx->b_slot_idx[1].p, (const wc_surfel *)ctx->b_slots.p,
+                                                           (const wc_surfel_id *)ctx->b_slot_ids.p, status, d_out, d_ids, cap);
+  WC_HIP(ctx, hipMemcpyAsync(ctx->h_status, status, 8, hipMemcpyDeviceToHost, st));
+  WC_HIP(ctx, hipGetLastError());
+  return WC_OK;
+}
+
+}  // namespace
+
+extern "C" int wc_voxel_keys(wc_ctx *ctx, const wc_points *pts, int32_t *d_keys_xyz) {
+  if (!ctx || !pts || !d_keys_xyz) return WC_ERR_ARG;
+  if (pts->n == 0) return WC_OK;
+  k_voxel_keys<<<(unsigned)((pts->n + 255) / 256), 256, 0, ctx->stream>>>(*pts, (double)ctx->P.voxel_size, d_keys_xyz);
+  WC_HIP(ctx, hipGetLastError());
+  WC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return WC_OK;
+}
+
+extern "C" int wc_extract_surfels_enqueue(wc_ctx *ctx, const wc_points *pts, double t_lo, double t_hi, wc_surfel *d_out,
+                                          wc_surfel_id *d_ids, uint64_t cap) {
+  if (!ctx || !pts) return WC_ERR_ARG;
+  if (pts->n >= (1ull << 32)) return wc_fail(ctx, WC_ERR_ARG, "at most 2^32-1 points per call");
+  ctx->ex.active = true;
+  ctx->ex.pts = *pts;
+  ctx->ex.d_out = d_out;
+  ctx->ex.d_ids = d_ids;
+  ctx->ex.cap = cap;
+  ctx->ex.wide = false;
+  ctx->h_status[0] = ctx->h_status[1] = 0;
+  if (pts->n == 0) return WC_OK;
+  if (t_lo > t_hi) {  // no hint: read the first and last timestamp back (input is time ordered)
+    WC_HIP(ctx, hipMemcpyAsync(&ctx->h_mail[0], pts->time, 8, hipMemcpyDeviceToHost, ctx->stream));
+    WC_HIP(ctx, hipMemcpyAsync(&ctx->h_mail[1], (const char *)pts->time + (pts->n - 1) * pts->time_stride, 8,
+                               hipMemcpyDeviceToHost, ctx->stream));
+    WC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    t_lo = ctx->h_mail[0];
+    t_hi = ctx->h_mail[1];
+  }
+  ctx->ex.t_lo = t_lo;
+  ctx->ex.t_hi = t_hi;
+  return run_pipeline<uint32_t>(ctx, *pts, t_lo, t_hi, d_out, d_ids, cap);
+}
+
+extern "C" int wc_extract_surfels_finish(wc_ctx *ctx, uint64_t *h_n_out) {
+  if (!ctx || !ctx->ex.active) return WC_ERR_ARG;
+  ctx->ex.active = false;
+  if (h_n_out) *h_n_out = 0;
+  if (ctx->ex.pts.n == 0) return WC_OK;
+  WC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if ((ctx->h_status[1] & kFlagKeyRange) && !ctx->ex.wide) {
+    // the sweep spans more than +-512 root voxels around its first point: redo with 21-bit-per-axis keys
+    ctx->ex.wide = true;
+    WC_TRY(run_pipeline<uint64_t>(ctx, ctx->ex.pts, ctx->ex.t_lo, ctx->ex.t_hi, ctx->ex.d_out, ctx->ex.d_ids, ctx->ex.cap));
+    WC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  const uint32_t flags = ctx->h_status[1];
+  if (h_n_out) *h_n_out = ctx->h_status[0];
+  if (flags & kFlagKeyRange) return wc_fail(ctx, WC_ERR_ARG, "point cloud extent exceeds 2^20 root voxels");
+  if (flags & kFlagSlotOverflow) return wc_fail(ctx, WC_ERR_HIP, "internal: candidate slot overflow");
+  if (flags & kFlagTimeRange) return wc_fail(ctx, WC_ERR_ARG, "surfel timestamp below the t_lo hint");
+  if (ctx->h_status[0] > ctx->ex.cap) return wc_fail(ctx, WC_ERR_CAPACITY, "output capacity %llu < %u surfels",
+                                                      (unsigned long long)ctx->ex.cap, ctx->h_status[0]);
+  return WC_OK;
+}
+
+extern "C" int wc_extract_surfels(wc_ctx *ctx, const wc_points *pts, double t_lo, double t_hi, wc_surfel *d_out,
+                                  wc_surfel_id *d_ids, uint64_t cap, uint64_t *h_n_out) {
+  WC_TRY(wc_extract_surfels_enqueue(ctx, pts, t_lo, t_hi, d_out, d_ids, cap));
+  return wc_extract_surfels_finish(ctx, h_n_out);
+}

@@ -1,0 +1,175 @@
+"""ctypes binding of libwildcat_hip.so (include/wildcat_hip.h).
+
+There is NO CPU fallback: if the HIP library is missing or no gfx950 device is visible, every compute entry
+point raises.  (`load()` alone works without a GPU so that the CPU test-suite can check the exported symbols.)
+"""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+
+from . import records as R
+
+_CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "csrc")
+_SO = os.path.join(_CSRC, "libwildcat_hip.so")
+_INCLUDE = os.path.join(os.path.dirname(os.path.dirname(_CSRC)), "include")
+_LIB = None
+
+WC_OK, WC_ERR_CAPACITY = 0, 1
+
+
+class WildcatError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"wildcat_hip error {code}: {msg}")
+        self.code = code
+
+
+def so_path():
+    return _SO
+
+
+def load():
+    """Load libwildcat_hip.so; raises if it has not been built (see __graft_entry__.build())."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(_SO):
+            raise FileNotFoundError(f"{_SO} not built — run `python -c 'import __graft_entry__ as g; g.build()'`")
+        _LIB = C.CDLL(_SO)
+        _LIB.wc_version.restype = C.c_char_p
+        _LIB.wc_last_error.restype = C.c_char_p
+    return _LIB
+
+
+def declared_symbols():
+    """Every function name declared in include/wildcat_hip.h."""
+    txt = open(os.path.join(_INCLUDE, "wildcat_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(wc_[a-z0-9_]+)\s*\(", txt)))
+
+
+def default_params():
+    p = R.Params()
+    load().wc_params_default(C.byref(p))
+    return p
+
+
+class DeviceBuffer:
+    """A block of HBM owned through the C-ABI (wc_dev_alloc / wc_dev_free)."""
+
+    def __init__(self, ctx, nbytes):
+        self.ctx, self.nbytes = ctx, int(nbytes)
+        p = C.c_void_p(0)
+        ctx._ck(ctx.lib.wc_dev_alloc(ctx.h, C.c_size_t(max(self.nbytes, 1)), C.byref(p)))
+        self.ptr = p.value
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr)
+        assert arr.nbytes <= self.nbytes
+        self.ctx._ck(self.ctx.lib.wc_h2d(self.ctx.h, C.c_void_p(self.ptr), R.ptr(arr), C.c_size_t(arr.nbytes)))
+        return self
+
+    def download(self, dtype, count):
+        out = np.zeros(count, dtype)
+        self.ctx._ck(self.ctx.lib.wc_d2h(self.ctx.h, R.ptr(out), C.c_void_p(self.ptr), C.c_size_t(out.nbytes)))
+        return out
+
+    def free(self):
+        if self.ptr:
+            self.ctx.lib.wc_dev_free(self.ctx.h, C.c_void_p(self.ptr))
+            self.ptr = 0
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Context:
+    """wc_ctx wrapper: one GPU, one stream."""
+
+    def __init__(self, device=0, params=None):
+        self.lib = load()
+        self.params = params or default_params()
+        h = C.c_void_p(0)
+        rc = self.lib.wc_ctx_create(C.byref(self.params), C.c_int(device), C.byref(h))
+        if rc != WC_OK:
+            raise WildcatError(rc, "wc_ctx_create failed (no gfx950 device visible?)")
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.wc_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc != WC_OK:
+            raise WildcatError(rc, self.lib.wc_last_error(self.h).decode())
+
+    def set_params(self, params):
+        self.params = params
+        self._ck(self.lib.wc_ctx_set_params(self.h, C.byref(params)))
+
+    def set_stream(self, stream_ptr):
+        self._ck(self.lib.wc_ctx_set_stream(self.h, C.c_void_p(stream_ptr)))
+
+    def alloc(self, nbytes):
+        return DeviceBuffer(self, nbytes)
+
+    def to_device(self, arr):
+        arr = np.ascontiguousarray(arr)
+        return DeviceBuffer(self, arr.nbytes).upload(arr)
+
+    def sync(self):
+        self._ck(self.lib.wc_sync(self.h))
+
+    def timer_start(self):
+        self._ck(self.lib.wc_timer_start(self.h))
+
+    def timer_stop_ms(self):
+        ms = C.c_float(0)
+        self._ck(self.lib.wc_timer_stop_ms(self.h, C.byref(ms)))
+        return ms.value
+
+    # ---- extraction ---------------------------------------------------------------------------------------------
+    def points_desc(self, d_points, n):
+        """descriptor for a device-resident array of 48-byte hilti_ros::Point records"""
+        return R.Points(d_points.ptr, d_points.ptr + 24, 48, 48, n)
+
+    def voxel_keys(self, points):
+        d = self.to_device(points)
+        out = self.alloc(12 * len(points))
+        desc = self.points_desc(d, len(points))
+        self._ck(self.lib.wc_voxel_keys(self.h, C.byref(desc), C.c_void_p(out.ptr)))
+        return out.download(np.int32, 3 * len(points)).reshape(-1, 3)
+
+    def extract_enqueue(self, desc, d_out, d_ids, cap, t_lo=1.0, t_hi=0.0):
+        self._ck(self.lib.wc_extract_surfels_enqueue(self.h, C.byref(desc), C.c_double(t_lo), C.c_double(t_hi), C.c_void_p(d_out.ptr),
+                                                     C.c_void_p(d_ids.ptr if d_ids else 0), C.c_uint64(cap)))
+
+    def extract_finish(self):
+        n = C.c_uint64(0)
+        self._ck(self.lib.wc_extract_surfels_finish(self.h, C.byref(n)))
+        return int(n.value)
+
+    def extract_surfels(self, points, hint=True, cap=None):
+        """host convenience: upload POINT array, extract, download -> (surfels, ids)"""
+        n = len(points)
+        cap = cap or max(1024, (3 * n) // 20 + 1)
+        d_pts = self.to_device(points) if n else self.alloc(48)
+        d_out, d_ids = self.alloc(cap * 144), self.alloc(cap * 16)
+        desc = self.points_desc(d_pts, n)
+        if hint and n:
+            t_lo, t_hi = float(points["time"][0]), float(points["time"][-1])
+        else:
+            t_lo, t_hi = 1.0, 0.0
+        self.extract_enqueue(desc, d_out, d_ids, cap, t_lo, t_hi)
+        m = self.extract_finish()
+        return d_out.download(R.SURFEL, m), d_ids.download(R.SURFEL_ID, m)
