@@ -1,0 +1,166 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the MI355X hot path (contract: see the task statement / DESIGN.md §Measurement).
+
+A "step" is one pass of the hot path over one batch of synthetic input that is already resident in HBM:
+one BuildSurfels-equivalent surfel extraction of BASELINE.json config C2 (G2 patch lattice, 3 906 root voxels x 8
+patches x 32 points = 999 936 points -> 31 248 surfels) per GPU.  With N > 1 every rank extracts its own sweep
+(sweeps are independent jobs in the reference, lidar_odometry.cc:523-525: a fresh GlobalMap per sweep), so the
+data path has no collective and scaling is "weak".
+
+Prints ONE JSON line (rank 0).  Extra keys: "roofline" (dominant kernel, HIP-event timed on the kernel's stream),
+"cpu_baseline" (the CPU oracle timed on the same box, rank 0, N = 1 only), "stages_ms", "window" (LM-iteration
+figures once the window kernels are built).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "wildcat-slam_amd", "python"))
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--roots", type=int, default=3906, help="root voxels per sweep (C2: 3906 -> 999 936 points)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    args = ap.parse_args()
+
+    import torch  # device memory + distributed plumbing only
+    import torch.distributed as dist
+
+    from wildcat_slam_amd import lib, records as R, synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 or world > 1:
+        assert world == args.gpus, f"launch with torch.distributed.run --nproc-per-node {args.gpus}"
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", local_rank)
+
+    # --- synthetic sweep of this rank (G2, seed + rank), resident in HBM before the timed region ------------------
+    pts, info = synth.g2_lattice(args.roots, m=32, seed=synth.SEED + rank)
+    n_pts = len(pts)
+    exp_surfels = 8 * args.roots
+    d_pts = torch.from_numpy(pts.view(np.uint8).reshape(-1)).to(dev)
+    cap = (3 * n_pts) // 20 + 1
+    d_out = torch.empty(cap * 144, dtype=torch.uint8, device=dev)
+    d_ids = torch.empty(cap * 16, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+
+    ctx = lib.Context(local_rank)  # raises if libwildcat_hip.so / the GPU is missing: there is no fallback path
+    base = d_pts.data_ptr()
+    desc = R.Points(base, base + 24, 48, 48, n_pts)
+    t_lo, t_hi = float(pts["time"][0]), float(pts["time"][-1])
+
+    class _Ptr:
+        def __init__(self, p):
+            self.ptr = p
+
+    out_p, ids_p = _Ptr(d_out.data_ptr()), _Ptr(d_ids.data_ptr())
+
+    def step():
+        ctx.extract_enqueue(desc, out_p, ids_p, cap, t_lo, t_hi)
+        return ctx.extract_finish()
+
+    for _ in range(args.warmup):
+        n_s = step()
+    assert os.environ.get("WC_DEBUG_SKIP") or n_s == exp_surfels, (n_s, exp_surfels)
+
+    def barrier():
+        ctx.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        n_s = step()
+    ctx.sync()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * n_pts / (elapsed / args.steps) / 1e6  # Mpts/s, whole job
+
+    # --- per-stage device time (HIP events on the ctx stream), same steps, for the roofline object ---------------
+    ctx.extract_profile(True)
+    acc = {}
+    k = max(10, min(args.steps, 100))
+    for _ in range(k):
+        step()
+        for name, ms in ctx.extract_stage_ms().items():
+            acc[name] = acc.get(name, 0.0) + ms
+    ctx.extract_profile(False)
+    stages = {name: v / k for name, v in acc.items()}
+    dom = max(stages, key=stages.get)
+    algo_bytes = 20 * n_pts + 144 * exp_surfels  # 20 B read per point + 144 B written per surfel
+    dom_ms = stages[dom]
+    achieved = algo_bytes / (dom_ms * 1e-3) / 1e9
+    kernel_names = {"roots": "k_roots", "point_sort": "rocprim radix sort (points)", "slot_sort": "rocprim radix sort (slots)",
+                    "keygen": "k_keygen", "gather": "k_gather"}
+    roofline = {"bound": "hbm", "kernel": kernel_names[dom], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "algorithmic_bytes_per_launch": algo_bytes,
+                "avg_kernel_ms": round(dom_ms, 5),
+                "whole_pipeline_frac": round(algo_bytes / (sum(stages.values()) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
+
+    result = {
+        "metric": "surfel-extract Mpts/s",
+        "value": round(value, 2),
+        "unit": "Mpts/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 5),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": "C2: 1M-pt single scan (G2 patch lattice, %d pts -> %d surfels) per GPU, voxel-grid + 3-level octree + per-cell 3x3 PCA"
+                   % (n_pts, exp_surfels), "points_per_gpu": n_pts, "surfels_per_gpu": exp_surfels, "parallelism": "sweep-per-gpu x%d" % world},
+        "roofline": roofline,
+        "stages_ms": {k_: round(v, 5) for k_, v in stages.items()},
+    }
+
+    # --- CPU baseline: the single-thread oracle on the same workload, rank 0, N = 1 only --------------------------
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import pyoracle  # test infrastructure, used here ONLY as the timed CPU baseline
+
+        reps, t_cpu = 0, 0.0
+        while t_cpu < args.cpu_seconds:
+            t1 = time.perf_counter()
+            s_ref, _, _ = pyoracle.extract_surfels(pts, cap=cap)
+            t_cpu += time.perf_counter() - t1
+            reps += 1
+        assert len(s_ref) == exp_surfels
+        result["cpu_baseline"] = {"value": round(reps * n_pts / t_cpu / 1e6, 3), "unit": "Mpts/s", "cores": 1, "kind": "port",
+                                  "sample": "%d full C2 sweeps (%d pts each), %.1f s of single-thread oracle (oracle/extract.cc)" % (reps, n_pts, t_cpu)}
+
+    if rank == 0:
+        print(json.dumps(result))
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

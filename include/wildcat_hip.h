@@ -73,6 +73,10 @@ int wc_extract_surfels(wc_ctx *ctx, const wc_points *pts, double t_lo, double t_
 int wc_extract_surfels_enqueue(wc_ctx *ctx, const wc_points *pts, double t_lo, double t_hi, wc_surfel *d_out,
                                wc_surfel_id *d_ids, uint64_t cap);
 int wc_extract_surfels_finish(wc_ctx *ctx, uint64_t *h_n_out);
+/* per-stage device time of the LAST enqueued extraction, measured with HIP events on the ctx stream:
+ * h_ms5 = {key generation, point radix sort, k_roots (octree + PCA), surfel-slot sort, gather}.  Enable first. */
+int wc_extract_profile(wc_ctx *ctx, int enable);
+int wc_extract_stage_ms(wc_ctx *ctx, float *h_ms5);
 /* root-voxel index of every point: VoxelLoc (src/odometry/surfel_extraction.h:55-64); d_keys_xyz = 3 int32 per point */
 int wc_voxel_keys(wc_ctx *ctx, const wc_points *pts, int32_t *d_keys_xyz);
 

@@ -42,6 +42,9 @@ struct wc_ctx {
     bool wide;
   } ex;
   wc_window_state *win = nullptr;
+  // optional per-stage HIP events of the extraction pipeline (wc_extract_profile)
+  bool ex_prof = false;
+  hipEvent_t ex_ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 };
 
 inline int wc_fail(wc_ctx *ctx, int code, const char *fmt, ...) {

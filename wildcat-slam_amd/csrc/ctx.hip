@@ -97,6 +97,8 @@ extern "C" void wc_ctx_destroy(wc_ctx *ctx) {
   if (ctx->h_mail) (void)hipHostFree(ctx->h_mail);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+  for (hipEvent_t e : ctx->ex_ev)
+    if (e) (void)hipEventDestroy(e);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
 }

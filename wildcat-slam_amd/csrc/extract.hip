@@ -20,6 +20,7 @@
 // The path is HBM/latency bound (20 B read per point, 144 B written per surfel); no MFMA.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <rocprim/rocprim.hpp>
 
@@ -28,8 +29,9 @@
 
 namespace {
 
-constexpr int kNodes = 73;  // 1 root + 8 layer-1 + 64 layer-2 nodes
+
 constexpr int kMom = 11;    // n, St, Sx, Sy, Sz, Sxx, Sxy, Sxz, Syy, Syz, Szz
+constexpr unsigned kRootsGrid = 256 * 10;  // persistent wavefronts: 256 CUs x ~LDS-limited residency
 constexpr uint32_t kFlagKeyRange = 1u, kFlagSlotOverflow = 2u, kFlagTimeRange = 4u;
 
 struct ExParams {
@@ -43,6 +45,7 @@ struct ExParams {
   double gap;
   int cluster_min;
   uint64_t t_lo_bits;  // ordered bits of the time hint lower bound
+  int dbg;             // WC_DEBUG_SKIP bits (profiling experiments only)
 };
 
 __device__ __forceinline__ uint64_t ordered_bits(double t) {
@@ -149,269 +152,312 @@ struct RootsArgs {
   wc_points pts;
   ExParams P;
   uint64_t n;
-  const uint32_t *vals;   // sorted point indices
-  double *cand;           // [total_slots][11] candidate cluster moments
-  uint32_t *cand_meta;    // [total_slots] node | ordinal << 8
-  wc_surfel *slots;       // [total_slots]
-  wc_surfel_id *slot_ids; // [total_slots]
-  uint64_t *slot_keys;    // [total_slots] time sort keys (memset to ~0 = invalid)
-  uint32_t *slot_idx;     // [total_slots] iota
+  const uint32_t *vals;    // sorted point indices
+  const uint32_t *heads;   // compacted heads of the live root segments (n > min_points); count in status[2]
+  double *cand;            // [total_slots][11] candidate cluster moments
+  uint32_t *cand_meta;     // [total_slots] local node | phase << 7 | ordinal << 8
+  wc_surfel *slots;        // [total_slots]
+  wc_surfel_id *slot_ids;  // [total_slots]
+  uint64_t *slot_keys;     // [total_slots] time sort keys (memset to ~0 = invalid)
   uint64_t total_slots;
-  uint32_t *status;       // [0] emitted count, [1] flags
+  uint32_t *status;        // [0] emitted count, [1] flags, [2] live roots, [3] dequeue cursor
 };
 
+// Heads of the root-voxel segments that can emit anything (n > min_points, InitOctoTree cc:129), compacted with one
+// wave-aggregated atomic per wavefront.  Order is irrelevant: every root owns a fixed slot range.
+template <typename K>
+__global__ void __launch_bounds__(256) k_heads(const K *__restrict__ keys, uint64_t n, int min_points, uint32_t *heads,
+                                              uint32_t *status) {
+  const uint64_t pos = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  bool live = false;
+  if (pos < n) {
+    const K k = keys[pos];
+    live = (pos == 0 || keys[pos - 1] != k) && (pos + (uint64_t)min_points < n) && keys[pos + min_points] == k;
+  }
+  const unsigned long long mask = __ballot(live);
+  if (!mask) return;
+  const int lane = threadIdx.x & 63;
+  uint32_t base = 0;
+  if (lane == __ffsll((long long)mask) - 1) base = atomicAdd(&status[2], (uint32_t)__popcll(mask));
+  base = __shfl(base, __ffsll((long long)mask) - 1);
+  if (live) heads[base + __popcll(mask & ((1ull << lane) - 1))] = (uint32_t)pos;
+}
+
+constexpr int kTab = 64;  // node-table rows: phase 1 uses 9 (root + 8 layer-1 nodes), phase 2 uses 64 (layer-2 nodes)
+
+// One wavefront per root voxel, roots pulled from a device-side queue (placement independent; a fixed
+// blockIdx -> segment map put all the work of a regular cloud on 2 of the 8 XCDs).
 template <typename K>
 __global__ void __launch_bounds__(64) k_roots(RootsArgs A, const K *__restrict__ keys) {
-  __shared__ double s_open[kNodes * kMom];
-  __shared__ double s_total[kNodes * kMom];
-  __shared__ double s_last[kNodes];
-  __shared__ uint32_t s_ord[kNodes];
-  __shared__ double s_stage[64 * 5];
+  __shared__ double s_open[kTab * kMom];
+  __shared__ double s_total[kTab * kMom];
+  __shared__ double s_last[kTab];
+  __shared__ int s_cnt[kTab];
+  __shared__ uint32_t s_ord[kTab];
+  __shared__ double s_stage[64 * 5];  // {1, t, x, y, z} of the staged chunk
   __shared__ uint32_t s_code[64];
-  __shared__ uint32_t s_plane[kNodes];
 
   const int lane = threadIdx.x;
-  const uint64_t tile = (uint64_t)blockIdx.x * 64;
-  const uint64_t mypos = tile + lane;
   const ExParams &P = A.P;
   constexpr int B = KeyTraits<K>::bits;
+  constexpr int half = 1 << (B - 1);
 
-  // segment heads inside this tile
-  bool is_head = false;
-  if (mypos < A.n) is_head = (mypos == 0) || (keys[mypos] != keys[mypos - 1]);
-  unsigned long long heads = __ballot(is_head);
-
-  // lane roles for the streaming phase
-  const bool act = lane < 3 * kMom;
-  const int L = lane / kMom;       // octree level handled by this lane (valid when act)
-  const int m = lane - L * kMom;   // moment handled by this lane
-  // moment m = stage[ia] * stage[ib] with stage = {1, t, x, y, z}
+  // lane roles while streaming: lane = (level, moment); moment m = stage[ia] * stage[ib], stage = {1, t, x, y, z}
+  const int Lq = lane / kMom;      // 0,1 used in phase 1; phase 2 uses lanes 0..10 only
+  const int m = lane - Lq * kMom;
   const int ia = (m <= 4) ? m : (m <= 7 ? 2 : (m <= 9 ? 3 : 4));
-  const int ib = (m <= 4) ? 0 : (m == 5 ? 2 : (m == 6 ? 3 : (m == 7 ? 4 : (m == 8 ? 3 : (m == 9 ? 4 : 4)))));
+  const int ib = (m <= 4) ? 0 : (m == 5 ? 2 : (m == 6 ? 3 : (m == 7 ? 4 : (m == 8 ? 3 : 4))));
 
   double x0, y0, z0;
   load_xyz(A.pts, 0, x0, y0, z0);
   const int k0x = vox(x0, P.vs), k0y = vox(y0, P.vs), k0z = vox(z0, P.vs);
+  const uint32_t nroots = A.status[2];
 
-  while (heads) {
-    const int hb = __ffsll((long long)heads) - 1;
-    heads &= heads - 1;
-    const uint64_t head = tile + hb;
+  // static striding over the compacted head list (a single dequeue word serialises at ~90 dequeues/us, which cost
+  // more than the imbalance it removed: 3.9k roots => ~45 us of pure queueing)
+  for (uint32_t r = blockIdx.x; r < nroots; r += gridDim.x) {
+    const uint64_t head = A.heads[r];
     const K rootkey = keys[head];
 
-    // ---- first chunk: also decides the cheap exit for sparse roots (InitOctoTree, cc:129) ----
-    uint64_t pos = head + lane;
-    bool valid = pos < A.n && keys[pos] == rootkey;
-    unsigned long long vm = __ballot(valid);
-    int nvalid = __popcll(vm);  // valid lanes are a prefix (keys sorted)
-    if (nvalid < 64 && nvalid <= P.min_points) continue;
-
     // absolute root voxel index and centre ((0.5 + k) * voxel_size, cc:208-210)
-    constexpr int half = 1 << (B - 1);
     const int kx = (int)(rootkey & ((K(1) << B) - 1)) - half + k0x;
     const int ky = (int)((rootkey >> B) & ((K(1) << B) - 1)) - half + k0y;
     const int kz = (int)((rootkey >> (2 * B)) & ((K(1) << B) - 1)) - half + k0z;
     const double cx = (0.5 + kx) * P.vs_f, cy = (0.5 + ky) * P.vs_f, cz = (0.5 + kz) * P.vs_f;
     const float q0 = P.vs_f / 4;  // quarter_length_ of the root (cc:207)
-
-    for (int i = lane; i < kNodes * kMom; i += 64) {
-      s_open[i] = 0.0;
-      s_total[i] = 0.0;
-    }
-    for (int i = lane; i < kNodes; i += 64) {
-      s_last[i] = 0.0;
-      s_ord[i] = 0;
-      s_plane[i] = 0;
-    }
     const uint64_t slot_base = (head * (uint64_t)(P.max_layer + 1)) / (uint64_t)P.cluster_min;
-    uint32_t ncand = 0;
-    __syncthreads();
+    uint32_t ncand = 0, emitted = 0;
+    unsigned long long split1 = 0;  // layer-1 octants that get split (tested, not a plane; cc:175-182)
 
-    uint64_t chunk_pos = head;
-    while (true) {
-      // ---- stage up to 64 points of this segment: {1, t, x, y, z} + octant code ----
+    for (int phase = 1; phase <= 2; ++phase) {
+      if (phase == 2 && split1 == 0) break;
+      const int nlev = (phase == 1) ? (P.max_layer >= 1 ? 2 : 1) : 1;
+      const bool act = lane < nlev * kMom;
+      const int ntab = (phase == 1) ? 9 : 64;
+      for (int i = lane; i < ntab * kMom; i += 64) {
+        s_open[i] = 0.0;
+        s_total[i] = 0.0;
+      }
+      for (int i = lane; i < ntab; i += 64) {
+        s_last[i] = 0.0;
+        s_cnt[i] = 0;
+        s_ord[i] = 0;
+      }
+      const uint32_t cand_begin = ncand;
+
+      // register-cached accumulators of the node this lane is currently feeding
+      int cur = -1, n_open = 0;
+      double a_open = 0.0, a_total = 0.0, last = 0.0;
+
+      // ---- software-pipelined chunk loop: the next 64 points are in flight while the current ones stream ----
+      uint64_t pos = head + lane;
+      bool valid = pos < A.n && keys[pos] == rootkey;
+      double px = 0, py = 0, pz = 0, pt = 0;
       if (valid) {
         const uint32_t idx = A.vals[pos];
-        double x, y, z;
-        load_xyz(A.pts, idx, x, y, z);
-        const double t = load_t(A.pts, idx);
-        // octant = 4*[x>cx] + 2*[y>cy] + [z>cz]  (strict >, cc:147-158); child centre = centre +- quarter (cc:163-165)
-        const int bx = x > cx, by = y > cy, bz = z > cz;
-        const double c1x = cx + (double)((float)(2 * bx - 1) * q0);
-        const double c1y = cy + (double)((float)(2 * by - 1) * q0);
-        const double c1z = cz + (double)((float)(2 * bz - 1) * q0);
-        const int o1 = 4 * bx + 2 * by + bz;
-        const int o2 = 4 * (x > c1x) + 2 * (y > c1y) + (z > c1z);
-        s_stage[lane * 5 + 0] = 1.0;
-        s_stage[lane * 5 + 1] = t;
-        s_stage[lane * 5 + 2] = x;
-        s_stage[lane * 5 + 3] = y;
-        s_stage[lane * 5 + 4] = z;
-        s_code[lane] = (uint32_t)(o1 * 8 + o2);
+        load_xyz(A.pts, idx, px, py, pz);
+        pt = load_t(A.pts, idx);
       }
-      __syncthreads();
-
-      // ---- stream the staged points in time order through the node accumulators ----
-      for (int j = 0; j < nvalid; ++j) {
-        int nu = 0;
-        double t = 0, cnt = 0;
-        bool close = false;
-        if (act) {
-          const uint32_t code = s_code[j];
-          nu = (L == 0) ? 0 : (L == 1 ? 1 + (int)(code >> 3) : 9 + (int)code);
-          t = s_stage[j * 5 + 1];
-          cnt = s_open[nu * kMom];
-          // new cluster when the gap to the previous point OF THIS NODE exceeds cluster_gap (cc:24)
-          close = cnt > 0.0 && (t - s_last[nu] > P.gap);
+      while (true) {
+        const int nvalid = __popcll(__ballot(valid));  // valid lanes are a prefix: keys are sorted
+        if (nvalid == 0) break;
+        __syncthreads();
+        if (valid) {
+          // octant = 4*[x>cx] + 2*[y>cy] + [z>cz] (strict >, cc:147-158); child centre = centre +- quarter (cc:163-165)
+          const int bx = px > cx, by = py > cy, bz = pz > cz;
+          const double c1x = cx + (double)((float)(2 * bx - 1) * q0);
+          const double c1y = cy + (double)((float)(2 * by - 1) * q0);
+          const double c1z = cz + (double)((float)(2 * bz - 1) * q0);
+          const int o1 = 4 * bx + 2 * by + bz;
+          const int o2 = 4 * (px > c1x) + 2 * (py > c1y) + (pz > c1z);
+          s_stage[lane * 5 + 0] = 1.0;
+          s_stage[lane * 5 + 1] = pt;
+          s_stage[lane * 5 + 2] = px;
+          s_stage[lane * 5 + 3] = py;
+          s_stage[lane * 5 + 4] = pz;
+          s_code[lane] = (uint32_t)(o1 * 8 + o2);
         }
-        const unsigned long long cm = __ballot(close);
-        if (cm) {
-          for (int l = 0; l <= P.max_layer; ++l) {
-            if (!((cm >> (l * kMom)) & 1ull)) continue;
-            const double cnt_l = __shfl(cnt, l * kMom);
-            const bool mine = act && (L == l);
-            if (cnt_l >= (double)P.cluster_min) {  // clusters with fewer points are dropped (cc:33)
-              const uint64_t slot = slot_base + ncand;
-              if (slot < A.total_slots) {
-                if (mine) {
-                  A.cand[slot * kMom + m] = s_open[nu * kMom + m];
-                  if (m == 0) A.cand_meta[slot] = (uint32_t)nu | (s_ord[nu] << 8);
-                }
-              } else if (lane == 0) {
-                atomicOr(&A.status[1], kFlagSlotOverflow);
+        __syncthreads();
+        // prefetch the next chunk
+        bool nvalid_next = false;
+        if (nvalid == 64) {
+          pos += 64;
+          nvalid_next = pos < A.n && keys[pos] == rootkey;
+          if (nvalid_next) {
+            const uint32_t idx = A.vals[pos];
+            load_xyz(A.pts, idx, px, py, pz);
+            pt = load_t(A.pts, idx);
+          }
+        }
+
+        // ---- stream the staged points in time order ----
+        // the reads of point j+1 are issued before point j is processed (LDS latency off the critical path)
+        uint32_t code_n = s_code[0];
+        double t_n = s_stage[1], a_n = s_stage[ia], b_n = s_stage[ib];
+        for (int j = 0; j < ((P.dbg & 1) ? 0 : nvalid); ++j) {
+          const uint32_t code = code_n;
+          const double t = t_n, va = a_n, vb = b_n;
+          const int jn = (j + 1 < 64) ? j + 1 : 63;
+          code_n = s_code[jn];
+          t_n = s_stage[jn * 5 + 1];
+          a_n = s_stage[jn * 5 + ia];
+          b_n = s_stage[jn * 5 + ib];
+          if (phase == 2 && !((split1 >> (code >> 3)) & 1ull)) continue;  // parent layer-1 node is not split
+          const int nu = (phase == 2) ? (int)code : (Lq == 0 ? 0 : 1 + (int)(code >> 3));
+          if (act && nu != cur) {  // switch node: write the cached accumulators back, fetch the new node's
+            if (cur >= 0) {
+              s_open[cur * kMom + m] = a_open;
+              s_total[cur * kMom + m] = a_total;
+              if (m == 0) {
+                s_last[cur] = last;
+                s_cnt[cur] = n_open;
               }
-              ++ncand;
             }
-            if (mine) {
-              s_open[nu * kMom + m] = 0.0;
-              if (m == 0) s_ord[nu] += 1;
+            a_open = s_open[nu * kMom + m];
+            a_total = s_total[nu * kMom + m];
+            last = s_last[nu];
+            n_open = s_cnt[nu];
+            cur = nu;
+          }
+          // a new cluster starts when the gap to the previous point OF THIS NODE exceeds cluster_gap (cc:24)
+          const bool close = act && n_open > 0 && (t - last > P.gap);
+          const unsigned long long cm = __ballot(close);
+          if (cm) {
+            for (int l = 0; l < nlev; ++l) {
+              if (!((cm >> (l * kMom)) & 1ull)) continue;
+              const int cnt_l = __shfl(n_open, l * kMom);
+              const bool mine = act && (Lq == l);
+              if (cnt_l >= P.cluster_min) {  // clusters with fewer points are dropped (cc:33)
+                const uint64_t slot = slot_base + ncand;
+                if (slot < A.total_slots) {
+                  if (mine) {
+                    A.cand[slot * kMom + m] = a_open;
+                    if (m == 0) A.cand_meta[slot] = (uint32_t)nu | ((uint32_t)(phase - 1) << 7) | (s_ord[nu] << 8);
+                  }
+                } else if (lane == 0) {
+                  atomicOr(&A.status[1], kFlagSlotOverflow);
+                }
+                ++ncand;
+              }
+              if (mine) {
+                a_open = 0.0;
+                n_open = 0;
+                if (m == 0) s_ord[nu] += 1;
+              }
             }
           }
+          if (act) {
+            const double v = va * vb;
+            a_open += v;
+            a_total += v;
+            n_open += 1;
+            last = t;
+          }
         }
-        if (act && L <= P.max_layer) {
-          const double v = s_stage[j * 5 + ia] * s_stage[j * 5 + ib];
-          s_open[nu * kMom + m] += v;
-          s_total[nu * kMom + m] += v;
-          if (m == 0) s_last[nu] = t;
+        if (nvalid < 64) break;
+        valid = nvalid_next;
+      }
+      // write the cached node back
+      if (act && cur >= 0) {
+        s_open[cur * kMom + m] = a_open;
+        s_total[cur * kMom + m] = a_total;
+        if (m == 0) {
+          s_last[cur] = last;
+          s_cnt[cur] = n_open;
         }
       }
       __syncthreads();
-      if (nvalid < 64) break;
-      chunk_pos += 64;
-      pos = chunk_pos + lane;
-      valid = pos < A.n && keys[pos] == rootkey;
-      vm = __ballot(valid);
-      nvalid = __popcll(vm);
-      if (nvalid == 0) break;
-    }
 
-    // ---- node tests: InitOctoTree / CutOctoTree gates (cc:129-138, :170-183) ----
-    const double n_root = s_total[0];
-    if (!(n_root > (double)P.min_points)) {
+      // still-open clusters become candidates too (end of ClusterSurfels' first loop)
+      for (int nu = 0; nu < ntab; ++nu) {
+        if (s_cnt[nu] >= P.cluster_min) {
+          const uint64_t slot = slot_base + ncand;
+          if (slot < A.total_slots) {
+            if (lane < kMom) A.cand[slot * kMom + lane] = s_open[nu * kMom + lane];
+            if (lane == 0) A.cand_meta[slot] = (uint32_t)nu | ((uint32_t)(phase - 1) << 7) | (s_ord[nu] << 8);
+          } else if (lane == 0) {
+            atomicOr(&A.status[1], kFlagSlotOverflow);
+          }
+          ++ncand;
+        }
+      }
+
+      if (P.dbg & 2) break;
+      // ---- node tests: InitOctoTree / CutOctoTree gates (cc:129-138, :170-183) ----
+      bool tested = false, plane = false;
+      if (lane < ntab) {
+        bool exists = true;
+        if (phase == 2) exists = (split1 >> (lane >> 3)) & 1ull;
+        const double cnt_n = s_total[lane * kMom];
+        if (exists && cnt_n > (double)P.min_points) {
+          tested = true;
+          double mom[kMom];
+          for (int i = 0; i < kMom; ++i) mom[i] = s_total[lane * kMom + i];
+          Pca rr;
+          pca_from_moments(mom, rr);
+          plane = (rr.ev[0] < P.thr) && (rr.like > P.min_like);  // cc:106-111
+        }
+      }
+      const unsigned long long plane_mask = __ballot(plane);
+      if (phase == 1) {
+        const bool root_tested = __shfl((int)tested, 0) != 0;
+        if (!root_tested) break;  // n <= min_points: nothing below this root exists (cc:129)
+        split1 = (P.max_layer >= 2) ? (__ballot(lane >= 1 && lane < 9 && tested && !plane) >> 1) : 0ull;
+      }
+      __threadfence_block();
       __syncthreads();
-      continue;
-    }
-    // flush the still-open clusters as candidates (end of ClusterSurfels' first loop)
-    for (int nu = 0; nu < kNodes; ++nu) {
-      const double cnt_n = s_open[nu * kMom];
-      if (cnt_n >= (double)P.cluster_min) {
-        const uint64_t slot = slot_base + ncand;
-        if (slot < A.total_slots) {
-          if (lane < kMom) A.cand[slot * kMom + lane] = s_open[nu * kMom + lane];
-          if (lane == 0) A.cand_meta[slot] = (uint32_t)nu | (s_ord[nu] << 8);
-        } else if (lane == 0) {
-          atomicOr(&A.status[1], kFlagSlotOverflow);
-        }
-        ++ncand;
-      }
-    }
-    // round 1: root + layer-1 nodes on lanes 0..8
-    bool plane = false, tested = false;
-    if (lane < 9) {
-      const double cnt_n = s_total[lane * kMom];
-      const bool exists = (lane == 0) || (P.max_layer >= 1);
-      if (exists && cnt_n > (double)P.min_points) {
-        tested = true;
-        double mom[kMom];
-        for (int i = 0; i < kMom; ++i) mom[i] = s_total[lane * kMom + i];
-        Pca r;
-        pca_from_moments(mom, r);
-        plane = (r.ev[0] < P.thr) && (r.like > P.min_like);  // cc:106-111
-      }
-      s_plane[lane] = plane ? 1u : 0u;
-    }
-    // a layer-1 node is split when it was tested and is not a plane (cc:175-182)
-    const unsigned long long split1 = __ballot(lane >= 1 && lane < 9 && tested && !plane && P.max_layer >= 2) >> 1;
-    {
-      const int o1 = lane >> 3;
-      bool p2 = false;
-      if ((split1 >> o1) & 1ull) {
-        const int nu = 9 + lane;
-        const double cnt_n = s_total[nu * kMom];
-        if (cnt_n > (double)P.min_points) {
-          double mom[kMom];
-          for (int i = 0; i < kMom; ++i) mom[i] = s_total[nu * kMom + i];
-          Pca r;
-          pca_from_moments(mom, r);
-          p2 = (r.ev[0] < P.thr) && (r.like > P.min_like);
-        }
-      }
-      s_plane[9 + lane] = p2 ? 1u : 0u;
-    }
-    __threadfence_block();
-    __syncthreads();
 
-    // ---- emission: ExtractSurfelInfo + ClusterSurfels second loop (cc:305-308, :32-64) ----
-    uint32_t emitted = 0;
-    const uint32_t ncap = (uint32_t)min((uint64_t)ncand, A.total_slots > slot_base ? A.total_slots - slot_base : 0);
-    for (uint32_t c0 = 0; c0 < ncap; c0 += 64) {
-      const uint32_t c = c0 + lane;
-      bool ok = false;
-      if (c < ncap) {
-        const uint64_t slot = slot_base + c;
-        const uint32_t meta = A.cand_meta[slot];
-        const int nu = (int)(meta & 0xFF);
-        const uint32_t ord = meta >> 8;
-        if (s_plane[nu]) {
-          double mom[kMom];
-          for (int i = 0; i < kMom; ++i) mom[i] = A.cand[slot * kMom + i];
-          Pca r;
-          pca_from_moments(mom, r);
-          if (!(r.ev[0] > P.thr || r.like < P.min_like)) {  // cc:54
-            double nx = r.nrm[0], ny = r.nrm[1], nz = r.nrm[2];
-            const double d = nx * (r.c[0] - P.view[0]) + ny * (r.c[1] - P.view[1]) + nz * (r.c[2] - P.view[2]);
-            if (d < 0) nx = -nx, ny = -ny, nz = -nz;  // cc:59-61
-            const int layer = nu == 0 ? 0 : (nu < 9 ? 1 : 2);
-            const float ql = layer == 0 ? q0 : (layer == 1 ? q0 / 2 : (q0 / 2) / 2);
-            wc_surfel s;
-            s.t = r.tmean;
-            s.center[0] = r.c[0], s.center[1] = r.c[1], s.center[2] = r.c[2];
-            for (int i = 0; i < 9; ++i) s.cov[i] = r.cov[i];
-            s.normal[0] = nx, s.normal[1] = ny, s.normal[2] = nz;
-            s.resolution = (double)(ql * 4);  // quarter_length_ * 4, float arithmetic (cc:307)
-            s.sigma = sqrt(r.ev[0]);
-            A.slots[slot] = s;
-            uint32_t node = (uint32_t)layer;
-            if (layer == 1) node |= (uint32_t)(nu - 1) << 2;
-            if (layer == 2) node |= ((uint32_t)((nu - 9) >> 3) << 2) | ((uint32_t)((nu - 9) & 7) << 5);
-            A.slot_ids[slot] = wc_surfel_id{kx, ky, kz, node | (ord << 8)};
-            const uint64_t ob = ordered_bits(r.tmean);
-            uint64_t key;
-            if (ob < P.t_lo_bits) {
-              atomicOr(&A.status[1], kFlagTimeRange);
-              key = 0;
-            } else {
-              key = ob - P.t_lo_bits;
+      // ---- emission: ExtractSurfelInfo + ClusterSurfels second loop (cc:305-308, :32-64) ----
+      const uint32_t ncap = (uint32_t)min((uint64_t)ncand, A.total_slots > slot_base ? A.total_slots - slot_base : 0);
+      for (uint32_t c0 = cand_begin; c0 < ncap; c0 += 64) {
+        const uint32_t c = c0 + lane;
+        bool ok = false;
+        if (c < ncap) {
+          const uint64_t slot = slot_base + c;
+          const uint32_t meta = A.cand_meta[slot];
+          const int nu = (int)(meta & 0x7F);
+          const uint32_t ord = meta >> 8;
+          if ((plane_mask >> nu) & 1ull) {
+            double mom[kMom];
+            for (int i = 0; i < kMom; ++i) mom[i] = A.cand[slot * kMom + i];
+            Pca rr;
+            pca_from_moments(mom, rr);
+            if (!(rr.ev[0] > P.thr || rr.like < P.min_like)) {  // cc:54
+              double nx = rr.nrm[0], ny = rr.nrm[1], nz = rr.nrm[2];
+              const double d = nx * (rr.c[0] - P.view[0]) + ny * (rr.c[1] - P.view[1]) + nz * (rr.c[2] - P.view[2]);
+              if (d < 0) nx = -nx, ny = -ny, nz = -nz;  // cc:59-61
+              const int layer = (phase == 2) ? 2 : (nu == 0 ? 0 : 1);
+              const float ql = layer == 0 ? q0 : (layer == 1 ? q0 / 2 : (q0 / 2) / 2);
+              wc_surfel sf;
+              sf.t = rr.tmean;
+              sf.center[0] = rr.c[0], sf.center[1] = rr.c[1], sf.center[2] = rr.c[2];
+              for (int i = 0; i < 9; ++i) sf.cov[i] = rr.cov[i];
+              sf.normal[0] = nx, sf.normal[1] = ny, sf.normal[2] = nz;
+              sf.resolution = (double)(ql * 4);  // quarter_length_ * 4, float arithmetic (cc:307)
+              sf.sigma = sqrt(rr.ev[0]);
+              A.slots[slot] = sf;
+              uint32_t node = (uint32_t)layer;
+              if (layer == 1) node |= (uint32_t)(nu - 1) << 2;
+              if (layer == 2) node |= ((uint32_t)(nu >> 3) << 2) | ((uint32_t)(nu & 7) << 5);
+              A.slot_ids[slot] = wc_surfel_id{kx, ky, kz, node | (ord << 8)};
+              const uint64_t ob = ordered_bits(rr.tmean);
+              uint64_t key;
+              if (ob < P.t_lo_bits) {
+                atomicOr(&A.status[1], kFlagTimeRange);
+                key = 0;
+              } else {
+                key = ob - P.t_lo_bits;
+              }
+              A.slot_keys[slot] = key;
+              ok = true;
             }
-            A.slot_keys[slot] = key;
-            ok = true;
           }
         }
+        emitted += (uint32_t)__popcll(__ballot(ok));
       }
-      emitted += (uint32_t)__popcll(__ballot(ok));
+      __syncthreads();
     }
     if (lane == 0 && emitted) atomicAdd(&A.status[0], emitted);
-    __syncthreads();
   }
 }
 
@@ -467,6 +513,7 @@ int run_pipeline(wc_ctx *ctx, const wc_points &pts, double t_lo, double t_hi, wc
   E.gap = P.cluster_gap;
   E.cluster_min = P.cluster_min_points;
   E.t_lo_bits = ordered_bits_host(t_lo);
+  E.dbg = getenv("WC_DEBUG_SKIP") ? atoi(getenv("WC_DEBUG_SKIP")) : 0;
   const uint64_t span = ordered_bits_host(t_hi) - E.t_lo_bits;
   unsigned tbits = 1;
   while (tbits < 64 && (span >> tbits)) ++tbits;
@@ -486,15 +533,22 @@ int run_pipeline(wc_ctx *ctx, const wc_points &pts, double t_lo, double t_hi, wc
   WC_TRY(wc_ensure(ctx, ctx->b_slot_idx[0], total_slots * 4));
   WC_TRY(wc_ensure(ctx, ctx->b_slot_idx[1], total_slots * 4));
   WC_TRY(wc_ensure(ctx, ctx->b_status, 64 * 4));
+  WC_TRY(wc_ensure(ctx, ctx->b_misc[0], (n / (uint64_t)(P.min_points + 1) + 2) * 4));
   uint32_t *status = (uint32_t *)ctx->b_status.p;
 
+  auto mark = [&](int i) {
+    if (ctx->ex_prof) (void)hipEventRecord(ctx->ex_ev[i], st);
+  };
+  mark(0);
   WC_HIP(ctx, hipMemsetAsync(status, 0, 64 * 4, st));
   WC_HIP(ctx, hipMemsetAsync(ctx->b_slot_keys[0].p, 0xFF, total_slots * 8, st));
   const unsigned g256 = (unsigned)((n + 255) / 256);
   k_keygen<K><<<g256, 256, 0, st>>>(pts, E.vs, (K *)ctx->b_keys[0].p, (uint32_t *)ctx->b_vals[0].p, status);
   k_iota<<<(unsigned)((total_slots + 255) / 256), 256, 0, st>>>((uint32_t *)ctx->b_slot_idx[0].p, total_slots);
+  mark(1);
   WC_TRY(sort_pairs<K>(ctx, (K *)ctx->b_keys[0].p, (K *)ctx->b_keys[1].p, (uint32_t *)ctx->b_vals[0].p,
                        (uint32_t *)ctx->b_vals[1].p, n, 3 * KeyTraits<K>::bits));
+  mark(2);
   RootsArgs A;
   A.pts = pts;
   A.P = E;
@@ -505,17 +559,21 @@ int run_pipeline(wc_ctx *ctx, const wc_points &pts, double t_lo, double t_hi, wc
   A.slots = (wc_surfel *)ctx->b_slots.p;
   A.slot_ids = (wc_surfel_id *)ctx->b_slot_ids.p;
   A.slot_keys = (uint64_t *)ctx->b_slot_keys[0].p;
-  A.slot_idx = (uint32_t *)ctx->b_slot_idx[0].p;
   A.total_slots = total_slots;
   A.status = status;
-  k_roots<K><<<(unsigned)((n + 63) / 64), 64, 0, st>>>(A, (const K *)ctx->b_keys[1].p);
+  A.heads = (const uint32_t *)ctx->b_misc[0].p;
+  k_heads<K><<<g256, 256, 0, st>>>((const K *)ctx->b_keys[1].p, n, P.min_points, (uint32_t *)ctx->b_misc[0].p, status);
+  k_roots<K><<<kRootsGrid, 64, 0, st>>>(A, (const K *)ctx->b_keys[1].p);
+  mark(3);
   WC_TRY(sort_pairs<uint64_t>(ctx, (uint64_t *)ctx->b_slot_keys[0].p, (uint64_t *)ctx->b_slot_keys[1].p,
                               (uint32_t *)ctx->b_slot_idx[0].p, (uint32_t *)ctx->b_slot_idx[1].p, total_slots,
                               slot_end_bit));
+  mark(4);
   const uint64_t gth = std::min<uint64_t>(total_slots, cap) * 10;
   if (gth)
     k_gather<<<(unsigned)((gth + 255) / 256), 256, 0, st>>>((const uint32_t *)ctx->b_slot_idx[1].p, (const wc_surfel *)ctx->b_slots.p,
                                                            (const wc_surfel_id *)ctx->b_slot_ids.p, status, d_out, d_ids, cap);
+  mark(5);
   WC_HIP(ctx, hipMemcpyAsync(ctx->h_status, status, 8, hipMemcpyDeviceToHost, st));
   WC_HIP(ctx, hipGetLastError());
   return WC_OK;
@@ -583,4 +641,19 @@ extern "C" int wc_extract_surfels(wc_ctx *ctx, const wc_points *pts, double t_lo
                                   wc_surfel_id *d_ids, uint64_t cap, uint64_t *h_n_out) {
   WC_TRY(wc_extract_surfels_enqueue(ctx, pts, t_lo, t_hi, d_out, d_ids, cap));
   return wc_extract_surfels_finish(ctx, h_n_out);
+}
+
+extern "C" int wc_extract_profile(wc_ctx *ctx, int enable) {
+  if (!ctx) return WC_ERR_ARG;
+  if (enable && !ctx->ex_ev[0])
+    for (int i = 0; i < 8; ++i) WC_HIP(ctx, hipEventCreate(&ctx->ex_ev[i]));
+  ctx->ex_prof = enable != 0;
+  return WC_OK;
+}
+
+extern "C" int wc_extract_stage_ms(wc_ctx *ctx, float *h_ms5) {
+  if (!ctx || !h_ms5 || !ctx->ex_ev[0]) return WC_ERR_ARG;
+  WC_HIP(ctx, hipEventSynchronize(ctx->ex_ev[5]));
+  for (int i = 0; i < 5; ++i) WC_HIP(ctx, hipEventElapsedTime(&h_ms5[i], ctx->ex_ev[i], ctx->ex_ev[i + 1]));
+  return WC_OK;
 }

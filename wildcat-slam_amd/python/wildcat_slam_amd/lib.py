@@ -159,6 +159,14 @@ class Context:
         self._ck(self.lib.wc_extract_surfels_finish(self.h, C.byref(n)))
         return int(n.value)
 
+    def extract_profile(self, enable=True):
+        self._ck(self.lib.wc_extract_profile(self.h, C.c_int(1 if enable else 0)))
+
+    def extract_stage_ms(self):
+        ms = (C.c_float * 5)()
+        self._ck(self.lib.wc_extract_stage_ms(self.h, ms))
+        return dict(zip(("keygen", "point_sort", "roots", "slot_sort", "gather"), [float(v) for v in ms]))
+
     def extract_surfels(self, points, hint=True, cap=None):
         """host convenience: upload POINT array, extract, download -> (surfels, ids)"""
         n = len(points)
