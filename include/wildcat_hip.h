@@ -80,6 +80,41 @@ int wc_extract_stage_ms(wc_ctx *ctx, float *h_ms5);
 /* root-voxel index of every point: VoxelLoc (src/odometry/surfel_extraction.h:55-64); d_keys_xyz = 3 int32 per point */
 int wc_voxel_keys(wc_ctx *ctx, const wc_points *pts, int32_t *d_keys_xyz);
 
+/* surfel pose update --------------------------------------------------------------------------------------------- */
+/* Replaces UpdateSurfelPoses(const std::deque<ImuState>&, std::deque<Surfel::Ptr>&) (src/odometry/lidar_odometry.cc:160-170)
+ * + Surfel::UpdatePose (src/odometry/surfel.h:48-58).  d_in_body[i] == 0 marks a surfel still in the world frame
+ * (fresh from wc_extract_surfels); it is converted to the body frame and the flag set.  WC_ERR_RANGE mirrors the
+ * CHECK at lidar_odometry.cc:164. */
+int wc_update_surfel_poses(wc_ctx *ctx, const wc_imu_state *d_imu, uint64_t n_imu, wc_surfel *d_surf, wc_pose *d_pose,
+                           uint8_t *d_in_body, uint64_t n);
+
+/* window problem: factors + Levenberg-Marquardt ----------------------------------------------------------------- */
+/* Replaces the ceres::Problem construction of lidar_odometry.cc:541-545:
+ *   BuildSldWinLidarResiduals (cc:254-297) — d_pairs_sld index the sliding-window surfels (older, newer),
+ *   BuildFixWinLidarResiduals (cc:299-317) — d_pairs_fix: first = fixed-window surfel, second = sliding-window surfel,
+ *   BuildImuResiduals         (cc:319-363) — h_imu: the window's IMU states (host; a few thousand records),
+ * with SampleState timestamps h_sample_times[ns] (ascending), gravity of the last sample state and the
+ * SubsetParameterization gauge flag (cc:556-560).  Surfels must already carry poses (wc_update_surfel_poses).
+ * The packed per-correspondence records are built once here; the calls below reuse them. */
+int wc_window_build(wc_ctx *ctx, const wc_surfel *d_sld_surf, const wc_pose *d_sld_pose, const wc_pair *d_pairs_sld,
+                    uint64_t n_pairs_sld, const wc_surfel *d_fix_surf, const wc_pose *d_fix_pose, const wc_pair *d_pairs_fix,
+                    uint64_t n_pairs_fix, const wc_imu_state *h_imu, uint64_t n_imu, const double *h_sample_times, uint64_t ns,
+                    const double *h_grav, int fix_first_pos);
+/* counts[4] = {binary factors, unary factors, imu factors, assembly pieces} */
+int wc_window_counts(wc_ctx *ctx, uint64_t counts[4]);
+/* problem.Evaluate(apply_loss_function = true) (lidar_odometry.cc:62-65): cost = 1/2 sum rho; d_residuals (may be NULL)
+ * receives the loss-corrected residuals in the reference's block order: binary, unary, 12 per IMU factor.
+ * h_x = the 12*ns correction blocks (SampleState::data_cor, surfel.h:13-17). */
+int wc_window_evaluate(wc_ctx *ctx, const double *h_x, double *h_cost, double *d_residuals);
+/* one linearisation: dense row-major H = J^T J (12ns x 12ns) and g = J^T r, loss-corrected, gauge columns zeroed */
+int wc_window_linearize(wc_ctx *ctx, const double *h_x, double *d_H, double *d_g, double *h_cost);
+/* ceres::Solve with the reference's options (lidar_odometry.cc:551-561): trust-region LM, <= max_iterations.
+ * h_x_inout: corrections in / optimised corrections out; h_first_step (may be NULL) receives the first LM increment. */
+int wc_window_solve(wc_ctx *ctx, double *h_x_inout, wc_solve_summary *summary, double *h_first_step);
+/* multi-GPU: install a "sum this device buffer over all ranks" callback (RCCL all-reduce); called once per
+ * linearisation on the packed {H, g, cost} buffer and once per candidate-cost evaluation. */
+int wc_window_set_allreduce(wc_ctx *ctx, int (*fn)(void *user, double *d_buf, uint64_t count), void *user);
+
 #ifdef __cplusplus
 }
 #endif

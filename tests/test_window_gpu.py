@@ -1,0 +1,115 @@
+"""GPU parity of the window problem (factors, J^T J / J^T r reduction, LM) against the CPU oracle.
+Reference: cost_functor.h (all factors), lidar_odometry.cc:254-363 (problem construction), :551-561 (solve).
+Tolerance (north_star): pose increments within 1e-6 relative; H, g, cost far tighter (pure fp64 re-association)."""
+import numpy as np
+import pytest
+
+from wildcat_slam_amd import records as R
+from wildcat_slam_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _mode2_pairs(w, count, rng):
+    """hand-made correspondences whose two surfels fall into the same sample interval (Mode 2, cost_functor.h:98)"""
+    t, st = w["surf"]["t"], w["sample_times"]
+    blk = np.searchsorted(st, t, side="right") - 1
+    out = []
+    for b in np.unique(blk):
+        idx = np.nonzero(blk == b)[0]
+        if len(idx) >= 2:
+            for _ in range(3):
+                i, j = rng.choice(idx, 2, replace=False)
+                if t[i] != t[j]:
+                    out.append((i, j) if t[i] < t[j] else (j, i))
+        if len(out) >= count:
+            break
+    p = np.zeros(len(out), R.PAIR)
+    p["first"], p["second"] = [a for a, _ in out], [b for _, b in out]
+    return p
+
+
+def _setup(gpu, oracle, n_scans=3, patches=300, fixed=120, quirks=1, fix_first=True, with_imu=True, extra_mode2=True, seed=11):
+    w = synth.surfel_window(n_scans, patches, seed=seed, fixed_patches=fixed)
+    params = oracle.default_params()
+    params.reference_quirks = quirks
+    pairs = oracle.match(w["surf"], w["pose"], w["surf"], w["pose"], True, params)
+    if extra_mode2:
+        m2 = _mode2_pairs(w, 25, np.random.default_rng(seed))
+        pairs = np.concatenate([pairs, m2])
+    pf = oracle.match(w["surf"], w["pose"], w["fix_surf"], w["fix_pose"], False, params) if fixed else np.zeros(0, R.PAIR)
+    W = oracle.Window(w["sample_times"], w["grav"], fix_first, params)
+    W.add_binary(w["surf"], w["pose"], pairs)
+    if fixed:
+        W.add_unary(w["fix_surf"], w["fix_pose"], w["surf"], w["pose"], pf)
+    if with_imu:
+        W.add_imu(w["imu"])
+    gpu.set_params(params)
+    d_surf, d_pose = gpu.to_device(w["surf"]), gpu.to_device(w["pose"])
+    d_pairs = gpu.to_device(pairs)
+    d_fs = gpu.to_device(w["fix_surf"]) if fixed else None
+    d_fp = gpu.to_device(w["fix_pose"]) if fixed else None
+    d_pf = gpu.to_device(pf) if fixed else None
+    gpu.window_build(d_surf, d_pose, d_pairs, len(pairs), w["imu"] if with_imu else None, w["sample_times"], w["grav"], fix_first,
+                     d_fs, d_fp, d_pf, len(pf))
+    keep = (d_surf, d_pose, d_pairs, d_fs, d_fp, d_pf)
+    return w, W, keep
+
+
+def _rel(a, b):
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+@pytest.mark.parametrize("quirks", [1, 0])
+def test_evaluate_and_linearize_match_oracle(gpu, oracle, quirks):
+    w, W, keep = _setup(gpu, oracle, quirks=quirks)
+    c = W.counts()
+    assert c[0] > 0 and c[1] > 0 and c[2] > 0 and c[3] > 0 and c[4] > 0 and c[5] > 0  # every factor mode present
+    nb, nu, ni, _ = gpu.window_counts()
+    assert nb == c[0] + c[1] + c[2] and nu == c[3] and ni == c[4] + c[5]
+    rng = np.random.default_rng(0)
+    for x in (np.zeros(12 * W.ns), 1e-3 * rng.normal(size=12 * W.ns)):
+        cost_ref, res_ref = W.evaluate(x, want_residuals=True)
+        cost, res = gpu.window_evaluate(x, want_residuals=True)
+        assert abs(cost - cost_ref) <= 1e-11 * cost_ref
+        assert np.abs(res - res_ref).max() <= 1e-9 * np.abs(res_ref).max()
+        H_ref, g_ref, cl_ref = W.linearize(x)
+        H, g, cl = gpu.window_linearize(x)
+        assert abs(cl - cl_ref) <= 1e-11 * cl_ref
+        assert _rel(H, H_ref) <= 1e-10 and _rel(g, g_ref) <= 1e-10
+        assert np.array_equal(H, H.T)
+        if True:  # gauge: columns 3..5 of block 0 do not exist (SubsetParameterization, cc:556-560)
+            assert not H[3:6].any() and not g[3:6].any()
+
+
+@pytest.mark.parametrize("cfg", [dict(), dict(quirks=0), dict(fix_first=False), dict(with_imu=False, fix_first=True), dict(fixed=0)])
+def test_lm_solve_matches_oracle(gpu, oracle, cfg):
+    w, W, keep = _setup(gpu, oracle, **cfg)
+    x0 = np.zeros(12 * W.ns)
+    x_ref, s_ref, first_ref = W.solve(x0)
+    x, s, first = gpu.window_solve(x0)
+    assert s.termination == s_ref.termination and s.iterations == s_ref.iterations
+    assert s.successful_steps == s_ref.successful_steps
+    assert abs(s.initial_cost - s_ref.initial_cost) <= 1e-11 * s_ref.initial_cost
+    assert abs(s.final_cost - s_ref.final_cost) <= 1e-8 * s_ref.final_cost
+    # north_star: pose increments within 1e-6 relative
+    assert _rel(first, first_ref) <= 1e-6, _rel(first, first_ref)
+    assert _rel(x, x_ref) <= 1e-6, _rel(x, x_ref)
+    assert s_ref.final_cost < 0.7 * s_ref.initial_cost  # the solve really removed the injected pose error
+
+
+def test_window_errors(gpu, oracle):
+    from wildcat_slam_amd import lib
+
+    w = synth.surfel_window(2, 50, seed=3)
+    d_surf, d_pose = gpu.to_device(w["surf"]), gpu.to_device(w["pose"])
+    bad = np.zeros(1, R.PAIR)
+    bad["first"], bad["second"] = 5, 5  # not (older, newer): CHECK_LT at lidar_odometry.cc:256
+    with pytest.raises(lib.WildcatError) as e:
+        gpu.window_build(d_surf, d_pose, gpu.to_device(bad), 1, None, w["sample_times"], w["grav"], True)
+    assert e.value.code == 3
+    ok = np.zeros(1, R.PAIR)
+    ok["first"], ok["second"] = 0, len(w["surf"]) - 1
+    with pytest.raises(lib.WildcatError) as e:  # sample states do not bracket the surfels: CHECKs at cc:259-265
+        gpu.window_build(d_surf, d_pose, gpu.to_device(ok), 1, None, w["sample_times"][:3], w["grav"], True)
+    assert e.value.code == 2

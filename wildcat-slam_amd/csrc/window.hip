@@ -1,0 +1,1269 @@
+// window.hip — the sliding-window optimisation problem on gfx950: residual + Jacobian assembly, the block
+// J^T J / J^T r reduction, cost evaluation and the Levenberg-Marquardt loop.
+//
+// Replaces, for the hot path, the reference's use of Ceres:
+//   BuildSldWinLidarResiduals / SurfelMatchBinaryFactor<0/1/2>   lidar_odometry.cc:254-297, cost_functor.h:100-241
+//   BuildFixWinLidarResiduals / SurfelMatchUnaryFactor           lidar_odometry.cc:299-317, cost_functor.h:16-69
+//   BuildImuResiduals / ImuFactor<0/1>                           lidar_odometry.cc:319-363, cost_functor.h:264-472
+//   problem.Evaluate (residual histograms)                       lidar_odometry.cc:56-94
+//   ceres::Solve, SPARSE_NORMAL_CHOLESKY, <= 100 iterations, SubsetParameterization gauge   lidar_odometry.cc:551-561
+// Factor formulas: SURVEY.md Appendix B (incl. quirks Q1, Q3 behind wc_params.reference_quirks).
+//
+// Data layout in HBM
+//   * one packed record per correspondence, struct-of-arrays, SORTED by the pair of sample intervals it touches:
+//       binary (136 B): n[3] w a1[3] a2[3] dp[3] f1 f2 + key      unary (96 B): n[3] w a2[3] d[3] f2 + key
+//     (a_k = R_k c_k, dp = p1 - p2, d = c1_world - p2: everything that does not depend on the unknowns is folded in
+//     once per solve; per LM iteration a record is read exactly once per pass.)
+//   * records with one key form a segment; segments are cut into pieces of <= 256 records; one workgroup per piece
+//     evaluates r and the 1 x 24 (1 x 12) Jacobian row of every record into LDS and reduces the piece's Gram matrix
+//     [J r]^T [J r] with lanes mapped to OUTPUT entries (no atomics, fixed summation order => bitwise reproducible,
+//     which keeps replicated LM state in lock-step across ranks after the all-reduce).
+//   * a gather kernel sums the piece partials into the dense normal equations H (12 ns x 12 ns) and g through a CSR
+//     source list built on the host once per solve.
+//   * LM: Jacobi scaling, damping, blocked Cholesky (own kernels, fp64), back substitution, step and candidate-cost
+//     evaluation all stay on the device; only a 6-double mailbox crosses PCIe per iteration.
+// The assembly is HBM/LDS bound (136 B in, ~0.9 kflop per record); no MFMA (rank-1 fp64 6-wide blocks).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include <rocprim/rocprim.hpp>
+
+#include "ctx.h"
+#include "dmath.h"
+
+using namespace wc;
+
+namespace {
+
+constexpr int kPiece = 256;   // records per piece (= threads per assembly workgroup)
+constexpr int kNB = 32;       // Cholesky block size
+
+// ------------------------------------------------------------------------------------------------------------------
+struct ImuRec {
+  wc_imu_state i1, i2, i3;
+  int sp1, mode;  // mode 0: blocks sp1, sp1+1, sp1+2; mode 1: sp1, sp1+1
+};
+
+struct Piece {
+  uint32_t begin, count;  // record range (imu: factor range)
+  uint32_t key;           // binary: sp1l | sp2l << 16, unary: sp2l, imu: sp1
+  uint32_t part_off;      // offset of this piece's partial in the partial buffer (doubles)
+};
+
+struct Src {  // one contribution to a 12x12 block pair (I,J) of H
+  uint32_t part_off;
+  uint8_t p, q, w, T;  // local block indices, local block width (6 or 12), packed-triangle dimension
+};
+struct GSrc {
+  uint32_t part_off;
+  uint8_t p, w, T, pad;
+};
+
+struct WinParams {
+  double sigma0_sq, cauchy_b, w_gyr, w_acc, w_bg, w_ba, dt, grav[3];
+  int quirks, ns, fix_first;
+};
+
+}  // namespace
+
+struct wc_window_state {
+  WinParams wp;
+  int ns = 0, n = 0, np = 0, ld = 0;
+  uint32_t nb = 0, nu = 0, ni = 0;
+  uint32_t npiece_b = 0, npiece_u = 0, npiece_i = 0, npart_doubles = 0;
+  uint32_t npairs = 0;
+  std::vector<double> times;
+  // device buffers
+  wc_buf times_d, brec, bkey, borig, urec, ukey, uorig, irec, pieces, partial, src, src_begin, gsrc, gsrc_begin;
+  wc_buf lin, Linv;  // lin = [H (n*n) | g (np) | cost, spare]: ONE contiguous buffer, the unit of the multi-GPU all-reduce
+  int (*allreduce)(void *, double *, uint64_t) = nullptr;
+  void *allreduce_user = nullptr;
+  wc_buf x, xc, H_unused, g_unused, scale, diag, A, y, mail, cost_part, keys_tmp[2], vals_tmp[2], heads, status;
+  bool built = false;
+};
+
+namespace {
+
+// ---- device-side factor arithmetic ---------------------------------------------------------------------------------
+__device__ __forceinline__ V3 ld3(const double *p) { return mk3(p[0], p[1], p[2]); }
+
+// one surfel side: correction interpolated between two sample blocks (cost_functor.h:124-136), rotated lever arm
+// and, if wanted, the 1x6 Jacobian w.r.t. the interpolated (rot_cor, pos_cor)  (cost_functor.h:147-150, :162-165)
+__device__ __forceinline__ void surfel_side(const double *xl, const double *xr, double f, V3 a, V3 wn, double sign,
+                                            V3 &rotated_plus_t, double j[6], bool want_jac) {
+  const V3 r = (1 - f) * ld3(xl) + f * ld3(xr);
+  const V3 t = (1 - f) * ld3(xl + 3) + f * ld3(xr + 3);
+  const Q4 E = so3_exp(r);
+  rotated_plus_t = qrot(E, a) + t;
+  if (want_jac) {
+    const M3 T = (qmat(E) * hat(a)) * so3_Jr(r);
+    const V3 row = vecmat(wn, T);
+    j[0] = sign * row.x, j[1] = sign * row.y, j[2] = sign * row.z;
+    j[3] = -sign * wn.x, j[4] = -sign * wn.y, j[5] = -sign * wn.z;
+  }
+}
+
+// ceres::CauchyLoss(a): rho(s) = b log(1 + s/b), b = a^2; returns rho, sets sqrt(rho') (Corrector with rho'' < 0)
+__device__ __forceinline__ double cauchy(double b, double s, double &sqrt_rho1) {
+  const double sum = 1 + s * (1 / b);
+  const double inv = 1 / sum;
+  sqrt_rho1 = sqrt(fmax(DBL_MIN, inv));
+  return b * log(sum);
+}
+
+// Evaluate one binary record -> loss-corrected residual, cost contribution, and (optionally) the padded 24-wide
+// Jacobian row in the reference's parameter-block layout including the overwrite quirk (Q1).
+__device__ __forceinline__ void eval_binary(const WinParams &wp, const double *rec, uint32_t nb, uint32_t k, uint32_t key,
+                                            const double *x, double &r_out, double &cost, double *v /*24 or null*/) {
+  const int sp1l = (int)(key & 0xFFFF), sp2l = (int)(key >> 16);
+  const V3 n = mk3(rec[0 * (size_t)nb + k], rec[1 * (size_t)nb + k], rec[2 * (size_t)nb + k]);
+  const double w = rec[3 * (size_t)nb + k];
+  const V3 a1 = mk3(rec[4 * (size_t)nb + k], rec[5 * (size_t)nb + k], rec[6 * (size_t)nb + k]);
+  const V3 a2 = mk3(rec[7 * (size_t)nb + k], rec[8 * (size_t)nb + k], rec[9 * (size_t)nb + k]);
+  const V3 dp = mk3(rec[10 * (size_t)nb + k], rec[11 * (size_t)nb + k], rec[12 * (size_t)nb + k]);
+  const double f1 = rec[13 * (size_t)nb + k], f2 = rec[14 * (size_t)nb + k];
+  const V3 wn = w * n;
+  V3 s1, s2;
+  double j1[6], j2[6];
+  surfel_side(x + 12 * sp1l, x + 12 * (sp1l + 1), f1, a1, wn, -1.0, s1, j1, v != nullptr);
+  surfel_side(x + 12 * sp2l, x + 12 * (sp2l + 1), f2, a2, wn, +1.0, s2, j2, v != nullptr);
+  double r = w * dot(n, (s1 + dp) - s2);  // cost_functor.h:140
+  double sc;
+  cost = 0.5 * cauchy(wp.cauchy_b, r * r, sc);
+  r_out = r * sc;
+  if (!v) return;
+  for (int i = 0; i < 24; ++i) v[i] = 0.0;
+  const int mode = (sp2l > sp1l + 1) ? 0 : (sp2l == sp1l + 1 ? 1 : 2);
+  // local slots of (sp1l, sp1r, sp2l, sp2r) among the distinct blocks (DispatchPtr, cost_functor.h:216-229)
+  const int s2l = mode == 0 ? 2 : (mode == 1 ? 1 : 0), s2r = s2l + 1;
+  if (wp.quirks) {  // four plain assignments, later write wins (Q1)
+    for (int c = 0; c < 6; ++c) v[0 * 6 + c] = j1[c] * (1 - f1);
+    for (int c = 0; c < 6; ++c) v[1 * 6 + c] = j1[c] * f1;
+    for (int c = 0; c < 6; ++c) v[s2l * 6 + c] = j2[c] * (1 - f2);
+    for (int c = 0; c < 6; ++c) v[s2r * 6 + c] = j2[c] * f2;
+  } else {
+    for (int c = 0; c < 6; ++c) v[0 * 6 + c] += j1[c] * (1 - f1);
+    for (int c = 0; c < 6; ++c) v[1 * 6 + c] += j1[c] * f1;
+    for (int c = 0; c < 6; ++c) v[s2l * 6 + c] += j2[c] * (1 - f2);
+    for (int c = 0; c < 6; ++c) v[s2r * 6 + c] += j2[c] * f2;
+  }
+  for (int i = 0; i < 24; ++i) v[i] *= sc;
+}
+
+__device__ __forceinline__ void eval_unary(const WinParams &wp, const double *rec, uint32_t nu, uint32_t k, uint32_t key,
+                                           const double *x, double &r_out, double &cost, double *v /*12 or null*/) {
+  const int sp2l = (int)key;
+  const V3 n = mk3(rec[0 * (size_t)nu + k], rec[1 * (size_t)nu + k], rec[2 * (size_t)nu + k]);
+  const double w = rec[3 * (size_t)nu + k];
+  const V3 a2 = mk3(rec[4 * (size_t)nu + k], rec[5 * (size_t)nu + k], rec[6 * (size_t)nu + k]);
+  const V3 d = mk3(rec[7 * (size_t)nu + k], rec[8 * (size_t)nu + k], rec[9 * (size_t)nu + k]);
+  const double f2 = rec[10 * (size_t)nu + k];
+  const V3 wn = w * n;
+  V3 s2;
+  double j2[6];
+  surfel_side(x + 12 * sp2l, x + 12 * (sp2l + 1), f2, a2, wn, +1.0, s2, j2, v != nullptr);
+  double r = w * dot(n, d - s2);  // cost_functor.h:39
+  double sc;
+  cost = 0.5 * cauchy(wp.cauchy_b, r * r, sc);
+  r_out = r * sc;
+  if (!v) return;
+  for (int c = 0; c < 6; ++c) {
+    v[c] = j2[c] * (1 - f2) * sc;
+    v[6 + c] = j2[c] * f2 * sc;
+  }
+}
+
+// interpolated state at an IMU timestamp (ComputeStateCorr, cost_functor.h:358-400)
+struct StateCorr {
+  V3 r, t, bg, ba;
+  int bl;  // local left block (0 or 1); right = bl + 1
+  double f;
+};
+__device__ __forceinline__ StateCorr state_corr(const double *x, const double *times, int sp1, int mode, double t) {
+  StateCorr c;
+  const bool first = (mode == 1) ? true : (t >= times[sp1] && t < times[sp1 + 1]);
+  c.bl = first ? 0 : 1;
+  const int gl = sp1 + c.bl;
+  const double *l = x + 12 * gl, *r = x + 12 * (gl + 1);
+  c.f = (t - times[gl]) / (times[gl + 1] - times[gl]);
+  c.r = (1 - c.f) * ld3(l) + c.f * ld3(r);
+  c.t = (1 - c.f) * ld3(l + 3) + c.f * ld3(r + 3);
+  c.bg = (1 - c.f) * ld3(l + 6) + c.f * ld3(r + 6);
+  c.ba = (1 - c.f) * ld3(l + 9) + c.f * ld3(r + 9);
+  return c;
+}
+__device__ __forceinline__ M3 Ffun(Q4 L, Q4 R, V3 r) {  // cost_functor.h:446-448
+  const V3 lg = so3_log(qmul(qmul(L, so3_exp(r)), R));
+  return (so3_Jr_inv(lg) * qmat(qconj(R))) * so3_Jr(r);
+}
+
+// IMU factor: 12 residuals; if rows != null also the 12 x 36 Jacobian, written as rows[row * stride + col]
+// (cost_functor.h:272-355)
+__device__ void eval_imu(const WinParams &wp, const ImuRec &f, const double *x, const double *times, double res[12],
+                         double *rows, int stride) {
+  const double dt = wp.dt;
+  const StateCorr c1 = state_corr(x, times, f.sp1, f.mode, f.i1.t);
+  const StateCorr c2 = state_corr(x, times, f.sp1, f.mode, f.i2.t);
+  const StateCorr c3 = state_corr(x, times, f.sp1, f.mode, f.i3.t);
+  const Q4 R1{f.i1.quat[0], f.i1.quat[1], f.i1.quat[2], f.i1.quat[3]};
+  const Q4 R2{f.i2.quat[0], f.i2.quat[1], f.i2.quat[2], f.i2.quat[3]};
+  const V3 p1 = ld3(f.i1.pos), p2 = ld3(f.i2.pos), p3 = ld3(f.i3.pos);
+  const Q4 E1R1 = qmul(so3_exp(c1.r), R1), E2R2 = qmul(so3_exp(c2.r), R2);
+  const V3 gyr_est = so3_log(qmul(qconj(E1R1), E2R2)) / dt;
+  const V3 acc_est = (((c3.t + p3) + (c1.t + p1)) - 2 * (c2.t + p2)) / (dt * dt);
+  const V3 grav = mk3(wp.grav[0], wp.grav[1], wp.grav[2]);
+  const V3 r0 = wp.w_gyr * (((ld3(f.i1.gyr) + ld3(f.i2.gyr)) / 2 - gyr_est) - c1.bg);
+  const V3 r1 = wp.w_acc * ((qrot(E1R1, ld3(f.i1.acc) - c1.ba) - acc_est) + grav);
+  const V3 r2 = wp.w_bg * (c1.bg - c2.bg);
+  const V3 r3 = wp.w_ba * (c1.ba - c2.ba);
+  res[0] = r0.x, res[1] = r0.y, res[2] = r0.z, res[3] = r1.x, res[4] = r1.y, res[5] = r1.z;
+  res[6] = r2.x, res[7] = r2.y, res[8] = r2.z, res[9] = r3.x, res[10] = r3.y, res[11] = r3.z;
+  if (!rows) return;
+  for (int r = 0; r < 12; ++r)
+    for (int c = 0; c < 36; ++c) rows[r * stride + c] = 0.0;
+  // tau Jacobians (cost_functor.h:301-321) scattered with (1 - f), f onto the bracketing blocks (:402-444)
+  auto add33 = [&](const StateCorr &c, int r0_, int c0_, const M3 &m, double s) {
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) {
+        const double val = s * m.m[i][j];
+        rows[(r0_ + i) * stride + c.bl * 12 + c0_ + j] += val * (1 - c.f);
+        rows[(r0_ + i) * stride + (c.bl + 1) * 12 + c0_ + j] += val * c.f;
+      }
+  };
+  const M3 I = m3_identity();
+  add33(c1, 0, 0, Ffun(qconj(R1), E2R2, c1.r), wp.w_gyr * (1 / dt));
+  add33(c1, 0, 6, I, -wp.w_gyr);
+  add33(c1, 3, 0, (qmat(so3_exp(c1.r)) * hat(qrot(R1, ld3(f.i1.acc) - c1.ba))) * so3_Jr(c1.r), -wp.w_acc);
+  add33(c1, 3, 3, I, -wp.w_acc * (1 / dt / dt));
+  add33(c1, 3, 9, qmat(E1R1), -wp.w_acc);
+  add33(c1, 6, 6, I, wp.w_bg);
+  add33(c1, 9, 9, I, wp.w_ba);
+  add33(c2, 0, 0, Ffun(qconj(E1R1), R2, c2.r), -wp.w_gyr * (1 / dt));
+  if (wp.quirks) add33(c2, 0, 6, I, -wp.w_gyr);  // Q3 (cost_functor.h:314)
+  add33(c2, 3, 3, I, wp.w_acc * (2 / dt / dt));
+  add33(c2, 6, 6, I, -wp.w_bg);
+  add33(c2, 9, 9, I, -wp.w_ba);
+  add33(c3, 3, 3, I, -wp.w_acc * (1 / dt / dt));
+}
+
+__device__ __forceinline__ uint32_t tri_index(uint32_t i, uint32_t j, uint32_t T) {  // i <= j, row-major upper
+  return i * T - (i * (i - 1)) / 2 + (j - i);
+}
+
+// ---- record construction (once per solve) ---------------------------------------------------------------------------
+__device__ __forceinline__ int upper_bound_times(const double *times, int ns, double t) {
+  int lo = 0, hi = ns;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (t < times[mid])
+      hi = mid;
+    else
+      lo = mid + 1;
+  }
+  return lo;
+}
+
+// sort keys of the correspondences: (sp1l, sp2l) from std::upper_bound on the sample timestamps (cc:258-268,:303-307)
+__global__ void __launch_bounds__(256) k_pair_keys(const wc_surfel *s1, const wc_surfel *s2, const wc_pair *pairs, uint32_t n,
+                                                  const double *times, int ns, int unary, uint32_t *keys, uint32_t *vals,
+                                                  uint32_t *status) {
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const double t1 = s1[pairs[k].first].t, t2 = s2[pairs[k].second].t;
+  if (!(t1 < t2)) atomicOr(&status[1], 2u);  // CHECK_LT (cc:256,:301)
+  const int i2 = upper_bound_times(times, ns, t2);
+  int i1 = 1;
+  if (!unary) i1 = upper_bound_times(times, ns, t1);
+  if (i2 == 0 || i2 == ns || i1 == 0 || i1 == ns) {
+    atomicOr(&status[1], 1u);
+    keys[k] = 0;
+  } else {
+    keys[k] = unary ? (uint32_t)(i2 - 1) : ((uint32_t)(i1 - 1) * (uint32_t)ns + (uint32_t)(i2 - 1));
+  }
+  vals[k] = k;
+}
+
+__device__ __forceinline__ void surfel_world(const wc_surfel &s, const wc_pose &p, V3 &a, V3 &pos, M3 &cov_w) {
+  const Q4 q{p.quat[0], p.quat[1], p.quat[2], p.quat[3]};
+  a = qrot(q, ld3(s.center));
+  pos = ld3(p.pos);
+  M3 C;
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) C.m[i][j] = s.cov[3 * i + j];
+  const M3 R = qmat(q);
+  cov_w = (R * C) * transpose(R);  // GetCovarianceInWorld (surfel.h:89-91)
+}
+
+// packed records in sorted order; ctor arithmetic of both surfel factors (cost_functor.h:21-25, :109-113)
+__global__ void __launch_bounds__(256) k_build_records(const wc_surfel *s1, const wc_pose *p1, const wc_surfel *s2,
+                                                      const wc_pose *p2, const wc_pair *pairs, const uint32_t *sorted_idx,
+                                                      const uint32_t *sorted_keys, uint32_t n, const double *times, int ns,
+                                                      int unary, double sigma0_sq, double *rec, uint32_t *key_out,
+                                                      uint32_t *orig_out) {
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  const uint32_t o = sorted_idx[k];
+  const wc_surfel A = s1[pairs[o].first], Bs = s2[pairs[o].second];
+  V3 a1, pos1, a2, pos2;
+  M3 c1, c2;
+  surfel_world(A, p1[pairs[o].first], a1, pos1, c1);
+  surfel_world(Bs, p2[pairs[o].second], a2, pos2, c2);
+  double ev[3];
+  M3 V;
+  eig3_sym(c1 + c2, ev, V);
+  const double w = 1 / sqrt(sigma0_sq + ev[0]);
+  const uint32_t key = sorted_keys[k];
+  const size_t N = n;
+  rec[0 * N + k] = V.m[0][0], rec[1 * N + k] = V.m[1][0], rec[2 * N + k] = V.m[2][0];
+  rec[3 * N + k] = w;
+  if (!unary) {
+    const int sp1l = (int)(key / (uint32_t)ns), sp2l = (int)(key % (uint32_t)ns);
+    rec[4 * N + k] = a1.x, rec[5 * N + k] = a1.y, rec[6 * N + k] = a1.z;
+    rec[7 * N + k] = a2.x, rec[8 * N + k] = a2.y, rec[9 * N + k] = a2.z;
+    const V3 dp = pos1 - pos2;
+    rec[10 * N + k] = dp.x, rec[11 * N + k] = dp.y, rec[12 * N + k] = dp.z;
+    rec[13 * N + k] = (A.t - times[sp1l]) / (times[sp1l + 1] - times[sp1l]);
+    rec[14 * N + k] = (Bs.t - times[sp2l]) / (times[sp2l + 1] - times[sp2l]);
+    key_out[k] = (uint32_t)sp1l | ((uint32_t)sp2l << 16);
+  } else {
+    const int sp2l = (int)key;
+    rec[4 * N + k] = a2.x, rec[5 * N + k] = a2.y, rec[6 * N + k] = a2.z;
+    const V3 d = (a1 + pos1) - pos2;  // c1_world - p2
+    rec[7 * N + k] = d.x, rec[8 * N + k] = d.y, rec[9 * N + k] = d.z;
+    rec[10 * N + k] = (Bs.t - times[sp2l]) / (times[sp2l + 1] - times[sp2l]);
+    key_out[k] = (uint32_t)sp2l;
+  }
+  orig_out[k] = o;
+}
+
+// segment heads of a sorted key array (unordered append; the host sorts the few thousand entries)
+__global__ void __launch_bounds__(256) k_seg_heads(const uint32_t *keys, uint32_t n, uint32_t *heads, uint32_t *status) {
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool head = k < n && (k == 0 || keys[k] != keys[k - 1]);
+  const unsigned long long mask = __ballot(head);
+  if (!mask) return;
+  const int lane = threadIdx.x & 63, leader = __ffsll((long long)mask) - 1;
+  uint32_t base = 0;
+  if (lane == leader) base = atomicAdd(&status[2], (uint32_t)__popcll(mask));
+  base = __shfl(base, leader);
+  if (head) {
+    const uint32_t o = base + __popcll(mask & ((1ull << lane) - 1));
+    heads[2 * o] = k;
+    heads[2 * o + 1] = keys[k];
+  }
+}
+
+// ---- assembly: one workgroup per piece ------------------------------------------------------------------------------
+// Phase A: thread k evaluates record k of the piece (residual + W-wide Jacobian row) into LDS.
+// Phase B: threads own OUTPUT entries of the packed upper triangle of [J r]^T [J r] ((W+1)(W+2)/2 values; the corner
+//          (W,W) carries the piece's cost instead of sum r^2) and loop over the records: fixed order, no atomics.
+template <int W, bool UNARY>
+__global__ void __launch_bounds__(kPiece) k_lin_surfel(WinParams wp, const Piece *pieces, const double *rec, const uint32_t *keys,
+                                                      uint32_t nrec, const double *x, double *partial) {
+  constexpr int T = W + 1;
+  __shared__ double sV[kPiece * T];
+  __shared__ double sC[kPiece];
+  const Piece pc = pieces[blockIdx.x];
+  const int tid = threadIdx.x;
+  if (tid < (int)pc.count) {
+    double v[W], r, c;
+    const uint32_t k = pc.begin + tid;
+    if (UNARY)
+      eval_unary(wp, rec, nrec, k, keys[k], x, r, c, v);
+    else
+      eval_binary(wp, rec, nrec, k, keys[k], x, r, c, v);
+#pragma unroll
+    for (int i = 0; i < W; ++i) sV[tid * T + i] = v[i];
+    sV[tid * T + W] = r;
+    sC[tid] = c;
+  }
+  __syncthreads();
+  constexpr int NOUT = T * (T + 1) / 2;
+  for (int e = tid; e < NOUT; e += kPiece) {
+    int i = 0, rem = e;
+    while (rem >= T - i) {
+      rem -= T - i;
+      ++i;
+    }
+    const int j = i + rem;
+    double acc = 0.0;
+    if (i == W) {
+      for (uint32_t k = 0; k < pc.count; ++k) acc += sC[k];
+    } else {
+      for (uint32_t k = 0; k < pc.count; ++k) acc += sV[k * T + i] * sV[k * T + j];
+    }
+    partial[pc.part_off + e] = acc;
+  }
+}
+
+// IMU factors of one sample interval: <= kImuMax factors x 12 residual rows, 36-wide Jacobian
+constexpr int kImuMax = 16;
+__global__ void __launch_bounds__(256) k_lin_imu(WinParams wp, const Piece *pieces, const ImuRec *recs, const double *x,
+                                                const double *times, double *partial) {
+  constexpr int T = 37;
+  __shared__ double sV[kImuMax * 12 * T];
+  __shared__ double sC[kImuMax];
+  const Piece pc = pieces[blockIdx.x];
+  const int tid = threadIdx.x;
+  if (tid < (int)pc.count) {
+    double res[12];
+    eval_imu(wp, recs[pc.begin + tid], x, times, res, &sV[tid * 12 * T], T);
+    double c = 0;
+    for (int r = 0; r < 12; ++r) {
+      sV[(tid * 12 + r) * T + 36] = res[r];
+      c += res[r] * res[r];
+    }
+    sC[tid] = 0.5 * c;  // TrivialLoss
+  }
+  __syncthreads();
+  constexpr int NOUT = T * (T + 1) / 2;
+  const int nrows = (int)pc.count * 12;
+  for (int e = tid; e < NOUT; e += 256) {
+    int i = 0, rem = e;
+    while (rem >= T - i) {
+      rem -= T - i;
+      ++i;
+    }
+    const int j = i + rem;
+    double acc = 0.0;
+    if (i == 36) {
+      for (uint32_t k = 0; k < pc.count; ++k) acc += sC[k];
+    } else {
+      for (int k = 0; k < nrows; ++k) acc += sV[k * T + i] * sV[k * T + j];
+    }
+    partial[pc.part_off + e] = acc;
+  }
+}
+
+// gather the piece partials into the dense normal equations: one workgroup per 12x12 block pair (I <= J)
+__global__ void __launch_bounds__(144) k_gather_H(const Src *src, const uint32_t *src_begin, const double *partial, int ns,
+                                                 int fix_first, double *H) {
+  const int pid = blockIdx.x;
+  // invert pid = I*ns - I(I-1)/2 + (J-I)
+  int I = 0, rem = pid;
+  while (rem >= ns - I) {
+    rem -= ns - I;
+    ++I;
+  }
+  const int J = I + rem;
+  const int u = threadIdx.x / 12, v = threadIdx.x % 12;
+  double acc = 0.0;
+  const uint32_t b = src_begin[pid], e = src_begin[pid + 1];
+  for (uint32_t s = b; s < e; ++s) {
+    const Src sr = src[s];
+    if (u < sr.w && v < sr.w) {
+      uint32_t r = sr.p * sr.w + u, c = sr.q * sr.w + v;
+      if (r > c) {
+        const uint32_t t = r;
+        r = c, c = t;
+      }
+      acc += partial[sr.part_off + tri_index(r, c, sr.T)];
+    }
+  }
+  const int n = 12 * ns;
+  const int gi = I * 12 + u, gj = J * 12 + v;
+  if (fix_first && ((gi >= 3 && gi < 6) || (gj >= 3 && gj < 6))) acc = 0.0;  // SubsetParameterization(12,{3,4,5})
+  H[(size_t)gi * n + gj] = acc;
+  H[(size_t)gj * n + gi] = acc;
+}
+
+__global__ void __launch_bounds__(64) k_gather_g(const GSrc *gsrc, const uint32_t *gsrc_begin, const double *partial, int fix_first,
+                                                double *g) {
+  const int I = blockIdx.x, u = threadIdx.x;
+  if (u >= 12) return;
+  double acc = 0.0;
+  for (uint32_t s = gsrc_begin[I]; s < gsrc_begin[I + 1]; ++s) {
+    const GSrc sr = gsrc[s];
+    if (u < sr.w) acc += partial[sr.part_off + tri_index(sr.p * sr.w + u, sr.T - 1, sr.T)];
+  }
+  const int gi = I * 12 + u;
+  if (fix_first && gi >= 3 && gi < 6) acc = 0.0;
+  g[gi] = acc;
+}
+
+// deterministic sum of the cost slots of all partials (+ max |g| over the active columns) -> mailbox
+__global__ void __launch_bounds__(1024) k_cost_sum(const Piece *pieces, uint32_t npieces, uint32_t nb_pieces, uint32_t nu_pieces,
+                                                  const double *partial, const double *g, int n, double *mail, int slot) {
+  __shared__ double s[1024];
+  const int tid = threadIdx.x;
+  double acc = 0.0;
+  for (uint32_t p = tid; p < npieces; p += 1024) {
+    const uint32_t T = p < nb_pieces ? 25 : (p < nb_pieces + nu_pieces ? 13 : 37);
+    acc += partial[pieces[p].part_off + T * (T + 1) / 2 - 1];
+  }
+  s[tid] = acc;
+  __syncthreads();
+  for (int st = 512; st > 0; st >>= 1) {
+    if (tid < st) s[tid] += s[tid + st];
+    __syncthreads();
+  }
+  if (tid == 0) mail[slot] = s[0];
+  __syncthreads();
+  if (g) {
+    double mx = 0.0;
+    for (int i = tid; i < n; i += 1024) mx = fmax(mx, fabs(g[i]));
+    s[tid] = mx;
+    __syncthreads();
+    for (int st = 512; st > 0; st >>= 1) {
+      if (tid < st) s[tid] = fmax(s[tid], s[tid + st]);
+      __syncthreads();
+    }
+    if (tid == 0) mail[slot + 1] = s[0];
+  }
+}
+
+// ---- cost-only evaluation (candidate step; problem.Evaluate) ----------------------------------------------------------
+template <bool UNARY>
+__global__ void __launch_bounds__(256) k_eval_surfel(WinParams wp, const double *rec, const uint32_t *keys, const uint32_t *orig,
+                                                    uint32_t n, const double *x, double *residuals, double *block_cost) {
+  __shared__ double s[256];
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  double c = 0.0;
+  if (k < n) {
+    double r;
+    if (UNARY)
+      eval_unary(wp, rec, n, k, keys[k], x, r, c, nullptr);
+    else
+      eval_binary(wp, rec, n, k, keys[k], x, r, c, nullptr);
+    if (residuals) residuals[orig[k]] = r;
+  }
+  s[threadIdx.x] = c;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if ((int)threadIdx.x < st) s[threadIdx.x] += s[threadIdx.x + st];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) block_cost[blockIdx.x] = s[0];
+}
+
+__global__ void __launch_bounds__(256) k_eval_imu(WinParams wp, const ImuRec *recs, uint32_t n, const double *x, const double *times,
+                                                 double *residuals, double *block_cost) {
+  __shared__ double s[256];
+  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  double c = 0.0;
+  if (k < n) {
+    double res[12];
+    eval_imu(wp, recs[k], x, times, res, nullptr, 0);
+    for (int r = 0; r < 12; ++r) {
+      c += res[r] * res[r];
+      if (residuals) residuals[(size_t)k * 12 + r] = res[r];
+    }
+    c *= 0.5;
+  }
+  s[threadIdx.x] = c;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if ((int)threadIdx.x < st) s[threadIdx.x] += s[threadIdx.x + st];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) block_cost[blockIdx.x] = s[0];
+}
+
+__global__ void __launch_bounds__(1024) k_sum_blocks(const double *v, uint32_t n, double *mail, int slot) {
+  __shared__ double s[1024];
+  const int tid = threadIdx.x;
+  double acc = 0.0;
+  for (uint32_t i = tid; i < n; i += 1024) acc += v[i];
+  s[tid] = acc;
+  __syncthreads();
+  for (int st = 512; st > 0; st >>= 1) {
+    if (tid < st) s[tid] += s[tid + st];
+    __syncthreads();
+  }
+  if (tid == 0) mail[slot] = s[0];
+}
+
+// ---- LM linear algebra on the device -------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_scale_init(const double *H, int n, double *scale) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) scale[i] = 1.0 / (1.0 + sqrt(H[(size_t)i * n + i]));  // ceres jacobi_scaling: 1 / (1 + ||col||)
+}
+
+// A (lower, row-major, ld) = S H S + diag(clamp(diag(S H S), 1e-6, 1e32) / radius); row n = (S g)^T; padding = identity
+__global__ void __launch_bounds__(256) k_damp(const double *H, const double *g, const double *scale, int n, int np, int ld,
+                                             double radius, double *A, double *diag) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = blockIdx.y;
+  if (j >= np || j > i) return;
+  double v;
+  if (i < n) {
+    v = H[(size_t)i * n + j] * scale[i] * scale[j];
+    if (i == j) {
+      const double d = fmin(fmax(v, 1e-6), 1e32);  // LM min/max diagonal
+      diag[i] = d / radius;
+      v += d / radius;
+    }
+  } else if (i == n) {
+    // augmented row: z = L^-1 (S g) falls out of the factorisation; the corner only has to keep the pivot positive
+    v = (j < n) ? g[j] * scale[j] : 1e300;
+  } else {
+    v = (i == j) ? 1.0 : 0.0;
+  }
+  A[(size_t)i * ld + j] = v;
+}
+
+// Panel step k of the blocked right-looking Cholesky: every workgroup factors the diagonal block (redundantly, in LDS),
+// inverts it, and turns its own row block A_ik into L_ik = A_ik L_kk^-T.
+__global__ void __launch_bounds__(64) k_chol_panel(double *A, int ld, int k, int *fail, double *Linv) {
+  __shared__ double sL[kNB][kNB + 1];
+  __shared__ double sInv[kNB][kNB + 1];
+  __shared__ double sA[kNB][kNB + 1];
+  const int lane = threadIdx.x;
+  const int ib = k + blockIdx.x;  // row block handled by this workgroup
+  double *Akk = A + (size_t)k * kNB * ld + (size_t)k * kNB;
+  for (int e = lane; e < kNB * kNB; e += 64) sL[e / kNB][e % kNB] = Akk[(size_t)(e / kNB) * ld + (e % kNB)];
+  __syncthreads();
+  // right-looking factorisation of the 32x32 block; lane r owns row r
+  for (int j = 0; j < kNB; ++j) {
+    const double ajj = sL[j][j];
+    if (!(ajj > 0.0)) {
+      if (lane == 0 && blockIdx.x == 0) atomicOr(fail, 1);
+      return;
+    }
+    const double inv = 1.0 / sqrt(ajj);
+    __syncthreads();
+    if (lane < kNB && lane >= j) sL[lane][j] = sL[lane][j] * inv;
+    __syncthreads();
+    if (lane < kNB && lane > j) {
+      const double lij = sL[lane][j];
+      for (int c = j + 1; c <= lane; ++c) sL[lane][c] -= lij * sL[c][j];
+    }
+    __syncthreads();
+  }
+  // inverse of the lower-triangular block: lane c solves L X[:,c] = e_c
+  if (lane < kNB) {
+    const int c = lane;
+    for (int r = 0; r < kNB; ++r) {
+      double s = (r == c) ? 1.0 : 0.0;
+      for (int m2 = c; m2 < r; ++m2) s -= sL[r][m2] * sInv[m2][c];
+      sInv[r][c] = (r < c) ? 0.0 : s / sL[r][r];
+    }
+  }
+  __syncthreads();
+  if (ib == k) {
+    for (int e = lane; e < kNB * kNB; e += 64) {
+      const int r = e / kNB, c = e % kNB;
+      Akk[(size_t)r * ld + c] = (c <= r) ? sL[r][c] : 0.0;
+    }
+    for (int e = lane; e < kNB * kNB; e += 64) Linv[(size_t)k * kNB * kNB + e] = sInv[e / kNB][e % kNB];
+  } else {
+    double *Aik = A + (size_t)ib * kNB * ld + (size_t)k * kNB;
+    for (int e = lane; e < kNB * kNB; e += 64) sA[e / kNB][e % kNB] = Aik[(size_t)(e / kNB) * ld + (e % kNB)];
+    __syncthreads();
+    // L_ik = A_ik * Linv^T : out[r][c] = sum_m A[r][m] * Linv[c][m]
+    for (int e = lane; e < kNB * kNB; e += 64) {
+      const int r = e / kNB, c = e % kNB;
+      double s = 0.0;
+      for (int m2 = 0; m2 <= c; ++m2) s += sA[r][m2] * sInv[c][m2];
+      Aik[(size_t)r * ld + c] = s;
+    }
+  }
+}
+
+// trailing update after panel k: A_ij -= L_ik L_jk^T for k < j <= i, 64x64 tiles, 4x4 outputs per thread
+__global__ void __launch_bounds__(256) k_chol_update(double *A, int ld, int k, int nblk) {
+  __shared__ double sI[64][kNB + 1];
+  __shared__ double sJ[64][kNB + 1];
+  // tile coordinates in units of 64 rows, counted from the first trailing block
+  const int first = (k + 1) * kNB;
+  const int ti = blockIdx.y, tj = blockIdx.x;
+  if (tj > ti) return;
+  const int row0 = first + ti * 64, col0 = first + tj * 64;
+  const int nrow = nblk * kNB;
+  const int tid = threadIdx.x;
+  for (int e = tid; e < 64 * kNB; e += 256) {
+    const int r = e / kNB, c = e % kNB;
+    sI[r][c] = (row0 + r < nrow) ? A[(size_t)(row0 + r) * ld + (size_t)k * kNB + c] : 0.0;
+    sJ[r][c] = (col0 + r < nrow) ? A[(size_t)(col0 + r) * ld + (size_t)k * kNB + c] : 0.0;
+  }
+  __syncthreads();
+  const int tr = (tid / 16) * 4, tc = (tid % 16) * 4;
+  double acc[4][4] = {{0}};
+  for (int m2 = 0; m2 < kNB; ++m2) {
+    double a[4], b[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      a[q] = sI[tr + q][m2];
+      b[q] = sJ[tc + q][m2];
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[p][q] += a[p] * b[q];
+  }
+#pragma unroll
+  for (int p = 0; p < 4; ++p)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int r = row0 + tr + p, c = col0 + tc + q;
+      if (r < nrow && c <= r) A[(size_t)r * ld + c] -= acc[p][q];
+    }
+}
+
+// back substitution L^T y = z (z = row n of the factored augmented matrix), right-looking over 32-wide blocks from
+// last to first in ONE workgroup: y_k = Linv_kk^T z_k, then z_j -= L[block k rows][j] . y_k for every j left of it
+// (row-contiguous, coalesced reads of L; 32 independent loads per thread).
+__global__ void __launch_bounds__(1024) k_chol_back(const double *A, int ld, int n, const double *Linv, double *y) {
+  __shared__ double sz[4096];
+  __shared__ double syk[kNB];
+  const int tid = threadIdx.x;
+  const int nblk = (n + kNB - 1) / kNB;
+  for (int i = tid; i < nblk * kNB; i += 1024) sz[i] = (i < n) ? A[(size_t)n * ld + i] : 0.0;
+  __syncthreads();
+  for (int kb = nblk - 1; kb >= 0; --kb) {
+    if (tid < kNB) {
+      const double *Li = Linv + (size_t)kb * kNB * kNB;
+      double acc = 0.0;
+      for (int m2 = tid; m2 < kNB; ++m2) acc += Li[m2 * kNB + tid] * sz[kb * kNB + m2];  // (Linv^T z)_c
+      syk[tid] = (kb * kNB + tid < n) ? acc : 0.0;
+    }
+    __syncthreads();
+    if (tid < kNB) sz[kb * kNB + tid] = syk[tid];
+    const int rows = min(kNB, n - kb * kNB);
+    for (int j = tid; j < kb * kNB; j += 1024) {
+      double acc = 0.0;
+#pragma unroll 8
+      for (int r = 0; r < rows; ++r) acc += A[(size_t)(kb * kNB + r) * ld + j] * syk[r];
+      sz[j] -= acc;
+    }
+    __syncthreads();
+  }
+  for (int i = tid; i < n; i += 1024) y[i] = sz[i];
+}
+
+// candidate point and the scalars the trust-region logic needs:
+//   xc = x - y * scale ; mail[2] = model_cost_change = (y.gs + sum D y^2) / 2 ; mail[3] = |step| ; mail[4] = |x|
+__global__ void __launch_bounds__(1024) k_step(const double *x, const double *y, const double *scale, const double *g,
+                                              const double *diag, int n, double *xc, double *mail) {
+  __shared__ double s0[1024], s1[1024], s2[1024];
+  const int tid = threadIdx.x;
+  double mc = 0.0, sn = 0.0, xn = 0.0;
+  for (int i = tid; i < n; i += 1024) {
+    const double d = -y[i] * scale[i];
+    xc[i] = x[i] + d;
+    mc += y[i] * (g[i] * scale[i]) + diag[i] * y[i] * y[i];
+    sn += d * d;
+    xn += x[i] * x[i];
+  }
+  s0[tid] = mc, s1[tid] = sn, s2[tid] = xn;
+  __syncthreads();
+  for (int st = 512; st > 0; st >>= 1) {
+    if (tid < st) {
+      s0[tid] += s0[tid + st];
+      s1[tid] += s1[tid + st];
+      s2[tid] += s2[tid + st];
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    mail[2] = 0.5 * s0[0];
+    mail[3] = sqrt(s1[0]);
+    mail[4] = sqrt(s2[0]);
+  }
+}
+
+// ---- host helpers ----------------------------------------------------------------------------------------------------
+int sort_u32(wc_ctx *ctx, wc_window_state *W, uint32_t *kin, uint32_t *kout, uint32_t *vin, uint32_t *vout, size_t n,
+             unsigned end_bit) {
+  size_t tmp = 0;
+  WC_HIP(ctx, rocprim::radix_sort_pairs(nullptr, tmp, kin, kout, vin, vout, n, 0u, end_bit, ctx->stream));
+  WC_TRY(wc_ensure(ctx, ctx->b_sorttmp, tmp));
+  tmp = ctx->b_sorttmp.cap;
+  WC_HIP(ctx, rocprim::radix_sort_pairs(ctx->b_sorttmp.p, tmp, kin, kout, vin, vout, n, 0u, end_bit, ctx->stream));
+  return WC_OK;
+}
+
+template <typename T>
+int upload(wc_ctx *ctx, wc_buf &b, const std::vector<T> &v) {
+  WC_TRY(wc_ensure(ctx, b, std::max<size_t>(v.size() * sizeof(T), 16)));
+  if (!v.empty()) WC_HIP(ctx, hipMemcpyAsync(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+  WC_HIP(ctx, hipStreamSynchronize(ctx->stream));  // v may be a temporary
+  return WC_OK;
+}
+
+struct Seg {
+  uint32_t start, count, key;
+};
+
+// sorted keys -> segments (device head detection, host ordering)
+int find_segments(wc_ctx *ctx, wc_window_state *W, const uint32_t *d_keys, uint32_t n, std::vector<Seg> &segs) {
+  segs.clear();
+  if (n == 0) return WC_OK;
+  WC_TRY(wc_ensure(ctx, W->heads, (size_t)n * 8));
+  WC_TRY(wc_ensure(ctx, W->status, 64 * 4));
+  WC_HIP(ctx, hipMemsetAsync(W->status.p, 0, 64 * 4, ctx->stream));
+  k_seg_heads<<<(n + 255) / 256, 256, 0, ctx->stream>>>(d_keys, n, (uint32_t *)W->heads.p, (uint32_t *)W->status.p);
+  uint32_t st[4];
+  WC_HIP(ctx, hipMemcpyAsync(st, W->status.p, 16, hipMemcpyDeviceToHost, ctx->stream));
+  WC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  const uint32_t nh = st[2];
+  std::vector<std::pair<uint32_t, uint32_t>> heads(nh);
+  WC_HIP(ctx, hipMemcpy(heads.data(), W->heads.p, (size_t)nh * 8, hipMemcpyDeviceToHost));
+  std::sort(heads.begin(), heads.end());
+  for (uint32_t i = 0; i < nh; ++i) {
+    const uint32_t end = (i + 1 < nh) ? heads[i + 1].first : n;
+    segs.push_back({heads[i].first, end - heads[i].first, heads[i].second});
+  }
+  return WC_OK;
+}
+
+}  // namespace
+
+void wc_window_free(wc_ctx *ctx) {
+  wc_window_state *W = ctx->win;
+  if (!W) return;
+  wc_buf *all[] = {&W->times_d, &W->brec, &W->bkey, &W->borig, &W->urec, &W->ukey, &W->uorig, &W->irec, &W->pieces, &W->partial,
+                   &W->src, &W->src_begin, &W->gsrc, &W->gsrc_begin, &W->x, &W->xc, &W->lin, &W->Linv, &W->scale, &W->diag, &W->A, &W->y,
+                   &W->mail, &W->cost_part, &W->keys_tmp[0], &W->keys_tmp[1], &W->vals_tmp[0], &W->vals_tmp[1], &W->heads, &W->status};
+  for (wc_buf *b : all)
+    if (b->p) (void)hipFree(b->p);
+  delete W;
+  ctx->win = nullptr;
+}
+
+namespace {
+
+// build one family of surfel records (binary or unary): keys -> sort -> packed records -> segments -> pieces
+int build_family(wc_ctx *ctx, wc_window_state *W, bool unary, const wc_surfel *s1, const wc_pose *p1, const wc_surfel *s2,
+                 const wc_pose *p2, const wc_pair *pairs, uint32_t n, wc_buf &rec, wc_buf &key, wc_buf &orig,
+                 std::vector<Seg> &segs) {
+  segs.clear();
+  if (n == 0) return WC_OK;
+  const int nf = unary ? 11 : 15;
+  WC_TRY(wc_ensure(ctx, W->keys_tmp[0], (size_t)n * 4));
+  WC_TRY(wc_ensure(ctx, W->keys_tmp[1], (size_t)n * 4));
+  WC_TRY(wc_ensure(ctx, W->vals_tmp[0], (size_t)n * 4));
+  WC_TRY(wc_ensure(ctx, W->vals_tmp[1], (size_t)n * 4));
+  WC_TRY(wc_ensure(ctx, rec, (size_t)n * nf * 8));
+  WC_TRY(wc_ensure(ctx, key, (size_t)n * 4));
+  WC_TRY(wc_ensure(ctx, orig, (size_t)n * 4));
+  WC_TRY(wc_ensure(ctx, W->status, 64 * 4));
+  WC_HIP(ctx, hipMemsetAsync(W->status.p, 0, 64 * 4, ctx->stream));
+  const unsigned grid = (n + 255) / 256;
+  k_pair_keys<<<grid, 256, 0, ctx->stream>>>(s1, s2, pairs, n, (const double *)W->times_d.p, W->ns, unary ? 1 : 0,
+                                            (uint32_t *)W->keys_tmp[0].p, (uint32_t *)W->vals_tmp[0].p, (uint32_t *)W->status.p);
+  uint32_t st[4];
+  WC_HIP(ctx, hipMemcpyAsync(st, W->status.p, 16, hipMemcpyDeviceToHost, ctx->stream));
+  WC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (st[1] & 2u) return wc_fail(ctx, WC_ERR_ORDER, "correspondence is not (older, newer)");
+  if (st[1] & 1u) return wc_fail(ctx, WC_ERR_RANGE, "surfel timestamp outside the sample-state range");
+  unsigned bits = 1;
+  const uint64_t maxkey = unary ? (uint64_t)W->ns : (uint64_t)W->ns * W->ns;
+  while ((1ull << bits) < maxkey + 1) ++bits;
+  WC_TRY(sort_u32(ctx, W, (uint32_t *)W->keys_tmp[0].p, (uint32_t *)W->keys_tmp[1].p, (uint32_t *)W->vals_tmp[0].p,
+                  (uint32_t *)W->vals_tmp[1].p, n, bits));
+  k_build_records<<<grid, 256, 0, ctx->stream>>>(s1, p1, s2, p2, pairs, (const uint32_t *)W->vals_tmp[1].p,
+                                                (const uint32_t *)W->keys_tmp[1].p, n, (const double *)W->times_d.p, W->ns,
+                                                unary ? 1 : 0, W->wp.sigma0_sq, (double *)rec.p, (uint32_t *)key.p, (uint32_t *)orig.p);
+  WC_HIP(ctx, hipGetLastError());
+  WC_TRY(find_segments(ctx, W, (const uint32_t *)key.p, n, segs));
+  return WC_OK;
+}
+
+}  // namespace
+
+extern "C" int wc_window_build(wc_ctx *ctx, const wc_surfel *d_sld_surf, const wc_pose *d_sld_pose, const wc_pair *d_pairs_sld,
+                               uint64_t n_pairs_sld, const wc_surfel *d_fix_surf, const wc_pose *d_fix_pose,
+                               const wc_pair *d_pairs_fix, uint64_t n_pairs_fix, const wc_imu_state *h_imu, uint64_t n_imu,
+                               const double *h_sample_times, uint64_t ns_, const double *h_grav, int fix_first_pos) {
+  if (!ctx || !h_sample_times || ns_ < 2 || ns_ > 340 || !h_grav) return WC_ERR_ARG;  // 12*ns <= 4096 (k_chol_back LDS)
+  if (n_pairs_sld >= (1ull << 31) || n_pairs_fix >= (1ull << 31)) return WC_ERR_ARG;
+  WC_HIP(ctx, hipSetDevice(ctx->device));
+  if (!ctx->win) ctx->win = new wc_window_state;
+  wc_window_state *W = ctx->win;
+  W->built = false;
+  const wc_params &P = ctx->P;
+  const int ns = (int)ns_;
+  W->ns = ns;
+  W->n = 12 * ns;
+  W->np = ((W->n + 1 + kNB - 1) / kNB) * kNB;
+  W->ld = W->np;
+  W->times.assign(h_sample_times, h_sample_times + ns);
+  WinParams &wp = W->wp;
+  wp.sigma0_sq = P.surfel_sigma0 * P.surfel_sigma0;
+  wp.cauchy_b = P.cauchy_a * P.cauchy_a;
+  wp.w_gyr = P.w_gyr, wp.w_acc = P.w_acc, wp.w_bg = P.w_bg, wp.w_ba = P.w_ba, wp.dt = P.imu_dt;
+  for (int i = 0; i < 3; ++i) wp.grav[i] = h_grav[i];
+  wp.quirks = P.reference_quirks;
+  wp.ns = ns;
+  wp.fix_first = fix_first_pos ? 1 : 0;
+  WC_TRY(upload(ctx, W->times_d, W->times));
+
+  std::vector<Seg> segs_b, segs_u;
+  W->nb = (uint32_t)n_pairs_sld;
+  W->nu = (uint32_t)n_pairs_fix;
+  WC_TRY(build_family(ctx, W, false, d_sld_surf, d_sld_pose, d_sld_surf, d_sld_pose, d_pairs_sld, W->nb, W->brec, W->bkey,
+                      W->borig, segs_b));
+  WC_TRY(build_family(ctx, W, true, d_fix_surf, d_fix_pose, d_sld_surf, d_sld_pose, d_pairs_fix, W->nu, W->urec, W->ukey,
+                      W->uorig, segs_u));
+
+  // IMU factors (BuildImuResiduals, lidar_odometry.cc:319-363), selected on the host: a few thousand records
+  std::vector<ImuRec> irecs;
+  std::vector<Seg> segs_i;
+  if (h_imu && n_imu >= 3) {
+    for (uint64_t i = 0; i + 2 < n_imu; ++i) {
+      if (h_imu[i].t < W->times.front()) continue;
+      if (h_imu[i + 2].t > W->times.back()) break;
+      const int it = (int)(std::upper_bound(W->times.begin(), W->times.end(), h_imu[i].t) - W->times.begin());
+      if (it == 0 || it == ns) return wc_fail(ctx, WC_ERR_RANGE, "IMU state outside the sample-state range");
+      ImuRec r;
+      r.i1 = h_imu[i], r.i2 = h_imu[i + 1], r.i3 = h_imu[i + 2];
+      r.sp1 = it - 1;
+      r.mode = (it == ns - 1) ? 1 : 0;
+      if (!segs_i.empty() && segs_i.back().key == (uint32_t)r.sp1 && segs_i.back().count < (uint32_t)kImuMax)
+        segs_i.back().count++;
+      else
+        segs_i.push_back({(uint32_t)irecs.size(), 1, (uint32_t)r.sp1});
+      irecs.push_back(r);
+    }
+  }
+  W->ni = (uint32_t)irecs.size();
+  WC_TRY(upload(ctx, W->irec, irecs));
+
+  // pieces + the CSR source lists of the gather
+  std::vector<Piece> pieces;
+  uint32_t off = 0;
+  auto cut = [&](const std::vector<Seg> &segs, uint32_t T, bool split) {
+    for (const Seg &s : segs) {
+      for (uint32_t b = 0; b < s.count; b += split ? kPiece : s.count) {
+        const uint32_t c = split ? std::min<uint32_t>(kPiece, s.count - b) : s.count;
+        pieces.push_back({s.start + b, c, s.key, off});
+        off += T * (T + 1) / 2;
+      }
+    }
+  };
+  cut(segs_b, 25, true);
+  W->npiece_b = (uint32_t)pieces.size();
+  cut(segs_u, 13, true);
+  W->npiece_u = (uint32_t)pieces.size() - W->npiece_b;
+  cut(segs_i, 37, false);
+  W->npiece_i = (uint32_t)pieces.size() - W->npiece_b - W->npiece_u;
+  W->npart_doubles = off;
+
+  const uint32_t npairs = (uint32_t)(ns * (ns + 1) / 2);
+  W->npairs = npairs;
+  auto pair_id = [&](int I, int J) { return (uint32_t)(I * ns - I * (I - 1) / 2 + (J - I)); };
+  std::vector<std::vector<Src>> per_pair(npairs);
+  std::vector<std::vector<GSrc>> per_blk(ns);
+  for (size_t pi = 0; pi < pieces.size(); ++pi) {
+    const Piece &pc = pieces[pi];
+    int blk[4], nblk;
+    uint8_t w, T;
+    if (pi < W->npiece_b) {
+      const int sp1l = pc.key & 0xFFFF, sp2l = pc.key >> 16;
+      w = 6, T = 25;
+      if (sp2l > sp1l + 1) {
+        nblk = 4, blk[0] = sp1l, blk[1] = sp1l + 1, blk[2] = sp2l, blk[3] = sp2l + 1;
+      } else if (sp2l == sp1l + 1) {
+        nblk = 3, blk[0] = sp1l, blk[1] = sp1l + 1, blk[2] = sp2l + 1;
+      } else {
+        nblk = 2, blk[0] = sp1l, blk[1] = sp1l + 1;
+      }
+    } else if (pi < W->npiece_b + W->npiece_u) {
+      w = 6, T = 13, nblk = 2, blk[0] = (int)pc.key, blk[1] = (int)pc.key + 1;
+    } else {
+      w = 12, T = 37;
+      const bool last = ((int)pc.key + 1 == ns - 1);
+      nblk = last ? 2 : 3;
+      blk[0] = (int)pc.key, blk[1] = (int)pc.key + 1, blk[2] = (int)pc.key + 2;
+    }
+    for (int p = 0; p < nblk; ++p) {
+      per_blk[blk[p]].push_back({pc.part_off, (uint8_t)p, w, T, 0});
+      for (int q = p; q < nblk; ++q) per_pair[pair_id(blk[p], blk[q])].push_back({pc.part_off, (uint8_t)p, (uint8_t)q, w, T});
+    }
+  }
+  std::vector<Src> src;
+  std::vector<uint32_t> src_begin(npairs + 1, 0);
+  for (uint32_t i = 0; i < npairs; ++i) {
+    src_begin[i] = (uint32_t)src.size();
+    src.insert(src.end(), per_pair[i].begin(), per_pair[i].end());
+  }
+  src_begin[npairs] = (uint32_t)src.size();
+  std::vector<GSrc> gsrc;
+  std::vector<uint32_t> gsrc_begin(ns + 1, 0);
+  for (int i = 0; i < ns; ++i) {
+    gsrc_begin[i] = (uint32_t)gsrc.size();
+    gsrc.insert(gsrc.end(), per_blk[i].begin(), per_blk[i].end());
+  }
+  gsrc_begin[ns] = (uint32_t)gsrc.size();
+  WC_TRY(upload(ctx, W->pieces, pieces));
+  WC_TRY(upload(ctx, W->src, src));
+  WC_TRY(upload(ctx, W->src_begin, src_begin));
+  WC_TRY(upload(ctx, W->gsrc, gsrc));
+  WC_TRY(upload(ctx, W->gsrc_begin, gsrc_begin));
+
+  const size_t n = W->n;
+  WC_TRY(wc_ensure(ctx, W->partial, std::max<size_t>((size_t)off * 8, 64)));
+  WC_TRY(wc_ensure(ctx, W->x, n * 8));
+  WC_TRY(wc_ensure(ctx, W->xc, n * 8));
+  WC_TRY(wc_ensure(ctx, W->lin, (n * n + (size_t)W->np + 2) * 8));
+  WC_TRY(wc_ensure(ctx, W->Linv, (size_t)W->np * kNB * 8));
+  WC_TRY(wc_ensure(ctx, W->scale, n * 8));
+  WC_TRY(wc_ensure(ctx, W->diag, n * 8));
+  WC_TRY(wc_ensure(ctx, W->A, (size_t)W->np * W->ld * 8));
+  WC_TRY(wc_ensure(ctx, W->y, (size_t)W->np * 8));
+  WC_TRY(wc_ensure(ctx, W->mail, 64 * 8));
+  const size_t ncb = (W->nb + 255) / 256 + (W->nu + 255) / 256 + (W->ni + 255) / 256 + 8;
+  WC_TRY(wc_ensure(ctx, W->cost_part, ncb * 8));
+  W->built = true;
+  return WC_OK;
+}
+
+namespace {
+
+inline double *lin_H(wc_window_state *W) { return (double *)W->lin.p; }
+inline double *lin_g(wc_window_state *W) { return (double *)W->lin.p + (size_t)W->n * W->n; }
+inline double *lin_cost(wc_window_state *W) { return lin_g(W) + W->np; }
+inline size_t lin_count(wc_window_state *W) { return (size_t)W->n * W->n + W->np + 2; }
+
+__global__ void __launch_bounds__(1024) k_post_reduce(const double *g, const double *cost, int n, double *mail, int slot) {
+  __shared__ double s[1024];
+  const int tid = threadIdx.x;
+  double mx = 0.0;
+  for (int i = tid; i < n; i += 1024) mx = fmax(mx, fabs(g[i]));
+  s[tid] = mx;
+  __syncthreads();
+  for (int st = 512; st > 0; st >>= 1) {
+    if (tid < st) s[tid] = fmax(s[tid], s[tid + st]);
+    __syncthreads();
+  }
+  if (tid == 0) {
+    mail[slot] = cost[0];
+    mail[slot + 1] = s[0];
+  }
+}
+
+// multi-GPU hook: sum a device buffer over all ranks (RCCL through the caller); no-op on one GPU
+int do_allreduce(wc_ctx *ctx, wc_window_state *W, double *d_buf, size_t count) {
+  if (!W->allreduce) return WC_OK;
+  WC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (W->allreduce(W->allreduce_user, d_buf, (uint64_t)count) != 0) return wc_fail(ctx, WC_ERR_HIP, "all-reduce callback failed");
+  return WC_OK;
+}
+
+// all kernels of one linearisation at x (device): partials -> H, g ; cost -> mail[slot], max|g| -> mail[slot+1]
+int enqueue_linearize(wc_ctx *ctx, wc_window_state *W, const double *d_x, int mail_slot) {
+  hipStream_t st = ctx->stream;
+  const Piece *pcs = (const Piece *)W->pieces.p;
+  double *partial = (double *)W->partial.p;
+  if (W->npiece_b)
+    k_lin_surfel<24, false><<<W->npiece_b, kPiece, 0, st>>>(W->wp, pcs, (const double *)W->brec.p, (const uint32_t *)W->bkey.p, W->nb,
+                                                          d_x, partial);
+  if (W->npiece_u)
+    k_lin_surfel<12, true><<<W->npiece_u, kPiece, 0, st>>>(W->wp, pcs + W->npiece_b, (const double *)W->urec.p,
+                                                         (const uint32_t *)W->ukey.p, W->nu, d_x, partial);
+  if (W->npiece_i)
+    k_lin_imu<<<W->npiece_i, 256, 0, st>>>(W->wp, pcs + W->npiece_b + W->npiece_u, (const ImuRec *)W->irec.p, d_x,
+                                          (const double *)W->times_d.p, partial);
+  k_gather_H<<<W->npairs, 144, 0, st>>>((const Src *)W->src.p, (const uint32_t *)W->src_begin.p, partial, W->ns, W->wp.fix_first,
+                                       lin_H(W));
+  k_gather_g<<<W->ns, 64, 0, st>>>((const GSrc *)W->gsrc.p, (const uint32_t *)W->gsrc_begin.p, partial, W->wp.fix_first, lin_g(W));
+  k_cost_sum<<<1, 1024, 0, st>>>(pcs, W->npiece_b + W->npiece_u + W->npiece_i, W->npiece_b, W->npiece_u, partial, nullptr, W->n,
+                                lin_cost(W), 0);
+  WC_HIP(ctx, hipGetLastError());
+  WC_TRY(do_allreduce(ctx, W, lin_H(W), lin_count(W)));  // the ONE collective of a linearisation
+  k_post_reduce<<<1, 1024, 0, st>>>(lin_g(W), lin_cost(W), W->n, (double *)W->mail.p, mail_slot);
+  WC_HIP(ctx, hipGetLastError());
+  return WC_OK;
+}
+
+// cost (and optionally residuals in the reference's block order: binary, unary, imu x 12) at x -> mail[slot]
+int enqueue_evaluate(wc_ctx *ctx, wc_window_state *W, const double *d_x, double *d_res, int mail_slot) {
+  hipStream_t st = ctx->stream;
+  double *cp = (double *)W->cost_part.p;
+  const uint32_t gb = (W->nb + 255) / 256, gu = (W->nu + 255) / 256, gi = (W->ni + 255) / 256;
+  if (gb)
+    k_eval_surfel<false><<<gb, 256, 0, st>>>(W->wp, (const double *)W->brec.p, (const uint32_t *)W->bkey.p, (const uint32_t *)W->borig.p,
+                                            W->nb, d_x, d_res, cp);
+  if (gu)
+    k_eval_surfel<true><<<gu, 256, 0, st>>>(W->wp, (const double *)W->urec.p, (const uint32_t *)W->ukey.p, (const uint32_t *)W->uorig.p,
+                                           W->nu, d_x, d_res ? d_res + W->nb : nullptr, cp + gb);
+  if (gi)
+    k_eval_imu<<<gi, 256, 0, st>>>(W->wp, (const ImuRec *)W->irec.p, W->ni, d_x, (const double *)W->times_d.p,
+                                  d_res ? d_res + W->nb + W->nu : nullptr, cp + gb + gu);
+  k_sum_blocks<<<1, 1024, 0, st>>>(cp, gb + gu + gi, (double *)W->mail.p, mail_slot);
+  WC_HIP(ctx, hipGetLastError());
+  WC_TRY(do_allreduce(ctx, W, (double *)W->mail.p + mail_slot, 1));
+  return WC_OK;
+}
+
+int read_mail(wc_ctx *ctx, wc_window_state *W, int count) {
+  WC_HIP(ctx, hipMemcpyAsync(ctx->h_mail, W->mail.p, (size_t)count * 8, hipMemcpyDeviceToHost, ctx->stream));
+  WC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return WC_OK;
+}
+
+}  // namespace
+
+extern "C" int wc_window_counts(wc_ctx *ctx, uint64_t counts[4]) {
+  if (!ctx || !ctx->win || !ctx->win->built) return WC_ERR_ARG;
+  counts[0] = ctx->win->nb, counts[1] = ctx->win->nu, counts[2] = ctx->win->ni;
+  counts[3] = ctx->win->npiece_b + ctx->win->npiece_u + ctx->win->npiece_i;
+  return WC_OK;
+}
+
+extern "C" int wc_window_evaluate(wc_ctx *ctx, const double *h_x, double *h_cost, double *d_residuals) {
+  if (!ctx || !ctx->win || !ctx->win->built || !h_x || !h_cost) return WC_ERR_ARG;
+  wc_window_state *W = ctx->win;
+  WC_HIP(ctx, hipMemcpyAsync(W->x.p, h_x, (size_t)W->n * 8, hipMemcpyHostToDevice, ctx->stream));
+  WC_TRY(enqueue_evaluate(ctx, W, (const double *)W->x.p, d_residuals, 0));
+  WC_TRY(read_mail(ctx, W, 1));
+  *h_cost = ctx->h_mail[0];
+  return WC_OK;
+}
+
+extern "C" int wc_window_linearize(wc_ctx *ctx, const double *h_x, double *d_H, double *d_g, double *h_cost) {
+  if (!ctx || !ctx->win || !ctx->win->built || !h_x) return WC_ERR_ARG;
+  wc_window_state *W = ctx->win;
+  WC_HIP(ctx, hipMemcpyAsync(W->x.p, h_x, (size_t)W->n * 8, hipMemcpyHostToDevice, ctx->stream));
+  WC_TRY(enqueue_linearize(ctx, W, (const double *)W->x.p, 0));
+  if (d_H) WC_HIP(ctx, hipMemcpyAsync(d_H, lin_H(W), (size_t)W->n * W->n * 8, hipMemcpyDeviceToDevice, ctx->stream));
+  if (d_g) WC_HIP(ctx, hipMemcpyAsync(d_g, lin_g(W), (size_t)W->n * 8, hipMemcpyDeviceToDevice, ctx->stream));
+  WC_TRY(read_mail(ctx, W, 2));
+  if (h_cost) *h_cost = ctx->h_mail[0];
+  return WC_OK;
+}
+
+// Multi-GPU: correspondences are sharded over ranks, the unknowns stay replicated.  The caller installs a callback that
+// sums a device buffer of doubles over all ranks (RCCL all-reduce over xGMI via torch.distributed or rccl directly);
+// it is invoked once per linearisation on the packed buffer {H, g, cost} and once per candidate-cost evaluation on one
+// double.  Every rank then runs the identical, deterministic LM logic on identical numbers.
+extern "C" int wc_window_set_allreduce(wc_ctx *ctx, int (*fn)(void *user, double *d_buf, uint64_t count), void *user) {
+  if (!ctx) return WC_ERR_ARG;
+  if (!ctx->win) ctx->win = new wc_window_state;
+  ctx->win->allreduce = fn;
+  ctx->win->allreduce_user = user;
+  return WC_OK;
+}
+
+// ceres::Solve with the reference's options (lidar_odometry.cc:551-561): Ceres-default trust-region LM restated
+// (upstream semantics, see oracle/window.cc for the per-rule citations).
+extern "C" int wc_window_solve(wc_ctx *ctx, double *h_x_inout, wc_solve_summary *summary, double *h_first_step) {
+  if (!ctx || !ctx->win || !ctx->win->built || !h_x_inout || !summary) return WC_ERR_ARG;
+  wc_window_state *W = ctx->win;
+  hipStream_t st = ctx->stream;
+  const int n = W->n, np = W->np, ld = W->ld, nblk = np / kNB;
+  std::memset(summary, 0, sizeof(*summary));
+  double *x = (double *)W->x.p, *xc = (double *)W->xc.p, *H = lin_H(W), *g = lin_g(W);
+  double *scale = (double *)W->scale.p, *diag = (double *)W->diag.p, *A = (double *)W->A.p, *y = (double *)W->y.p;
+  double *mail = (double *)W->mail.p;
+  int *fail = (int *)((double *)W->mail.p + 32);
+  std::vector<double> best(h_x_inout, h_x_inout + n), cur(best), cand(n);
+
+  WC_HIP(ctx, hipMemcpyAsync(x, cur.data(), (size_t)n * 8, hipMemcpyHostToDevice, st));
+  WC_TRY(enqueue_linearize(ctx, W, x, 0));
+  k_scale_init<<<(n + 255) / 256, 256, 0, st>>>(H, n, scale);
+  WC_TRY(read_mail(ctx, W, 2));
+  summary->n_linearizations = 1;
+  double cost = ctx->h_mail[0], gmax = ctx->h_mail[1];
+  summary->initial_cost = cost;
+  double min_cost = cost, radius = 1e4, decrease = 2.0, x_norm = 0.0;
+  for (int i = 0; i < n; ++i) x_norm += cur[i] * cur[i];
+  x_norm = std::sqrt(x_norm);
+  int iter = 0, consecutive_invalid = 0;
+  bool first_recorded = false;
+  summary->termination = 1;
+  if (gmax <= 1e-10) {
+    summary->termination = 0;
+  } else {
+    while (true) {
+      if (iter >= ctx->P.max_iterations) {
+        summary->termination = 1;
+        break;
+      }
+      if (gmax <= 1e-10 || radius <= 1e-32) {
+        summary->termination = 0;
+        break;
+      }
+      ++iter;
+      // LevenbergMarquardtStrategy::ComputeStep on the device
+      WC_HIP(ctx, hipMemsetAsync(fail, 0, 4, st));
+      {
+        dim3 grid((np + 255) / 256, np);
+        k_damp<<<grid, 256, 0, st>>>(H, g, scale, n, np, ld, radius, A, diag);
+      }
+      for (int k = 0; k < nblk; ++k) {
+        k_chol_panel<<<nblk - k, 64, 0, st>>>(A, ld, k, fail, (double *)W->Linv.p);
+        const int rem = nblk - k - 1;
+        if (rem > 0) {
+          const int tiles = (rem * kNB + 63) / 64;
+          k_chol_update<<<dim3(tiles, tiles), 256, 0, st>>>(A, ld, k, nblk);
+        }
+      }
+      k_chol_back<<<1, 1024, 0, st>>>(A, ld, n, (const double *)W->Linv.p, y);
+      k_step<<<1, 1024, 0, st>>>(x, y, scale, g, diag, n, xc, mail);
+      WC_TRY(enqueue_evaluate(ctx, W, xc, nullptr, 5));
+      WC_HIP(ctx, hipGetLastError());
+      WC_HIP(ctx, hipMemcpyAsync(ctx->h_mail, mail, 40 * 8, hipMemcpyDeviceToHost, st));
+      WC_HIP(ctx, hipStreamSynchronize(st));
+      summary->n_cost_evaluations++;
+      int hfail;
+      std::memcpy(&hfail, &ctx->h_mail[32], 4);
+      const double model_change = ctx->h_mail[2], step_norm = ctx->h_mail[3], cand_cost = ctx->h_mail[5];
+      if (hfail || !(model_change > 0) || !std::isfinite(step_norm)) {  // HandleInvalidStep
+        if (++consecutive_invalid >= 5) {
+          summary->termination = 2;
+          break;
+        }
+        radius *= 0.5;
+        summary->unsuccessful_steps++;
+        continue;
+      }
+      consecutive_invalid = 0;
+      if (!first_recorded) {
+        first_recorded = true;
+        summary->first_step[0] = step_norm;
+        if (h_first_step) {
+          WC_HIP(ctx, hipMemcpy(cand.data(), xc, (size_t)n * 8, hipMemcpyDeviceToHost));
+          for (int i = 0; i < n; ++i) h_first_step[i] = cand[i] - cur[i];
+        }
+      }
+      if (step_norm <= 1e-8 * (x_norm + 1e-8)) {  // ParameterToleranceReached
+        summary->termination = 0;
+        break;
+      }
+      const double cost_change = cost - cand_cost;
+      if (std::fabs(cost_change) <= 1e-6 * cost) {  // FunctionToleranceReached
+        summary->termination = 0;
+        break;
+      }
+      const double rho = cost_change / model_change;
+      if (rho > 1e-3) {  // HandleSuccessfulStep
+        std::swap(W->x, W->xc);
+        x = (double *)W->x.p, xc = (double *)W->xc.p;
+        WC_TRY(enqueue_linearize(ctx, W, x, 0));
+        // |x| of the accepted point: k_step computed |x_old|; recompute from the candidate on the host side
+        WC_HIP(ctx, hipMemcpyAsync(cur.data(), x, (size_t)n * 8, hipMemcpyDeviceToHost, st));
+        WC_TRY(read_mail(ctx, W, 2));
+        summary->n_linearizations++;
+        cost = ctx->h_mail[0];
+        gmax = ctx->h_mail[1];
+        x_norm = 0.0;
+        for (int i = 0; i < n; ++i) x_norm += cur[i] * cur[i];
+        x_norm = std::sqrt(x_norm);
+        radius = radius / std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * rho - 1.0, 3));
+        radius = std::min(1e16, radius);
+        decrease = 2.0;
+        summary->successful_steps++;
+        if (cost < min_cost) {
+          min_cost = cost;
+          best = cur;
+        }
+      } else {  // HandleUnsuccessfulStep
+        radius = radius / decrease;
+        decrease *= 2;
+        summary->unsuccessful_steps++;
+      }
+    }
+  }
+  summary->iterations = iter;
+  summary->final_cost = min_cost;
+  std::memcpy(h_x_inout, best.data(), (size_t)n * 8);
+  return WC_OK;
+}

@@ -181,3 +181,68 @@ class Context:
         self.extract_enqueue(desc, d_out, d_ids, cap, t_lo, t_hi)
         m = self.extract_finish()
         return d_out.download(R.SURFEL, m), d_ids.download(R.SURFEL_ID, m)
+
+    # ---- pose update / window problem ------------------------------------------------------------------------------
+    def update_surfel_poses(self, d_imu, n_imu, d_surf, d_pose, d_in_body, n):
+        self._ck(self.lib.wc_update_surfel_poses(self.h, C.c_void_p(d_imu.ptr), C.c_uint64(n_imu), C.c_void_p(d_surf.ptr), C.c_void_p(d_pose.ptr),
+                                                 C.c_void_p(d_in_body.ptr), C.c_uint64(n)))
+
+    def window_build(self, d_surf, d_pose, d_pairs, n_pairs, imu, sample_times, grav, fix_first_pos, d_fix_surf=None, d_fix_pose=None,
+                     d_pairs_fix=None, n_pairs_fix=0):
+        """imu: host IMU_STATE array (or None); sample_times/grav: host arrays"""
+        st = np.ascontiguousarray(sample_times, np.float64)
+        gr = np.ascontiguousarray(grav, np.float64)
+        self._ns = len(st)
+        null = C.c_void_p(0)
+        self._ck(self.lib.wc_window_build(
+            self.h, C.c_void_p(d_surf.ptr), C.c_void_p(d_pose.ptr), C.c_void_p(d_pairs.ptr) if d_pairs else null, C.c_uint64(n_pairs),
+            C.c_void_p(d_fix_surf.ptr) if d_fix_surf else null, C.c_void_p(d_fix_pose.ptr) if d_fix_pose else null,
+            C.c_void_p(d_pairs_fix.ptr) if d_pairs_fix else null, C.c_uint64(n_pairs_fix),
+            R.ptr(imu) if imu is not None and len(imu) else null, C.c_uint64(len(imu) if imu is not None else 0), R.ptr(st), C.c_uint64(len(st)),
+            R.ptr(gr), C.c_int(int(fix_first_pos))))
+
+    def window_counts(self):
+        c = (C.c_uint64 * 4)()
+        self._ck(self.lib.wc_window_counts(self.h, c))
+        return list(c)
+
+    def window_evaluate(self, x, want_residuals=False):
+        x = np.ascontiguousarray(x, np.float64)
+        cost = C.c_double(0)
+        if want_residuals:
+            nb, nu, ni, _ = self.window_counts()
+            d_res = self.alloc(8 * (nb + nu + 12 * ni))
+            self._ck(self.lib.wc_window_evaluate(self.h, R.ptr(x), C.byref(cost), C.c_void_p(d_res.ptr)))
+            return cost.value, d_res.download(np.float64, nb + nu + 12 * ni)
+        self._ck(self.lib.wc_window_evaluate(self.h, R.ptr(x), C.byref(cost), C.c_void_p(0)))
+        return cost.value
+
+    def window_linearize(self, x):
+        x = np.ascontiguousarray(x, np.float64)
+        n = 12 * self._ns
+        d_H, d_g = self.alloc(8 * n * n), self.alloc(8 * n)
+        cost = C.c_double(0)
+        self._ck(self.lib.wc_window_linearize(self.h, R.ptr(x), C.c_void_p(d_H.ptr), C.c_void_p(d_g.ptr), C.byref(cost)))
+        return d_H.download(np.float64, n * n).reshape(n, n), d_g.download(np.float64, n), cost.value
+
+    def window_solve(self, x):
+        x = np.ascontiguousarray(x, np.float64).copy()
+        s = R.SolveSummary()
+        first = np.zeros(len(x))
+        self._ck(self.lib.wc_window_solve(self.h, R.ptr(x), C.byref(s), R.ptr(first)))
+        return x, s, first
+
+    def window_set_allreduce(self, fn):
+        """fn(d_ptr: int, count: int) -> None; kept alive on the context"""
+        CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64)
+
+        def _tramp(user, ptr, count):
+            try:
+                fn(ptr, count)
+                return 0
+            except Exception as e:  # pragma: no cover
+                print("allreduce callback failed:", e)
+                return 1
+
+        self._cb = CB(_tramp) if fn else C.cast(None, CB)
+        self._ck(self.lib.wc_window_set_allreduce(self.h, self._cb, C.c_void_p(0)))
