@@ -88,6 +88,19 @@ int wc_voxel_keys(wc_ctx *ctx, const wc_points *pts, int32_t *d_keys_xyz);
 int wc_update_surfel_poses(wc_ctx *ctx, const wc_imu_state *d_imu, uint64_t n_imu, wc_surfel *d_surf, wc_pose *d_pose,
                            uint8_t *d_in_body, uint64_t n);
 
+/* correspondence -------------------------------------------------------------------------------------------------- */
+/* Replaces KnnSurfelMatcher::BuildIndex(const std::deque<Surfel::Ptr>&) + Match(std::deque<Surfel::Ptr>&,
+ * std::vector<SurfelCorrespondence>&) (src/odometry/knn_surfel_matcher.h:17-19, .cc:3-49; calls lidar_odometry.cc:532-538).
+ *   same_set != 0 : sliding-window matcher, the targets ARE the queries (pass the same arrays twice); pairs are
+ *                   (older, newer) indices into that set, at most one per query, in query order
+ *   same_set == 0 : fixed-window matcher; pair.first indexes the targets (fixed window), pair.second the queries
+ *   d_knn_idx / d_knn_d2 (may be NULL): the raw exact k nearest neighbours per query (k = wc_params.knn_k), the output
+ *                   of FLANNKNearestSearch (cc:75-89), for known-answer tests
+ * Surfels must be in the body frame with poses attached (wc_update_surfel_poses). */
+int wc_match(wc_ctx *ctx, const wc_surfel *d_q_surf, const wc_pose *d_q_pose, uint64_t nq, const wc_surfel *d_t_surf,
+             const wc_pose *d_t_pose, uint64_t nt, int same_set, wc_pair *d_pairs, uint64_t cap, uint64_t *h_n_pairs,
+             uint32_t *d_knn_idx, double *d_knn_d2);
+
 /* window problem: factors + Levenberg-Marquardt ----------------------------------------------------------------- */
 /* Replaces the ceres::Problem construction of lidar_odometry.cc:541-545:
  *   BuildSldWinLidarResiduals (cc:254-297) — d_pairs_sld index the sliding-window surfels (older, newer),

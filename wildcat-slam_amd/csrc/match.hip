@@ -1,0 +1,361 @@
+// match.hip — surfel-to-surfel correspondence on gfx950.  Replaces KnnSurfelMatcher::BuildIndex / Match
+// (src/odometry/knn_surfel_matcher.cc:3-49) and the FLANN kd-tree beneath it (cc:65-89):
+//   * 6-D feature [centre_world / 1.0, normal_world / 5deg] per target (ToVector, cc:91-98)
+//   * EXACT k = 10 nearest neighbours in squared L2 (FLANN SearchParams(-1, 0.0): exact, sorted), ties by index
+//   * first neighbour passing |dt| >= 0.06, acos(n.n) <= 5deg, |n.(c - c')| <= 0.1 and "pair not seen yet" (cc:25-47)
+// Index: targets sorted by the 1-unit cell of their (scaled) centre, x fastest, so that a run of cells along x is one
+// contiguous range found by two binary searches; the query expands a cube of cells shell by shell and stops as soon as
+// the k-th best distance is inside the searched cube (the 6-D distance is bounded below by the 3-D centre distance),
+// which keeps the search exact.  The reference's order dependence (std::set of already-paired surfels, queries visited
+// in order) is a recurrence choice(q) = f(choice(c) : c < q); it is solved by fixed-point iteration on the device.
+// Memory bound gather/scan work; no MFMA.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include <rocprim/rocprim.hpp>
+
+#include "ctx.h"
+#include "dmath.h"
+
+using namespace wc;
+
+namespace {
+
+constexpr int kMaxK = 16;
+constexpr uint32_t kNone = 0xFFFFFFFFu;
+
+struct MatchParams {
+  double cs, as;        // centre / angular scale
+  double time_min, ang_max, dist_max;
+  int k;
+  double h;             // cell size in scaled units
+  double org[3];        // grid origin (scaled units)
+  int dim[3];           // cells per axis (<= 1024)
+};
+
+__device__ __forceinline__ void feature6(const wc_surfel &s, const wc_pose &p, double cs, double as, double f[6], V3 &cw, V3 &nw) {
+  const Q4 q{p.quat[0], p.quat[1], p.quat[2], p.quat[3]};
+  cw = qrot(q, mk3(s.center[0], s.center[1], s.center[2])) + mk3(p.pos[0], p.pos[1], p.pos[2]);  // surfel.h:67-69
+  nw = qrot(q, mk3(s.normal[0], s.normal[1], s.normal[2]));                                      // surfel.h:78-80
+  f[0] = cw.x / cs, f[1] = cw.y / cs, f[2] = cw.z / cs;
+  f[3] = nw.x / as, f[4] = nw.y / as, f[5] = nw.z / as;
+}
+
+__device__ __forceinline__ unsigned long long enc_min(double v) {  // order-preserving encoding for atomicMin/Max
+  unsigned long long u = (unsigned long long)__double_as_longlong(v);
+  return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+inline double dec_host(unsigned long long u) {
+  u = (u >> 63) ? (u & 0x7FFFFFFFFFFFFFFFull) : ~u;
+  double d;
+  memcpy(&d, &u, 8);
+  return d;
+}
+
+__global__ void __launch_bounds__(256) k_features(const wc_surfel *surf, const wc_pose *pose, uint32_t n, double cs, double as,
+                                                 double *feat, double *world, unsigned long long *bbox) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double f[6];
+  V3 cw, nw;
+  feature6(surf[i], pose[i], cs, as, f, cw, nw);
+  for (int d = 0; d < 6; ++d) feat[(size_t)i * 6 + d] = f[d];
+  double *w = world + (size_t)i * 7;
+  w[0] = cw.x, w[1] = cw.y, w[2] = cw.z, w[3] = nw.x, w[4] = nw.y, w[5] = nw.z, w[6] = surf[i].t;
+  for (int d = 0; d < 3; ++d) {
+    atomicMin(&bbox[d], enc_min(f[d]));
+    atomicMax(&bbox[3 + d], enc_min(f[d]));
+  }
+}
+
+__device__ __forceinline__ int cell_of(double v, double org, double h, int dim) {
+  int c = (int)floor((v - org) / h);
+  return min(max(c, 0), dim - 1);
+}
+
+__global__ void __launch_bounds__(256) k_cell_keys(const double *feat, uint32_t n, MatchParams M, uint32_t *keys, uint32_t *vals) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int cx = cell_of(feat[(size_t)i * 6 + 0], M.org[0], M.h, M.dim[0]);
+  const int cy = cell_of(feat[(size_t)i * 6 + 1], M.org[1], M.h, M.dim[1]);
+  const int cz = cell_of(feat[(size_t)i * 6 + 2], M.org[2], M.h, M.dim[2]);
+  keys[i] = (uint32_t)cx | ((uint32_t)cy << 10) | ((uint32_t)cz << 20);
+  vals[i] = i;
+}
+
+__global__ void __launch_bounds__(256) k_sorted_feat(const double *feat, const uint32_t *sorted_idx, uint32_t n, double *sfeat) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t o = sorted_idx[i];
+  for (int d = 0; d < 6; ++d) sfeat[(size_t)i * 6 + d] = feat[(size_t)o * 6 + d];
+}
+
+__device__ __forceinline__ uint32_t lower_bound_u32(const uint32_t *a, uint32_t n, uint32_t key) {
+  uint32_t lo = 0, hi = n;
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (a[mid] < key)
+      lo = mid + 1;
+    else
+      hi = mid;
+  }
+  return lo;
+}
+
+struct TopK {
+  double d[kMaxK];
+  uint32_t id[kMaxK];
+  int k, cnt;
+  __device__ __forceinline__ double worst() const { return cnt < k ? 1e300 : d[k - 1]; }
+  // sorted insertion with static indexing (keeps the arrays in registers); order = (distance, index)
+  __device__ __forceinline__ void push(double dist, uint32_t idx) {
+    if (cnt == k && !(dist < d[k - 1] || (dist == d[k - 1] && idx < id[k - 1]))) return;
+    double cd = dist;
+    uint32_t ci = idx;
+#pragma unroll
+    for (int i = 0; i < kMaxK; ++i) {
+      if (i < k) {
+        const bool empty = i >= cnt;
+        const bool before = empty || cd < d[i] || (cd == d[i] && ci < id[i]);
+        if (before) {
+          const double td = d[i];
+          const uint32_t ti = id[i];
+          d[i] = cd, id[i] = ci;
+          cd = td, ci = ti;
+          if (empty) {
+            cd = 1e300;  // nothing real is carried further
+          }
+        }
+      }
+    }
+    if (cnt < k) ++cnt;
+  }
+};
+
+// exact k-NN + gates.  gated[q][j] = j-th neighbour passing the first three gates (kNone-terminated).
+__global__ void __launch_bounds__(128) k_knn_gate(const wc_surfel *q_surf, const wc_pose *q_pose, uint32_t nq, const double *sfeat,
+                                                 const uint32_t *skeys, const uint32_t *sorig, const double *tworld, uint32_t nt,
+                                                 MatchParams M, uint32_t *gated, uint32_t *knn_idx, double *knn_d2) {
+  const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= nq) return;
+  double f[6];
+  V3 cq, nq_w;
+  feature6(q_surf[q], q_pose[q], M.cs, M.as, f, cq, nq_w);
+  const double tq = q_surf[q].t;
+  TopK top;
+  top.k = M.k;
+  top.cnt = 0;
+  for (int i = 0; i < kMaxK; ++i) {
+    top.d[i] = 1e300;
+    top.id[i] = 0;
+  }
+  // query cell (unclamped, so that the distance bound stays valid for queries outside the target bbox)
+  const double gx = (f[0] - M.org[0]) / M.h, gy = (f[1] - M.org[1]) / M.h, gz = (f[2] - M.org[2]) / M.h;
+  const int cx = (int)floor(gx), cy = (int)floor(gy), cz = (int)floor(gz);
+  // distance from the query to the nearest face of its own cell, in scaled units
+  const double in_cell = fmin(fmin(fmin(gx - cx, cx + 1 - gx), fmin(gy - cy, cy + 1 - gy)), fmin(gz - cz, cz + 1 - gz)) * M.h;
+  const int rmax = max(max(max(cx, M.dim[0] - 1 - cx), max(cy, M.dim[1] - 1 - cy)), max(cz, M.dim[2] - 1 - cz));
+
+  auto scan_range = [&](int x0, int x1, int y, int z) {
+    if (y < 0 || y >= M.dim[1] || z < 0 || z >= M.dim[2]) return;
+    x0 = max(x0, 0);
+    x1 = min(x1, M.dim[0] - 1);
+    if (x0 > x1) return;
+    const uint32_t base = ((uint32_t)y << 10) | ((uint32_t)z << 20);
+    const uint32_t b = lower_bound_u32(skeys, nt, base | (uint32_t)x0);
+    const uint32_t e = lower_bound_u32(skeys, nt, (base | (uint32_t)x1) + 1u);
+    for (uint32_t i = b; i < e; ++i) {
+      const double *p = sfeat + (size_t)i * 6;
+      double s = 0.0;
+#pragma unroll
+      for (int d = 0; d < 6; ++d) {  // flann::L2_Simple: plain running sum of squared differences
+        const double df = f[d] - p[d];
+        s += df * df;
+      }
+      top.push(s, sorig[i]);
+    }
+  };
+
+  for (int r = 0; r <= rmax; ++r) {
+    if (r == 0) {
+      scan_range(cx, cx, cy, cz);
+    } else {
+      for (int dz = -r; dz <= r; ++dz)
+        for (int dy = -r; dy <= r; ++dy) {
+          if (max(abs(dy), abs(dz)) == r) {
+            scan_range(cx - r, cx + r, cy + dy, cz + dz);
+          } else {
+            scan_range(cx - r, cx - r, cy + dy, cz + dz);
+            scan_range(cx + r, cx + r, cy + dy, cz + dz);
+          }
+        }
+    }
+    // everything not yet scanned is at least `bound` away from the query (in 3-D, hence in 6-D)
+    const double bound = r * M.h + in_cell;
+    if (top.cnt == top.k && top.worst() < bound * bound) break;
+  }
+  // Q10: FLANN leaves the tail of the result untouched (zero-initialised) when fewer than k targets exist
+  uint32_t out = 0;
+  for (int j = 0; j < kMaxK; ++j) {
+    if (j >= M.k) break;
+    const uint32_t c = (j < top.cnt) ? top.id[j] : 0u;
+    if (knn_idx) {
+      knn_idx[(size_t)q * M.k + j] = c;
+      knn_d2[(size_t)q * M.k + j] = (j < top.cnt) ? top.d[j] : 0.0;
+    }
+    const double *w = tworld + (size_t)c * 7;
+    if (fabs(w[6] - tq) < M.time_min) continue;                                      // cc:26
+    const V3 nc = mk3(w[3], w[4], w[5]);
+    if (acos(dot(nq_w, nc)) > M.ang_max) continue;                                    // cc:29, surfel.h:105-107
+    if (fabs(dot(nq_w, cq - mk3(w[0], w[1], w[2]))) > M.dist_max) continue;           // cc:32
+    gated[(size_t)q * M.k + out++] = c;
+  }
+  for (; out < (uint32_t)M.k; ++out) gated[(size_t)q * M.k + out] = kNone;
+}
+
+// choice(q) = first gated candidate c that is not already paired with q from c's own turn (c < q and choice(c) == q)
+__global__ void __launch_bounds__(256) k_resolve(const uint32_t *gated, uint32_t nq, int k, int same_set, const uint32_t *choice_in,
+                                                uint32_t *choice_out, uint32_t *changed) {
+  const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= nq) return;
+  uint32_t pick = kNone;
+  for (int j = 0; j < k; ++j) {
+    const uint32_t c = gated[(size_t)q * k + j];
+    if (c == kNone) break;
+    if (same_set && c < q && choice_in[c] == q) continue;  // {c, q} is already in surfel_pairs (cc:35-38)
+    pick = c;
+    break;
+  }
+  choice_out[q] = pick;
+  if (pick != choice_in[q]) atomicOr(changed, 1u);
+}
+
+__global__ void __launch_bounds__(256) k_flags(const uint32_t *choice, uint32_t nq, uint32_t *flags) {
+  const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q < nq) flags[q] = choice[q] != kNone ? 1u : 0u;
+}
+
+__global__ void __launch_bounds__(256) k_emit_pairs(const uint32_t *choice, const uint32_t *offsets, uint32_t nq, const wc_surfel *q_surf,
+                                                   const double *tworld, int same_set, wc_pair *pairs, uint64_t cap, uint32_t *status) {
+  const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= nq) return;
+  const uint32_t c = choice[q];
+  if (c == kNone) return;
+  const uint32_t o = offsets[q];
+  atomicMax(&status[0], o + 1);  // total = last offset + 1
+  if (o >= cap) return;
+  const double tq = q_surf[q].t, tc = tworld[(size_t)c * 7 + 6];
+  if (same_set) {
+    pairs[o] = (tq < tc) ? wc_pair{(int32_t)q, (int32_t)c} : wc_pair{(int32_t)c, (int32_t)q};  // (older, newer), cc:41-45
+  } else {
+    if (!(tc < tq)) atomicOr(&status[1], 2u);  // the fixed-window surfel must be the older one (CHECK_LT, cc:301)
+    pairs[o] = wc_pair{(int32_t)c, (int32_t)q};
+  }
+}
+
+}  // namespace
+
+// scratch lives in ctx->b_misc[1..7] slots to avoid another state struct
+extern "C" int wc_match(wc_ctx *ctx, const wc_surfel *d_q_surf, const wc_pose *d_q_pose, uint64_t nq_, const wc_surfel *d_t_surf,
+                        const wc_pose *d_t_pose, uint64_t nt_, int same_set, wc_pair *d_pairs, uint64_t cap, uint64_t *h_n_pairs,
+                        uint32_t *d_knn_idx, double *d_knn_d2) {
+  if (!ctx || !h_n_pairs) return WC_ERR_ARG;
+  *h_n_pairs = 0;
+  if (nt_ == 0 || nq_ == 0) return WC_OK;  // knn_surfel_matcher.cc:18-20
+  if (nq_ >= (1ull << 31) || nt_ >= (1ull << 31)) return WC_ERR_ARG;
+  const uint32_t nq = (uint32_t)nq_, nt = (uint32_t)nt_;
+  const wc_params &P = ctx->P;
+  hipStream_t st = ctx->stream;
+  wc_buf &b_feat = ctx->b_misc[1], &b_world = ctx->b_misc[2], &b_sfeat = ctx->b_misc[3], &b_gated = ctx->b_misc[4],
+         &b_choice = ctx->b_misc[5], &b_aux = ctx->b_misc[6], &b_scan = ctx->b_misc[7];
+  WC_TRY(wc_ensure(ctx, b_feat, (size_t)nt * 6 * 8));
+  WC_TRY(wc_ensure(ctx, b_world, (size_t)nt * 7 * 8));
+  WC_TRY(wc_ensure(ctx, b_sfeat, (size_t)nt * 6 * 8));
+  WC_TRY(wc_ensure(ctx, b_gated, (size_t)nq * P.knn_k * 4));
+  WC_TRY(wc_ensure(ctx, b_choice, (size_t)nq * 4 * 4));  // choice[2], flags, offsets
+  WC_TRY(wc_ensure(ctx, ctx->b_keys[0], (size_t)nt * 4));
+  WC_TRY(wc_ensure(ctx, ctx->b_keys[1], (size_t)nt * 4));
+  WC_TRY(wc_ensure(ctx, ctx->b_vals[0], (size_t)nt * 4));
+  WC_TRY(wc_ensure(ctx, ctx->b_vals[1], (size_t)nt * 4));
+  WC_TRY(wc_ensure(ctx, b_aux, 256));
+  WC_TRY(wc_ensure(ctx, ctx->b_status, 64 * 4));
+  uint32_t *status = (uint32_t *)ctx->b_status.p;
+  unsigned long long *bbox = (unsigned long long *)b_aux.p;
+  uint32_t *changed = (uint32_t *)((char *)b_aux.p + 64);
+
+  // 1. features + bounding box of the scaled centres
+  unsigned long long init[6] = {~0ull, ~0ull, ~0ull, 0ull, 0ull, 0ull};
+  WC_HIP(ctx, hipMemcpyAsync(bbox, init, sizeof(init), hipMemcpyHostToDevice, st));
+  WC_HIP(ctx, hipMemsetAsync(status, 0, 64 * 4, st));
+  k_features<<<(nt + 255) / 256, 256, 0, st>>>(d_t_surf, d_t_pose, nt, P.center_scale, P.angular_scale, (double *)b_feat.p,
+                                              (double *)b_world.p, bbox);
+  unsigned long long hb[6];
+  WC_HIP(ctx, hipMemcpyAsync(hb, bbox, sizeof(hb), hipMemcpyDeviceToHost, st));
+  WC_HIP(ctx, hipStreamSynchronize(st));
+  MatchParams M;
+  M.cs = P.center_scale, M.as = P.angular_scale;
+  M.time_min = P.time_diff_min, M.ang_max = P.angular_scale, M.dist_max = P.surfel_dist_max;
+  M.k = P.knn_k;
+  double lo[3], hi[3], ext = 0;
+  for (int d = 0; d < 3; ++d) {
+    lo[d] = dec_host(hb[d]);
+    hi[d] = dec_host(hb[3 + d]);
+    if (!std::isfinite(lo[d]) || !std::isfinite(hi[d])) return wc_fail(ctx, WC_ERR_ARG, "non-finite surfel centre");
+    ext = std::max(ext, hi[d] - lo[d]);
+  }
+  M.h = std::max(1.0, ext / 1000.0);  // one scaled unit (= 1 m) per cell unless the cloud spans more than 1000 cells
+  for (int d = 0; d < 3; ++d) {
+    M.org[d] = lo[d];
+    M.dim[d] = std::min(1024, (int)std::floor((hi[d] - lo[d]) / M.h) + 1);
+  }
+  // 2. sort targets by cell (x fastest)
+  uint32_t *k0 = (uint32_t *)ctx->b_keys[0].p, *k1 = (uint32_t *)ctx->b_keys[1].p;
+  uint32_t *v0 = (uint32_t *)ctx->b_vals[0].p, *v1 = (uint32_t *)ctx->b_vals[1].p;
+  k_cell_keys<<<(nt + 255) / 256, 256, 0, st>>>((const double *)b_feat.p, nt, M, k0, v0);
+  {
+    size_t tmp = 0;
+    WC_HIP(ctx, rocprim::radix_sort_pairs(nullptr, tmp, k0, k1, v0, v1, (size_t)nt, 0u, 30u, st));
+    WC_TRY(wc_ensure(ctx, ctx->b_sorttmp, tmp));
+    tmp = ctx->b_sorttmp.cap;
+    WC_HIP(ctx, rocprim::radix_sort_pairs(ctx->b_sorttmp.p, tmp, k0, k1, v0, v1, (size_t)nt, 0u, 30u, st));
+  }
+  k_sorted_feat<<<(nt + 255) / 256, 256, 0, st>>>((const double *)b_feat.p, v1, nt, (double *)b_sfeat.p);
+  // 3. exact k-NN + gates
+  k_knn_gate<<<(nq + 127) / 128, 128, 0, st>>>(d_q_surf, d_q_pose, nq, (const double *)b_sfeat.p, k1, v1, (const double *)b_world.p, nt, M,
+                                              (uint32_t *)b_gated.p, d_knn_idx, d_knn_d2);
+  WC_HIP(ctx, hipGetLastError());
+  // 4. resolve the order-dependent "pair already seen" rule by fixed-point iteration
+  uint32_t *choice[2] = {(uint32_t *)b_choice.p, (uint32_t *)b_choice.p + nq};
+  uint32_t *flags = (uint32_t *)b_choice.p + 2 * (size_t)nq, *offsets = (uint32_t *)b_choice.p + 3 * (size_t)nq;
+  WC_HIP(ctx, hipMemsetAsync(choice[0], 0xFF, (size_t)nq * 4, st));
+  int cur = 0;
+  for (int it = 0; it < 1000000; ++it) {
+    WC_HIP(ctx, hipMemsetAsync(changed, 0, 4, st));
+    k_resolve<<<(nq + 255) / 256, 256, 0, st>>>((const uint32_t *)b_gated.p, nq, P.knn_k, same_set, choice[cur], choice[cur ^ 1], changed);
+    uint32_t hc = 0;
+    WC_HIP(ctx, hipMemcpyAsync(&hc, changed, 4, hipMemcpyDeviceToHost, st));
+    WC_HIP(ctx, hipStreamSynchronize(st));
+    cur ^= 1;
+    if (!hc || !same_set) break;
+  }
+  // 5. compact in query order
+  k_flags<<<(nq + 255) / 256, 256, 0, st>>>(choice[cur], nq, flags);
+  {
+    size_t tmp = 0;
+    WC_HIP(ctx, rocprim::exclusive_scan(nullptr, tmp, flags, offsets, 0u, (size_t)nq, rocprim::plus<uint32_t>(), st));
+    WC_TRY(wc_ensure(ctx, b_scan, tmp + 16));
+    tmp = b_scan.cap;
+    WC_HIP(ctx, rocprim::exclusive_scan(b_scan.p, tmp, flags, offsets, 0u, (size_t)nq, rocprim::plus<uint32_t>(), st));
+  }
+  k_emit_pairs<<<(nq + 255) / 256, 256, 0, st>>>(choice[cur], offsets, nq, d_q_surf, (const double *)b_world.p, same_set, d_pairs, cap, status);
+  WC_HIP(ctx, hipGetLastError());
+  WC_HIP(ctx, hipMemcpyAsync(ctx->h_status, status, 8, hipMemcpyDeviceToHost, st));
+  WC_HIP(ctx, hipStreamSynchronize(st));
+  *h_n_pairs = ctx->h_status[0];
+  if (ctx->h_status[1] & 2u) return wc_fail(ctx, WC_ERR_ORDER, "fixed-window surfel newer than its sliding-window match");
+  if (ctx->h_status[0] > cap) return wc_fail(ctx, WC_ERR_CAPACITY, "pair capacity %llu < %u", (unsigned long long)cap, ctx->h_status[0]);
+  return WC_OK;
+}

@@ -246,3 +246,29 @@ class Context:
 
         self._cb = CB(_tramp) if fn else C.cast(None, CB)
         self._ck(self.lib.wc_window_set_allreduce(self.h, self._cb, C.c_void_p(0)))
+
+    # ---- correspondence ---------------------------------------------------------------------------------------------
+    def match_device(self, d_q_surf, d_q_pose, nq, d_t_surf, d_t_pose, nt, same_set, d_pairs, cap, d_knn_idx=None, d_knn_d2=None):
+        n = C.c_uint64(0)
+        self._ck(self.lib.wc_match(self.h, C.c_void_p(d_q_surf.ptr), C.c_void_p(d_q_pose.ptr), C.c_uint64(nq), C.c_void_p(d_t_surf.ptr),
+                                   C.c_void_p(d_t_pose.ptr), C.c_uint64(nt), C.c_int(1 if same_set else 0), C.c_void_p(d_pairs.ptr), C.c_uint64(cap),
+                                   C.byref(n), C.c_void_p(d_knn_idx.ptr if d_knn_idx else 0), C.c_void_p(d_knn_d2.ptr if d_knn_d2 else 0)))
+        return int(n.value)
+
+    def match(self, q_surf, q_pose, t_surf, t_pose, same_set, want_knn=False):
+        """host convenience -> pairs[PAIR] (and the raw k-NN table if want_knn)"""
+        nq, nt = len(q_surf), len(t_surf)
+        dq, dqp = self.to_device(q_surf), self.to_device(q_pose)
+        if same_set:
+            dt, dtp = dq, dqp
+        else:
+            dt, dtp = self.to_device(t_surf), self.to_device(t_pose)
+        d_pairs = self.alloc(8 * max(nq, 1))
+        k = self.params.knn_k
+        d_idx = self.alloc(4 * max(nq, 1) * k) if want_knn else None
+        d_d2 = self.alloc(8 * max(nq, 1) * k) if want_knn else None
+        n = self.match_device(dq, dqp, nq, dt, dtp, nt, same_set, d_pairs, nq, d_idx, d_d2)
+        pairs = d_pairs.download(R.PAIR, n)
+        if want_knn:
+            return pairs, d_idx.download(np.uint32, nq * k).reshape(nq, k), d_d2.download(np.float64, nq * k).reshape(nq, k)
+        return pairs
