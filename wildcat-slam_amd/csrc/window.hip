@@ -43,6 +43,7 @@ namespace {
 
 constexpr int kPiece = 256;   // records per piece (= threads per assembly workgroup)
 constexpr int kNB = 32;       // Cholesky block size
+constexpr uint32_t kHeavySrc = 24;  // block pairs with more gather sources than this get the multi-group gather
 
 // ------------------------------------------------------------------------------------------------------------------
 struct ImuRec {
@@ -81,7 +82,8 @@ struct wc_window_state {
   std::vector<double> times;
   // device buffers
   wc_buf times_d, brec, bkey, borig, urec, ukey, uorig, irec, pieces, partial, src, src_begin, gsrc, gsrc_begin;
-  wc_buf lin, Linv;  // lin = [H (n*n) | g (np) | cost, spare]: ONE contiguous buffer, the unit of the multi-GPU all-reduce
+  wc_buf lin, Linv, heavy, Lmat;
+  uint32_t nheavy = 0;  // lin = [H (n*n) | g (np) | cost, spare]: ONE contiguous buffer, the unit of the multi-GPU all-reduce
   int (*allreduce)(void *, double *, uint64_t) = nullptr;
   void *allreduce_user = nullptr;
   wc_buf x, xc, H_unused, g_unused, scale, diag, A, y, mail, cost_part, keys_tmp[2], vals_tmp[2], heads, status;
@@ -441,10 +443,14 @@ __global__ void __launch_bounds__(256) k_lin_imu(WinParams wp, const Piece *piec
   }
 }
 
-// gather the piece partials into the dense normal equations: one workgroup per 12x12 block pair (I <= J)
-__global__ void __launch_bounds__(144) k_gather_H(const Src *src, const uint32_t *src_begin, const double *partial, int ns,
-                                                 int fix_first, double *H) {
-  const int pid = blockIdx.x;
+// gather the piece partials into the dense normal equations: one workgroup per 12x12 block pair (I <= J).
+// G groups of 144 threads stride over the pair's source list (diagonal-band pairs have hundreds of sources, the rest
+// at most four); the group partial sums are combined in fixed order, so the result is bitwise reproducible.
+template <int G>
+__global__ void __launch_bounds__(144 * G) k_gather_H(const Src *src, const uint32_t *src_begin, const double *partial, int ns,
+                                                     int fix_first, const uint32_t *pair_list, double *H) {
+  __shared__ double sred[G][144];
+  const int pid = pair_list ? (int)pair_list[blockIdx.x] : (int)blockIdx.x;
   // invert pid = I*ns - I(I-1)/2 + (J-I)
   int I = 0, rem = pid;
   while (rem >= ns - I) {
@@ -452,10 +458,12 @@ __global__ void __launch_bounds__(144) k_gather_H(const Src *src, const uint32_t
     ++I;
   }
   const int J = I + rem;
-  const int u = threadIdx.x / 12, v = threadIdx.x % 12;
+  const int grp = threadIdx.x / 144, e = threadIdx.x % 144;
+  const int u = e / 12, v = e % 12;
   double acc = 0.0;
-  const uint32_t b = src_begin[pid], e = src_begin[pid + 1];
-  for (uint32_t s = b; s < e; ++s) {
+  const uint32_t b = src_begin[pid], eend = src_begin[pid + 1];
+  if (G == 1 && eend - b > kHeavySrc) return;  // long source lists are handled by the 7-group launch
+  for (uint32_t s = b + grp; s < eend; s += G) {
     const Src sr = src[s];
     if (u < sr.w && v < sr.w) {
       uint32_t r = sr.p * sr.w + u, c = sr.q * sr.w + v;
@@ -466,6 +474,13 @@ __global__ void __launch_bounds__(144) k_gather_H(const Src *src, const uint32_t
       acc += partial[sr.part_off + tri_index(r, c, sr.T)];
     }
   }
+  if (G > 1) {
+    sred[grp][e] = acc;
+    __syncthreads();
+    if (grp != 0) return;
+    acc = 0.0;
+    for (int q = 0; q < G; ++q) acc += sred[q][e];
+  }
   const int n = 12 * ns;
   const int gi = I * 12 + u, gj = J * 12 + v;
   if (fix_first && ((gi >= 3 && gi < 6) || (gj >= 3 && gj < 6))) acc = 0.0;  // SubsetParameterization(12,{3,4,5})
@@ -473,15 +488,21 @@ __global__ void __launch_bounds__(144) k_gather_H(const Src *src, const uint32_t
   H[(size_t)gj * n + gi] = acc;
 }
 
-__global__ void __launch_bounds__(64) k_gather_g(const GSrc *gsrc, const uint32_t *gsrc_begin, const double *partial, int fix_first,
-                                                double *g) {
-  const int I = blockIdx.x, u = threadIdx.x;
-  if (u >= 12) return;
+// g = J^T r: one workgroup per sample block, 16 groups of 12 lanes stride over the block's source list
+__global__ void __launch_bounds__(192) k_gather_g(const GSrc *gsrc, const uint32_t *gsrc_begin, const double *partial, int fix_first,
+                                                 double *g) {
+  __shared__ double sred[16][12];
+  const int I = blockIdx.x, grp = threadIdx.x / 12, u = threadIdx.x % 12;
   double acc = 0.0;
-  for (uint32_t s = gsrc_begin[I]; s < gsrc_begin[I + 1]; ++s) {
+  for (uint32_t s = gsrc_begin[I] + grp; s < gsrc_begin[I + 1]; s += 16) {
     const GSrc sr = gsrc[s];
     if (u < sr.w) acc += partial[sr.part_off + tri_index(sr.p * sr.w + u, sr.T - 1, sr.T)];
   }
+  sred[grp][u] = acc;
+  __syncthreads();
+  if (grp != 0) return;
+  acc = 0.0;
+  for (int q = 0; q < 16; ++q) acc += sred[q][u];
   const int gi = I * 12 + u;
   if (fix_first && gi >= 3 && gi < 6) acc = 0.0;
   g[gi] = acc;
@@ -608,119 +629,219 @@ __global__ void __launch_bounds__(256) k_damp(const double *H, const double *g, 
   A[(size_t)i * ld + j] = v;
 }
 
-// Panel step k of the blocked right-looking Cholesky: every workgroup factors the diagonal block (redundantly, in LDS),
-// inverts it, and turns its own row block A_ik into L_ik = A_ik L_kk^-T.
-__global__ void __launch_bounds__(64) k_chol_panel(double *A, int ld, int k, int *fail, double *Linv) {
-  __shared__ double sL[kNB][kNB + 1];
-  __shared__ double sInv[kNB][kNB + 1];
-  __shared__ double sA[kNB][kNB + 1];
-  const int lane = threadIdx.x;
-  const int ib = k + blockIdx.x;  // row block handled by this workgroup
-  double *Akk = A + (size_t)k * kNB * ld + (size_t)k * kNB;
-  for (int e = lane; e < kNB * kNB; e += 64) sL[e / kNB][e % kNB] = Akk[(size_t)(e / kNB) * ld + (e % kNB)];
-  __syncthreads();
-  // right-looking factorisation of the 32x32 block; lane r owns row r
+// ---- blocked right-looking Cholesky, one launch per 32-column panel ----------------------------------------------------
+// Step k consumes L_kk^-1 (left behind by step k-1) and, for every 64x64 tile (ti >= tj) of the trailing matrix:
+//   L_ik = A_ik L_kk^-T for the tile's rows and columns (recomputed per tile: two 64x32x32 products, cheaper than a
+//   separate TRSM launch and its dependency), A_ij -= L_ik L_jk^T, and (tiles of the first column) L_ik -> Lmat.
+// Tile (0,0) then factors the next diagonal block in place (look-ahead), so the whole factorisation is nblk launches
+// with no separate diagonal kernel on the critical path.  L is collected in Lmat (A keeps being updated in place).
+
+// Cholesky factor of the 32x32 block sB (lower part, in place), by ONE wavefront (no workgroup barriers on the
+// sequential pivot chain): lane = (row r, column half h).  Returns false on a non-positive pivot.
+__device__ __forceinline__ bool factor32_wave(double (*sB)[kNB + 1]) {
+  const int l = threadIdx.x & 63;
+  const int r = l & 31, h = l >> 5;
+  bool ok = true;
   for (int j = 0; j < kNB; ++j) {
-    const double ajj = sL[j][j];
+    const double ajj = sB[j][j];
     if (!(ajj > 0.0)) {
-      if (lane == 0 && blockIdx.x == 0) atomicOr(fail, 1);
-      return;
+      ok = false;
+      break;  // uniform
     }
-    const double inv = 1.0 / sqrt(ajj);
-    __syncthreads();
-    if (lane < kNB && lane >= j) sL[lane][j] = sL[lane][j] * inv;
-    __syncthreads();
-    if (lane < kNB && lane > j) {
-      const double lij = sL[lane][j];
-      for (int c = j + 1; c <= lane; ++c) sL[lane][c] -= lij * sL[c][j];
+    double inv = __builtin_amdgcn_rsq(ajj);              // v_rsq_f64 seed + two Newton steps
+    inv = inv * (1.5 - 0.5 * ajj * inv * inv);
+    inv = inv * (1.5 - 0.5 * ajj * inv * inv);
+    __builtin_amdgcn_wave_barrier();
+    if (h == 0 && r >= j) sB[r][j] *= inv;  // column j of L (diagonal becomes sqrt(a_jj))
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // trailing update of the block: lane (r, h) owns columns h*16 .. h*16+15 of row r; loads batched before stores
+    const double lrj = sB[r][j];
+    double v[16], lc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int c = h * 16 + i;
+      v[i] = sB[r][c];
+      lc[i] = sB[c][j];
     }
-    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int c = h * 16 + i;
+      if (c > j && c <= r) sB[r][c] = v[i] - lrj * lc[i];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
   }
-  // inverse of the lower-triangular block: lane c solves L X[:,c] = e_c
-  if (lane < kNB) {
-    const int c = lane;
-    for (int r = 0; r < kNB; ++r) {
-      double s = (r == c) ? 1.0 : 0.0;
-      for (int m2 = c; m2 < r; ++m2) s -= sL[r][m2] * sInv[m2][c];
-      sInv[r][c] = (r < c) ? 0.0 : s / sL[r][r];
-    }
-  }
+  return ok;
+}
+
+// inverse of the lower-triangular 32x32 block sL into sXi by forward elimination applied to the identity; all 256
+// threads of the block take part (4 elements each)
+__device__ __forceinline__ void invert32(double (*sL)[kNB + 1], double (*sXi)[kNB + 1]) {
+  const int t = threadIdx.x;
+  const int c = t & 31, r0 = t >> 5;  // rows r0, r0+8, r0+16, r0+24
+  for (int e = t; e < kNB * kNB; e += 256) sXi[e / kNB][e % kNB] = (e / kNB == e % kNB) ? 1.0 : 0.0;
   __syncthreads();
-  if (ib == k) {
-    for (int e = lane; e < kNB * kNB; e += 64) {
-      const int r = e / kNB, c = e % kNB;
-      Akk[(size_t)r * ld + c] = (c <= r) ? sL[r][c] : 0.0;
-    }
-    for (int e = lane; e < kNB * kNB; e += 64) Linv[(size_t)k * kNB * kNB + e] = sInv[e / kNB][e % kNB];
-  } else {
-    double *Aik = A + (size_t)ib * kNB * ld + (size_t)k * kNB;
-    for (int e = lane; e < kNB * kNB; e += 64) sA[e / kNB][e % kNB] = Aik[(size_t)(e / kNB) * ld + (e % kNB)];
+  for (int j = 0; j < kNB; ++j) {
+    if (t < kNB) sXi[j][t] /= sL[j][j];
     __syncthreads();
-    // L_ik = A_ik * Linv^T : out[r][c] = sum_m A[r][m] * Linv[c][m]
-    for (int e = lane; e < kNB * kNB; e += 64) {
-      const int r = e / kNB, c = e % kNB;
-      double s = 0.0;
-      for (int m2 = 0; m2 <= c; ++m2) s += sA[r][m2] * sInv[c][m2];
-      Aik[(size_t)r * ld + c] = s;
+    const double xj = sXi[j][c];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int r = r0 + 8 * q;
+      if (r > j && c <= j) sXi[r][c] -= sL[r][j] * xj;
     }
+    __syncthreads();
   }
 }
 
-// trailing update after panel k: A_ij -= L_ik L_jk^T for k < j <= i, 64x64 tiles, 4x4 outputs per thread
-__global__ void __launch_bounds__(256) k_chol_update(double *A, int ld, int k, int nblk) {
-  __shared__ double sI[64][kNB + 1];
-  __shared__ double sJ[64][kNB + 1];
-  // tile coordinates in units of 64 rows, counted from the first trailing block
-  const int first = (k + 1) * kNB;
-  const int ti = blockIdx.y, tj = blockIdx.x;
-  if (tj > ti) return;
-  const int row0 = first + ti * 64, col0 = first + tj * 64;
-  const int nrow = nblk * kNB;
-  const int tid = threadIdx.x;
-  for (int e = tid; e < 64 * kNB; e += 256) {
-    const int r = e / kNB, c = e % kNB;
-    sI[r][c] = (row0 + r < nrow) ? A[(size_t)(row0 + r) * ld + (size_t)k * kNB + c] : 0.0;
-    sJ[r][c] = (col0 + r < nrow) ? A[(size_t)(col0 + r) * ld + (size_t)k * kNB + c] : 0.0;
+__global__ void __launch_bounds__(64) k_chol_first(const double *A, int ld, double *Lmat, int *fail) {
+  __shared__ double sB[kNB][kNB + 1];
+  for (int e = threadIdx.x; e < kNB * kNB; e += 64) sB[e / kNB][e % kNB] = A[(size_t)(e / kNB) * ld + e % kNB];
+  __syncthreads();
+  if (!factor32_wave(sB)) {
+    if (threadIdx.x == 0) atomicOr(fail, 1);
+    return;
   }
   __syncthreads();
+  for (int e = threadIdx.x; e < kNB * kNB; e += 64) {
+    const int r = e / kNB, c = e % kNB;
+    Lmat[(size_t)r * ld + c] = (c <= r) ? sB[r][c] : 0.0;
+  }
+}
+
+__global__ void __launch_bounds__(256) k_chol_step(double *A, int ld, int k, int nblk, double *Lmat, double *Linv, int *fail) {
+  __shared__ double sA[64][kNB + 1];
+  __shared__ double sLi[64][kNB + 1];
+  __shared__ double sLj[64][kNB + 1];
+  __shared__ double sX[kNB][kNB + 1];
+  const int ti = blockIdx.y, tj = blockIdx.x;
+  if (tj > ti) return;
+  if (*fail) return;
+  const int tid = threadIdx.x;
+  const int nrow = nblk * kNB;
+  const int first = (k + 1) * kNB;
+  const int row0 = first + ti * 64, col0 = first + tj * 64;
+  const size_t pc = (size_t)k * kNB;  // first column of the panel
+  // L_kk^-1, rebuilt by every tile from the diagonal block the previous launch left in Lmat (parallel, off the
+  // sequential pivot chain); tile (0,0) also keeps it for the back substitution
+  for (int e = tid; e < kNB * kNB; e += 256) sLj[e / kNB][e % kNB] = Lmat[(size_t)(pc + e / kNB) * ld + pc + e % kNB];
+  __syncthreads();
+  invert32(sLj, sX);
+  if (ti == 0 && tj == 0)
+    for (int e = tid; e < kNB * kNB; e += 256) Linv[(size_t)k * kNB * kNB + e] = sX[e / kNB][e % kNB];
+  // L rows of this tile's row range: Li = A[row0.., panel] * Linv^T
+  for (int e = tid; e < 64 * kNB; e += 256) {
+    const int r = e / kNB, c = e % kNB;
+    sA[r][c] = (row0 + r < nrow) ? A[(size_t)(row0 + r) * ld + pc + c] : 0.0;
+  }
+  __syncthreads();
+  {
+    const int r = tid >> 2, c0 = (tid & 3) * 8;
+    double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int m2 = 0; m2 < kNB; ++m2) {
+      const double a = sA[r][m2];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) acc[q] += a * sX[c0 + q][m2];
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) sLi[r][c0 + q] = acc[q];
+    if (tj == 0 && row0 + r < nrow) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) Lmat[(size_t)(row0 + r) * ld + pc + c0 + q] = acc[q];
+    }
+  }
+  __syncthreads();
+  if (ti != tj) {
+    for (int e = tid; e < 64 * kNB; e += 256) {
+      const int r = e / kNB, c = e % kNB;
+      sA[r][c] = (col0 + r < nrow) ? A[(size_t)(col0 + r) * ld + pc + c] : 0.0;
+    }
+    __syncthreads();
+    const int r = tid >> 2, c0 = (tid & 3) * 8;
+    double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int m2 = 0; m2 < kNB; ++m2) {
+      const double a = sA[r][m2];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) acc[q] += a * sX[c0 + q][m2];
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) sLj[r][c0 + q] = acc[q];
+  } else {
+    for (int e = tid; e < 64 * kNB; e += 256) sLj[e / kNB][e % kNB] = sLi[e / kNB][e % kNB];
+  }
+  __syncthreads();
+  // trailing update of this tile: A_ij -= Li Lj^T, 4x4 outputs per thread
   const int tr = (tid / 16) * 4, tc = (tid % 16) * 4;
   double acc[4][4] = {{0}};
   for (int m2 = 0; m2 < kNB; ++m2) {
     double a[4], b[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      a[q] = sI[tr + q][m2];
-      b[q] = sJ[tc + q][m2];
+      a[q] = sLi[tr + q][m2];
+      b[q] = sLj[tc + q][m2];
     }
 #pragma unroll
     for (int p = 0; p < 4; ++p)
 #pragma unroll
       for (int q = 0; q < 4; ++q) acc[p][q] += a[p] * b[q];
   }
+  const bool lead = (ti == 0 && tj == 0);
 #pragma unroll
   for (int p = 0; p < 4; ++p)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int r = row0 + tr + p, c = col0 + tc + q;
-      if (r < nrow && c <= r) A[(size_t)r * ld + c] -= acc[p][q];
+      if (r < nrow && c <= r) {
+        const double v = A[(size_t)r * ld + c] - acc[p][q];
+        A[(size_t)r * ld + c] = v;
+        if (lead && tr + p < kNB && tc + q < kNB) sA[tr + p][tc + q] = v;  // next diagonal block (lower part)
+      }
     }
+  if (!lead) return;
+  // look-ahead: factor the next diagonal block right away (one wavefront, barrier-free)
+  __syncthreads();
+  bool ok = true;
+  if (tid < 64) ok = factor32_wave(sA);  // rows 0..31 of sA hold the block
+  __syncthreads();
+  if (tid < 64 && !ok) {
+    if (tid == 0) atomicOr(fail, 1);
+  }
+  for (int e = tid; e < kNB * kNB; e += 256) {
+    const int r = e / kNB, c = e % kNB;
+    Lmat[(size_t)(first + r) * ld + first + c] = (c <= r) ? sA[r][c] : 0.0;
+  }
+}
+
+// inverse of the LAST diagonal block (no further step rebuilds it) for the back substitution
+__global__ void __launch_bounds__(256) k_chol_last_inv(const double *Lmat, int ld, int kb, double *Linv) {
+  __shared__ double sL[kNB][kNB + 1];
+  __shared__ double sXi[kNB][kNB + 1];
+  const size_t pc = (size_t)kb * kNB;
+  for (int e = threadIdx.x; e < kNB * kNB; e += 256) sL[e / kNB][e % kNB] = Lmat[(pc + e / kNB) * ld + pc + e % kNB];
+  __syncthreads();
+  invert32(sL, sXi);
+  for (int e = threadIdx.x; e < kNB * kNB; e += 256) Linv[(size_t)kb * kNB * kNB + e] = sXi[e / kNB][e % kNB];
 }
 
 // back substitution L^T y = z (z = row n of the factored augmented matrix), right-looking over 32-wide blocks from
-// last to first in ONE workgroup: y_k = Linv_kk^T z_k, then z_j -= L[block k rows][j] . y_k for every j left of it
-// (row-contiguous, coalesced reads of L; 32 independent loads per thread).
+// last to first in ONE workgroup: y_k = Linv_kk^T z_k (32x32 products + column sums), then z_j -= L[block k rows][j] . y_k
+// for every j left of it (row-contiguous, coalesced reads of L; 32 independent loads per thread).
 __global__ void __launch_bounds__(1024) k_chol_back(const double *A, int ld, int n, const double *Linv, double *y) {
   __shared__ double sz[4096];
+  __shared__ double sP[kNB][kNB + 1];
   __shared__ double syk[kNB];
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, m = tid >> 5, c = tid & 31;
   const int nblk = (n + kNB - 1) / kNB;
   for (int i = tid; i < nblk * kNB; i += 1024) sz[i] = (i < n) ? A[(size_t)n * ld + i] : 0.0;
   __syncthreads();
   for (int kb = nblk - 1; kb >= 0; --kb) {
+    sP[m][c] = (m >= c) ? Linv[(size_t)kb * kNB * kNB + tid] * sz[kb * kNB + m] : 0.0;  // Linv[m][c] z[m]
+    __syncthreads();
     if (tid < kNB) {
-      const double *Li = Linv + (size_t)kb * kNB * kNB;
       double acc = 0.0;
-      for (int m2 = tid; m2 < kNB; ++m2) acc += Li[m2 * kNB + tid] * sz[kb * kNB + m2];  // (Linv^T z)_c
+#pragma unroll
+      for (int q = 0; q < kNB; ++q) acc += sP[q][tid];
       syk[tid] = (kb * kNB + tid < n) ? acc : 0.0;
     }
     __syncthreads();
@@ -728,8 +849,9 @@ __global__ void __launch_bounds__(1024) k_chol_back(const double *A, int ld, int
     const int rows = min(kNB, n - kb * kNB);
     for (int j = tid; j < kb * kNB; j += 1024) {
       double acc = 0.0;
+      const double *col = A + (size_t)kb * kNB * ld + j;
 #pragma unroll 8
-      for (int r = 0; r < rows; ++r) acc += A[(size_t)(kb * kNB + r) * ld + j] * syk[r];
+      for (int rr = 0; rr < rows; ++rr) acc += col[(size_t)rr * ld] * syk[rr];
       sz[j] -= acc;
     }
     __syncthreads();
@@ -819,7 +941,7 @@ void wc_window_free(wc_ctx *ctx) {
   wc_window_state *W = ctx->win;
   if (!W) return;
   wc_buf *all[] = {&W->times_d, &W->brec, &W->bkey, &W->borig, &W->urec, &W->ukey, &W->uorig, &W->irec, &W->pieces, &W->partial,
-                   &W->src, &W->src_begin, &W->gsrc, &W->gsrc_begin, &W->x, &W->xc, &W->lin, &W->Linv, &W->scale, &W->diag, &W->A, &W->y,
+                   &W->src, &W->src_begin, &W->gsrc, &W->gsrc_begin, &W->x, &W->xc, &W->lin, &W->Linv, &W->heavy, &W->Lmat, &W->scale, &W->diag, &W->A, &W->y,
                    &W->mail, &W->cost_part, &W->keys_tmp[0], &W->keys_tmp[1], &W->vals_tmp[0], &W->vals_tmp[1], &W->heads, &W->status};
   for (wc_buf *b : all)
     if (b->p) (void)hipFree(b->p);
@@ -985,6 +1107,11 @@ extern "C" int wc_window_build(wc_ctx *ctx, const wc_surfel *d_sld_surf, const w
     src.insert(src.end(), per_pair[i].begin(), per_pair[i].end());
   }
   src_begin[npairs] = (uint32_t)src.size();
+  std::vector<uint32_t> heavy;
+  for (uint32_t i = 0; i < npairs; ++i)
+    if (src_begin[i + 1] - src_begin[i] > kHeavySrc) heavy.push_back(i);
+  W->nheavy = (uint32_t)heavy.size();
+  WC_TRY(upload(ctx, W->heavy, heavy));
   std::vector<GSrc> gsrc;
   std::vector<uint32_t> gsrc_begin(ns + 1, 0);
   for (int i = 0; i < ns; ++i) {
@@ -1007,6 +1134,7 @@ extern "C" int wc_window_build(wc_ctx *ctx, const wc_surfel *d_sld_surf, const w
   WC_TRY(wc_ensure(ctx, W->scale, n * 8));
   WC_TRY(wc_ensure(ctx, W->diag, n * 8));
   WC_TRY(wc_ensure(ctx, W->A, (size_t)W->np * W->ld * 8));
+  WC_TRY(wc_ensure(ctx, W->Lmat, (size_t)W->np * W->ld * 8));
   WC_TRY(wc_ensure(ctx, W->y, (size_t)W->np * 8));
   WC_TRY(wc_ensure(ctx, W->mail, 64 * 8));
   const size_t ncb = (W->nb + 255) / 256 + (W->nu + 255) / 256 + (W->ni + 255) / 256 + 8;
@@ -1061,9 +1189,12 @@ int enqueue_linearize(wc_ctx *ctx, wc_window_state *W, const double *d_x, int ma
   if (W->npiece_i)
     k_lin_imu<<<W->npiece_i, 256, 0, st>>>(W->wp, pcs + W->npiece_b + W->npiece_u, (const ImuRec *)W->irec.p, d_x,
                                           (const double *)W->times_d.p, partial);
-  k_gather_H<<<W->npairs, 144, 0, st>>>((const Src *)W->src.p, (const uint32_t *)W->src_begin.p, partial, W->ns, W->wp.fix_first,
-                                       lin_H(W));
-  k_gather_g<<<W->ns, 64, 0, st>>>((const GSrc *)W->gsrc.p, (const uint32_t *)W->gsrc_begin.p, partial, W->wp.fix_first, lin_g(W));
+  k_gather_H<1><<<W->npairs, 144, 0, st>>>((const Src *)W->src.p, (const uint32_t *)W->src_begin.p, partial, W->ns, W->wp.fix_first,
+                                          nullptr, lin_H(W));
+  if (W->nheavy)  // block pairs with long source lists (the diagonal band): 7 thread groups split each list
+    k_gather_H<7><<<W->nheavy, 144 * 7, 0, st>>>((const Src *)W->src.p, (const uint32_t *)W->src_begin.p, partial, W->ns,
+                                                W->wp.fix_first, (const uint32_t *)W->heavy.p, lin_H(W));
+  k_gather_g<<<W->ns, 192, 0, st>>>((const GSrc *)W->gsrc.p, (const uint32_t *)W->gsrc_begin.p, partial, W->wp.fix_first, lin_g(W));
   k_cost_sum<<<1, 1024, 0, st>>>(pcs, W->npiece_b + W->npiece_u + W->npiece_i, W->npiece_b, W->npiece_u, partial, nullptr, W->n,
                                 lin_cost(W), 0);
   WC_HIP(ctx, hipGetLastError());
@@ -1152,6 +1283,7 @@ extern "C" int wc_window_solve(wc_ctx *ctx, double *h_x_inout, wc_solve_summary 
   std::memset(summary, 0, sizeof(*summary));
   double *x = (double *)W->x.p, *xc = (double *)W->xc.p, *H = lin_H(W), *g = lin_g(W);
   double *scale = (double *)W->scale.p, *diag = (double *)W->diag.p, *A = (double *)W->A.p, *y = (double *)W->y.p;
+  double *Lmat = (double *)W->Lmat.p;
   double *mail = (double *)W->mail.p;
   int *fail = (int *)((double *)W->mail.p + 32);
   std::vector<double> best(h_x_inout, h_x_inout + n), cur(best), cand(n);
@@ -1188,15 +1320,13 @@ extern "C" int wc_window_solve(wc_ctx *ctx, double *h_x_inout, wc_solve_summary 
         dim3 grid((np + 255) / 256, np);
         k_damp<<<grid, 256, 0, st>>>(H, g, scale, n, np, ld, radius, A, diag);
       }
-      for (int k = 0; k < nblk; ++k) {
-        k_chol_panel<<<nblk - k, 64, 0, st>>>(A, ld, k, fail, (double *)W->Linv.p);
-        const int rem = nblk - k - 1;
-        if (rem > 0) {
-          const int tiles = (rem * kNB + 63) / 64;
-          k_chol_update<<<dim3(tiles, tiles), 256, 0, st>>>(A, ld, k, nblk);
-        }
+      k_chol_first<<<1, 64, 0, st>>>(A, ld, Lmat, fail);
+      for (int k = 0; k + 1 < nblk; ++k) {
+        const int tiles = ((nblk - k - 1) * kNB + 63) / 64;
+        k_chol_step<<<dim3(tiles, tiles), 256, 0, st>>>(A, ld, k, nblk, Lmat, (double *)W->Linv.p, fail);
       }
-      k_chol_back<<<1, 1024, 0, st>>>(A, ld, n, (const double *)W->Linv.p, y);
+      k_chol_last_inv<<<1, 256, 0, st>>>(Lmat, ld, nblk - 1, (double *)W->Linv.p);
+      k_chol_back<<<1, 1024, 0, st>>>(Lmat, ld, n, (const double *)W->Linv.p, y);
       k_step<<<1, 1024, 0, st>>>(x, y, scale, g, diag, n, xc, mail);
       WC_TRY(enqueue_evaluate(ctx, W, xc, nullptr, 5));
       WC_HIP(ctx, hipGetLastError());

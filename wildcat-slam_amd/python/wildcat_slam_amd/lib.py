@@ -225,6 +225,13 @@ class Context:
         self._ck(self.lib.wc_window_linearize(self.h, R.ptr(x), C.c_void_p(d_H.ptr), C.c_void_p(d_g.ptr), C.byref(cost)))
         return d_H.download(np.float64, n * n).reshape(n, n), d_g.download(np.float64, n), cost.value
 
+    def window_linearize_only(self, x):
+        """linearise without copying H / g out (benchmarks)"""
+        x = np.ascontiguousarray(x, np.float64)
+        cost = C.c_double(0)
+        self._ck(self.lib.wc_window_linearize(self.h, R.ptr(x), C.c_void_p(0), C.c_void_p(0), C.byref(cost)))
+        return cost.value
+
     def window_solve(self, x):
         x = np.ascontiguousarray(x, np.float64).copy()
         s = R.SolveSummary()
