@@ -171,18 +171,11 @@ def main():
         dist.destroy_process_group()
 
 
-class _DevView:
-    """zero-copy torch view of a raw device pointer (for the RCCL all-reduce of the packed normal equations)"""
-
-    def __init__(self, ptr, count):
-        self.__cuda_array_interface__ = {"shape": (int(count),), "typestr": "<f8", "data": (int(ptr), False), "version": 2}
-
-
 def bench_window(ctx, args, world, rank, dev, torch, dist):
     """LM ("GN") iterations per second on a C4-like window: `scans` sweeps x `patches` surfels, binary + unary surfel
     factors + IMU factors, correspondences from the GPU matcher.  With N > 1 the correspondences are sharded over the
     ranks (unknowns replicated) and every linearisation ends in ONE RCCL all-reduce of the packed {H, g, cost}."""
-    from wildcat_slam_amd import records as R, synth
+    from wildcat_slam_amd import dist as wdist, records as R, synth
 
     t_gen = time.perf_counter()
     w = synth.surfel_window(args.window_scans, args.window_patches, seed=synth.SEED + 7, fixed_patches=args.window_patches)
@@ -198,24 +191,15 @@ def bench_window(ctx, args, world, rank, dev, torch, dist):
     n_u = ctx.match_device(d_surf, d_pose, n_s, d_fs, d_fp, len(w["fix_surf"]), False, d_pf, n_s)
     t_match = time.perf_counter() - t0
     # shard the correspondences (contiguous slices), IMU factors on rank 0 only
-    def shard(n):
-        lo = (n * rank) // world
-        return lo, (n * (rank + 1)) // world - lo
-
-    lo_b, cnt_b = shard(n_b)
-    lo_u, cnt_u = shard(n_u)
+    lo_b, cnt_b = wdist.shard_range(n_b, rank, world)
+    lo_u, cnt_u = wdist.shard_range(n_u, rank, world)
 
     class _Off:
         def __init__(self, ptr):
             self.ptr = ptr
 
     if world > 1:
-        def allreduce(ptr, count):
-            t = torch.as_tensor(_DevView(ptr, count), device=dev)
-            dist.all_reduce(t)
-            torch.cuda.synchronize()
-
-        ctx.window_set_allreduce(allreduce)
+        ctx.window_set_allreduce(wdist.make_allreduce(torch, dist, dev))
     ctx.window_build(d_surf, d_pose, _Off(d_pairs.ptr + 8 * lo_b), cnt_b, w["imu"] if rank == 0 else None, w["sample_times"], w["grav"],
                      False, d_fs, d_fp, _Off(d_pf.ptr + 8 * lo_u), cnt_u)
     ns = len(w["sample_times"])

@@ -52,6 +52,7 @@ int wc_dev_alloc(wc_ctx *ctx, size_t bytes, void **d_ptr);
 int wc_dev_free(wc_ctx *ctx, void *d_ptr);
 int wc_h2d(wc_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);
 int wc_d2h(wc_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);
+int wc_d2d(wc_ctx *ctx, void *d_dst, const void *d_src, size_t bytes);
 int wc_memset(wc_ctx *ctx, void *d_dst, int value, size_t bytes);
 int wc_sync(wc_ctx *ctx);
 /* HIP-event timing on the ctx stream (used by bench.py: torch.cuda.Event only sees torch's stream) */

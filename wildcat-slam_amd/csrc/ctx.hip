@@ -145,6 +145,13 @@ extern "C" int wc_d2h(wc_ctx *ctx, void *h_dst, const void *d_src, size_t bytes)
   WC_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return WC_OK;
 }
+extern "C" int wc_d2d(wc_ctx *ctx, void *d_dst, const void *d_src, size_t bytes) {
+  if (!ctx) return WC_ERR_ARG;
+  if (!bytes) return WC_OK;
+  WC_HIP(ctx, hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+  WC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return WC_OK;
+}
 extern "C" int wc_memset(wc_ctx *ctx, void *d_dst, int value, size_t bytes) {
   if (!ctx) return WC_ERR_ARG;
   if (!bytes) return WC_OK;

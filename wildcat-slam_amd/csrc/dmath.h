@@ -6,9 +6,20 @@
 //   sym. 3x3 eigensolve  Eigen::SelfAdjointEigenSolver<Matrix3d> at surfel_extraction.cc:49,98, cost_functor.h:23,111
 // Compile the including TU with -ffp-contract=off: gate decisions are compared bit-for-bit with the CPU path.
 #pragma once
+#if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
-
 #define WC_HD __host__ __device__ __forceinline__
+#else  // plain host translation units (the C++ facade) use the same arithmetic
+#include <cmath>
+#define WC_HD inline
+using std::acos;
+using std::atan2;
+using std::cos;
+using std::fabs;
+using std::floor;
+using std::sin;
+using std::sqrt;
+#endif
 
 namespace wc {
 

@@ -1,0 +1,447 @@
+// lidar_odometry.cc — host orchestration of one odometry instance around the MI355X C-ABI (see lidar_odometry.h).
+// Every block names the reference lines it stands in for (src/odometry/lidar_odometry.cc unless noted).
+#include "lidar_odometry.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "../csrc/dmath.h"
+
+using namespace wc;
+
+namespace {
+
+inline V3 v3(const double *p) { return mk3(p[0], p[1], p[2]); }
+inline Q4 q4(const double *p) { return Q4{p[0], p[1], p[2], p[3]}; }
+inline void st3(double *d, V3 v) { d[0] = v.x, d[1] = v.y, d[2] = v.z; }
+inline void stq(double *d, Q4 q) { d[0] = q.w, d[1] = q.x, d[2] = q.y, d[3] = q.z; }
+
+// rotation matrix (row-major) -> unit quaternion; stands in for Eigen::Quaterniond(Matrix3d) + Rigid3's normalisation
+Q4 quat_from_matrix(const double *m) {
+  const double tr = m[0] + m[4] + m[8];
+  Q4 q;
+  if (tr > 0) {
+    double s = std::sqrt(tr + 1.0) * 2;
+    q = {0.25 * s, (m[7] - m[5]) / s, (m[2] - m[6]) / s, (m[3] - m[1]) / s};
+  } else if (m[0] > m[4] && m[0] > m[8]) {
+    double s = std::sqrt(1.0 + m[0] - m[4] - m[8]) * 2;
+    q = {(m[7] - m[5]) / s, 0.25 * s, (m[1] + m[3]) / s, (m[2] + m[6]) / s};
+  } else if (m[4] > m[8]) {
+    double s = std::sqrt(1.0 + m[4] - m[0] - m[8]) * 2;
+    q = {(m[2] - m[6]) / s, (m[1] + m[3]) / s, 0.25 * s, (m[5] + m[7]) / s};
+  } else {
+    double s = std::sqrt(1.0 + m[8] - m[0] - m[4]) * 2;
+    q = {(m[3] - m[1]) / s, (m[2] + m[6]) / s, (m[5] + m[7]) / s, 0.25 * s};
+  }
+  const double n = std::sqrt(q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z);
+  return {q.w / n, q.x / n, q.y / n, q.z / n};
+}
+
+// PredictPoseOfNewImuState (:106-123): constant-acceleration / mid-point gyro dead reckoning
+void PredictPoseOfNewImuState(const wc_imu_state &i1, const wc_imu_state &i2, V3 ba, V3 bg, V3 grav, wc_imu_state &i3) {
+  const double dt = i3.t - i2.t;
+  stq(i3.quat, qmul(q4(i2.quat), so3_exp(((v3(i2.gyr) + v3(i3.gyr)) / 2 - bg) * dt)));
+  st3(i3.pos, ((qrot(q4(i1.quat), v3(i1.acc) - ba) + grav) * dt) * dt + 2 * v3(i2.pos) - v3(i1.pos));
+}
+
+// CubicBSplineInterpolator (src/odometry/spline_interpolation.h:42-113): uniform cubic B-spline through Np samples,
+// control points from the normal equations of the knot-evaluation matrix, end indices clamped.
+class CubicBSpline {
+ public:
+  CubicBSpline(const std::vector<double> &ts, const std::vector<V3> &pts) : ts_(ts), np_((int)ts.size()), q_(ts.size()) {
+    const int n = np_;
+    std::vector<double> N((size_t)n * n, 0.0);
+    const double w[4] = {1.0 / 6, 4.0 / 6, 1.0 / 6, 0.0};  // (0,0,0,1) . M / 6
+    for (int i = 0; i < n; ++i)
+      for (int j = 0; j < 4; ++j) N[(size_t)i * n + std::min(std::max(i - 1 + j, 0), n - 1)] += w[j];
+    std::vector<double> A((size_t)n * n, 0.0), B((size_t)n * 3, 0.0);
+    for (int i = 0; i < n; ++i)
+      for (int k = 0; k < n; ++k) {
+        const double nki = N[(size_t)k * n + i];
+        if (nki == 0.0) continue;
+        for (int j = 0; j < n; ++j) A[(size_t)i * n + j] += nki * N[(size_t)k * n + j];
+        B[(size_t)i * 3 + 0] += nki * pts[k].x, B[(size_t)i * 3 + 1] += nki * pts[k].y, B[(size_t)i * 3 + 2] += nki * pts[k].z;
+      }
+    // Cholesky solve of the (symmetric positive definite) normal equations
+    for (int j = 0; j < n; ++j) {
+      double d = A[(size_t)j * n + j];
+      for (int k = 0; k < j; ++k) d -= A[(size_t)j * n + k] * A[(size_t)j * n + k];
+      d = std::sqrt(d);
+      A[(size_t)j * n + j] = d;
+      for (int i = j + 1; i < n; ++i) {
+        double s = A[(size_t)i * n + j];
+        for (int k = 0; k < j; ++k) s -= A[(size_t)i * n + k] * A[(size_t)j * n + k];
+        A[(size_t)i * n + j] = s / d;
+      }
+    }
+    for (int c = 0; c < 3; ++c) {
+      std::vector<double> y(n);
+      for (int i = 0; i < n; ++i) {
+        double s = B[(size_t)i * 3 + c];
+        for (int k = 0; k < i; ++k) s -= A[(size_t)i * n + k] * y[k];
+        y[i] = s / A[(size_t)i * n + i];
+      }
+      for (int i = n - 1; i >= 0; --i) {
+        double s = y[i];
+        for (int k = i + 1; k < n; ++k) s -= A[(size_t)k * n + i] * y[k];
+        y[i] = s / A[(size_t)i * n + i];
+      }
+      for (int i = 0; i < n; ++i) (c == 0 ? q_[i].x : (c == 1 ? q_[i].y : q_[i].z)) = y[i];
+    }
+  }
+  bool Interp(double t, V3 &out) const {  // :51-72
+    if (t < ts_.front() || t > ts_.back()) return false;
+    const double index_f = (t - ts_.front()) / (ts_.back() - ts_.front()) * (np_ - 1) + 1.0;
+    const int index_int = (int)std::floor(index_f);
+    const double u = index_f - index_int;
+    static const double M[4][4] = {{-1, 3, -3, 1}, {3, -6, 3, 0}, {-3, 0, 3, 0}, {1, 4, 1, 0}};
+    const double tv[4] = {u * u * u, u * u, u, 1.0};
+    out = mk3(0, 0, 0);
+    for (int j = 0; j < 4; ++j) {
+      double wj = 0;
+      for (int k = 0; k < 4; ++k) wj += tv[k] * M[k][j];
+      out = out + wj * q_[std::min(std::max(index_int - 2 + j, 0), np_ - 1)];
+    }
+    out = out / 6.0;
+    return true;
+  }
+
+ private:
+  std::vector<double> ts_;
+  int np_;
+  std::vector<V3> q_;
+};
+
+}  // namespace
+
+void LidarOdometry::Fatal(const char *what, int rc) const {
+  // the reference aborts through glog CHECK / LOG(FATAL); so does the facade
+  std::fprintf(stderr, "[wildcat] FATAL %s (rc=%d): %s\n", what, rc, ctx_ ? wc_last_error(ctx_) : "");
+  std::abort();
+}
+#define WC_CHECK(cond)                                                                           \
+  do {                                                                                           \
+    if (!(cond)) {                                                                               \
+      std::fprintf(stderr, "[wildcat] CHECK failed: %s (%s:%d)\n", #cond, __FILE__, __LINE__);   \
+      std::abort();                                                                              \
+    }                                                                                            \
+  } while (0)
+#define WC_CALL(expr)                  \
+  do {                                 \
+    int rc_ = (expr);                  \
+    if (rc_ != WC_OK) Fatal(#expr, rc_); \
+  } while (0)
+
+LidarOdometry::LidarOdometry() : LidarOdometry(0) {}
+
+LidarOdometry::LidarOdometry(int device) {
+  wc_params P;
+  wc_params_default(&P);
+  P.max_iterations = config_.inner_iter_num_max;
+  int rc = wc_ctx_create(&P, device, &ctx_);
+  if (rc != WC_OK) {
+    std::fprintf(stderr, "[wildcat] FATAL: no MI355X context (rc=%d); there is no CPU fallback\n", rc);
+    std::abort();
+  }
+  stq(ext_quat_, quat_from_matrix(config_.ext_rotation));
+}
+
+LidarOdometry::~LidarOdometry() {
+  if (!ctx_) return;
+  void *bufs[] = {d_surf_, d_pose_, d_inbody_, d_pairs_sld_, d_pairs_fix_, d_imu_, d_sweep_};
+  for (void *b : bufs)
+    if (b) wc_dev_free(ctx_, b);
+  wc_ctx_destroy(ctx_);
+}
+
+void LidarOdometry::AddImuData(const ImuData &msg) { imu_buff_.push_back(msg); }  // :607-611
+
+bool LidarOdometry::latest_state(SampleStateView *out) const {
+  return !samples_.empty() && sample_state(samples_.size() - 1, out);
+}
+bool LidarOdometry::sample_state(size_t i, SampleStateView *out) const {
+  if (i >= samples_.size()) return false;
+  const Sample &s = samples_[i];
+  out->timestamp = s.timestamp;
+  std::memcpy(out->pos, s.pos, 24);
+  std::memcpy(out->quat, s.quat, 32);
+  std::memcpy(out->bg, s.cor + 6, 24);
+  std::memcpy(out->ba, s.cor + 9, 24);
+  return true;
+}
+
+void LidarOdometry::EnsureSurfelCapacity(size_t n) {
+  if (n <= cap_surfels_) return;
+  const size_t cap = std::max<size_t>(n + n / 2, 1 << 16);
+  void *ns = nullptr, *np = nullptr, *nb = nullptr, *p1 = nullptr, *p2 = nullptr;
+  WC_CALL(wc_dev_alloc(ctx_, cap * sizeof(wc_surfel), &ns));
+  WC_CALL(wc_dev_alloc(ctx_, cap * sizeof(wc_pose), &np));
+  WC_CALL(wc_dev_alloc(ctx_, cap, &nb));
+  WC_CALL(wc_dev_alloc(ctx_, cap * sizeof(wc_pair), &p1));
+  WC_CALL(wc_dev_alloc(ctx_, cap * sizeof(wc_pair), &p2));
+  if (n_surfels_) {
+    WC_CALL(wc_d2d(ctx_, ns, d_surf_, n_surfels_ * sizeof(wc_surfel)));
+    WC_CALL(wc_d2d(ctx_, np, d_pose_, n_surfels_ * sizeof(wc_pose)));
+    WC_CALL(wc_d2d(ctx_, nb, d_inbody_, n_surfels_));
+  }
+  void *old[] = {d_surf_, d_pose_, d_inbody_, d_pairs_sld_, d_pairs_fix_};
+  for (void *b : old)
+    if (b) WC_CALL(wc_dev_free(ctx_, b));
+  d_surf_ = (wc_surfel *)ns, d_pose_ = (wc_pose *)np, d_inbody_ = (uint8_t *)nb;
+  d_pairs_sld_ = (wc_pair *)p1, d_pairs_fix_ = (wc_pair *)p2;
+  cap_surfels_ = cap;
+}
+
+// SyncHeadingMsgs (:457-485)
+bool LidarOdometry::SyncHeadingMsgs() {
+  if (sync_done_) return true;
+  if (imu_buff_.empty() || points_buff_.empty()) return false;
+  if (imu_buff_.back().timestamp < points_buff_.front().time) return false;
+  while (imu_buff_.front().timestamp < points_buff_.front().time) {
+    imu_buff_.pop_front();
+    WC_CHECK(!imu_buff_.empty());
+  }
+  while (points_buff_.front().time < imu_buff_.front().timestamp) {
+    points_buff_.pop_front();
+    WC_CHECK(!points_buff_.empty());
+  }
+  sync_done_ = true;
+  return true;
+}
+
+// PredictImuStatesAndSampleStates (:365-455)
+void LidarOdometry::PredictImuStatesAndSampleStates(double end_time) {
+  WC_CHECK(imu_buff_.size() >= 2);
+  const double dt = 1 / config_.imu_rate;
+  if (!init_sld_win_) {
+    for (int i = 0; i < 2; ++i) {
+      const ImuData m = imu_buff_.front();
+      imu_buff_.pop_front();
+      wc_imu_state s{};
+      s.t = m.timestamp;
+      for (int d = 0; d < 3; ++d) s.acc[d] = m.linear_acceleration[d], s.gyr[d] = m.angular_velocity[d], s.pos[d] = 0;
+      if (i == 0)
+        stq(s.quat, Q4{1, 0, 0, 0});
+      else
+        stq(s.quat, so3_exp(((v3(imu_states_.back().gyr) + v3(s.gyr)) / 2) * dt));
+      imu_states_.push_back(s);
+    }
+    Sample ss{};
+    ss.timestamp = imu_states_.front().t;
+    const V3 a0 = v3(imu_states_.front().acc);
+    st3(ss.grav, (-config_.gravity_norm) * (a0 / norm(a0)));
+    std::memcpy(ss.quat, imu_states_.front().quat, 32);
+    std::memcpy(ss.pos, imu_states_.front().pos, 24);
+    samples_.push_back(ss);
+    first_sample_time_ = ss.timestamp;
+    first_sample_known_ = true;
+    init_sld_win_ = true;
+  }
+  const double old_last = samples_.back().timestamp;
+  const int add_size = (int)((end_time - old_last) / config_.sample_dt);
+  const double add_last = old_last + config_.sample_dt * add_size;
+  const V3 ba = v3(samples_.back().cor + 9), bg = v3(samples_.back().cor + 6), grav = v3(samples_.back().grav);
+  while (!imu_buff_.empty()) {
+    const size_t size = imu_states_.size();
+    const ImuData m = imu_buff_.front();
+    imu_buff_.pop_front();
+    wc_imu_state s{};
+    s.t = m.timestamp;
+    for (int d = 0; d < 3; ++d) s.acc[d] = m.linear_acceleration[d], s.gyr[d] = m.angular_velocity[d];
+    WC_CHECK(std::fabs((s.t - imu_states_[size - 1].t) - (imu_states_[size - 1].t - imu_states_[size - 2].t)) <= 1e-6);
+    PredictPoseOfNewImuState(imu_states_[size - 2], imu_states_[size - 1], ba, bg, grav, s);
+    imu_states_.push_back(s);
+    if (s.t >= add_last) break;  // enough imu states
+  }
+  for (int i = 1; i <= add_size; ++i) {
+    const double t = old_last + i * config_.sample_dt;
+    Sample ss{};
+    ss.timestamp = t;
+    st3(ss.cor + 9, ba), st3(ss.cor + 6, bg), st3(ss.grav, grav);
+    size_t idx = std::lower_bound(imu_states_.begin(), imu_states_.end(), t,
+                                  [](const wc_imu_state &a, double b) { return a.t < b; }) - imu_states_.begin();
+    WC_CHECK(idx != 0 && idx != imu_states_.size());
+    const wc_imu_state &a = imu_states_[idx - 1], &b = imu_states_[idx];
+    const double f = (t - a.t) / (b.t - a.t);
+    stq(ss.quat, qslerp(q4(a.quat), f, q4(b.quat)));
+    st3(ss.pos, (1 - f) * v3(a.pos) + f * v3(b.pos));
+    WC_CHECK(f >= 0 && f <= 1);
+    samples_.push_back(ss);
+  }
+}
+
+// UndistortSweep (:143-158)
+void LidarOdometry::UndistortSweep(const std::vector<hilti_ros::Point> &in, std::vector<hilti_ros::Point> &out) const {
+  out.clear();
+  out.reserve(in.size());
+  size_t idx = 1;
+  for (const hilti_ros::Point &pt : in) {
+    while (idx < imu_states_.size() && imu_states_[idx].t < pt.time) ++idx;  // lower_bound; points are time ordered
+    size_t lb = idx;
+    while (lb > 0 && !(imu_states_[lb - 1].t < pt.time)) --lb;
+    if (!(lb >= 1 && lb < imu_states_.size()))
+      std::fprintf(stderr, "[wildcat] undistort: pt.time=%.6f imu=[%.6f, %.6f] n=%zu lb=%zu sweep=%d\n", pt.time, imu_states_.front().t,
+                   imu_states_.back().t, imu_states_.size(), lb, sweep_id_);
+    WC_CHECK(lb >= 1 && lb < imu_states_.size());
+    const wc_imu_state &a = imu_states_[lb - 1], &b = imu_states_[lb];
+    const double f = (pt.time - a.t) / (b.t - a.t);
+    const V3 pos = v3(a.pos) * (1 - f) + v3(b.pos) * f;
+    const Q4 rot = qslerp(q4(a.quat), f, q4(b.quat));
+    const V3 w = qrot(rot, mk3((double)pt.x, (double)pt.y, (double)pt.z)) + pos;
+    hilti_ros::Point np = pt;
+    np.x = (float)w.x, np.y = (float)w.y, np.z = (float)w.z;
+    out.push_back(np);
+  }
+}
+
+void LidarOdometry::UpdateSurfelPosesOnDevice() {  // UpdateSurfelPoses (:160-170) over the sliding window
+  const size_t n_imu = imu_states_.size();
+  if (n_imu > cap_imu_) {
+    if (d_imu_) WC_CALL(wc_dev_free(ctx_, d_imu_));
+    cap_imu_ = n_imu * 2;
+    void *p = nullptr;
+    WC_CALL(wc_dev_alloc(ctx_, cap_imu_ * sizeof(wc_imu_state), &p));
+    d_imu_ = (wc_imu_state *)p;
+  }
+  std::vector<wc_imu_state> flat(imu_states_.begin(), imu_states_.end());
+  WC_CALL(wc_h2d(ctx_, d_imu_, flat.data(), n_imu * sizeof(wc_imu_state)));
+  const size_t n = n_surfels_ - sld_begin_;
+  if (n) WC_CALL(wc_update_surfel_poses(ctx_, d_imu_, n_imu, d_surf_ + sld_begin_, d_pose_ + sld_begin_, d_inbody_ + sld_begin_, n));
+}
+
+// UpdateImuPoses (:187-215) with the CubicBSplineSampleCorrector (:22-54)
+void LidarOdometry::UpdateImuPoses() {
+  std::vector<double> ts;
+  std::vector<V3> rc, pc;
+  for (const Sample &s : samples_) {
+    ts.push_back(s.timestamp);
+    rc.push_back(v3(s.cor));
+    pc.push_back(v3(s.cor + 3));
+  }
+  CubicBSpline rot_interp(ts, rc), pos_interp(ts, pc);
+  long first = -1, last = -1;
+  for (size_t i = 0; i < imu_states_.size(); ++i) {
+    V3 r, p;
+    const bool ok = rot_interp.Interp(imu_states_[i].t, r);
+    const bool ok2 = pos_interp.Interp(imu_states_[i].t, p);
+    WC_CHECK(ok == ok2);
+    if (!ok) continue;
+    stq(imu_states_[i].quat, qmul(so3_exp(r), q4(imu_states_[i].quat)));
+    st3(imu_states_[i].pos, p + v3(imu_states_[i].pos));
+    if (first < 0) first = (long)i;
+    last = (long)i;
+  }
+  if (first != -1) {
+    WC_CHECK(first == 0);
+    WC_CHECK(last == (long)imu_states_.size() - 2);
+    const size_t n = imu_states_.size();
+    const Sample &b = samples_.back();
+    PredictPoseOfNewImuState(imu_states_[n - 3], imu_states_[n - 2], v3(b.cor + 9), v3(b.cor + 6), v3(b.grav), imu_states_[n - 1]);
+  }
+}
+
+void LidarOdometry::UpdateSamplePoses() {  // :172-179
+  for (Sample &s : samples_) {
+    stq(s.quat, qmul(so3_exp(v3(s.cor)), q4(s.quat)));
+    st3(s.pos, v3(s.cor + 3) + v3(s.pos));
+    for (int d = 0; d < 6; ++d) s.cor[d] = 0;
+  }
+}
+
+// ShrinkToFit (:228-250).  Surfels live in one time-ordered device array, so moving the oldest sliding-window surfels
+// to the fixed window is an index bump; like the reference (Q11) the fixed window is never trimmed.
+void LidarOdometry::ShrinkToFit() {
+  if (samples_.empty() || samples_.back().timestamp - samples_.front().timestamp <= config_.sliding_window_duration) return;
+  while (samples_.back().timestamp - samples_.front().timestamp > config_.sliding_window_duration) samples_.pop_front();
+  while (imu_states_.front().t < samples_.front().timestamp) imu_states_.pop_front();
+  while (sld_begin_ < n_surfels_ && surfel_times_[sld_begin_] < imu_states_.front().t) ++sld_begin_;
+}
+
+void LidarOdometry::AddLidarScan(const pcl::PointCloud<hilti_ros::Point>::Ptr &msg) {
+  // lidar frame -> imu frame, range / blind-box filter (:489-496)
+  const Q4 eq = q4(ext_quat_);
+  const V3 et = v3(config_.ext_translation);
+  for (hilti_ros::Point pt : *msg) {
+    const V3 p = qrot(eq, mk3((double)pt.x, (double)pt.y, (double)pt.z)) + et;
+    pt.x = (float)p.x, pt.y = (float)p.y, pt.z = (float)p.z;
+    WC_CHECK(points_buff_.empty() || pt.time >= points_buff_.back().time);
+    const float nrm = std::sqrt(pt.x * pt.x + pt.y * pt.y + pt.z * pt.z);
+    const bool blind = (double)pt.x >= config_.blind_min[0] && (double)pt.x <= config_.blind_max[0] &&
+                       (double)pt.y >= config_.blind_min[1] && (double)pt.y <= config_.blind_max[1] &&
+                       (double)pt.z >= config_.blind_min[2] && (double)pt.z <= config_.blind_max[2];
+    if (nrm < config_.min_range || nrm > config_.max_range || blind) continue;
+    points_buff_.push_back(pt);
+  }
+  if (!SyncHeadingMsgs()) return;
+
+  // 1. collect scan to sweep (:501-509)
+  double sweep_endtime = points_buff_.front().time + config_.sweep_duration;
+  if (points_buff_.back().time < sweep_endtime || imu_buff_.empty() || imu_buff_.back().timestamp < sweep_endtime) return;
+
+  // 2. integrate IMU poses in windows (:512-513)
+  PredictImuStatesAndSampleStates(sweep_endtime);
+  sweep_endtime = samples_.back().timestamp;
+  std::vector<hilti_ros::Point> sweep;  // BuildSweep (:134-141)
+  while (!points_buff_.empty() && points_buff_.front().time < sweep_endtime) {
+    sweep.push_back(points_buff_.front());
+    points_buff_.pop_front();
+  }
+  WC_CHECK(!sweep.empty());
+
+  // 3. undistort sweep by IMU poses (:519-520)
+  std::vector<hilti_ros::Point> und;
+  UndistortSweep(sweep, und);
+
+  // 4. ---- hot path: extract surfels, attach poses (:523-527) ----
+  if (und.size() > cap_sweep_) {
+    if (d_sweep_) WC_CALL(wc_dev_free(ctx_, d_sweep_));
+    cap_sweep_ = und.size() * 2;
+    WC_CALL(wc_dev_alloc(ctx_, cap_sweep_ * sizeof(hilti_ros::Point), &d_sweep_));
+  }
+  WC_CALL(wc_h2d(ctx_, d_sweep_, und.data(), und.size() * sizeof(hilti_ros::Point)));
+  const size_t max_new = (3 * und.size()) / 20 + 1;
+  EnsureSurfelCapacity(n_surfels_ + max_new);
+  wc_points desc{d_sweep_, (const char *)d_sweep_ + WC_HILTI_POINT_TIME_OFFSET, WC_HILTI_POINT_BYTES, WC_HILTI_POINT_BYTES, und.size()};
+  uint64_t n_new = 0;
+  WC_CALL(wc_extract_surfels(ctx_, &desc, und.front().time, und.back().time, d_surf_ + n_surfels_, nullptr, max_new, &n_new));
+  if (n_new) {
+    WC_CALL(wc_memset(ctx_, d_inbody_ + n_surfels_, 0, n_new));
+    std::vector<wc_surfel> fresh(n_new);
+    WC_CALL(wc_d2h(ctx_, fresh.data(), d_surf_ + n_surfels_, n_new * sizeof(wc_surfel)));
+    for (const wc_surfel &s : fresh) surfel_times_.push_back(s.t);
+    n_surfels_ += n_new;
+  }
+  UpdateSurfelPosesOnDevice();
+
+  for (int iter = 0; iter < config_.outer_iter_num_max; ++iter) {
+    const size_t n_sld = n_surfels_ - sld_begin_;
+    // correspondences (:530-538)
+    uint64_t n_b = 0, n_u = 0;
+    WC_CALL(wc_match(ctx_, d_surf_ + sld_begin_, d_pose_ + sld_begin_, n_sld, d_surf_ + sld_begin_, d_pose_ + sld_begin_, n_sld, 1,
+                     d_pairs_sld_, cap_surfels_, &n_b, nullptr, nullptr));
+    WC_CALL(wc_match(ctx_, d_surf_ + sld_begin_, d_pose_ + sld_begin_, n_sld, d_surf_, d_pose_, sld_begin_, 0, d_pairs_fix_,
+                     cap_surfels_, &n_u, nullptr, nullptr));
+    last_corr_[0] = n_b, last_corr_[1] = n_u;
+    // 5. solve poses in windows (:541-562)
+    std::vector<double> ts, x;
+    for (const Sample &s : samples_) {
+      ts.push_back(s.timestamp);
+      x.insert(x.end(), s.cor, s.cor + 12);
+    }
+    std::vector<wc_imu_state> flat(imu_states_.begin(), imu_states_.end());
+    const bool fix_first = first_sample_known_ && samples_.front().timestamp == first_sample_time_;  // :556-560
+    WC_CALL(wc_window_build(ctx_, d_surf_ + sld_begin_, d_pose_ + sld_begin_, d_pairs_sld_, n_b, d_surf_, d_pose_, d_pairs_fix_, n_u,
+                            flat.data(), flat.size(), ts.data(), ts.size(), samples_.back().grav, fix_first ? 1 : 0));
+    WC_CALL(wc_window_solve(ctx_, x.data(), &last_summary_, nullptr));
+    for (size_t i = 0; i < samples_.size(); ++i) std::memcpy(samples_[i].cor, &x[12 * i], 96);
+    // state update (:564-566)
+    UpdateImuPoses();
+    UpdateSurfelPosesOnDevice();
+    UpdateSamplePoses();
+  }
+  ShrinkToFit();  // :574-580
+  ++sweep_id_;
+}

@@ -1,0 +1,93 @@
+// lidar_odometry.h — host-side drop-in for the reference's odometry facade.
+//
+// Public surface identical to the reference's src/odometry/lidar_odometry.h:11-25
+//     LidarOdometry();  void AddImuData(const ImuData&);  void AddLidarScan(const pcl::PointCloud<hilti_ros::Point>::Ptr&);
+// so that src/wildcat_slam_node.cc (:42, :51, :66) compiles against it unchanged where ROS / PCL exist.  Everything the
+// reference does between lidar_odometry.cc:523 and :566 (surfel extraction, surfel pose update, correspondence,
+// factor construction, the Ceres solve) goes through the C-ABI of libwildcat_hip.so; the window bookkeeping around it
+// (point pre-filter :489-496, SyncHeadingMsgs :457-485, PredictImuStatesAndSampleStates :365-455, BuildSweep :134-141,
+// UndistortSweep :143-158, UpdateImuPoses + B-spline corrector :22-54,:187-215, UpdateSamplePoses :172-179,
+// ShrinkToFit :228-250) is restated here as plain host C++.  All state is per instance (the reference keeps some of it
+// in function-local statics).  ROS publishing is replaced by the accessors at the bottom.
+#pragma once
+#include <cstdint>
+#include <deque>
+#include <memory>
+#include <vector>
+
+#ifndef WC_HAVE_REFERENCE_TYPES
+#include "shim/common.h"
+#endif
+#include "../../include/wildcat_hip.h"
+#include "lio_config.h"
+
+class LidarOdometry {
+ public:
+  LidarOdometry();
+  explicit LidarOdometry(int device);
+  ~LidarOdometry();
+  LidarOdometry(const LidarOdometry &) = delete;
+  LidarOdometry &operator=(const LidarOdometry &) = delete;
+
+  /** Add raw imu measurements to queue (lidar_odometry.h:14-18) */
+  void AddImuData(const ImuData &msg);
+  /** Add raw lidar points with timestamp (lidar_odometry.h:20-25) */
+  void AddLidarScan(const pcl::PointCloud<hilti_ros::Point>::Ptr &msg);
+
+  // ---- not in the reference: read-outs instead of ROS topics / TF (lidar_odometry.cc:582-602) ----
+  struct SampleStateView {
+    double timestamp;
+    double pos[3];
+    double quat[4];  // w, x, y, z
+    double bg[3], ba[3];
+  };
+  int sweeps_done() const { return sweep_id_; }
+  bool latest_state(SampleStateView *out) const;
+  size_t num_sample_states() const { return samples_.size(); }
+  bool sample_state(size_t i, SampleStateView *out) const;
+  size_t sliding_window_surfels() const { return n_surfels_ - sld_begin_; }
+  size_t fixed_window_surfels() const { return sld_begin_; }
+  const wc_solve_summary &last_solve() const { return last_summary_; }
+  uint64_t last_correspondences(int which) const { return last_corr_[which]; }
+  LioConfig &config() { return config_; }
+
+ private:
+  struct Sample {  // reference SampleState (surfel.h:9-23)
+    double timestamp;
+    double cor[12];  // rot_cor, pos_cor, bg, ba
+    double grav[3];
+    double quat[4];
+    double pos[3];
+  };
+  void PredictImuStatesAndSampleStates(double end_time);
+  bool SyncHeadingMsgs();
+  void UndistortSweep(const std::vector<hilti_ros::Point> &in, std::vector<hilti_ros::Point> &out) const;
+  void UpdateImuPoses();
+  void UpdateSamplePoses();
+  void UpdateSurfelPosesOnDevice();
+  void ShrinkToFit();
+  void EnsureSurfelCapacity(size_t n);
+  void Fatal(const char *what, int rc) const;
+
+  LioConfig config_;
+  wc_ctx *ctx_ = nullptr;
+  std::deque<ImuData> imu_buff_;
+  std::deque<hilti_ros::Point> points_buff_;
+  std::deque<Sample> samples_;
+  std::deque<wc_imu_state> imu_states_;
+  double ext_quat_[4];
+  bool init_sld_win_ = false, sync_done_ = false, first_sample_known_ = false;
+  double first_sample_time_ = 0.0;
+  int sweep_id_ = 0;
+  // all surfels ever kept, time ordered, in HBM: [0, sld_begin_) = fixed window, [sld_begin_, n_surfels_) = sliding
+  wc_surfel *d_surf_ = nullptr;
+  wc_pose *d_pose_ = nullptr;
+  uint8_t *d_inbody_ = nullptr;
+  wc_pair *d_pairs_sld_ = nullptr, *d_pairs_fix_ = nullptr;
+  wc_imu_state *d_imu_ = nullptr;
+  void *d_sweep_ = nullptr;
+  size_t cap_surfels_ = 0, n_surfels_ = 0, sld_begin_ = 0, cap_imu_ = 0, cap_sweep_ = 0;
+  std::vector<double> surfel_times_;  // host copy of the surfel timestamps (window bookkeeping only)
+  wc_solve_summary last_summary_{};
+  uint64_t last_corr_[2] = {0, 0};
+};

@@ -1,0 +1,29 @@
+// lio_config.h — the reference's hard-coded configuration (src/odometry/lio_config.h:8-46), values unchanged.
+#pragma once
+#include <cmath>
+
+struct LioConfig {
+  // IMU noise model (lio_config.h:10-14)
+  double gyroscope_noise_density = 0.00015198973532354657;
+  double accelerometer_noise_density = 0.006308226052016165;
+  double gyroscope_random_walk = 0.00011673723527962174;
+  double accelerometer_random_walk = 2.664506559330434e-06;
+  double imu_factor_weight = 0.01;
+  // preprocessing (lio_config.h:18-30)
+  double max_range = 120;
+  double min_range = 0.3;
+  double blind_min[3] = {-0.8, -0.5, -0.4};  // Eigen::AlignedBox in imu_link
+  double blind_max[3] = {0.3, 0.5, 0.4};
+  double ext_translation[3] = {-0.001, -0.00855, 0.055};  // lidar -> imu
+  double ext_rotation[9] = {-5.32125e-08, -1, 0, -1, -5.32125e-08, -0, 0, 0, -1};
+  // windows (lio_config.h:32-36)
+  double imu_rate = 200;
+  double sample_dt = 0.08;
+  double fixed_window_duration = 20.0;
+  double sliding_window_duration = 6.0;
+  double sweep_duration = 0.5;
+  // optimisation (lio_config.h:39-45)
+  double gravity_norm = 9.81;
+  int outer_iter_num_max = 1;
+  int inner_iter_num_max = 100;
+};

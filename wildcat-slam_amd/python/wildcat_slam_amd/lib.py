@@ -279,3 +279,43 @@ class Context:
         if want_knn:
             return pairs, d_idx.download(np.uint32, nq * k).reshape(nq, k), d_d2.download(np.float64, nq * k).reshape(nq, k)
         return pairs
+
+
+class Odometry:
+    """the C++ LidarOdometry facade (host/lidar_odometry.h) through its flat C wrapper (host/odom_c_api.cc)"""
+
+    def __init__(self, device=0):
+        so = os.path.join(os.path.dirname(_CSRC), "host", "libwildcat_odometry.so")
+        load()
+        self.lib = C.CDLL(so)
+        self.lib.wc_odom_create.restype = C.c_void_p
+        self.lib.wc_odom_num_samples.restype = C.c_uint64
+        self.h = C.c_void_p(self.lib.wc_odom_create(C.c_int(device)))
+
+    def close(self):
+        if self.h:
+            self.lib.wc_odom_destroy(self.h)
+            self.h = None
+
+    def add_imu(self, t, acc, gyr):
+        a, g = (C.c_double * 3)(*acc), (C.c_double * 3)(*gyr)
+        self.lib.wc_odom_add_imu(self.h, C.c_double(t), a, g)
+
+    def add_scan(self, points):
+        assert points.dtype == R.POINT
+        self.lib.wc_odom_add_scan(self.h, R.ptr(points), C.c_uint64(len(points)))
+
+    def sweeps(self):
+        return int(self.lib.wc_odom_sweeps(self.h))
+
+    def samples(self):
+        n = int(self.lib.wc_odom_num_samples(self.h))
+        out = np.zeros((n, 15))
+        for i in range(n):
+            self.lib.wc_odom_sample(self.h, C.c_uint64(i), R.ptr(out[i]))
+        return out
+
+    def stats(self):
+        s = np.zeros(8)
+        self.lib.wc_odom_stats(self.h, R.ptr(s))
+        return dict(zip(("sld_surfels", "fix_surfels", "binary", "unary", "lm_iters", "cost0", "cost1", "termination"), s.tolist()))

@@ -275,3 +275,73 @@ def surfel_window(n_scans, patches_per_scan, seed=SEED, sample_dt=0.08, scan_dur
         fp["quat"][:, 0] = 1.0
         out.update(fix_surf=fs, fix_pose=fp, fix_patch_index=fidx)
     return out
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# raw sensor stream for the host facade (LidarOdometry): lidar messages in the LIDAR frame + 200 Hz IMU messages
+EXT_R = np.array([[-5.32125e-08, -1, 0], [-1, -5.32125e-08, 0], [0, 0, -1]])  # lio_config.h:23-28 (lidar -> imu)
+EXT_T = np.array([-0.001, -0.00855, 0.055])
+
+
+def _room_hits(o, d, z_floor=-1.5):
+    planes = [
+        (0, -20.0, None), (0, 20.0, None), (1, -15.0, None), (1, 15.0, None), (2, z_floor, None), (2, z_floor + 10.0, None),
+        (0, -8.0, ((-15, 2), (z_floor, z_floor + 10))), (0, 9.0, ((-3, 15), (z_floor, z_floor + 10))),
+        (1, -6.0, ((-20, -2), (z_floor, z_floor + 10))), (1, 5.0, ((3, 20), (z_floor, z_floor + 10))),
+    ]
+    best = np.full(len(o), np.inf)
+    for axis, coord, bounds in planes:
+        with np.errstate(divide="ignore", invalid="ignore"):
+            s = (coord - o[:, axis]) / d[:, axis]
+            hit = o + s[:, None] * d
+        ok = (s > 0.3) & np.isfinite(s)
+        if bounds is not None:
+            others = [a for a in range(3) if a != axis]
+            for a, (lo, hi) in zip(others, bounds):
+                ok &= (hit[:, a] >= lo) & (hit[:, a] <= hi)
+        best = np.where(ok & (s < best), s, best)
+    return best
+
+
+def raw_stream(duration, pts_per_s=600_000, seed=SEED, t_start=T0, msg_dt=0.1, gyro_bias=(0.0, 0.0, 0.0), range_noise=0.01,
+               imu_rate=200.0, beams=32, spin_hz=10.0, imu_clock_skew=1e-6):
+    """-> (list of lidar messages [POINT arrays, lidar frame], imu dict(t, acc, gyr), truth callable t -> (pos, R))"""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    n = int(duration * pts_per_s)
+    tr = duration * np.arange(n) / n
+    beam = np.arange(n) % beams
+    elev = np.deg2rad(-16 + 32.0 * beam / (beams - 1))
+    az = 2 * np.pi * spin_hz * tr + 0.3 * beam
+    d_imu = np.stack([np.cos(elev) * np.cos(az), np.cos(elev) * np.sin(az), np.sin(elev)], -1)
+    Rw, o = traj_rot(tr), traj_pos(tr)
+    d_w = np.einsum("nij,nj->ni", Rw, d_imu)
+    rng_true = _room_hits(o, d_w)
+    good = np.isfinite(rng_true) & (rng_true < 100.0)
+    p_imu = d_imu * (rng_true + range_noise * rng.normal(size=n))[:, None]
+    p_lidar = (p_imu - EXT_T) @ EXT_R  # R^T (p - t)
+    pts = make_points(p_lidar[good], t_start + tr[good])
+    msgs = []
+    tt = pts["time"] - t_start
+    k = 0
+    while k * msg_dt < duration:
+        sel = (tt >= k * msg_dt) & (tt < (k + 1) * msg_dt)
+        msgs.append(pts[sel].copy())
+        k += 1
+    # IMU at imu_rate from the analytic trajectory (central differences)
+    # the IMU clock is offset by half a period: a lidar point stamped exactly on an IMU sample trips the reference's own
+    # CHECK(idx >= 1) in UndistortSweep (lidar_odometry.cc:150)
+    # ... and a tiny clock skew keeps IMU stamps from landing exactly on the sample-state grid (first_imu + k * 0.08), where
+    # the reference's CHECK_EQ(corrected_last_idx, size - 2) (lidar_odometry.cc:210) would abort
+    ti = (np.arange(int(duration * imu_rate) + 3) / imu_rate) * (1 + imu_clock_skew) - 0.5 / imu_rate + 1.37e-4
+    h = 1e-4
+    acc_w = (traj_pos(ti + h) + traj_pos(ti - h) - 2 * traj_pos(ti)) / (h * h)
+    Rm = traj_rot(ti)
+    acc = np.einsum("nji,nj->ni", Rm, acc_w + np.array([0, 0, 9.81]))
+    dR = np.einsum("nji,njk->nik", traj_rot(ti - h), traj_rot(ti + h))
+    gyr = np.stack([dR[:, 2, 1] - dR[:, 1, 2], dR[:, 0, 2] - dR[:, 2, 0], dR[:, 1, 0] - dR[:, 0, 1]], -1) / (4 * h)
+    imu = dict(t=t_start + ti, acc=acc, gyr=gyr + np.asarray(gyro_bias))
+
+    def truth(t):
+        return traj_pos(t - t_start), traj_rot(t - t_start)
+
+    return msgs, imu, truth
