@@ -100,3 +100,11 @@ def test_c2_full_size_properties(gpu, oracle):
     assert np.all(s_gpu["resolution"] == np.float64(np.float32(0.4)))
     s_ref, id_ref, st = oracle.extract_surfels(pts)
     helpers.check_surfels(s_gpu, id_gpu, s_ref, id_ref, tol=1e-6, t_tol=1e-5)
+
+
+def test_dense_voxels_overflow_fast_sort_and_fall_back(gpu, oracle):
+    # 3 root voxels with ~9 000 points each: a bucket of the fast (bucket) sort overflows and the general radix path
+    # must take over transparently; huge roots also exercise the multi-chunk streaming of k_roots
+    pts, _ = synth.g2_lattice(3, m=1100, span=4, seed=17)
+    assert len(pts) == 3 * 8 * 1100
+    _run(gpu, oracle, pts)

@@ -40,6 +40,7 @@ struct wc_ctx {
     wc_surfel_id *d_ids;
     uint64_t cap;
     bool wide;
+    bool general;
   } ex;
   wc_window_state *win = nullptr;
   // optional per-stage HIP events of the extraction pipeline (wc_extract_profile)

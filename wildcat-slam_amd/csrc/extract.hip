@@ -32,7 +32,7 @@ namespace {
 
 constexpr int kMom = 11;    // n, St, Sx, Sy, Sz, Sxx, Sxy, Sxz, Syy, Syz, Szz
 constexpr unsigned kRootsGrid = 256 * 10;  // persistent wavefronts: 256 CUs x ~LDS-limited residency
-constexpr uint32_t kFlagKeyRange = 1u, kFlagSlotOverflow = 2u, kFlagTimeRange = 4u;
+constexpr uint32_t kFlagKeyRange = 1u, kFlagSlotOverflow = 2u, kFlagTimeRange = 4u, kFlagBucketOverflow = 8u;
 
 struct ExParams {
   double vs;           // (double)voxel_size
@@ -194,6 +194,7 @@ __global__ void __launch_bounds__(64) k_roots(RootsArgs A, const K *__restrict__
   const ExParams &P = A.P;
   constexpr int B = KeyTraits<K>::bits;
   constexpr int half = 1 << (B - 1);
+  if (A.status[1] & (kFlagBucketOverflow | kFlagKeyRange)) return;  // the sort was abandoned: its outputs are not valid
 
   // lane roles while streaming: lane = (level, moment); moment m = stage[ia] * stage[ib], stage = {1, t, x, y, z}
   const int Lq = lane / kMom;      // 0,1 used in phase 1; phase 2 uses lanes 0..10 only
@@ -469,6 +470,7 @@ __global__ void __launch_bounds__(256) k_iota(uint32_t *v, uint64_t n) {
 __global__ void __launch_bounds__(256) k_gather(const uint32_t *__restrict__ sorted_slot, const wc_surfel *__restrict__ slots,
                                                const wc_surfel_id *__restrict__ slot_ids, const uint32_t *status,
                                                wc_surfel *out, wc_surfel_id *out_ids, uint64_t cap) {
+  if (status[1] & (kFlagBucketOverflow | kFlagKeyRange)) return;
   const uint64_t n = min((uint64_t)status[0], cap);
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const uint64_t rec = i / 10, part = i - rec * 10;
@@ -485,19 +487,213 @@ __global__ void __launch_bounds__(256) k_gather(const uint32_t *__restrict__ sor
   }
 }
 
+// ---- bucket sort of 64-bit composites (group-by with a fixed order inside the group) -----------------------------------
+// Both sorts of the extraction only need "equal keys contiguous, ascending index inside a key".  Packing (key, index)
+// into one 64-bit composite makes ANY sort of the composites stable by construction, so the global pass can be an
+// unordered MSD scatter into 1024 buckets (per-tile LDS histograms, one global atomic per non-empty (tile, bucket)) and
+// each bucket is finished by a bitonic sort in LDS.  For the points the bucket digit is built from the LOW bits of the
+// voxel index (x&15, y&7, z&7): neighbouring voxels land in different buckets, so planar scenes do not overload one
+// bucket; the order of the voxels among each other is irrelevant (only grouping matters).  3 launches instead of
+// rocPRIM's ~20 (merge path) for 1 M pairs.  A bucket larger than kBucketCap raises a flag and the caller falls back
+// to the rocPRIM radix sort.
+constexpr int kBuckets = 1024;
+constexpr int kBucketCap = 4096;
+constexpr int kTile = 4096;  // items per workgroup in the histogram / scatter passes
+
+__device__ __forceinline__ uint32_t key_digit(uint32_t key) {
+  const uint32_t x = key & 1023u, y = (key >> 10) & 1023u, z = key >> 20;
+  return (x & 15u) | ((y & 7u) << 4) | ((z & 7u) << 7);
+}
+__device__ __forceinline__ uint32_t key_rest(uint32_t key) {
+  const uint32_t x = key & 1023u, y = (key >> 10) & 1023u, z = key >> 20;
+  return (x >> 4) | ((y >> 3) << 6) | ((z >> 3) << 13);
+}
+__device__ __forceinline__ uint32_t key_join(uint32_t d, uint32_t r) {
+  const uint32_t x = (d & 15u) | ((r & 63u) << 4), y = ((d >> 4) & 7u) | (((r >> 6) & 127u) << 3),
+                 z = ((d >> 7) & 7u) | (((r >> 13) & 127u) << 3);
+  return x | (y << 10) | (z << 20);
+}
+
+struct PointSrc {  // composite = rest(voxel key) << 32 | point index
+  wc_points pts;
+  double vs;
+  __device__ __forceinline__ bool get(uint64_t i, uint32_t &digit, uint64_t &comp, uint32_t *status) const {
+    double x0, y0, z0, x, y, z;
+    load_xyz(pts, 0, x0, y0, z0);
+    load_xyz(pts, i, x, y, z);
+    int rx = vox(x, vs) - vox(x0, vs) + 512, ry = vox(y, vs) - vox(y0, vs) + 512, rz = vox(z, vs) - vox(z0, vs) + 512;
+    if ((unsigned)rx >= 1024u || (unsigned)ry >= 1024u || (unsigned)rz >= 1024u) {
+      atomicOr(&status[1], kFlagKeyRange);
+      rx = min(max(rx, 0), 1023), ry = min(max(ry, 0), 1023), rz = min(max(rz, 0), 1023);
+    }
+    const uint32_t key = (uint32_t)rx | ((uint32_t)ry << 10) | ((uint32_t)rz << 20);
+    digit = key_digit(key);
+    comp = ((uint64_t)key_rest(key) << 32) | (uint64_t)(uint32_t)i;
+    return true;
+  }
+};
+struct SlotSrc {  // composite = time key << 32 | slot index; empty slots (key = ~0) are dropped => compaction for free
+  const uint64_t *keys;
+  uint32_t shift;
+  __device__ __forceinline__ bool get(uint64_t i, uint32_t &digit, uint64_t &comp, uint32_t *status) const {
+    const uint64_t k = keys[i];
+    if (k == ~0ull) return false;
+    if (k >> 32) atomicOr(&status[1], kFlagTimeRange);
+    digit = min((uint32_t)(k >> shift), (uint32_t)(kBuckets - 1));
+    comp = (k << 32) | (uint64_t)(uint32_t)i;
+    return true;
+  }
+};
+
+template <typename Src>
+__global__ void __launch_bounds__(256) k_bucket_hist(Src src, uint64_t n, uint32_t *counts, uint32_t *status) {
+  __shared__ uint32_t s_h[kBuckets];
+  for (int b = threadIdx.x; b < kBuckets; b += 256) s_h[b] = 0;
+  __syncthreads();
+  const uint64_t t0 = (uint64_t)blockIdx.x * kTile;
+  for (int j = 0; j < kTile / 256; ++j) {
+    const uint64_t i = t0 + (uint64_t)j * 256 + threadIdx.x;
+    uint32_t d;
+    uint64_t c;
+    if (i < n && src.get(i, d, c, status)) atomicAdd(&s_h[d], 1u);
+  }
+  __syncthreads();
+  for (int b = threadIdx.x; b < kBuckets; b += 256)
+    if (s_h[b]) atomicAdd(&counts[b], s_h[b]);
+}
+
+// exclusive prefix of the 1024 bucket counts into LDS (every workgroup recomputes it: 4 KB, cheaper than a launch)
+__device__ __forceinline__ void bucket_bases(const uint32_t *counts, uint32_t *s_base, uint32_t *s_tmp) {
+  const int t = threadIdx.x;
+  uint32_t c[4], sum = 0;
+  for (int q = 0; q < 4; ++q) {
+    c[q] = counts[4 * t + q];
+    sum += c[q];
+  }
+  s_tmp[t] = sum;
+  __syncthreads();
+  for (int off = 1; off < 256; off <<= 1) {
+    const uint32_t v = (t >= off) ? s_tmp[t - off] : 0u;
+    __syncthreads();
+    s_tmp[t] += v;
+    __syncthreads();
+  }
+  uint32_t run = s_tmp[t] - sum;
+  for (int q = 0; q < 4; ++q) {
+    s_base[4 * t + q] = run;
+    run += c[q];
+  }
+  __syncthreads();
+}
+
+template <typename Src>
+__global__ void __launch_bounds__(256) k_bucket_scatter(Src src, uint64_t n, const uint32_t *counts, uint32_t *cursor, uint64_t *comp_out,
+                                                       uint32_t *status) {
+  __shared__ uint32_t s_base[kBuckets];
+  __shared__ uint32_t s_cnt[kBuckets];
+  __shared__ uint32_t s_tmp[256];
+  bucket_bases(counts, s_base, s_tmp);
+  for (int b = threadIdx.x; b < kBuckets; b += 256) s_cnt[b] = 0;
+  __syncthreads();
+  const uint64_t t0 = (uint64_t)blockIdx.x * kTile;
+  uint32_t dig[kTile / 256], rank[kTile / 256];
+  uint64_t comp[kTile / 256];
+#pragma unroll
+  for (int j = 0; j < kTile / 256; ++j) {
+    const uint64_t i = t0 + (uint64_t)j * 256 + threadIdx.x;
+    dig[j] = 0xFFFFFFFFu;
+    if (i < n && src.get(i, dig[j], comp[j], status))
+      rank[j] = atomicAdd(&s_cnt[dig[j]], 1u);
+    else
+      dig[j] = 0xFFFFFFFFu;
+  }
+  __syncthreads();
+  for (int b = threadIdx.x; b < kBuckets; b += 256) {
+    const uint32_t c = s_cnt[b];
+    s_cnt[b] = c ? atomicAdd(&cursor[b], c) : 0u;  // this tile's range inside bucket b
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < kTile / 256; ++j)
+    if (dig[j] != 0xFFFFFFFFu) comp_out[(size_t)s_base[dig[j]] + s_cnt[dig[j]] + rank[j]] = comp[j];
+}
+
+// one workgroup per bucket: bitonic sort of the composites in LDS, then the (key, index) pair arrays the rest of the
+// pipeline consumes.  POINTS: key = voxel key rebuilt from (bucket digit, rest); otherwise only the index is written.
+template <bool POINTS>
+__global__ void __launch_bounds__(256) k_bucket_sort(const uint64_t *comp, const uint32_t *counts, uint32_t *keys_out, uint32_t *idx_out,
+                                                    uint32_t *status) {
+  __shared__ uint64_t s[kBucketCap];
+  __shared__ uint32_t s_red[256];
+  const int b = blockIdx.x, t = threadIdx.x;
+  uint32_t part = 0;
+  for (int q = t; q < b; q += 256) part += counts[q];
+  s_red[t] = part;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if (t < st) s_red[t] += s_red[t + st];
+    __syncthreads();
+  }
+  const uint32_t base = s_red[0], nb = counts[b];
+  if (nb == 0) return;
+  if (nb > (uint32_t)kBucketCap) {
+    if (t == 0) atomicOr(&status[1], kFlagBucketOverflow);
+    return;
+  }
+  uint32_t N = 64;
+  while (N < nb) N <<= 1;
+  for (uint32_t i = t; i < N; i += 256) s[i] = (i < nb) ? comp[(size_t)base + i] : ~0ull;
+  __syncthreads();
+  for (uint32_t k = 2; k <= N; k <<= 1)
+    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+      for (uint32_t p = t; p < N / 2; p += 256) {
+        const uint32_t i = 2 * p - (p & (j - 1));  // lower element of the pair (bit j clear)
+        const uint32_t l = i + j;
+        const uint64_t a = s[i], c = s[l];
+        const bool asc = (i & k) == 0;
+        if ((a > c) == asc) {
+          s[i] = c;
+          s[l] = a;
+        }
+      }
+      __syncthreads();
+    }
+  for (uint32_t i = t; i < nb; i += 256) {
+    const uint64_t c = s[i];
+    idx_out[(size_t)base + i] = (uint32_t)c;
+    if (POINTS) keys_out[(size_t)base + i] = key_join((uint32_t)b, (uint32_t)(c >> 32));
+  }
+}
+
+template <typename Src, bool POINTS>
+int bucket_sort(wc_ctx *ctx, const Src &src, uint64_t n, uint64_t *comp_buf, uint32_t *keys_out, uint32_t *idx_out, uint32_t *counts,
+                uint32_t *status) {
+  hipStream_t st = ctx->stream;
+  WC_HIP(ctx, hipMemsetAsync(counts, 0, 2 * kBuckets * 4, st));  // counts + cursors
+  const unsigned tiles = (unsigned)((n + kTile - 1) / kTile);
+  k_bucket_hist<Src><<<tiles, 256, 0, st>>>(src, n, counts, status);
+  k_bucket_scatter<Src><<<tiles, 256, 0, st>>>(src, n, counts, counts + kBuckets, comp_buf, status);
+  k_bucket_sort<POINTS><<<kBuckets, 256, 0, st>>>(comp_buf, counts, keys_out, idx_out, status);
+  WC_HIP(ctx, hipGetLastError());
+  return WC_OK;
+}
+
 template <typename K>
 int sort_pairs(wc_ctx *ctx, K *kin, K *kout, uint32_t *vin, uint32_t *vout, size_t n, unsigned end_bit) {
+  // rocPRIM's default switches to a ~20-launch merge sort below 2^20 items (MergeSortLimit); the Onesweep radix path is
+  // several times faster for (u32 key, u32 index) pairs at these sizes, so the limit is set to zero.
+  using cfg = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 0>;
   size_t tmp = 0;
-  WC_HIP(ctx, rocprim::radix_sort_pairs(nullptr, tmp, kin, kout, vin, vout, n, 0u, end_bit, ctx->stream));
+  WC_HIP(ctx, rocprim::radix_sort_pairs<cfg>(nullptr, tmp, kin, kout, vin, vout, n, 0u, end_bit, ctx->stream));
   WC_TRY(wc_ensure(ctx, ctx->b_sorttmp, tmp));
   tmp = ctx->b_sorttmp.cap;
-  WC_HIP(ctx, rocprim::radix_sort_pairs(ctx->b_sorttmp.p, tmp, kin, kout, vin, vout, n, 0u, end_bit, ctx->stream));
+  WC_HIP(ctx, rocprim::radix_sort_pairs<cfg>(ctx->b_sorttmp.p, tmp, kin, kout, vin, vout, n, 0u, end_bit, ctx->stream));
   return WC_OK;
 }
 
 template <typename K>
 int run_pipeline(wc_ctx *ctx, const wc_points &pts, double t_lo, double t_hi, wc_surfel *d_out, wc_surfel_id *d_ids,
-                 uint64_t cap) {
+                 uint64_t cap, bool fast) {
   const wc_params &P = ctx->P;
   const uint64_t n = pts.n;
   hipStream_t st = ctx->stream;
@@ -542,11 +738,24 @@ int run_pipeline(wc_ctx *ctx, const wc_points &pts, double t_lo, double t_hi, wc
   WC_HIP(ctx, hipMemsetAsync(status, 0, 64 * 4, st));
   WC_HIP(ctx, hipMemsetAsync(ctx->b_slot_keys[0].p, 0xFF, total_slots * 8, st));
   const unsigned g256 = (unsigned)((n + 255) / 256);
-  k_keygen<K><<<g256, 256, 0, st>>>(pts, E.vs, (K *)ctx->b_keys[0].p, (uint32_t *)ctx->b_vals[0].p, status);
-  k_iota<<<(unsigned)((total_slots + 255) / 256), 256, 0, st>>>((uint32_t *)ctx->b_slot_idx[0].p, total_slots);
-  mark(1);
-  WC_TRY(sort_pairs<K>(ctx, (K *)ctx->b_keys[0].p, (K *)ctx->b_keys[1].p, (uint32_t *)ctx->b_vals[0].p,
-                       (uint32_t *)ctx->b_vals[1].p, n, 3 * KeyTraits<K>::bits));
+  // fast path (32-bit keys): bucket sort of (voxel key, index) composites; general path: rocPRIM radix sort
+  const bool fast_pts = fast && sizeof(K) == 4;
+  const bool fast_slots = fast && tbits <= 31 && total_slots < (1ull << 32);
+  if (fast_pts || fast_slots) {
+    WC_TRY(wc_ensure(ctx, ctx->b_misc[1], std::max<uint64_t>(n, total_slots) * 8));
+    WC_TRY(wc_ensure(ctx, ctx->b_misc[2], 2 * kBuckets * 4));
+  }
+  if (fast_pts) {
+    mark(1);
+    PointSrc src{pts, E.vs};
+    WC_TRY((bucket_sort<PointSrc, true>(ctx, src, n, (uint64_t *)ctx->b_misc[1].p, (uint32_t *)ctx->b_keys[1].p,
+                                        (uint32_t *)ctx->b_vals[1].p, (uint32_t *)ctx->b_misc[2].p, status)));
+  } else {
+    k_keygen<K><<<g256, 256, 0, st>>>(pts, E.vs, (K *)ctx->b_keys[0].p, (uint32_t *)ctx->b_vals[0].p, status);
+    mark(1);
+    WC_TRY(sort_pairs<K>(ctx, (K *)ctx->b_keys[0].p, (K *)ctx->b_keys[1].p, (uint32_t *)ctx->b_vals[0].p,
+                         (uint32_t *)ctx->b_vals[1].p, n, 3 * KeyTraits<K>::bits));
+  }
   mark(2);
   RootsArgs A;
   A.pts = pts;
@@ -566,9 +775,16 @@ int run_pipeline(wc_ctx *ctx, const wc_points &pts, double t_lo, double t_hi, wc
   k_heads<K><<<g256, 256, 0, st>>>((const K *)ctx->b_keys[1].p, n, P.min_points, (uint32_t *)ctx->b_misc[0].p);
   k_roots<K><<<kRootsGrid, 64, 0, st>>>(A, (const K *)ctx->b_keys[1].p);
   mark(3);
-  WC_TRY(sort_pairs<uint64_t>(ctx, (uint64_t *)ctx->b_slot_keys[0].p, (uint64_t *)ctx->b_slot_keys[1].p,
-                              (uint32_t *)ctx->b_slot_idx[0].p, (uint32_t *)ctx->b_slot_idx[1].p, total_slots,
-                              slot_end_bit));
+  if (fast_slots) {
+    SlotSrc ssrc{(const uint64_t *)ctx->b_slot_keys[0].p, tbits > 10 ? tbits - 10 : 0u};
+    WC_TRY((bucket_sort<SlotSrc, false>(ctx, ssrc, total_slots, (uint64_t *)ctx->b_misc[1].p, nullptr, (uint32_t *)ctx->b_slot_idx[1].p,
+                                        (uint32_t *)ctx->b_misc[2].p, status)));
+  } else {
+    k_iota<<<(unsigned)((total_slots + 255) / 256), 256, 0, st>>>((uint32_t *)ctx->b_slot_idx[0].p, total_slots);
+    WC_TRY(sort_pairs<uint64_t>(ctx, (uint64_t *)ctx->b_slot_keys[0].p, (uint64_t *)ctx->b_slot_keys[1].p,
+                                (uint32_t *)ctx->b_slot_idx[0].p, (uint32_t *)ctx->b_slot_idx[1].p, total_slots,
+                                slot_end_bit));
+  }
   mark(4);
   const uint64_t gth = std::min<uint64_t>(total_slots, cap) * 10;
   if (gth)
@@ -613,7 +829,8 @@ extern "C" int wc_extract_surfels_enqueue(wc_ctx *ctx, const wc_points *pts, dou
   }
   ctx->ex.t_lo = t_lo;
   ctx->ex.t_hi = t_hi;
-  return run_pipeline<uint32_t>(ctx, *pts, t_lo, t_hi, d_out, d_ids, cap);
+  ctx->ex.general = false;
+  return run_pipeline<uint32_t>(ctx, *pts, t_lo, t_hi, d_out, d_ids, cap, getenv("WC_NO_BUCKET_SORT") == nullptr);
 }
 
 extern "C" int wc_extract_surfels_finish(wc_ctx *ctx, uint64_t *h_n_out) {
@@ -622,10 +839,16 @@ extern "C" int wc_extract_surfels_finish(wc_ctx *ctx, uint64_t *h_n_out) {
   if (h_n_out) *h_n_out = 0;
   if (ctx->ex.pts.n == 0) return WC_OK;
   WC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if ((ctx->h_status[1] & kFlagBucketOverflow) && !(ctx->h_status[1] & kFlagKeyRange) && !ctx->ex.general) {
+    // a bucket of the fast sort overflowed (very many points in few voxels): redo with the general radix sort
+    ctx->ex.general = true;
+    WC_TRY(run_pipeline<uint32_t>(ctx, ctx->ex.pts, ctx->ex.t_lo, ctx->ex.t_hi, ctx->ex.d_out, ctx->ex.d_ids, ctx->ex.cap, false));
+    WC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
   if ((ctx->h_status[1] & kFlagKeyRange) && !ctx->ex.wide) {
     // the sweep spans more than +-512 root voxels around its first point: redo with 21-bit-per-axis keys
     ctx->ex.wide = true;
-    WC_TRY(run_pipeline<uint64_t>(ctx, ctx->ex.pts, ctx->ex.t_lo, ctx->ex.t_hi, ctx->ex.d_out, ctx->ex.d_ids, ctx->ex.cap));
+    WC_TRY(run_pipeline<uint64_t>(ctx, ctx->ex.pts, ctx->ex.t_lo, ctx->ex.t_hi, ctx->ex.d_out, ctx->ex.d_ids, ctx->ex.cap, false));
     WC_HIP(ctx, hipStreamSynchronize(ctx->stream));
   }
   const uint32_t flags = ctx->h_status[1];
