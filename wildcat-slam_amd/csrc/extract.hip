@@ -490,27 +490,27 @@ __global__ void __launch_bounds__(256) k_gather(const uint32_t *__restrict__ sor
 // ---- bucket sort of 64-bit composites (group-by with a fixed order inside the group) -----------------------------------
 // Both sorts of the extraction only need "equal keys contiguous, ascending index inside a key".  Packing (key, index)
 // into one 64-bit composite makes ANY sort of the composites stable by construction, so the global pass can be an
-// unordered MSD scatter into 1024 buckets (per-tile LDS histograms, one global atomic per non-empty (tile, bucket)) and
-// each bucket is finished by a bitonic sort in LDS.  For the points the bucket digit is built from the LOW bits of the
-// voxel index (x&15, y&7, z&7): neighbouring voxels land in different buckets, so planar scenes do not overload one
+// unordered MSD scatter into 4096 buckets (per-tile LDS histograms, one global atomic per non-empty (tile, bucket)) and
+// each bucket is finished by a bitonic sort in LDS (4096 small buckets: bitonic cost grows as n log^2 n).  For the points
+// the bucket digit is built from the LOW bits of the voxel index (x&15, y&15, z&15): neighbouring voxels land in different buckets, so planar scenes do not overload one
 // bucket; the order of the voxels among each other is irrelevant (only grouping matters).  3 launches instead of
 // rocPRIM's ~20 (merge path) for 1 M pairs.  A bucket larger than kBucketCap raises a flag and the caller falls back
 // to the rocPRIM radix sort.
-constexpr int kBuckets = 1024;
+constexpr int kBuckets = 4096;
 constexpr int kBucketCap = 4096;
 constexpr int kTile = 4096;  // items per workgroup in the histogram / scatter passes
 
 __device__ __forceinline__ uint32_t key_digit(uint32_t key) {
   const uint32_t x = key & 1023u, y = (key >> 10) & 1023u, z = key >> 20;
-  return (x & 15u) | ((y & 7u) << 4) | ((z & 7u) << 7);
+  return (x & 15u) | ((y & 15u) << 4) | ((z & 15u) << 8);
 }
 __device__ __forceinline__ uint32_t key_rest(uint32_t key) {
   const uint32_t x = key & 1023u, y = (key >> 10) & 1023u, z = key >> 20;
-  return (x >> 4) | ((y >> 3) << 6) | ((z >> 3) << 13);
+  return (x >> 4) | ((y >> 4) << 6) | ((z >> 4) << 12);
 }
 __device__ __forceinline__ uint32_t key_join(uint32_t d, uint32_t r) {
-  const uint32_t x = (d & 15u) | ((r & 63u) << 4), y = ((d >> 4) & 7u) | (((r >> 6) & 127u) << 3),
-                 z = ((d >> 7) & 7u) | (((r >> 13) & 127u) << 3);
+  const uint32_t x = (d & 15u) | ((r & 63u) << 4), y = ((d >> 4) & 15u) | (((r >> 6) & 63u) << 4),
+                 z = ((d >> 8) & 15u) | (((r >> 12) & 63u) << 4);
   return x | (y << 10) | (z << 20);
 }
 
@@ -562,37 +562,11 @@ __global__ void __launch_bounds__(256) k_bucket_hist(Src src, uint64_t n, uint32
     if (s_h[b]) atomicAdd(&counts[b], s_h[b]);
 }
 
-// exclusive prefix of the 1024 bucket counts into LDS (every workgroup recomputes it: 4 KB, cheaper than a launch)
-__device__ __forceinline__ void bucket_bases(const uint32_t *counts, uint32_t *s_base, uint32_t *s_tmp) {
-  const int t = threadIdx.x;
-  uint32_t c[4], sum = 0;
-  for (int q = 0; q < 4; ++q) {
-    c[q] = counts[4 * t + q];
-    sum += c[q];
-  }
-  s_tmp[t] = sum;
-  __syncthreads();
-  for (int off = 1; off < 256; off <<= 1) {
-    const uint32_t v = (t >= off) ? s_tmp[t - off] : 0u;
-    __syncthreads();
-    s_tmp[t] += v;
-    __syncthreads();
-  }
-  uint32_t run = s_tmp[t] - sum;
-  for (int q = 0; q < 4; ++q) {
-    s_base[4 * t + q] = run;
-    run += c[q];
-  }
-  __syncthreads();
-}
-
 template <typename Src>
 __global__ void __launch_bounds__(256) k_bucket_scatter(Src src, uint64_t n, const uint32_t *counts, uint32_t *cursor, uint64_t *comp_out,
                                                        uint32_t *status) {
-  __shared__ uint32_t s_base[kBuckets];
   __shared__ uint32_t s_cnt[kBuckets];
-  __shared__ uint32_t s_tmp[256];
-  bucket_bases(counts, s_base, s_tmp);
+  const uint32_t *s_base = counts + 2 * kBuckets;  // written by k_bucket_prefix
   for (int b = threadIdx.x; b < kBuckets; b += 256) s_cnt[b] = 0;
   __syncthreads();
   const uint64_t t0 = (uint64_t)blockIdx.x * kTile;
@@ -624,17 +598,8 @@ template <bool POINTS>
 __global__ void __launch_bounds__(256) k_bucket_sort(const uint64_t *comp, const uint32_t *counts, uint32_t *keys_out, uint32_t *idx_out,
                                                     uint32_t *status) {
   __shared__ uint64_t s[kBucketCap];
-  __shared__ uint32_t s_red[256];
   const int b = blockIdx.x, t = threadIdx.x;
-  uint32_t part = 0;
-  for (int q = t; q < b; q += 256) part += counts[q];
-  s_red[t] = part;
-  __syncthreads();
-  for (int st = 128; st > 0; st >>= 1) {
-    if (t < st) s_red[t] += s_red[t + st];
-    __syncthreads();
-  }
-  const uint32_t base = s_red[0], nb = counts[b];
+  const uint32_t base = counts[2 * kBuckets + b], nb = counts[b];
   if (nb == 0) return;
   if (nb > (uint32_t)kBucketCap) {
     if (t == 0) atomicOr(&status[1], kFlagBucketOverflow);
@@ -665,6 +630,201 @@ __global__ void __launch_bounds__(256) k_bucket_sort(const uint64_t *comp, const
   }
 }
 
+// ---- run-compressed bucket sort of the points -----------------------------------------------------------------------
+// A sweep is time ordered and a scan line stays inside one 0.8 m voxel for many consecutive points, so the unit that
+// is sorted is the RUN (maximal stretch of consecutive points with one voxel key, cut at tile boundaries), not the
+// point: k_pt_hist writes the per-point keys once (the only pass over the 48-byte AoS input), counts runs and points
+// per bucket; k_pt_scatter drops (key rest | start index) composites of the run heads into their buckets and the run
+// length next to the start index; k_pt_bucket sorts a bucket's runs and EXPANDS them into the per-point (key, index)
+// arrays k_heads / k_roots consume.  Points of one voxel end up contiguous and in time order (runs sorted by start).
+__device__ __forceinline__ uint32_t point_key(const wc_points &pts, double vs, uint64_t i, uint32_t *status) {
+  double x0, y0, z0, x, y, z;
+  load_xyz(pts, 0, x0, y0, z0);
+  load_xyz(pts, i, x, y, z);
+  int rx = vox(x, vs) - vox(x0, vs) + 512, ry = vox(y, vs) - vox(y0, vs) + 512, rz = vox(z, vs) - vox(z0, vs) + 512;
+  if ((unsigned)rx >= 1024u || (unsigned)ry >= 1024u || (unsigned)rz >= 1024u) {
+    atomicOr(&status[1], kFlagKeyRange);
+    rx = min(max(rx, 0), 1023), ry = min(max(ry, 0), 1023), rz = min(max(rz, 0), 1023);
+  }
+  return (uint32_t)rx | ((uint32_t)ry << 10) | ((uint32_t)rz << 20);
+}
+
+// run heads of a tile held in s_key[0..cnt): bit i of the bitmap is set when point i starts a run; returns the run
+// length of head i (distance to the next head or to the end of the tile)
+__device__ __forceinline__ uint32_t run_length(const unsigned long long *s_bits, uint32_t i, uint32_t cnt) {
+  uint32_t w = (i + 1) >> 6;
+  unsigned long long m = (w < kTile / 64) ? (s_bits[w] & (~0ull << ((i + 1) & 63))) : 0ull;
+  while (m == 0ull && ++w < kTile / 64) m = s_bits[w];
+  const uint32_t nxt = m ? (w * 64 + (uint32_t)__ffsll((long long)m) - 1) : cnt;
+  return min(nxt, cnt) - i;
+}
+
+// exclusive prefixes of the per-bucket run and point counts (one small workgroup; every later workgroup just reads them)
+__global__ void __launch_bounds__(1024) k_bucket_prefix(const uint32_t *counts, uint32_t *bases, int narrays) {
+  __shared__ uint32_t s_tmp[1024];
+  constexpr int PER = kBuckets / 1024;
+  const int t = threadIdx.x;
+  for (int a = 0; a < narrays; ++a) {
+    uint32_t c[PER], sum = 0;
+    for (int q = 0; q < PER; ++q) {
+      c[q] = counts[a * kBuckets + PER * t + q];
+      sum += c[q];
+    }
+    s_tmp[t] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+      const uint32_t v = (t >= off) ? s_tmp[t - off] : 0u;
+      __syncthreads();
+      s_tmp[t] += v;
+      __syncthreads();
+    }
+    uint32_t run = s_tmp[t] - sum;
+    for (int q = 0; q < PER; ++q) {
+      bases[a * kBuckets + PER * t + q] = run;
+      run += c[q];
+    }
+    __syncthreads();
+  }
+}
+
+template <bool SCATTER>
+__global__ void __launch_bounds__(256) k_pt_runs(wc_points pts, double vs, uint64_t n, uint32_t *keys_raw, uint32_t *counts /*runs|pts*/,
+                                                uint32_t *cursor, uint64_t *comp_out, uint16_t *run_len, uint32_t *status) {
+  __shared__ uint32_t s_key[kTile];
+  __shared__ unsigned long long s_bits[kTile / 64];
+  __shared__ uint32_t s_runs[kBuckets];
+  __shared__ uint32_t s_pts[SCATTER ? 1 : kBuckets];
+  const int t = threadIdx.x;
+  const uint64_t t0 = (uint64_t)blockIdx.x * kTile;
+  const uint32_t cnt = (uint32_t)min((uint64_t)kTile, n - t0);
+  const uint32_t *bases = counts + 3 * kBuckets;  // written by k_bucket_prefix
+  for (int b = t; b < kBuckets; b += 256) {
+    s_runs[b] = 0;
+    if (!SCATTER) s_pts[b] = 0;
+  }
+  if (t < kTile / 64) s_bits[t] = 0ull;
+  for (uint32_t i = t; i < cnt; i += 256) {
+    uint32_t k;
+    if (SCATTER) {
+      k = keys_raw[t0 + i];
+    } else {
+      k = point_key(pts, vs, t0 + i, status);
+      keys_raw[t0 + i] = k;
+    }
+    s_key[i] = k;
+  }
+  __syncthreads();
+  for (uint32_t i = t; i < cnt; i += 256)
+    if (i == 0 || s_key[i] != s_key[i - 1]) atomicOr(&s_bits[i >> 6], 1ull << (i & 63));
+  __syncthreads();
+  uint32_t rank[kTile / 256];
+#pragma unroll
+  for (int j = 0; j < kTile / 256; ++j) {
+    const uint32_t i = (uint32_t)j * 256 + t;
+    rank[j] = 0xFFFFFFFFu;
+    if (i < cnt && ((s_bits[i >> 6] >> (i & 63)) & 1ull)) {
+      const uint32_t d = key_digit(s_key[i]);
+      rank[j] = atomicAdd(&s_runs[d], 1u);
+      if (!SCATTER) atomicAdd(&s_pts[d], run_length(s_bits, i, cnt));
+    }
+  }
+  __syncthreads();
+  if (!SCATTER) {
+    for (int b = t; b < kBuckets; b += 256)
+      if (s_runs[b]) {
+        atomicAdd(&counts[b], s_runs[b]);
+        atomicAdd(&counts[kBuckets + b], s_pts[b]);
+      }
+    return;
+  }
+  for (int b = t; b < kBuckets; b += 256) {
+    const uint32_t c = s_runs[b];
+    s_runs[b] = c ? atomicAdd(&cursor[b], c) : 0u;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < kTile / 256; ++j) {
+    if (rank[j] == 0xFFFFFFFFu) continue;
+    const uint32_t i = (uint32_t)j * 256 + t;
+    const uint32_t k = s_key[i], d = key_digit(k);
+    comp_out[(size_t)bases[d] + s_runs[d] + rank[j]] = ((uint64_t)key_rest(k) << 32) | (uint64_t)(uint32_t)(t0 + i);
+    run_len[t0 + i] = (uint16_t)run_length(s_bits, i, cnt);
+  }
+}
+
+// one workgroup per bucket: sort the bucket's runs (bitonic on the composites), then expand them to per-point output
+__global__ void __launch_bounds__(256) k_pt_bucket(const uint64_t *comp, const uint32_t *counts, const uint16_t *run_len, uint32_t *keys_out,
+                                                  uint32_t *idx_out, uint32_t *status) {
+  __shared__ uint64_t s[kBucketCap];
+  __shared__ uint32_t s_off[kBucketCap];
+  const int b = blockIdx.x, t = threadIdx.x;
+  const uint32_t rbase = counts[3 * kBuckets + b], pbase = counts[4 * kBuckets + b], nb = counts[b];
+  if (nb == 0) return;
+  if (nb > (uint32_t)kBucketCap) {
+    if (t == 0) atomicOr(&status[1], kFlagBucketOverflow);
+    return;
+  }
+  uint32_t N = 64;
+  while (N < nb) N <<= 1;
+  for (uint32_t i = t; i < N; i += 256) s[i] = (i < nb) ? comp[(size_t)rbase + i] : ~0ull;
+  __syncthreads();
+  for (uint32_t k = 2; k <= N; k <<= 1)
+    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+      for (uint32_t p = t; p < N / 2; p += 256) {
+        const uint32_t i = 2 * p - (p & (j - 1));
+        const uint32_t l = i + j;
+        const uint64_t a = s[i], c = s[l];
+        if ((a > c) == ((i & k) == 0)) {
+          s[i] = c;
+          s[l] = a;
+        }
+      }
+      __syncthreads();
+    }
+  // exclusive prefix of the run lengths (sorted order) -> output offsets
+  for (uint32_t i = t; i < N; i += 256) s_off[i] = (i < nb) ? (uint32_t)run_len[(uint32_t)s[i]] : 0u;
+  __syncthreads();
+  if (t == 0) {  // buckets hold a handful of runs on regular clouds; a serial scan of <= 4096 entries is the tail case
+    uint32_t run = 0;
+    for (uint32_t i = 0; i < nb; ++i) {
+      const uint32_t l = s_off[i];
+      s_off[i] = run;
+      run += l;
+    }
+  }
+  __syncthreads();
+  const int lane = t & 63, wave = t >> 6;
+  for (uint32_t r = wave; r < nb; r += 4) {  // one wavefront per run: contiguous, coalesced expansion
+    const uint64_t c = s[r];
+    const uint32_t start = (uint32_t)c, len = run_len[start], key = key_join((uint32_t)b, (uint32_t)(c >> 32));
+    const size_t o = (size_t)pbase + s_off[r];
+    for (uint32_t j = lane; j < len; j += 64) {
+      keys_out[o + j] = key;
+      idx_out[o + j] = start + j;
+    }
+  }
+}
+
+int point_sort_runs(wc_ctx *ctx, const wc_points &pts, double vs, uint32_t *keys_out, uint32_t *idx_out, uint32_t *status) {
+  hipStream_t st = ctx->stream;
+  const uint64_t n = pts.n;
+  WC_TRY(wc_ensure(ctx, ctx->b_misc[1], n * 8));            // run composites (at most one per point)
+  WC_TRY(wc_ensure(ctx, ctx->b_misc[2], 5 * kBuckets * 4));  // run counts | point counts | cursors | run bases | point bases
+  WC_TRY(wc_ensure(ctx, ctx->b_misc[3], n * 2));            // run lengths, indexed by the run's first point
+  WC_TRY(wc_ensure(ctx, ctx->b_keys[0], n * 4));            // per-point keys
+  uint32_t *counts = (uint32_t *)ctx->b_misc[2].p;
+  WC_HIP(ctx, hipMemsetAsync(counts, 0, 3 * kBuckets * 4, st));
+  const unsigned tiles = (unsigned)((n + kTile - 1) / kTile);
+  k_pt_runs<false><<<tiles, 256, 0, st>>>(pts, vs, n, (uint32_t *)ctx->b_keys[0].p, counts, nullptr, nullptr, nullptr, status);
+  k_bucket_prefix<<<1, 1024, 0, st>>>(counts, counts + 3 * kBuckets, 2);
+  k_pt_runs<true><<<tiles, 256, 0, st>>>(pts, vs, n, (uint32_t *)ctx->b_keys[0].p, counts, counts + 2 * kBuckets,
+                                        (uint64_t *)ctx->b_misc[1].p, (uint16_t *)ctx->b_misc[3].p, status);
+  k_pt_bucket<<<kBuckets, 256, 0, st>>>((const uint64_t *)ctx->b_misc[1].p, counts, (const uint16_t *)ctx->b_misc[3].p, keys_out, idx_out,
+                                       status);
+  WC_HIP(ctx, hipGetLastError());
+  return WC_OK;
+}
+
 template <typename Src, bool POINTS>
 int bucket_sort(wc_ctx *ctx, const Src &src, uint64_t n, uint64_t *comp_buf, uint32_t *keys_out, uint32_t *idx_out, uint32_t *counts,
                 uint32_t *status) {
@@ -672,6 +832,7 @@ int bucket_sort(wc_ctx *ctx, const Src &src, uint64_t n, uint64_t *comp_buf, uin
   WC_HIP(ctx, hipMemsetAsync(counts, 0, 2 * kBuckets * 4, st));  // counts + cursors
   const unsigned tiles = (unsigned)((n + kTile - 1) / kTile);
   k_bucket_hist<Src><<<tiles, 256, 0, st>>>(src, n, counts, status);
+  k_bucket_prefix<<<1, 1024, 0, st>>>(counts, counts + 2 * kBuckets, 1);
   k_bucket_scatter<Src><<<tiles, 256, 0, st>>>(src, n, counts, counts + kBuckets, comp_buf, status);
   k_bucket_sort<POINTS><<<kBuckets, 256, 0, st>>>(comp_buf, counts, keys_out, idx_out, status);
   WC_HIP(ctx, hipGetLastError());
@@ -743,13 +904,11 @@ int run_pipeline(wc_ctx *ctx, const wc_points &pts, double t_lo, double t_hi, wc
   const bool fast_slots = fast && tbits <= 31 && total_slots < (1ull << 32);
   if (fast_pts || fast_slots) {
     WC_TRY(wc_ensure(ctx, ctx->b_misc[1], std::max<uint64_t>(n, total_slots) * 8));
-    WC_TRY(wc_ensure(ctx, ctx->b_misc[2], 2 * kBuckets * 4));
+    WC_TRY(wc_ensure(ctx, ctx->b_misc[2], 5 * kBuckets * 4));
   }
   if (fast_pts) {
     mark(1);
-    PointSrc src{pts, E.vs};
-    WC_TRY((bucket_sort<PointSrc, true>(ctx, src, n, (uint64_t *)ctx->b_misc[1].p, (uint32_t *)ctx->b_keys[1].p,
-                                        (uint32_t *)ctx->b_vals[1].p, (uint32_t *)ctx->b_misc[2].p, status)));
+    WC_TRY(point_sort_runs(ctx, pts, E.vs, (uint32_t *)ctx->b_keys[1].p, (uint32_t *)ctx->b_vals[1].p, status));
   } else {
     k_keygen<K><<<g256, 256, 0, st>>>(pts, E.vs, (K *)ctx->b_keys[0].p, (uint32_t *)ctx->b_vals[0].p, status);
     mark(1);
@@ -776,7 +935,7 @@ int run_pipeline(wc_ctx *ctx, const wc_points &pts, double t_lo, double t_hi, wc
   k_roots<K><<<kRootsGrid, 64, 0, st>>>(A, (const K *)ctx->b_keys[1].p);
   mark(3);
   if (fast_slots) {
-    SlotSrc ssrc{(const uint64_t *)ctx->b_slot_keys[0].p, tbits > 10 ? tbits - 10 : 0u};
+    SlotSrc ssrc{(const uint64_t *)ctx->b_slot_keys[0].p, tbits > 12 ? tbits - 12 : 0u};
     WC_TRY((bucket_sort<SlotSrc, false>(ctx, ssrc, total_slots, (uint64_t *)ctx->b_misc[1].p, nullptr, (uint32_t *)ctx->b_slot_idx[1].p,
                                         (uint32_t *)ctx->b_misc[2].p, status)));
   } else {
