@@ -257,10 +257,13 @@ __global__ void __launch_bounds__(64) k_roots(RootsArgs A, const K *__restrict__
         load_xyz(A.pts, idx, px, py, pz);
         pt = load_t(A.pts, idx);
       }
+      int carry_o1 = -2;      // layer-1 octant / timestamp of the last point of the previous chunk
+      double carry_t = 0.0;
       while (true) {
         const int nvalid = __popcll(__ballot(valid));  // valid lanes are a prefix: keys are sorted
         if (nvalid == 0) break;
         __syncthreads();
+        int my_o1 = -1;
         if (valid) {
           // octant = 4*[x>cx] + 2*[y>cy] + [z>cz] (strict >, cc:147-158); child centre = centre +- quarter (cc:163-165)
           const int bx = px > cx, by = py > cy, bz = pz > cz;
@@ -275,6 +278,23 @@ __global__ void __launch_bounds__(64) k_roots(RootsArgs A, const K *__restrict__
           s_stage[lane * 5 + 3] = py;
           s_stage[lane * 5 + 4] = pz;
           s_code[lane] = (uint32_t)(o1 * 8 + o2);
+          my_o1 = o1;
+        }
+        // EVENT points (lane-parallel, before the sequential pass): a point needs the full per-point logic only when its
+        // layer-1 node differs from its predecessor's or the time gap to its predecessor exceeds cluster_gap; between
+        // two events every level keeps feeding the same node and no cluster can close, so the sequential pass can run a
+        // bare multiply-accumulate loop over whole segments.  (Phase 2 skips points, so there every point is an event.)
+        unsigned long long ev = ~0ull;
+        if (phase == 1) {
+          int po1 = __shfl_up(my_o1, 1);
+          double ptv = __shfl_up(pt, 1);
+          if (lane == 0) {
+            po1 = carry_o1;
+            ptv = carry_t;
+          }
+          ev = __ballot(valid && (my_o1 != po1 || pt - ptv > P.gap));
+          carry_o1 = __shfl(my_o1, nvalid - 1);
+          carry_t = __shfl(pt, nvalid - 1);
         }
         __syncthreads();
         // prefetch the next chunk
@@ -290,17 +310,32 @@ __global__ void __launch_bounds__(64) k_roots(RootsArgs A, const K *__restrict__
         }
 
         // ---- stream the staged points in time order ----
-        // the reads of point j+1 are issued before point j is processed (LDS latency off the critical path)
-        uint32_t code_n = s_code[0];
-        double t_n = s_stage[1], a_n = s_stage[ia], b_n = s_stage[ib];
-        for (int j = 0; j < ((P.dbg & 1) ? 0 : nvalid); ++j) {
-          const uint32_t code = code_n;
-          const double t = t_n, va = a_n, vb = b_n;
-          const int jn = (j + 1 < 64) ? j + 1 : 63;
-          code_n = s_code[jn];
-          t_n = s_stage[jn * 5 + 1];
-          a_n = s_stage[jn * 5 + ia];
-          b_n = s_stage[jn * 5 + ib];
+        int j = (P.dbg & 1) ? nvalid : 0;
+        while (j < nvalid) {
+          const unsigned long long rem = ev >> j;
+          const int je = rem ? j + (__ffsll((long long)rem) - 1) : nvalid;  // next event (or end of chunk)
+          if (je > j) {  // event-free segment: every active lane keeps accumulating into its cached node
+            if (act) {
+              double ao = a_open, at = a_total;
+#pragma unroll 4
+              for (int q = j; q < je; ++q) {
+                const double v = s_stage[q * 5 + ia] * s_stage[q * 5 + ib];
+                ao += v;
+                at += v;
+              }
+              a_open = ao;
+              a_total = at;
+              n_open += je - j;
+              last = s_stage[(je - 1) * 5 + 1];
+            }
+            j = je;
+            if (j >= nvalid) break;
+          }
+          // ---- event point: full logic ----
+          const uint32_t code = s_code[j];
+          const double t = s_stage[j * 5 + 1];
+          const double va = s_stage[j * 5 + ia], vb = s_stage[j * 5 + ib];
+          ++j;
           if (phase == 2 && !((split1 >> (code >> 3)) & 1ull)) continue;  // parent layer-1 node is not split
           const int nu = (phase == 2) ? (int)code : (Lq == 0 ? 0 : 1 + (int)(code >> 3));
           if (act && nu != cur) {  // switch node: write the cached accumulators back, fetch the new node's
