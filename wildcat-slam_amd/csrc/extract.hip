@@ -32,6 +32,9 @@ namespace {
 
 constexpr int kMom = 11;    // n, St, Sx, Sy, Sz, Sxx, Sxy, Sxz, Syy, Syz, Szz
 constexpr unsigned kRootsGrid = 256 * 10;  // persistent wavefronts: 256 CUs x ~LDS-limited residency
+constexpr int kBuckets = 4096;    // buckets of the composite sorts
+constexpr int kBucketCap = 4096;  // largest bucket the in-LDS bitonic sort takes
+constexpr int kTile = 4096;       // items per workgroup in the histogram / scatter passes
 constexpr uint32_t kFlagKeyRange = 1u, kFlagSlotOverflow = 2u, kFlagTimeRange = 4u, kFlagBucketOverflow = 8u;
 
 struct ExParams {
@@ -161,7 +164,9 @@ struct RootsArgs {
   wc_surfel_id *slot_ids;  // [total_slots]
   uint64_t *slot_keys;     // [total_slots] time sort keys (memset to ~0 = invalid)
   uint64_t total_slots;
-  uint32_t *status;        // [0] emitted count, [1] flags, [2] live roots, [3] dequeue cursor
+  uint32_t *status;        // [0] emitted count, [1] flags
+  uint32_t *slot_counts;   // bucket histogram of the surfel time keys (fast slot sort), or null
+  uint32_t slot_shift;
 };
 
 // Heads of the root-voxel segments that can emit anything (n > min_points, InitOctoTree cc:129).  Two live heads are at
@@ -483,6 +488,7 @@ __global__ void __launch_bounds__(64) k_roots(RootsArgs A, const K *__restrict__
                 key = ob - P.t_lo_bits;
               }
               A.slot_keys[slot] = key;
+              if (A.slot_counts) atomicAdd(&A.slot_counts[min((uint32_t)(key >> A.slot_shift), (uint32_t)(kBuckets - 1))], 1u);
               ok = true;
             }
           }
@@ -531,9 +537,6 @@ __global__ void __launch_bounds__(256) k_gather(const uint32_t *__restrict__ sor
 // bucket; the order of the voxels among each other is irrelevant (only grouping matters).  3 launches instead of
 // rocPRIM's ~20 (merge path) for 1 M pairs.  A bucket larger than kBucketCap raises a flag and the caller falls back
 // to the rocPRIM radix sort.
-constexpr int kBuckets = 4096;
-constexpr int kBucketCap = 4096;
-constexpr int kTile = 4096;  // items per workgroup in the histogram / scatter passes
 
 __device__ __forceinline__ uint32_t key_digit(uint32_t key) {
   const uint32_t x = key & 1023u, y = (key >> 10) & 1023u, z = key >> 20;
@@ -862,11 +865,13 @@ int point_sort_runs(wc_ctx *ctx, const wc_points &pts, double vs, uint32_t *keys
 
 template <typename Src, bool POINTS>
 int bucket_sort(wc_ctx *ctx, const Src &src, uint64_t n, uint64_t *comp_buf, uint32_t *keys_out, uint32_t *idx_out, uint32_t *counts,
-                uint32_t *status) {
+                uint32_t *status, bool have_hist) {
   hipStream_t st = ctx->stream;
-  WC_HIP(ctx, hipMemsetAsync(counts, 0, 2 * kBuckets * 4, st));  // counts + cursors
   const unsigned tiles = (unsigned)((n + kTile - 1) / kTile);
-  k_bucket_hist<Src><<<tiles, 256, 0, st>>>(src, n, counts, status);
+  if (!have_hist) {
+    WC_HIP(ctx, hipMemsetAsync(counts, 0, 2 * kBuckets * 4, st));  // counts + cursors
+    k_bucket_hist<Src><<<tiles, 256, 0, st>>>(src, n, counts, status);
+  }
   k_bucket_prefix<<<1, 1024, 0, st>>>(counts, counts + 2 * kBuckets, 1);
   k_bucket_scatter<Src><<<tiles, 256, 0, st>>>(src, n, counts, counts + kBuckets, comp_buf, status);
   k_bucket_sort<POINTS><<<kBuckets, 256, 0, st>>>(comp_buf, counts, keys_out, idx_out, status);
@@ -933,10 +938,14 @@ int run_pipeline(wc_ctx *ctx, const wc_points &pts, double t_lo, double t_hi, wc
   mark(0);
   WC_HIP(ctx, hipMemsetAsync(status, 0, 64 * 4, st));
   WC_HIP(ctx, hipMemsetAsync(ctx->b_slot_keys[0].p, 0xFF, total_slots * 8, st));
+  const bool fast_slots = fast && tbits <= 31 && total_slots < (1ull << 32);
+  if (fast_slots) {
+    WC_TRY(wc_ensure(ctx, ctx->b_misc[4], 3 * kBuckets * 4));
+    WC_HIP(ctx, hipMemsetAsync(ctx->b_misc[4].p, 0, 2 * kBuckets * 4, st));  // slot bucket counts (filled by k_roots) + cursors
+  }
   const unsigned g256 = (unsigned)((n + 255) / 256);
   // fast path (32-bit keys): bucket sort of (voxel key, index) composites; general path: rocPRIM radix sort
   const bool fast_pts = fast && sizeof(K) == 4;
-  const bool fast_slots = fast && tbits <= 31 && total_slots < (1ull << 32);
   if (fast_pts || fast_slots) {
     WC_TRY(wc_ensure(ctx, ctx->b_misc[1], std::max<uint64_t>(n, total_slots) * 8));
     WC_TRY(wc_ensure(ctx, ctx->b_misc[2], 5 * kBuckets * 4));
@@ -963,6 +972,8 @@ int run_pipeline(wc_ctx *ctx, const wc_points &pts, double t_lo, double t_hi, wc
   A.slot_keys = (uint64_t *)ctx->b_slot_keys[0].p;
   A.total_slots = total_slots;
   A.status = status;
+  A.slot_counts = fast_slots ? (uint32_t *)ctx->b_misc[4].p : nullptr;
+  A.slot_shift = tbits > 12 ? tbits - 12 : 0u;
   A.heads = (const uint32_t *)ctx->b_misc[0].p;
   A.nslots = (uint32_t)(n / (uint64_t)(P.min_points + 1) + 1);
   WC_HIP(ctx, hipMemsetAsync(ctx->b_misc[0].p, 0xFF, (size_t)A.nslots * 4, st));
@@ -972,7 +983,7 @@ int run_pipeline(wc_ctx *ctx, const wc_points &pts, double t_lo, double t_hi, wc
   if (fast_slots) {
     SlotSrc ssrc{(const uint64_t *)ctx->b_slot_keys[0].p, tbits > 12 ? tbits - 12 : 0u};
     WC_TRY((bucket_sort<SlotSrc, false>(ctx, ssrc, total_slots, (uint64_t *)ctx->b_misc[1].p, nullptr, (uint32_t *)ctx->b_slot_idx[1].p,
-                                        (uint32_t *)ctx->b_misc[2].p, status)));
+                                        (uint32_t *)ctx->b_misc[4].p, status, true)));
   } else {
     k_iota<<<(unsigned)((total_slots + 255) / 256), 256, 0, st>>>((uint32_t *)ctx->b_slot_idx[0].p, total_slots);
     WC_TRY(sort_pairs<uint64_t>(ctx, (uint64_t *)ctx->b_slot_keys[0].p, (uint64_t *)ctx->b_slot_keys[1].p,

@@ -636,77 +636,74 @@ __global__ void __launch_bounds__(256) k_damp(const double *H, const double *g, 
 // Tile (0,0) then factors the next diagonal block in place (look-ahead), so the whole factorisation is nblk launches
 // with no separate diagonal kernel on the critical path.  L is collected in Lmat (A keeps being updated in place).
 
-// Cholesky factor of the 32x32 block sB (lower part, in place), by ONE wavefront (no workgroup barriers on the
-// sequential pivot chain): lane = (row r, column half h).  Returns false on a non-positive pivot.
-__device__ __forceinline__ bool factor32_wave(double (*sB)[kNB + 1]) {
-  const int l = threadIdx.x & 63;
-  const int r = l & 31, h = l >> 5;
+// Cholesky factor L of a 32x32 block AND its inverse, by ONE wavefront with everything in registers: lanes 0..31 hold
+// the rows of the block (-> rows of L), lanes 32..63 the rows of the identity (-> rows of L^-1, built by applying the
+// same column eliminations).  Fully unrolled: a[] indices are compile-time constants, operands of other lanes come
+// through v_readlane with uniform lane ids, no LDS and no barriers on the 32-step pivot chain.
+// in: sB rows 0..31 (lower part).  out: sB = L (lower), sXi = L^-1.  Returns false on a non-positive pivot.
+__device__ __forceinline__ double readlane_d(double v, int src_lane) {  // src_lane must be wave-uniform: v_readlane_b32 x2
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_readlane((int)(b & 0xFFFFFFFFll), src_lane);
+  const int hi = __builtin_amdgcn_readlane((int)(b >> 32), src_lane);
+  return __longlong_as_double(((long long)hi << 32) | (long long)(unsigned int)lo);
+}
+
+__device__ __forceinline__ bool factor_inv32_regs(double (*sB)[kNB + 1], double (*sXi)[kNB + 1]) {
+  const int lane = threadIdx.x & 63;
+  const int r = lane & 31;
+  const bool upper = lane >= 32;
+  double a[kNB];
+#pragma unroll
+  for (int c = 0; c < kNB; ++c) a[c] = upper ? (c == r ? 1.0 : 0.0) : sB[r][c];
+  double my_inv = 0.0;
   bool ok = true;
+#pragma unroll
   for (int j = 0; j < kNB; ++j) {
-    const double ajj = sB[j][j];
-    if (!(ajj > 0.0)) {
-      ok = false;
-      break;  // uniform
-    }
-    double inv = __builtin_amdgcn_rsq(ajj);              // v_rsq_f64 seed + two Newton steps
+    const double ajj = readlane_d(a[j], j);
+    if (!(ajj > 0.0)) ok = false;
+    double inv = __builtin_amdgcn_rsq(ajj);
     inv = inv * (1.5 - 0.5 * ajj * inv * inv);
     inv = inv * (1.5 - 0.5 * ajj * inv * inv);
-    __builtin_amdgcn_wave_barrier();
-    if (h == 0 && r >= j) sB[r][j] *= inv;  // column j of L (diagonal becomes sqrt(a_jj))
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    // trailing update of the block: lane (r, h) owns columns h*16 .. h*16+15 of row r; loads batched before stores
-    const double lrj = sB[r][j];
-    double v[16], lc[16];
+    if (r == j) my_inv = inv;
+    const double lj = a[j] * inv;            // lower lanes: L[r][j]
+    if (!upper) a[j] = lj;
+    const double lrj = __shfl(lj, r);        // upper lane 32+r fetches L[r][j] from lane r
+    const double multL = upper ? 0.0 : lj;
+    const double multU = (upper && r > j) ? lrj * inv : 0.0;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int c = h * 16 + i;
-      v[i] = sB[r][c];
-      lc[i] = sB[c][j];
+    for (int c = 0; c < kNB; ++c) {
+      if (c > j) {
+        const double lcj = readlane_d(lj, c);  // L[c][j]
+        a[c] -= multL * lcj;                   // trailing update of the block (rows r >= c are the meaningful ones)
+      } else {
+        const double bjc = readlane_d(a[c], 32 + j);  // unscaled row j of the inverse-in-progress
+        a[c] -= multU * bjc;                   // forward elimination applied to the identity
+      }
     }
+  }
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int c = h * 16 + i;
-      if (c > j && c <= r) sB[r][c] = v[i] - lrj * lc[i];
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+  for (int c = 0; c < kNB; ++c) {
+    if (upper)
+      sXi[r][c] = (c <= r) ? a[c] * my_inv : 0.0;
+    else
+      sB[r][c] = (c <= r) ? a[c] : 0.0;
   }
   return ok;
 }
 
-// inverse of the lower-triangular 32x32 block sL into sXi by forward elimination applied to the identity; all 256
-// threads of the block take part (4 elements each)
-__device__ __forceinline__ void invert32(double (*sL)[kNB + 1], double (*sXi)[kNB + 1]) {
-  const int t = threadIdx.x;
-  const int c = t & 31, r0 = t >> 5;  // rows r0, r0+8, r0+16, r0+24
-  for (int e = t; e < kNB * kNB; e += 256) sXi[e / kNB][e % kNB] = (e / kNB == e % kNB) ? 1.0 : 0.0;
-  __syncthreads();
-  for (int j = 0; j < kNB; ++j) {
-    if (t < kNB) sXi[j][t] /= sL[j][j];
-    __syncthreads();
-    const double xj = sXi[j][c];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int r = r0 + 8 * q;
-      if (r > j && c <= j) sXi[r][c] -= sL[r][j] * xj;
-    }
-    __syncthreads();
-  }
-}
-
-__global__ void __launch_bounds__(64) k_chol_first(const double *A, int ld, double *Lmat, int *fail) {
+__global__ void __launch_bounds__(64) k_chol_first(const double *A, int ld, double *Lmat, double *Linv, int *fail) {
   __shared__ double sB[kNB][kNB + 1];
+  __shared__ double sXi[kNB][kNB + 1];
   for (int e = threadIdx.x; e < kNB * kNB; e += 64) sB[e / kNB][e % kNB] = A[(size_t)(e / kNB) * ld + e % kNB];
   __syncthreads();
-  if (!factor32_wave(sB)) {
+  if (!factor_inv32_regs(sB, sXi)) {
     if (threadIdx.x == 0) atomicOr(fail, 1);
-    return;
   }
   __syncthreads();
   for (int e = threadIdx.x; e < kNB * kNB; e += 64) {
     const int r = e / kNB, c = e % kNB;
-    Lmat[(size_t)r * ld + c] = (c <= r) ? sB[r][c] : 0.0;
+    Lmat[(size_t)r * ld + c] = sB[r][c];
+    Linv[e] = sXi[r][c];
   }
 }
 
@@ -723,13 +720,8 @@ __global__ void __launch_bounds__(256) k_chol_step(double *A, int ld, int k, int
   const int first = (k + 1) * kNB;
   const int row0 = first + ti * 64, col0 = first + tj * 64;
   const size_t pc = (size_t)k * kNB;  // first column of the panel
-  // L_kk^-1, rebuilt by every tile from the diagonal block the previous launch left in Lmat (parallel, off the
-  // sequential pivot chain); tile (0,0) also keeps it for the back substitution
-  for (int e = tid; e < kNB * kNB; e += 256) sLj[e / kNB][e % kNB] = Lmat[(size_t)(pc + e / kNB) * ld + pc + e % kNB];
-  __syncthreads();
-  invert32(sLj, sX);
-  if (ti == 0 && tj == 0)
-    for (int e = tid; e < kNB * kNB; e += 256) Linv[(size_t)k * kNB * kNB + e] = sX[e / kNB][e % kNB];
+  // L_kk^-1 was left behind by the previous launch (tile (0,0) factors and inverts the next diagonal block in registers)
+  for (int e = tid; e < kNB * kNB; e += 256) sX[e / kNB][e % kNB] = Linv[(size_t)k * kNB * kNB + e];
   // L rows of this tile's row range: Li = A[row0.., panel] * Linv^T
   for (int e = tid; e < 64 * kNB; e += 256) {
     const int r = e / kNB, c = e % kNB;
@@ -799,29 +791,17 @@ __global__ void __launch_bounds__(256) k_chol_step(double *A, int ld, int k, int
       }
     }
   if (!lead) return;
-  // look-ahead: factor the next diagonal block right away (one wavefront, barrier-free)
+  // look-ahead: factor + invert the next diagonal block right away (one wavefront, register resident)
   __syncthreads();
   bool ok = true;
-  if (tid < 64) ok = factor32_wave(sA);  // rows 0..31 of sA hold the block
+  if (tid < 64) ok = factor_inv32_regs(sA, sLi);  // rows 0..31 of sA hold the block; the inverse lands in sLi
   __syncthreads();
-  if (tid < 64 && !ok) {
-    if (tid == 0) atomicOr(fail, 1);
-  }
+  if (tid == 0 && !ok) atomicOr(fail, 1);
   for (int e = tid; e < kNB * kNB; e += 256) {
     const int r = e / kNB, c = e % kNB;
-    Lmat[(size_t)(first + r) * ld + first + c] = (c <= r) ? sA[r][c] : 0.0;
+    Lmat[(size_t)(first + r) * ld + first + c] = sA[r][c];
+    Linv[(size_t)(k + 1) * kNB * kNB + e] = sLi[r][c];
   }
-}
-
-// inverse of the LAST diagonal block (no further step rebuilds it) for the back substitution
-__global__ void __launch_bounds__(256) k_chol_last_inv(const double *Lmat, int ld, int kb, double *Linv) {
-  __shared__ double sL[kNB][kNB + 1];
-  __shared__ double sXi[kNB][kNB + 1];
-  const size_t pc = (size_t)kb * kNB;
-  for (int e = threadIdx.x; e < kNB * kNB; e += 256) sL[e / kNB][e % kNB] = Lmat[(pc + e / kNB) * ld + pc + e % kNB];
-  __syncthreads();
-  invert32(sL, sXi);
-  for (int e = threadIdx.x; e < kNB * kNB; e += 256) Linv[(size_t)kb * kNB * kNB + e] = sXi[e / kNB][e % kNB];
 }
 
 // back substitution L^T y = z (z = row n of the factored augmented matrix), right-looking over 32-wide blocks from
@@ -1320,12 +1300,11 @@ extern "C" int wc_window_solve(wc_ctx *ctx, double *h_x_inout, wc_solve_summary 
         dim3 grid((np + 255) / 256, np);
         k_damp<<<grid, 256, 0, st>>>(H, g, scale, n, np, ld, radius, A, diag);
       }
-      k_chol_first<<<1, 64, 0, st>>>(A, ld, Lmat, fail);
+      k_chol_first<<<1, 64, 0, st>>>(A, ld, Lmat, (double *)W->Linv.p, fail);
       for (int k = 0; k + 1 < nblk; ++k) {
         const int tiles = ((nblk - k - 1) * kNB + 63) / 64;
         k_chol_step<<<dim3(tiles, tiles), 256, 0, st>>>(A, ld, k, nblk, Lmat, (double *)W->Linv.p, fail);
       }
-      k_chol_last_inv<<<1, 256, 0, st>>>(Lmat, ld, nblk - 1, (double *)W->Linv.p);
       k_chol_back<<<1, 1024, 0, st>>>(Lmat, ld, n, (const double *)W->Linv.p, y);
       k_step<<<1, 1024, 0, st>>>(x, y, scale, g, diag, n, xc, mail);
       WC_TRY(enqueue_evaluate(ctx, W, xc, nullptr, 5));
