@@ -24,7 +24,6 @@ using namespace wc;
 
 namespace {
 
-constexpr int kMaxK = 16;
 constexpr uint32_t kNone = 0xFFFFFFFFu;
 
 struct MatchParams {
@@ -34,6 +33,8 @@ struct MatchParams {
   double h;             // cell size in scaled units
   double org[3];        // grid origin (scaled units)
   int dim[3];           // cells per axis (<= 1024)
+  const uint32_t *cell_start;  // dense per-cell [start, end) into the sorted targets, or null (binary search fallback)
+  const uint32_t *cell_end;
 };
 
 __device__ __forceinline__ void feature6(const wc_surfel &s, const wc_pose &p, double cs, double as, double f[6], V3 &cw, V3 &nw) {
@@ -86,6 +87,16 @@ __global__ void __launch_bounds__(256) k_cell_keys(const double *feat, uint32_t 
   vals[i] = i;
 }
 
+// dense cell table: first / one-past-last sorted target of every non-empty cell (empty cells keep start = end = 0)
+__global__ void __launch_bounds__(256) k_cell_table(const uint32_t *skeys, uint32_t n, MatchParams M, uint32_t *cell_start, uint32_t *cell_end) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t k = skeys[i];
+  const size_t c = (size_t)(k & 1023u) + (size_t)M.dim[0] * ((size_t)((k >> 10) & 1023u) + (size_t)M.dim[1] * (size_t)(k >> 20));
+  if (i == 0 || skeys[i - 1] != k) cell_start[c] = i;
+  if (i == n - 1 || skeys[i + 1] != k) cell_end[c] = i + 1;
+}
+
 __global__ void __launch_bounds__(256) k_sorted_feat(const double *feat, const uint32_t *sorted_idx, uint32_t n, double *sfeat) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -105,37 +116,33 @@ __device__ __forceinline__ uint32_t lower_bound_u32(const uint32_t *a, uint32_t 
   return lo;
 }
 
+template <int K>
 struct TopK {
-  double d[kMaxK];
-  uint32_t id[kMaxK];
-  int k, cnt;
-  __device__ __forceinline__ double worst() const { return cnt < k ? 1e300 : d[k - 1]; }
+  double d[K];
+  uint32_t id[K];
+  int cnt;
+  __device__ __forceinline__ double worst() const { return cnt < K ? 1e300 : d[K - 1]; }
   // sorted insertion with static indexing (keeps the arrays in registers); order = (distance, index)
   __device__ __forceinline__ void push(double dist, uint32_t idx) {
-    if (cnt == k && !(dist < d[k - 1] || (dist == d[k - 1] && idx < id[k - 1]))) return;
+    if (cnt == K && !(dist < d[K - 1] || (dist == d[K - 1] && idx < id[K - 1]))) return;
     double cd = dist;
     uint32_t ci = idx;
 #pragma unroll
-    for (int i = 0; i < kMaxK; ++i) {
-      if (i < k) {
-        const bool empty = i >= cnt;
-        const bool before = empty || cd < d[i] || (cd == d[i] && ci < id[i]);
-        if (before) {
-          const double td = d[i];
-          const uint32_t ti = id[i];
-          d[i] = cd, id[i] = ci;
-          cd = td, ci = ti;
-          if (empty) {
-            cd = 1e300;  // nothing real is carried further
-          }
-        }
+    for (int i = 0; i < K; ++i) {
+      const bool before = cd < d[i] || (cd == d[i] && ci < id[i]);  // empty slots hold (1e300, ~0): always "after"
+      if (before) {
+        const double td = d[i];
+        const uint32_t ti = id[i];
+        d[i] = cd, id[i] = ci;
+        cd = td, ci = ti;
       }
     }
-    if (cnt < k) ++cnt;
+    if (cnt < K) ++cnt;
   }
 };
 
 // exact k-NN + gates.  gated[q][j] = j-th neighbour passing the first three gates (kNone-terminated).
+template <int K>
 __global__ void __launch_bounds__(128) k_knn_gate(const wc_surfel *q_surf, const wc_pose *q_pose, uint32_t nq, const double *sfeat,
                                                  const uint32_t *skeys, const uint32_t *sorig, const double *tworld, uint32_t nt,
                                                  MatchParams M, uint32_t *gated, uint32_t *knn_idx, double *knn_d2) {
@@ -145,12 +152,12 @@ __global__ void __launch_bounds__(128) k_knn_gate(const wc_surfel *q_surf, const
   V3 cq, nq_w;
   feature6(q_surf[q], q_pose[q], M.cs, M.as, f, cq, nq_w);
   const double tq = q_surf[q].t;
-  TopK top;
-  top.k = M.k;
+  TopK<K> top;
   top.cnt = 0;
-  for (int i = 0; i < kMaxK; ++i) {
+#pragma unroll
+  for (int i = 0; i < K; ++i) {
     top.d[i] = 1e300;
-    top.id[i] = 0;
+    top.id[i] = 0xFFFFFFFFu;
   }
   // query cell (unclamped, so that the distance bound stays valid for queries outside the target bbox)
   const double gx = (f[0] - M.org[0]) / M.h, gy = (f[1] - M.org[1]) / M.h, gz = (f[2] - M.org[2]) / M.h;
@@ -159,61 +166,67 @@ __global__ void __launch_bounds__(128) k_knn_gate(const wc_surfel *q_surf, const
   const double in_cell = fmin(fmin(fmin(gx - cx, cx + 1 - gx), fmin(gy - cy, cy + 1 - gy)), fmin(gz - cz, cz + 1 - gz)) * M.h;
   const int rmax = max(max(max(cx, M.dim[0] - 1 - cx), max(cy, M.dim[1] - 1 - cy)), max(cz, M.dim[2] - 1 - cz));
 
-  auto scan_range = [&](int x0, int x1, int y, int z) {
-    if (y < 0 || y >= M.dim[1] || z < 0 || z >= M.dim[2]) return;
-    x0 = max(x0, 0);
-    x1 = min(x1, M.dim[0] - 1);
-    if (x0 > x1) return;
-    const uint32_t base = ((uint32_t)y << 10) | ((uint32_t)z << 20);
-    const uint32_t b = lower_bound_u32(skeys, nt, base | (uint32_t)x0);
-    const uint32_t e = lower_bound_u32(skeys, nt, (base | (uint32_t)x1) + 1u);
-    for (uint32_t i = b; i < e; ++i) {
-      const double *p = sfeat + (size_t)i * 6;
-      double s = 0.0;
-#pragma unroll
-      for (int d = 0; d < 6; ++d) {  // flann::L2_Simple: plain running sum of squared differences
-        const double df = f[d] - p[d];
-        s += df * df;
-      }
-      top.push(s, sorig[i]);
-    }
-  };
-
   for (int r = 0; r <= rmax; ++r) {
-    if (r == 0) {
-      scan_range(cx, cx, cy, cz);
-    } else {
-      for (int dz = -r; dz <= r; ++dz)
-        for (int dy = -r; dy <= r; ++dy) {
-          if (max(abs(dy), abs(dz)) == r) {
-            scan_range(cx - r, cx + r, cy + dy, cz + dz);
-          } else {
-            scan_range(cx - r, cx - r, cy + dy, cz + dz);
-            scan_range(cx + r, cx + r, cy + dy, cz + dz);
+    // shell r of the cube of cells around the query: rows (dy, dz); full x-span on the faces |dy| = r or |dz| = r,
+    // only the two end cells elsewhere.  ONE scan site (the kernel stays small enough to keep the top-k in registers).
+    for (int dz = -r; dz <= r; ++dz)
+      for (int dy = -r; dy <= r; ++dy) {
+        const int y = cy + dy, z = cz + dz;
+        if (y < 0 || y >= M.dim[1] || z < 0 || z >= M.dim[2]) continue;
+        const bool face = max(abs(dy), abs(dz)) == r;
+        const int nparts = (face || r == 0) ? 1 : 2;
+        for (int part = 0; part < nparts; ++part) {
+          int x0 = face ? cx - r : (part == 0 ? cx - r : cx + r);
+          int x1 = face ? cx + r : x0;
+          x0 = max(x0, 0);
+          x1 = min(x1, M.dim[0] - 1);
+          if (x0 > x1) continue;
+          uint32_t b, e;
+          const size_t row = (size_t)M.dim[0] * ((size_t)y + (size_t)M.dim[1] * (size_t)z);
+          for (int x = x0; x <= x1; ++x) {
+            if (M.cell_start) {
+              b = M.cell_start[row + x];
+              e = M.cell_end[row + x];
+            } else {  // binary-search fallback: the whole x-run at once
+              const uint32_t base = ((uint32_t)y << 10) | ((uint32_t)z << 20);
+              b = lower_bound_u32(skeys, nt, base | (uint32_t)x0);
+              e = lower_bound_u32(skeys, nt, (base | (uint32_t)x1) + 1u);
+              x = x1;
+            }
+            for (uint32_t i = b; i < e; ++i) {
+              const double *p = sfeat + (size_t)i * 6;
+              double s = 0.0;
+#pragma unroll
+              for (int d = 0; d < 6; ++d) {  // flann::L2_Simple: plain running sum of squared differences
+                const double df = f[d] - p[d];
+                s += df * df;
+              }
+              top.push(s, sorig[i]);
+            }
           }
         }
-    }
+      }
     // everything not yet scanned is at least `bound` away from the query (in 3-D, hence in 6-D)
     const double bound = r * M.h + in_cell;
-    if (top.cnt == top.k && top.worst() < bound * bound) break;
+    if (top.cnt == K && top.worst() < bound * bound) break;
   }
   // Q10: FLANN leaves the tail of the result untouched (zero-initialised) when fewer than k targets exist
   uint32_t out = 0;
-  for (int j = 0; j < kMaxK; ++j) {
-    if (j >= M.k) break;
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
     const uint32_t c = (j < top.cnt) ? top.id[j] : 0u;
     if (knn_idx) {
-      knn_idx[(size_t)q * M.k + j] = c;
-      knn_d2[(size_t)q * M.k + j] = (j < top.cnt) ? top.d[j] : 0.0;
+      knn_idx[(size_t)q * K + j] = c;
+      knn_d2[(size_t)q * K + j] = (j < top.cnt) ? top.d[j] : 0.0;
     }
     const double *w = tworld + (size_t)c * 7;
     if (fabs(w[6] - tq) < M.time_min) continue;                                      // cc:26
     const V3 nc = mk3(w[3], w[4], w[5]);
     if (acos(dot(nq_w, nc)) > M.ang_max) continue;                                    // cc:29, surfel.h:105-107
     if (fabs(dot(nq_w, cq - mk3(w[0], w[1], w[2]))) > M.dist_max) continue;           // cc:32
-    gated[(size_t)q * M.k + out++] = c;
+    gated[(size_t)q * K + out++] = c;
   }
-  for (; out < (uint32_t)M.k; ++out) gated[(size_t)q * M.k + out] = kNone;
+  for (; out < (uint32_t)K; ++out) gated[(size_t)q * K + out] = kNone;
 }
 
 // choice(q) = first gated candidate c that is not already paired with q from c's own turn (c < q and choice(c) == q)
@@ -306,7 +319,11 @@ extern "C" int wc_match(wc_ctx *ctx, const wc_surfel *d_q_surf, const wc_pose *d
     if (!std::isfinite(lo[d]) || !std::isfinite(hi[d])) return wc_fail(ctx, WC_ERR_ARG, "non-finite surfel centre");
     ext = std::max(ext, hi[d] - lo[d]);
   }
-  M.h = std::max(1.0, ext / 1000.0);  // one scaled unit (= 1 m) per cell unless the cloud spans more than 1000 cells
+  // cell size: about 4 targets per occupied-volume cell, at most one scaled unit (= 1 m), at least extent / 1000
+  double vol = 1.0;
+  for (int d = 0; d < 3; ++d) vol *= std::max(hi[d] - lo[d], 0.05);
+  M.h = std::min(1.0, std::cbrt(4.0 * vol / (double)nt));
+  M.h = std::max(M.h, std::max(ext / 1000.0, 1e-3));
   for (int d = 0; d < 3; ++d) {
     M.org[d] = lo[d];
     M.dim[d] = std::min(1024, (int)std::floor((hi[d] - lo[d]) / M.h) + 1);
@@ -323,9 +340,38 @@ extern "C" int wc_match(wc_ctx *ctx, const wc_surfel *d_q_surf, const wc_pose *d
     WC_HIP(ctx, rocprim::radix_sort_pairs(ctx->b_sorttmp.p, tmp, k0, k1, v0, v1, (size_t)nt, 0u, 30u, st));
   }
   k_sorted_feat<<<(nt + 255) / 256, 256, 0, st>>>((const double *)b_feat.p, v1, nt, (double *)b_sfeat.p);
+  const size_t ncell = (size_t)M.dim[0] * M.dim[1] * M.dim[2];
+  M.cell_start = M.cell_end = nullptr;
+  if (ncell <= (1u << 24)) {  // dense [start, end) table (<= 128 MB); larger grids fall back to binary searches
+    WC_TRY(wc_ensure(ctx, ctx->b_misc[0], ncell * 8));
+    WC_HIP(ctx, hipMemsetAsync(ctx->b_misc[0].p, 0, ncell * 8, st));
+    M.cell_start = (const uint32_t *)ctx->b_misc[0].p;
+    M.cell_end = M.cell_start + ncell;
+    k_cell_table<<<(nt + 255) / 256, 256, 0, st>>>(k1, nt, M, (uint32_t *)ctx->b_misc[0].p, (uint32_t *)ctx->b_misc[0].p + ncell);
+  }
   // 3. exact k-NN + gates
-  k_knn_gate<<<(nq + 127) / 128, 128, 0, st>>>(d_q_surf, d_q_pose, nq, (const double *)b_sfeat.p, k1, v1, (const double *)b_world.p, nt, M,
-                                              (uint32_t *)b_gated.p, d_knn_idx, d_knn_d2);
+#define WC_KNN_LAUNCH(KK)                                                                                                        \
+  k_knn_gate<KK><<<(nq + 127) / 128, 128, 0, st>>>(d_q_surf, d_q_pose, nq, (const double *)b_sfeat.p, k1, v1, (const double *)b_world.p, \
+                                                  nt, M, (uint32_t *)b_gated.p, d_knn_idx, d_knn_d2)
+  switch (P.knn_k) {  // the reference's k = 10 gets its own instantiation (top-k in 30 registers)
+    case 10: WC_KNN_LAUNCH(10); break;
+    case 1: WC_KNN_LAUNCH(1); break;
+    case 2: WC_KNN_LAUNCH(2); break;
+    case 3: WC_KNN_LAUNCH(3); break;
+    case 4: WC_KNN_LAUNCH(4); break;
+    case 5: WC_KNN_LAUNCH(5); break;
+    case 6: WC_KNN_LAUNCH(6); break;
+    case 7: WC_KNN_LAUNCH(7); break;
+    case 8: WC_KNN_LAUNCH(8); break;
+    case 9: WC_KNN_LAUNCH(9); break;
+    case 11: WC_KNN_LAUNCH(11); break;
+    case 12: WC_KNN_LAUNCH(12); break;
+    case 13: WC_KNN_LAUNCH(13); break;
+    case 14: WC_KNN_LAUNCH(14); break;
+    case 15: WC_KNN_LAUNCH(15); break;
+    default: WC_KNN_LAUNCH(16); break;
+  }
+#undef WC_KNN_LAUNCH
   WC_HIP(ctx, hipGetLastError());
   // 4. resolve the order-dependent "pair already seen" rule by fixed-point iteration
   uint32_t *choice[2] = {(uint32_t *)b_choice.p, (uint32_t *)b_choice.p + nq};
