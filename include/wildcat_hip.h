@@ -81,6 +81,17 @@ int wc_extract_stage_ms(wc_ctx *ctx, float *h_ms5);
 /* root-voxel index of every point: VoxelLoc (src/odometry/surfel_extraction.h:55-64); d_keys_xyz = 3 int32 per point */
 int wc_voxel_keys(wc_ctx *ctx, const wc_points *pts, int32_t *d_keys_xyz);
 
+/* sweep preparation ("next" row f-1 of SURVEY.md §8: the per-point stages right in front of the hot path) ------------ */
+/* Replaces the per-point loop of LidarOdometry::AddLidarScan (src/odometry/lidar_odometry.cc:489-496): lidar->imu
+ * extrinsic in double (quat = w,x,y,z), cast to float, drop points with |p| < min_range, |p| > max_range or inside the
+ * blind box; survivors keep their order.  Records are the 48-byte hilti_ros::Point (common.h:12-28). */
+int wc_prefilter_points(wc_ctx *ctx, const void *d_pts_in, uint64_t n, const double ext_quat[4], const double ext_t[3],
+                        double min_range, double max_range, const double blind_min[3], const double blind_max[3],
+                        void *d_pts_out, uint64_t cap, uint64_t *h_n_out);
+/* Replaces UndistortSweep(sweep_in, imu_states, sweep_out) (src/odometry/lidar_odometry.cc:143-158).
+ * WC_ERR_RANGE mirrors the CHECK at :149. */
+int wc_undistort_sweep(wc_ctx *ctx, const void *d_pts_in, uint64_t n, const wc_imu_state *d_imu, uint64_t n_imu, void *d_pts_out);
+
 /* surfel pose update --------------------------------------------------------------------------------------------- */
 /* Replaces UpdateSurfelPoses(const std::deque<ImuState>&, std::deque<Surfel::Ptr>&) (src/odometry/lidar_odometry.cc:160-170)
  * + Surfel::UpdatePose (src/odometry/surfel.h:48-58).  d_in_body[i] == 0 marks a surfel still in the world frame

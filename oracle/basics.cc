@@ -5,6 +5,7 @@
 //   Surfel::UpdatePose  src/odometry/surfel.h:48-58
 #include <algorithm>
 #include <cmath>
+#include <cstring>
 
 #include "math3.h"
 #include "wc_oracle.h"
@@ -104,6 +105,65 @@ extern "C" int wco_update_surfel_poses(const wc_imu_state *imu, uint64_t n_imu, 
         for (int j = 0; j < 3; ++j) surf[s].cov[3 * i + j] = Cb.m[i][j];
       }
     }
+  }
+  return 0;
+}
+
+// ---- "next" row f-1: point pre-filter (lidar_odometry.cc:489-496) and UndistortSweep (lidar_odometry.cc:143-158) --------
+// records are the reference's 48-byte hilti_ros::Point (x,y,z float @0, time double @24)
+static inline float *pt_xyz(void *base, uint64_t i) { return (float *)((char *)base + 48 * i); }
+static inline const float *pt_xyz(const void *base, uint64_t i) { return (const float *)((const char *)base + 48 * i); }
+static inline double pt_time(const void *base, uint64_t i) {
+  double t;
+  std::memcpy(&t, (const char *)base + 48 * i + 24, 8);
+  return t;
+}
+
+extern "C" int wco_prefilter_points(const void *pts_in, uint64_t n, const double ext_quat[4], const double ext_t[3], double min_range,
+                                    double max_range, const double blind_min[3], const double blind_max[3], void *pts_out,
+                                    uint64_t *n_out) {
+  const Q4 q{ext_quat[0], ext_quat[1], ext_quat[2], ext_quat[3]};
+  const V3 t{ext_t[0], ext_t[1], ext_t[2]};
+  uint64_t o = 0;
+  for (uint64_t i = 0; i < n; ++i) {
+    const float *f = pt_xyz(pts_in, i);
+    // pt = (ext_lidar2imu * pt.cast<double>()).cast<float>()   (cc:490)
+    const V3 p = qrot(q, V3{(double)f[0], (double)f[1], (double)f[2]}) + t;
+    const float x = (float)p.x, y = (float)p.y, z = (float)p.z;
+    const float nrm = std::sqrt(x * x + y * y + z * z);  // Eigen float norm
+    const bool blind = (double)x >= blind_min[0] && (double)x <= blind_max[0] && (double)y >= blind_min[1] &&
+                       (double)y <= blind_max[1] && (double)z >= blind_min[2] && (double)z <= blind_max[2];
+    if (nrm < min_range || nrm > max_range || blind) continue;  // cc:492-494
+    std::memcpy((char *)pts_out + 48 * o, (const char *)pts_in + 48 * i, 48);
+    float *g = pt_xyz(pts_out, o);
+    g[0] = x, g[1] = y, g[2] = z;
+    ++o;
+  }
+  *n_out = o;
+  return 0;
+}
+
+extern "C" int wco_undistort_sweep(const void *pts_in, uint64_t n, const wc_imu_state *imu, uint64_t n_imu, void *pts_out) {
+  for (uint64_t i = 0; i < n; ++i) {
+    const double t = pt_time(pts_in, i);
+    uint64_t lo = 0, hi = n_imu;  // std::lower_bound (cc:147)
+    while (lo < hi) {
+      const uint64_t mid = (lo + hi) / 2;
+      if (imu[mid].t < t)
+        lo = mid + 1;
+      else
+        hi = mid;
+    }
+    if (!(lo >= 1 && lo < n_imu)) return 2;  // CHECK(idx >= 1 && idx < size) (cc:149)
+    const wc_imu_state &a = imu[lo - 1], &b = imu[lo];
+    const double f = (t - a.t) / (b.t - a.t);
+    const V3 pos = V3{a.pos[0], a.pos[1], a.pos[2]} * (1 - f) + V3{b.pos[0], b.pos[1], b.pos[2]} * f;
+    const Q4 rot = qslerp({a.quat[0], a.quat[1], a.quat[2], a.quat[3]}, f, {b.quat[0], b.quat[1], b.quat[2], b.quat[3]});
+    const float *fin = pt_xyz(pts_in, i);
+    const V3 w = qrot(rot, V3{(double)fin[0], (double)fin[1], (double)fin[2]}) + pos;
+    std::memcpy((char *)pts_out + 48 * i, (const char *)pts_in + 48 * i, 48);
+    float *g = pt_xyz(pts_out, i);
+    g[0] = (float)w.x, g[1] = (float)w.y, g[2] = (float)w.z;
   }
   return 0;
 }

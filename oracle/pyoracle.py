@@ -126,6 +126,20 @@ def update_surfel_poses(imu, surf, pose, in_body):
     return rc
 
 
+def prefilter_points(points, ext_quat, ext_t, min_range, max_range, blind_min, blind_max):
+    out = np.zeros(len(points), R.POINT)
+    n = C.c_uint64(0)
+    lib().wco_prefilter_points(R.ptr(points), C.c_uint64(len(points)), R.ptr(_vec(ext_quat)), R.ptr(_vec(ext_t)), C.c_double(min_range),
+                               C.c_double(max_range), R.ptr(_vec(blind_min)), R.ptr(_vec(blind_max)), R.ptr(out), C.byref(n))
+    return out[: n.value].copy()
+
+
+def undistort_sweep(points, imu):
+    out = np.zeros(len(points), R.POINT)
+    rc = lib().wco_undistort_sweep(R.ptr(points), C.c_uint64(len(points)), R.ptr(imu), C.c_uint64(len(imu)), R.ptr(out))
+    return rc, out
+
+
 def knn6(cloud, query, k=10):
     cloud = np.ascontiguousarray(cloud, np.float64)
     query = np.ascontiguousarray(query, np.float64)

@@ -55,6 +55,12 @@ int wco_extract_surfels(const wc_points *pts, const wc_params *P, wc_surfel *out
 int wco_update_surfel_poses(const wc_imu_state *imu, uint64_t n_imu, wc_surfel *surf, wc_pose *pose, uint8_t *in_body,
                             uint64_t n);
 
+/* ---- "next" row f-1: point pre-filter (lidar_odometry.cc:489-496) + UndistortSweep (lidar_odometry.cc:143-158) ----
+ * pts_*: arrays of the 48-byte hilti_ros::Point record */
+int wco_prefilter_points(const void *pts_in, uint64_t n, const double ext_quat[4], const double ext_t[3], double min_range,
+                         double max_range, const double blind_min[3], const double blind_max[3], void *pts_out, uint64_t *n_out);
+int wco_undistort_sweep(const void *pts_in, uint64_t n, const wc_imu_state *imu, uint64_t n_imu, void *pts_out);
+
 /* ---- correspondence (knn_surfel_matcher.cc) ---- */
 /* exact k nearest neighbours in the raw 6-D feature space (FLANNKNearestSearch, cc:75-89) */
 int wco_knn6(const double *cloud6, uint64_t n, const double *query6, uint64_t nq, int k, int32_t *idx, double *dist2);

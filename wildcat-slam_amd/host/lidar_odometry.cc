@@ -151,7 +151,7 @@ LidarOdometry::LidarOdometry(int device) {
 
 LidarOdometry::~LidarOdometry() {
   if (!ctx_) return;
-  void *bufs[] = {d_surf_, d_pose_, d_inbody_, d_pairs_sld_, d_pairs_fix_, d_imu_, d_sweep_};
+  void *bufs[] = {d_surf_, d_pose_, d_inbody_, d_pairs_sld_, d_pairs_fix_, d_imu_, d_sweep_, d_sweep_raw_};
   for (void *b : bufs)
     if (b) wc_dev_free(ctx_, b);
   wc_ctx_destroy(ctx_);
@@ -273,31 +273,7 @@ void LidarOdometry::PredictImuStatesAndSampleStates(double end_time) {
   }
 }
 
-// UndistortSweep (:143-158)
-void LidarOdometry::UndistortSweep(const std::vector<hilti_ros::Point> &in, std::vector<hilti_ros::Point> &out) const {
-  out.clear();
-  out.reserve(in.size());
-  size_t idx = 1;
-  for (const hilti_ros::Point &pt : in) {
-    while (idx < imu_states_.size() && imu_states_[idx].t < pt.time) ++idx;  // lower_bound; points are time ordered
-    size_t lb = idx;
-    while (lb > 0 && !(imu_states_[lb - 1].t < pt.time)) --lb;
-    if (!(lb >= 1 && lb < imu_states_.size()))
-      std::fprintf(stderr, "[wildcat] undistort: pt.time=%.6f imu=[%.6f, %.6f] n=%zu lb=%zu sweep=%d\n", pt.time, imu_states_.front().t,
-                   imu_states_.back().t, imu_states_.size(), lb, sweep_id_);
-    WC_CHECK(lb >= 1 && lb < imu_states_.size());
-    const wc_imu_state &a = imu_states_[lb - 1], &b = imu_states_[lb];
-    const double f = (pt.time - a.t) / (b.t - a.t);
-    const V3 pos = v3(a.pos) * (1 - f) + v3(b.pos) * f;
-    const Q4 rot = qslerp(q4(a.quat), f, q4(b.quat));
-    const V3 w = qrot(rot, mk3((double)pt.x, (double)pt.y, (double)pt.z)) + pos;
-    hilti_ros::Point np = pt;
-    np.x = (float)w.x, np.y = (float)w.y, np.z = (float)w.z;
-    out.push_back(np);
-  }
-}
-
-void LidarOdometry::UpdateSurfelPosesOnDevice() {  // UpdateSurfelPoses (:160-170) over the sliding window
+void LidarOdometry::UploadImuStates() {
   const size_t n_imu = imu_states_.size();
   if (n_imu > cap_imu_) {
     if (d_imu_) WC_CALL(wc_dev_free(ctx_, d_imu_));
@@ -308,8 +284,13 @@ void LidarOdometry::UpdateSurfelPosesOnDevice() {  // UpdateSurfelPoses (:160-17
   }
   std::vector<wc_imu_state> flat(imu_states_.begin(), imu_states_.end());
   WC_CALL(wc_h2d(ctx_, d_imu_, flat.data(), n_imu * sizeof(wc_imu_state)));
+}
+
+void LidarOdometry::UpdateSurfelPosesOnDevice() {  // UpdateSurfelPoses (:160-170) over the sliding window
+  UploadImuStates();
   const size_t n = n_surfels_ - sld_begin_;
-  if (n) WC_CALL(wc_update_surfel_poses(ctx_, d_imu_, n_imu, d_surf_ + sld_begin_, d_pose_ + sld_begin_, d_inbody_ + sld_begin_, n));
+  if (n)
+    WC_CALL(wc_update_surfel_poses(ctx_, d_imu_, imu_states_.size(), d_surf_ + sld_begin_, d_pose_ + sld_begin_, d_inbody_ + sld_begin_, n));
 }
 
 // UpdateImuPoses (:187-215) with the CubicBSplineSampleCorrector (:22-54)
@@ -391,17 +372,21 @@ void LidarOdometry::AddLidarScan(const pcl::PointCloud<hilti_ros::Point>::Ptr &m
   }
   WC_CHECK(!sweep.empty());
 
-  // 3. undistort sweep by IMU poses (:519-520)
-  std::vector<hilti_ros::Point> und;
-  UndistortSweep(sweep, und);
-
-  // 4. ---- hot path: extract surfels, attach poses (:523-527) ----
-  if (und.size() > cap_sweep_) {
+  // 3. undistort sweep by IMU poses (:519-520) — on the device (wc_undistort_sweep replaces UndistortSweep :143-158);
+  //    the undistorted sweep never comes back to the host, extraction reads it where it lies
+  if (sweep.size() > cap_sweep_) {
+    if (d_sweep_raw_) WC_CALL(wc_dev_free(ctx_, d_sweep_raw_));
     if (d_sweep_) WC_CALL(wc_dev_free(ctx_, d_sweep_));
-    cap_sweep_ = und.size() * 2;
+    cap_sweep_ = sweep.size() * 2;
+    WC_CALL(wc_dev_alloc(ctx_, cap_sweep_ * sizeof(hilti_ros::Point), &d_sweep_raw_));
     WC_CALL(wc_dev_alloc(ctx_, cap_sweep_ * sizeof(hilti_ros::Point), &d_sweep_));
   }
-  WC_CALL(wc_h2d(ctx_, d_sweep_, und.data(), und.size() * sizeof(hilti_ros::Point)));
+  WC_CALL(wc_h2d(ctx_, d_sweep_raw_, sweep.data(), sweep.size() * sizeof(hilti_ros::Point)));
+  UploadImuStates();
+  WC_CALL(wc_undistort_sweep(ctx_, d_sweep_raw_, sweep.size(), d_imu_, imu_states_.size(), d_sweep_));
+  const std::vector<hilti_ros::Point> &und = sweep;  // (only sizes and timestamps are used below)
+
+  // 4. ---- hot path: extract surfels, attach poses (:523-527) ----
   const size_t max_new = (3 * und.size()) / 20 + 1;
   EnsureSurfelCapacity(n_surfels_ + max_new);
   wc_points desc{d_sweep_, (const char *)d_sweep_ + WC_HILTI_POINT_TIME_OFFSET, WC_HILTI_POINT_BYTES, WC_HILTI_POINT_BYTES, und.size()};

@@ -3,10 +3,10 @@
 // Public surface identical to the reference's src/odometry/lidar_odometry.h:11-25
 //     LidarOdometry();  void AddImuData(const ImuData&);  void AddLidarScan(const pcl::PointCloud<hilti_ros::Point>::Ptr&);
 // so that src/wildcat_slam_node.cc (:42, :51, :66) compiles against it unchanged where ROS / PCL exist.  Everything the
-// reference does between lidar_odometry.cc:523 and :566 (surfel extraction, surfel pose update, correspondence,
+// reference does between lidar_odometry.cc:520 and :566 (sweep undistortion, surfel extraction, surfel pose update, correspondence,
 // factor construction, the Ceres solve) goes through the C-ABI of libwildcat_hip.so; the window bookkeeping around it
 // (point pre-filter :489-496, SyncHeadingMsgs :457-485, PredictImuStatesAndSampleStates :365-455, BuildSweep :134-141,
-// UndistortSweep :143-158, UpdateImuPoses + B-spline corrector :22-54,:187-215, UpdateSamplePoses :172-179,
+// UpdateImuPoses + B-spline corrector :22-54,:187-215, UpdateSamplePoses :172-179,
 // ShrinkToFit :228-250) is restated here as plain host C++.  All state is per instance (the reference keeps some of it
 // in function-local statics).  ROS publishing is replaced by the accessors at the bottom.
 #pragma once
@@ -61,7 +61,7 @@ class LidarOdometry {
   };
   void PredictImuStatesAndSampleStates(double end_time);
   bool SyncHeadingMsgs();
-  void UndistortSweep(const std::vector<hilti_ros::Point> &in, std::vector<hilti_ros::Point> &out) const;
+  void UploadImuStates();
   void UpdateImuPoses();
   void UpdateSamplePoses();
   void UpdateSurfelPosesOnDevice();
@@ -85,7 +85,7 @@ class LidarOdometry {
   uint8_t *d_inbody_ = nullptr;
   wc_pair *d_pairs_sld_ = nullptr, *d_pairs_fix_ = nullptr;
   wc_imu_state *d_imu_ = nullptr;
-  void *d_sweep_ = nullptr;
+  void *d_sweep_ = nullptr, *d_sweep_raw_ = nullptr;
   size_t cap_surfels_ = 0, n_surfels_ = 0, sld_begin_ = 0, cap_imu_ = 0, cap_sweep_ = 0;
   std::vector<double> surfel_times_;  // host copy of the surfel timestamps (window bookkeeping only)
   wc_solve_summary last_summary_{};

@@ -182,6 +182,22 @@ class Context:
         m = self.extract_finish()
         return d_out.download(R.SURFEL, m), d_ids.download(R.SURFEL_ID, m)
 
+    # ---- sweep preparation (row f-1) -------------------------------------------------------------------------------------
+    def prefilter_points(self, points, ext_quat, ext_t, min_range, max_range, blind_min, blind_max):
+        n = len(points)
+        d_in, d_out = self.to_device(points), self.alloc(48 * max(n, 1))
+        m = C.c_uint64(0)
+        v = lambda a: R.ptr(np.ascontiguousarray(a, np.float64))  # noqa: E731
+        self._ck(self.lib.wc_prefilter_points(self.h, C.c_void_p(d_in.ptr), C.c_uint64(n), v(ext_quat), v(ext_t), C.c_double(min_range),
+                                              C.c_double(max_range), v(blind_min), v(blind_max), C.c_void_p(d_out.ptr), C.c_uint64(n), C.byref(m)))
+        return d_out.download(R.POINT, int(m.value))
+
+    def undistort_sweep(self, points, imu):
+        n = len(points)
+        d_in, d_out, d_imu = self.to_device(points), self.alloc(48 * max(n, 1)), self.to_device(imu)
+        self._ck(self.lib.wc_undistort_sweep(self.h, C.c_void_p(d_in.ptr), C.c_uint64(n), C.c_void_p(d_imu.ptr), C.c_uint64(len(imu)), C.c_void_p(d_out.ptr)))
+        return d_out.download(R.POINT, n)
+
     # ---- pose update / window problem ------------------------------------------------------------------------------
     def update_surfel_poses(self, d_imu, n_imu, d_surf, d_pose, d_in_body, n):
         self._ck(self.lib.wc_update_surfel_poses(self.h, C.c_void_p(d_imu.ptr), C.c_uint64(n_imu), C.c_void_p(d_surf.ptr), C.c_void_p(d_pose.ptr),
