@@ -78,6 +78,9 @@ int wc_extract_surfels_finish(wc_ctx *ctx, uint64_t *h_n_out);
  * h_ms5 = {key generation, point radix sort, k_roots (octree + PCA), surfel-slot sort, gather}.  Enable first. */
 int wc_extract_profile(wc_ctx *ctx, int enable);
 int wc_extract_stage_ms(wc_ctx *ctx, float *h_ms5);
+/* raw status words of the last extraction (profiling aid; words 16.. hold per-section cycle sums when the library
+ * is built with -DWC_PROF_ROOTS) */
+int wc_debug_status(wc_ctx *ctx, uint32_t *h_out64);
 /* root-voxel index of every point: VoxelLoc (src/odometry/surfel_extraction.h:55-64); d_keys_xyz = 3 int32 per point */
 int wc_voxel_keys(wc_ctx *ctx, const wc_points *pts, int32_t *d_keys_xyz);
 

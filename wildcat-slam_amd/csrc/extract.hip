@@ -31,7 +31,8 @@ namespace {
 
 
 constexpr int kMom = 11;    // n, St, Sx, Sy, Sz, Sxx, Sxy, Sxz, Syy, Syz, Szz
-constexpr unsigned kRootsGrid = 256 * 10;  // persistent wavefronts: 256 CUs x ~LDS-limited residency
+constexpr unsigned kRootsGrid = 256 * 16;  // wavefronts of the layer-0/1 pass (static work split; <= 128 VGPRs => all resident)
+constexpr unsigned kRoots2Grid = 256 * 4;  // wavefronts of the (rare) layer-2 pass
 constexpr int kBuckets = 4096;    // buckets of the composite sorts
 constexpr int kBucketCap = 4096;  // largest bucket the in-LDS bitonic sort takes
 constexpr int kTile = 4096;       // items per workgroup in the histogram / scatter passes
@@ -151,6 +152,7 @@ __device__ __forceinline__ void pca_from_moments(const double *m, Pca &r) {
   r.like = 2 * (r.ev[1] - r.ev[0]) / ((r.ev[0] + r.ev[1]) + r.ev[2]);
 }
 
+struct SplitJob;
 struct RootsArgs {
   wc_points pts;
   ExParams P;
@@ -167,6 +169,10 @@ struct RootsArgs {
   uint32_t *status;        // [0] emitted count, [1] flags
   uint32_t *slot_counts;   // bucket histogram of the surfel time keys (fast slot sort), or null
   uint32_t slot_shift;
+  struct SplitJob *split_jobs;  // roots queued for the layer-2 pass; count in status[4]
+  uint32_t *prof;               // WC_PROF_ROOTS builds: 8 section timers per head slot
+  double *node_tot;             // [head slot][9][11] node totals of the layer-0/1 pass
+  uint32_t *root_ncand;         // [head slot] candidates written by the layer-0/1 pass
 };
 
 // Heads of the root-voxel segments that can emit anything (n > min_points, InitOctoTree cc:129).  Two live heads are at
@@ -181,17 +187,40 @@ __global__ void __launch_bounds__(256) k_heads(const K *__restrict__ keys, uint6
   if (live) head_slots[pos / (uint64_t)(min_points + 1)] = (uint32_t)pos;
 }
 
-constexpr int kTab = 64;  // node-table rows: phase 1 uses 9 (root + 8 layer-1 nodes), phase 2 uses 64 (layer-2 nodes)
+#ifdef WC_PROF_ROOTS
+// per-root section timers (cycle counter), kept in registers and written once per root to a private row: no shared
+// counters (a hot atomic would sit in the same in-order memory queue as the loads being timed)
+#define WC_TICK(i)                                                  \
+  do {                                                              \
+    const unsigned long long now_ = __builtin_readcyclecounter();   \
+    prof_[i] += (uint32_t)(now_ - tick_);                           \
+    tick_ = now_;                                                   \
+  } while (0)
+#else
+#define WC_TICK(i)
+#endif
 
-// One wavefront per root voxel, roots pulled from a device-side queue (placement independent; a fixed
-// blockIdx -> segment map put all the work of a regular cloud on 2 of the 8 XCDs).
-template <typename K>
+struct SplitJob {  // a root whose layer-1 nodes need the layer-2 pass (k_roots<K, 2>)
+  uint32_t head, ncand;
+  unsigned long long split1;
+};
+
+// One wavefront per root voxel.  PHASE 1 streams the root + its eight layer-1 nodes (9 table rows); roots with layer-1
+// nodes that were tested and are not planes (CutOctoTree recursion, cc:175-182) are queued for PHASE 2, a second launch
+// of the same code over the 64 layer-2 nodes (rare on regular scenes, so the common case keeps a 5 KB LDS footprint).
+// Static work assignment (every wavefront owns a contiguous run of head slots): a device-side dequeue word serialised
+// at ~90 dequeues/us and cost more than it balanced.
+template <typename K, int PHASE>
 __global__ void __launch_bounds__(64) k_roots(RootsArgs A, const K *__restrict__ keys) {
-  __shared__ double s_open[kTab * kMom];
-  __shared__ double s_total[kTab * kMom];
-  __shared__ double s_last[kTab];
-  __shared__ int s_cnt[kTab];
-  __shared__ uint32_t s_ord[kTab];
+  constexpr int phase = (PHASE == 2) ? 2 : 1;       // octree pass: 1 = root + layer 1, 2 = layer 2
+  constexpr bool do_stream = (PHASE != 3);          // PHASE 1: stream only; PHASE 3: node tests + emission only
+  constexpr bool do_emit = (PHASE != 1);            // PHASE 2: both (the rare layer-2 pass stays fused)
+  constexpr int ntab = (phase == 1) ? 9 : 64;
+  __shared__ double s_open[ntab * kMom];
+  __shared__ double s_total[ntab * kMom];
+  __shared__ double s_last[ntab];
+  __shared__ int s_cnt[ntab];
+  __shared__ uint32_t s_ord[ntab];
   __shared__ double s_stage[64 * 5];  // {1, t, x, y, z} of the staged chunk
   __shared__ uint32_t s_code[64];
 
@@ -206,21 +235,50 @@ __global__ void __launch_bounds__(64) k_roots(RootsArgs A, const K *__restrict__
   const int m = lane - Lq * kMom;
   const int ia = (m <= 4) ? m : (m <= 7 ? 2 : (m <= 9 ? 3 : 4));
   const int ib = (m <= 4) ? 0 : (m == 5 ? 2 : (m == 6 ? 3 : (m == 7 ? 4 : (m == 8 ? 3 : 4))));
+  const int nlev = (phase == 1) ? (P.max_layer >= 1 ? 2 : 1) : 1;
+  const bool act = lane < nlev * kMom;
 
   double x0, y0, z0;
   load_xyz(A.pts, 0, x0, y0, z0);
   const int k0x = vox(x0, P.vs), k0y = vox(y0, P.vs), k0z = vox(z0, P.vs);
-  // every wavefront owns a contiguous run of head slots (<= 64): one coalesced load finds its roots.  Static
-  // assignment: a device-side dequeue word serialised at ~90 dequeues/us and cost more than it balanced.
-  const uint32_t per_wave = (A.nslots + gridDim.x - 1) / gridDim.x;
-  for (uint32_t s0 = blockIdx.x * per_wave; s0 < min((blockIdx.x + 1) * per_wave, A.nslots); s0 += 64) {
-   const uint32_t s_end = min((blockIdx.x + 1) * per_wave, A.nslots);
-   const uint32_t my_head = (s0 + lane < s_end) ? A.heads[s0 + lane] : 0xFFFFFFFFu;
-   unsigned long long live_mask = __ballot(my_head != 0xFFFFFFFFu);
+
+  // ---- work items of this wavefront ----
+  uint32_t it = 0, it_end = 0, it_step = 1;
+  if (PHASE != 2) {
+    const uint32_t per_wave = (A.nslots + gridDim.x - 1) / gridDim.x;
+    it = blockIdx.x * per_wave;
+    it_end = min((blockIdx.x + 1) * per_wave, A.nslots);
+  } else {
+    it = blockIdx.x;
+    it_end = A.status[4];
+    it_step = gridDim.x;
+  }
+  for (; it < it_end; it += (PHASE != 2 ? 64u : it_step)) {
+   uint32_t my_head = 0xFFFFFFFFu;
+   unsigned long long live_mask = 1ull;
+   if (PHASE != 2) {
+     my_head = (it + lane < it_end) ? A.heads[it + lane] : 0xFFFFFFFFu;
+     live_mask = __ballot(my_head != 0xFFFFFFFFu);
+   }
    while (live_mask) {
     const int hb = __ffsll((long long)live_mask) - 1;
     live_mask &= live_mask - 1;
-    const uint64_t head = __shfl(my_head, hb);
+    uint64_t head;
+    uint32_t ncand = 0, emitted = 0;
+    unsigned long long split1 = 0;  // layer-1 octants that get split (tested, not a plane; cc:175-182)
+    if (PHASE != 2) {
+      head = __shfl(my_head, hb);
+      if (PHASE == 3) ncand = A.root_ncand[head / (uint64_t)(P.min_points + 1)];
+    } else {
+      const SplitJob job = A.split_jobs[it];
+      head = job.head;
+      ncand = job.ncand;
+      split1 = job.split1;
+    }
+#ifdef WC_PROF_ROOTS
+    unsigned long long tick_ = __builtin_readcyclecounter();
+    uint32_t prof_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
     const K rootkey = keys[head];
 
     // absolute root voxel index and centre ((0.5 + k) * voxel_size, cc:208-210)
@@ -230,274 +288,307 @@ __global__ void __launch_bounds__(64) k_roots(RootsArgs A, const K *__restrict__
     const double cx = (0.5 + kx) * P.vs_f, cy = (0.5 + ky) * P.vs_f, cz = (0.5 + kz) * P.vs_f;
     const float q0 = P.vs_f / 4;  // quarter_length_ of the root (cc:207)
     const uint64_t slot_base = (head * (uint64_t)(P.max_layer + 1)) / (uint64_t)P.cluster_min;
-    uint32_t ncand = 0, emitted = 0;
-    unsigned long long split1 = 0;  // layer-1 octants that get split (tested, not a plane; cc:175-182)
 
-    for (int phase = 1; phase <= 2; ++phase) {
-      if (phase == 2 && split1 == 0) break;
-      const int nlev = (phase == 1) ? (P.max_layer >= 1 ? 2 : 1) : 1;
-      const bool act = lane < nlev * kMom;
-      const int ntab = (phase == 1) ? 9 : 64;
-      for (int i = lane; i < ntab * kMom; i += 64) {
-        s_open[i] = 0.0;
-        s_total[i] = 0.0;
-      }
-      for (int i = lane; i < ntab; i += 64) {
-        s_last[i] = 0.0;
-        s_cnt[i] = 0;
-        s_ord[i] = 0;
-      }
-      const uint32_t cand_begin = ncand;
+    const uint32_t cand_begin = (PHASE == 3) ? 0u : ncand;
+    if (do_stream) {
+    for (int i = lane; i < ntab * kMom; i += 64) {
+      s_open[i] = 0.0;
+      s_total[i] = 0.0;
+    }
+    for (int i = lane; i < ntab; i += 64) {
+      s_last[i] = 0.0;
+      s_cnt[i] = 0;
+      s_ord[i] = 0;
+    }
 
-      // register-cached accumulators of the node this lane is currently feeding
-      int cur = -1, n_open = 0;
-      double a_open = 0.0, a_total = 0.0, last = 0.0;
+    // register-cached accumulators of the node this lane is currently feeding
+    int cur = -1, n_open = 0;
+    double a_open = 0.0, a_total = 0.0, last = 0.0;
 
-      // ---- software-pipelined chunk loop: the next 64 points are in flight while the current ones stream ----
-      uint64_t pos = head + lane;
-      bool valid = pos < A.n && keys[pos] == rootkey;
-      double px = 0, py = 0, pz = 0, pt = 0;
+    // ---- software-pipelined chunk loop: the next 64 points are in flight while the current ones stream ----
+    uint64_t pos = head + lane;
+    bool valid = pos < A.n && keys[pos] == rootkey;
+    double px = 0, py = 0, pz = 0, pt = 0;
+    if (valid) {
+      const uint32_t idx = A.vals[pos];
+      load_xyz(A.pts, idx, px, py, pz);
+      pt = load_t(A.pts, idx);
+    }
+    WC_TICK(0);  // head -> first loads issued
+    int carry_o1 = -2;      // layer-1 octant / timestamp of the last point of the previous chunk
+    double carry_t = 0.0;
+    while (true) {
+      const int nvalid = __popcll(__ballot(valid));  // valid lanes are a prefix: keys are sorted
+      if (nvalid == 0) break;
+      __syncthreads();
+      int my_o1 = -1;
       if (valid) {
-        const uint32_t idx = A.vals[pos];
-        load_xyz(A.pts, idx, px, py, pz);
-        pt = load_t(A.pts, idx);
+        // octant = 4*[x>cx] + 2*[y>cy] + [z>cz] (strict >, cc:147-158); child centre = centre +- quarter (cc:163-165)
+        const int bx = px > cx, by = py > cy, bz = pz > cz;
+        const double c1x = cx + (double)((float)(2 * bx - 1) * q0);
+        const double c1y = cy + (double)((float)(2 * by - 1) * q0);
+        const double c1z = cz + (double)((float)(2 * bz - 1) * q0);
+        const int o1 = 4 * bx + 2 * by + bz;
+        const int o2 = 4 * (px > c1x) + 2 * (py > c1y) + (pz > c1z);
+        s_stage[lane * 5 + 0] = 1.0;
+        s_stage[lane * 5 + 1] = pt;
+        s_stage[lane * 5 + 2] = px;
+        s_stage[lane * 5 + 3] = py;
+        s_stage[lane * 5 + 4] = pz;
+        s_code[lane] = (uint32_t)(o1 * 8 + o2);
+        my_o1 = o1;
       }
-      int carry_o1 = -2;      // layer-1 octant / timestamp of the last point of the previous chunk
-      double carry_t = 0.0;
-      while (true) {
-        const int nvalid = __popcll(__ballot(valid));  // valid lanes are a prefix: keys are sorted
-        if (nvalid == 0) break;
-        __syncthreads();
-        int my_o1 = -1;
-        if (valid) {
-          // octant = 4*[x>cx] + 2*[y>cy] + [z>cz] (strict >, cc:147-158); child centre = centre +- quarter (cc:163-165)
-          const int bx = px > cx, by = py > cy, bz = pz > cz;
-          const double c1x = cx + (double)((float)(2 * bx - 1) * q0);
-          const double c1y = cy + (double)((float)(2 * by - 1) * q0);
-          const double c1z = cz + (double)((float)(2 * bz - 1) * q0);
-          const int o1 = 4 * bx + 2 * by + bz;
-          const int o2 = 4 * (px > c1x) + 2 * (py > c1y) + (pz > c1z);
-          s_stage[lane * 5 + 0] = 1.0;
-          s_stage[lane * 5 + 1] = pt;
-          s_stage[lane * 5 + 2] = px;
-          s_stage[lane * 5 + 3] = py;
-          s_stage[lane * 5 + 4] = pz;
-          s_code[lane] = (uint32_t)(o1 * 8 + o2);
-          my_o1 = o1;
+      // EVENT points (lane-parallel, before the sequential pass): a point needs the full per-point logic only when its
+      // layer-1 node differs from its predecessor's or the time gap to its predecessor exceeds cluster_gap; between
+      // two events every level keeps feeding the same node and no cluster can close, so the sequential pass can run a
+      // bare multiply-accumulate loop over whole segments.  (Phase 2 skips points, so there every point is an event.)
+      unsigned long long ev = ~0ull;
+      if (phase == 1) {
+        int po1 = __shfl_up(my_o1, 1);
+        double ptv = __shfl_up(pt, 1);
+        if (lane == 0) {
+          po1 = carry_o1;
+          ptv = carry_t;
         }
-        // EVENT points (lane-parallel, before the sequential pass): a point needs the full per-point logic only when its
-        // layer-1 node differs from its predecessor's or the time gap to its predecessor exceeds cluster_gap; between
-        // two events every level keeps feeding the same node and no cluster can close, so the sequential pass can run a
-        // bare multiply-accumulate loop over whole segments.  (Phase 2 skips points, so there every point is an event.)
-        unsigned long long ev = ~0ull;
-        if (phase == 1) {
-          int po1 = __shfl_up(my_o1, 1);
-          double ptv = __shfl_up(pt, 1);
-          if (lane == 0) {
-            po1 = carry_o1;
-            ptv = carry_t;
-          }
-          ev = __ballot(valid && (my_o1 != po1 || pt - ptv > P.gap));
-          carry_o1 = __shfl(my_o1, nvalid - 1);
-          carry_t = __shfl(pt, nvalid - 1);
-        }
-        __syncthreads();
-        // prefetch the next chunk
-        bool nvalid_next = false;
-        if (nvalid == 64) {
-          pos += 64;
-          nvalid_next = pos < A.n && keys[pos] == rootkey;
-          if (nvalid_next) {
-            const uint32_t idx = A.vals[pos];
-            load_xyz(A.pts, idx, px, py, pz);
-            pt = load_t(A.pts, idx);
-          }
-        }
-
-        // ---- stream the staged points in time order ----
-        int j = (P.dbg & 1) ? nvalid : 0;
-        while (j < nvalid) {
-          const unsigned long long rem = ev >> j;
-          const int je = rem ? j + (__ffsll((long long)rem) - 1) : nvalid;  // next event (or end of chunk)
-          if (je > j) {  // event-free segment: every active lane keeps accumulating into its cached node
-            if (act) {
-              double ao = a_open, at = a_total;
-#pragma unroll 4
-              for (int q = j; q < je; ++q) {
-                const double v = s_stage[q * 5 + ia] * s_stage[q * 5 + ib];
-                ao += v;
-                at += v;
-              }
-              a_open = ao;
-              a_total = at;
-              n_open += je - j;
-              last = s_stage[(je - 1) * 5 + 1];
-            }
-            j = je;
-            if (j >= nvalid) break;
-          }
-          // ---- event point: full logic ----
-          const uint32_t code = s_code[j];
-          const double t = s_stage[j * 5 + 1];
-          const double va = s_stage[j * 5 + ia], vb = s_stage[j * 5 + ib];
-          ++j;
-          if (phase == 2 && !((split1 >> (code >> 3)) & 1ull)) continue;  // parent layer-1 node is not split
-          const int nu = (phase == 2) ? (int)code : (Lq == 0 ? 0 : 1 + (int)(code >> 3));
-          if (act && nu != cur) {  // switch node: write the cached accumulators back, fetch the new node's
-            if (cur >= 0) {
-              s_open[cur * kMom + m] = a_open;
-              s_total[cur * kMom + m] = a_total;
-              if (m == 0) {
-                s_last[cur] = last;
-                s_cnt[cur] = n_open;
-              }
-            }
-            a_open = s_open[nu * kMom + m];
-            a_total = s_total[nu * kMom + m];
-            last = s_last[nu];
-            n_open = s_cnt[nu];
-            cur = nu;
-          }
-          // a new cluster starts when the gap to the previous point OF THIS NODE exceeds cluster_gap (cc:24)
-          const bool close = act && n_open > 0 && (t - last > P.gap);
-          const unsigned long long cm = __ballot(close);
-          if (cm) {
-            for (int l = 0; l < nlev; ++l) {
-              if (!((cm >> (l * kMom)) & 1ull)) continue;
-              const int cnt_l = __shfl(n_open, l * kMom);
-              const bool mine = act && (Lq == l);
-              if (cnt_l >= P.cluster_min) {  // clusters with fewer points are dropped (cc:33)
-                const uint64_t slot = slot_base + ncand;
-                if (slot < A.total_slots) {
-                  if (mine) {
-                    A.cand[slot * kMom + m] = a_open;
-                    if (m == 0) A.cand_meta[slot] = (uint32_t)nu | ((uint32_t)(phase - 1) << 7) | (s_ord[nu] << 8);
-                  }
-                } else if (lane == 0) {
-                  atomicOr(&A.status[1], kFlagSlotOverflow);
-                }
-                ++ncand;
-              }
-              if (mine) {
-                a_open = 0.0;
-                n_open = 0;
-                if (m == 0) s_ord[nu] += 1;
-              }
-            }
-          }
-          if (act) {
-            const double v = va * vb;
-            a_open += v;
-            a_total += v;
-            n_open += 1;
-            last = t;
-          }
-        }
-        if (nvalid < 64) break;
-        valid = nvalid_next;
-      }
-      // write the cached node back
-      if (act && cur >= 0) {
-        s_open[cur * kMom + m] = a_open;
-        s_total[cur * kMom + m] = a_total;
-        if (m == 0) {
-          s_last[cur] = last;
-          s_cnt[cur] = n_open;
-        }
+        ev = __ballot(valid && (my_o1 != po1 || pt - ptv > P.gap));
+        carry_o1 = __shfl(my_o1, nvalid - 1);
+        carry_t = __shfl(pt, nvalid - 1);
       }
       __syncthreads();
-
-      // still-open clusters become candidates too (end of ClusterSurfels' first loop)
-      for (int nu = 0; nu < ntab; ++nu) {
-        if (s_cnt[nu] >= P.cluster_min) {
-          const uint64_t slot = slot_base + ncand;
-          if (slot < A.total_slots) {
-            if (lane < kMom) A.cand[slot * kMom + lane] = s_open[nu * kMom + lane];
-            if (lane == 0) A.cand_meta[slot] = (uint32_t)nu | ((uint32_t)(phase - 1) << 7) | (s_ord[nu] << 8);
-          } else if (lane == 0) {
-            atomicOr(&A.status[1], kFlagSlotOverflow);
-          }
-          ++ncand;
+      // prefetch the next chunk
+      bool nvalid_next = false;
+      if (nvalid == 64) {
+        pos += 64;
+        nvalid_next = pos < A.n && keys[pos] == rootkey;
+        if (nvalid_next) {
+          const uint32_t idx = A.vals[pos];
+          load_xyz(A.pts, idx, px, py, pz);
+          pt = load_t(A.pts, idx);
         }
       }
 
-      if (P.dbg & 2) break;
-      // ---- node tests: InitOctoTree / CutOctoTree gates (cc:129-138, :170-183) ----
-      bool tested = false, plane = false;
-      if (lane < ntab) {
+      WC_TICK(1);  // staging (incl. waiting for the gather)
+      // ---- stream the staged points in time order ----
+      int j = (P.dbg & 1) ? nvalid : 0;
+      while (j < nvalid) {
+        const unsigned long long rem = ev >> j;
+        const int je = rem ? j + (__ffsll((long long)rem) - 1) : nvalid;  // next event (or end of chunk)
+        if (je > j) {  // event-free segment: every active lane keeps accumulating into its cached node
+          if (act) {
+            double ao = a_open, at = a_total;
+#pragma unroll 4
+            for (int q = j; q < je; ++q) {
+              const double v = s_stage[q * 5 + ia] * s_stage[q * 5 + ib];
+              ao += v;
+              at += v;
+            }
+            a_open = ao;
+            a_total = at;
+            n_open += je - j;
+            last = s_stage[(je - 1) * 5 + 1];
+          }
+          j = je;
+          if (j >= nvalid) break;
+        }
+        // ---- event point: full logic ----
+        const uint32_t code = s_code[j];
+        const double t = s_stage[j * 5 + 1];
+        const double va = s_stage[j * 5 + ia], vb = s_stage[j * 5 + ib];
+        ++j;
+        if (phase == 2 && !((split1 >> (code >> 3)) & 1ull)) continue;  // parent layer-1 node is not split
+        const int nu = (phase == 2) ? (int)code : (Lq == 0 ? 0 : 1 + (int)(code >> 3));
+        if (act && nu != cur) {  // switch node: write the cached accumulators back, fetch the new node's
+          if (cur >= 0) {
+            s_open[cur * kMom + m] = a_open;
+            s_total[cur * kMom + m] = a_total;
+            if (m == 0) {
+              s_last[cur] = last;
+              s_cnt[cur] = n_open;
+            }
+          }
+          a_open = s_open[nu * kMom + m];
+          a_total = s_total[nu * kMom + m];
+          last = s_last[nu];
+          n_open = s_cnt[nu];
+          cur = nu;
+        }
+        // a new cluster starts when the gap to the previous point OF THIS NODE exceeds cluster_gap (cc:24)
+        const bool close = act && n_open > 0 && (t - last > P.gap);
+        const unsigned long long cm = __ballot(close);
+        if (cm) {
+          for (int l = 0; l < nlev; ++l) {
+            if (!((cm >> (l * kMom)) & 1ull)) continue;
+            const int cnt_l = __shfl(n_open, l * kMom);
+            const bool mine = act && (Lq == l);
+            if (cnt_l >= P.cluster_min) {  // clusters with fewer points are dropped (cc:33)
+              const uint64_t slot = slot_base + ncand;
+              if (slot < A.total_slots) {
+                if (mine) {
+                  A.cand[slot * kMom + m] = a_open;
+                  if (m == 0) A.cand_meta[slot] = (uint32_t)nu | ((uint32_t)(phase - 1) << 7) | (s_ord[nu] << 8);
+                }
+              } else if (lane == 0) {
+                atomicOr(&A.status[1], kFlagSlotOverflow);
+              }
+              ++ncand;
+            }
+            if (mine) {
+              a_open = 0.0;
+              n_open = 0;
+              if (m == 0) s_ord[nu] += 1;
+            }
+          }
+        }
+        if (act) {
+          const double v = va * vb;
+          a_open += v;
+          a_total += v;
+          n_open += 1;
+          last = t;
+        }
+      }
+      WC_TICK(2);  // sequential pass
+      if (nvalid < 64) break;
+      valid = nvalid_next;
+    }
+    // write the cached node back
+    if (act && cur >= 0) {
+      s_open[cur * kMom + m] = a_open;
+      s_total[cur * kMom + m] = a_total;
+      if (m == 0) {
+        s_last[cur] = last;
+        s_cnt[cur] = n_open;
+      }
+    }
+    __syncthreads();
+
+    // still-open clusters become candidates too (end of ClusterSurfels' first loop)
+    for (int nu = 0; nu < ntab; ++nu) {
+      if (s_cnt[nu] >= P.cluster_min) {
+        const uint64_t slot = slot_base + ncand;
+        if (slot < A.total_slots) {
+          if (lane < kMom) A.cand[slot * kMom + lane] = s_open[nu * kMom + lane];
+          if (lane == 0) A.cand_meta[slot] = (uint32_t)nu | ((uint32_t)(phase - 1) << 7) | (s_ord[nu] << 8);
+        } else if (lane == 0) {
+          atomicOr(&A.status[1], kFlagSlotOverflow);
+        }
+        ++ncand;
+      }
+    }
+    }
+    if (PHASE == 1) {  // hand the node totals and the candidate count to k_roots<K, 3> (tests + emission, full occupancy)
+      const uint64_t hs = head / (uint64_t)(P.min_points + 1);
+      for (int i = lane; i < ntab * kMom; i += 64) A.node_tot[hs * (9 * kMom) + i] = s_total[i];
+      if (lane == 0) A.root_ncand[hs] = ncand;
+      WC_TICK(3);
+      __syncthreads();
+      continue;
+    }
+    __threadfence_block();
+    __syncthreads();
+    WC_TICK(3);  // write-back + open-cluster flush + fence
+    if (P.dbg & 2) continue;
+
+    // ---- ONE pass of 3x3 PCAs for the node tests (InitOctoTree / CutOctoTree gates, cc:129-138, :170-183) and for
+    //      the candidate clusters (ClusterSurfels' second loop, cc:32-64): lanes [0, ntab) take the nodes, the lanes
+    //      above them the first candidates, so a root costs one eigen-solve latency instead of two ----
+    const uint32_t ncap = (uint32_t)min((uint64_t)ncand, A.total_slots > slot_base ? A.total_slots - slot_base : 0);
+    unsigned long long plane_mask = 0;
+    bool stop = false;
+    for (uint32_t batch = 0;; ++batch) {
+      // lane job: node test (first batch only) or candidate
+      const bool node_lane = (batch == 0) && lane < ntab;
+      const int cand_lane0 = (batch == 0) ? ntab : 0;
+      const uint32_t cbase = cand_begin + (batch == 0 ? 0u : (uint32_t)(64 - ntab) + (batch - 1) * 64u);
+      const uint32_t c = cbase + (uint32_t)(lane - cand_lane0);
+      const bool cand_lane = lane >= cand_lane0 && c < ncap;
+      if (batch > 0 && cbase >= ncap) break;
+      double mom[kMom];
+      bool have = false;
+      int nu = 0;
+      uint32_t ord = 0;
+      uint64_t slot = 0;
+      if (node_lane) {
         bool exists = true;
         if (phase == 2) exists = (split1 >> (lane >> 3)) & 1ull;
-        const double cnt_n = s_total[lane * kMom];
+        nu = lane;
+        const double *tot = (PHASE == 3) ? A.node_tot + (head / (uint64_t)(P.min_points + 1)) * (9 * kMom) + lane * kMom : nullptr;
+        const double cnt_n = (PHASE == 3) ? tot[0] : s_total[lane * kMom];
         if (exists && cnt_n > (double)P.min_points) {
-          tested = true;
-          double mom[kMom];
-          for (int i = 0; i < kMom; ++i) mom[i] = s_total[lane * kMom + i];
-          Pca rr;
-          pca_from_moments(mom, rr);
-          plane = (rr.ev[0] < P.thr) && (rr.like > P.min_like);  // cc:106-111
+          have = true;
+          for (int i = 0; i < kMom; ++i) mom[i] = (PHASE == 3) ? tot[i] : s_total[lane * kMom + i];
         }
+      } else if (cand_lane) {
+        slot = slot_base + c;
+        const uint32_t meta = A.cand_meta[slot];
+        nu = (int)(meta & 0x7F);
+        ord = meta >> 8;
+        have = true;
+        for (int i = 0; i < kMom; ++i) mom[i] = A.cand[slot * kMom + i];
       }
-      const unsigned long long plane_mask = __ballot(plane);
-      if (phase == 1) {
-        const bool root_tested = __shfl((int)tested, 0) != 0;
-        if (!root_tested) break;  // n <= min_points: nothing below this root exists (cc:129)
-        split1 = (P.max_layer >= 2) ? (__ballot(lane >= 1 && lane < 9 && tested && !plane) >> 1) : 0ull;
-      }
-      __threadfence_block();
-      __syncthreads();
-
-      // ---- emission: ExtractSurfelInfo + ClusterSurfels second loop (cc:305-308, :32-64) ----
-      const uint32_t ncap = (uint32_t)min((uint64_t)ncand, A.total_slots > slot_base ? A.total_slots - slot_base : 0);
-      for (uint32_t c0 = cand_begin; c0 < ncap; c0 += 64) {
-        const uint32_t c = c0 + lane;
-        bool ok = false;
-        if (c < ncap) {
-          const uint64_t slot = slot_base + c;
-          const uint32_t meta = A.cand_meta[slot];
-          const int nu = (int)(meta & 0x7F);
-          const uint32_t ord = meta >> 8;
-          if ((plane_mask >> nu) & 1ull) {
-            double mom[kMom];
-            for (int i = 0; i < kMom; ++i) mom[i] = A.cand[slot * kMom + i];
-            Pca rr;
-            pca_from_moments(mom, rr);
-            if (!(rr.ev[0] > P.thr || rr.like < P.min_like)) {  // cc:54
-              double nx = rr.nrm[0], ny = rr.nrm[1], nz = rr.nrm[2];
-              const double d = nx * (rr.c[0] - P.view[0]) + ny * (rr.c[1] - P.view[1]) + nz * (rr.c[2] - P.view[2]);
-              if (d < 0) nx = -nx, ny = -ny, nz = -nz;  // cc:59-61
-              const int layer = (phase == 2) ? 2 : (nu == 0 ? 0 : 1);
-              const float ql = layer == 0 ? q0 : (layer == 1 ? q0 / 2 : (q0 / 2) / 2);
-              wc_surfel sf;
-              sf.t = rr.tmean;
-              sf.center[0] = rr.c[0], sf.center[1] = rr.c[1], sf.center[2] = rr.c[2];
-              for (int i = 0; i < 9; ++i) sf.cov[i] = rr.cov[i];
-              sf.normal[0] = nx, sf.normal[1] = ny, sf.normal[2] = nz;
-              sf.resolution = (double)(ql * 4);  // quarter_length_ * 4, float arithmetic (cc:307)
-              sf.sigma = sqrt(rr.ev[0]);
-              A.slots[slot] = sf;
-              uint32_t node = (uint32_t)layer;
-              if (layer == 1) node |= (uint32_t)(nu - 1) << 2;
-              if (layer == 2) node |= ((uint32_t)(nu >> 3) << 2) | ((uint32_t)(nu & 7) << 5);
-              A.slot_ids[slot] = wc_surfel_id{kx, ky, kz, node | (ord << 8)};
-              const uint64_t ob = ordered_bits(rr.tmean);
-              uint64_t key;
-              if (ob < P.t_lo_bits) {
-                atomicOr(&A.status[1], kFlagTimeRange);
-                key = 0;
-              } else {
-                key = ob - P.t_lo_bits;
-              }
-              A.slot_keys[slot] = key;
-              if (A.slot_counts) atomicAdd(&A.slot_counts[min((uint32_t)(key >> A.slot_shift), (uint32_t)(kBuckets - 1))], 1u);
-              ok = true;
-            }
+      WC_TICK(4);  // moments loaded
+      Pca rr;
+      if (have && !(P.dbg & 4)) pca_from_moments(mom, rr);
+      WC_TICK(5);  // eigen-solves
+      if (P.dbg & 4) { rr.ev[0] = 1e-5; rr.ev[1] = rr.ev[2] = 1e-2; rr.like = 0.9; rr.tmean = mom[1] / mom[0]; for (int i = 0; i < 3; ++i) { rr.c[i] = mom[2 + i] / mom[0]; rr.nrm[i] = 0.577; } for (int i = 0; i < 9; ++i) rr.cov[i] = 0; }
+      if (batch == 0) {
+        const bool plane = node_lane && have && (rr.ev[0] < P.thr) && (rr.like > P.min_like);  // cc:106-111
+        plane_mask = __ballot(plane);
+        if (phase == 1) {
+          const bool root_tested = __shfl((int)(node_lane && have), 0) != 0;
+          if (!root_tested) {
+            stop = true;  // n <= min_points: nothing below this root exists (cc:129)
+            break;
           }
+          split1 = (P.max_layer >= 2) ? (__ballot(lane >= 1 && lane < 9 && have && !plane) >> 1) : 0ull;
         }
-        emitted += (uint32_t)__popcll(__ballot(ok));
       }
-      __syncthreads();
+      bool ok = false;
+      if (cand_lane && have && ((plane_mask >> nu) & 1ull) && !(rr.ev[0] > P.thr || rr.like < P.min_like)) {  // cc:54
+        double nx = rr.nrm[0], ny = rr.nrm[1], nz = rr.nrm[2];
+        const double d = nx * (rr.c[0] - P.view[0]) + ny * (rr.c[1] - P.view[1]) + nz * (rr.c[2] - P.view[2]);
+        if (d < 0) nx = -nx, ny = -ny, nz = -nz;  // cc:59-61
+        const int layer = (phase == 2) ? 2 : (nu == 0 ? 0 : 1);
+        const float ql = layer == 0 ? q0 : (layer == 1 ? q0 / 2 : (q0 / 2) / 2);
+        wc_surfel sf;
+        sf.t = rr.tmean;
+        sf.center[0] = rr.c[0], sf.center[1] = rr.c[1], sf.center[2] = rr.c[2];
+        for (int i = 0; i < 9; ++i) sf.cov[i] = rr.cov[i];
+        sf.normal[0] = nx, sf.normal[1] = ny, sf.normal[2] = nz;
+        sf.resolution = (double)(ql * 4);  // quarter_length_ * 4, float arithmetic (cc:307)
+        sf.sigma = sqrt(rr.ev[0]);
+        A.slots[slot] = sf;
+        uint32_t node = (uint32_t)layer;
+        if (layer == 1) node |= (uint32_t)(nu - 1) << 2;
+        if (layer == 2) node |= ((uint32_t)(nu >> 3) << 2) | ((uint32_t)(nu & 7) << 5);
+        A.slot_ids[slot] = wc_surfel_id{kx, ky, kz, node | (ord << 8)};
+        const uint64_t ob = ordered_bits(rr.tmean);
+        uint64_t key;
+        if (ob < P.t_lo_bits) {
+          atomicOr(&A.status[1], kFlagTimeRange);
+          key = 0;
+        } else {
+          key = ob - P.t_lo_bits;
+        }
+        A.slot_keys[slot] = key;
+        if (A.slot_counts) atomicAdd(&A.slot_counts[min((uint32_t)(key >> A.slot_shift), (uint32_t)(kBuckets - 1))], 1u);
+        ok = true;
+      }
+      emitted += (uint32_t)__popcll(__ballot(ok));
+      WC_TICK(6);  // gates + surfel stores
     }
-    if (lane == 0 && emitted) atomicAdd(&A.status[0], emitted);
+    if (PHASE == 3 && !stop && split1 != 0 && lane == 0) {  // layer-2 pass needed: queue the root for k_roots<K, 2>
+      const uint32_t q = atomicAdd(&A.status[4], 1u);
+      A.split_jobs[q] = SplitJob{(uint32_t)head, ncand, split1};
+    }
+    // the surfel count: with the slot histogram it is the histogram total (k_bucket_prefix); a per-root atomic on one
+    // word serialises at ~12 ns per root once every wavefront reaches this point at the same time (47 us for 3.9 k roots)
+    if (lane == 0 && emitted && !A.slot_counts) atomicAdd(&A.status[0], emitted);
+#ifdef WC_PROF_ROOTS
+    if (lane == 0 && PHASE != 2 && A.prof)
+      for (int i = 0; i < 8; ++i) A.prof[(head / 21) * 8 + i] += prof_[i];
+#endif
+    __syncthreads();
    }
   }
 }
@@ -698,7 +789,7 @@ __device__ __forceinline__ uint32_t run_length(const unsigned long long *s_bits,
 }
 
 // exclusive prefixes of the per-bucket run and point counts (one small workgroup; every later workgroup just reads them)
-__global__ void __launch_bounds__(1024) k_bucket_prefix(const uint32_t *counts, uint32_t *bases, int narrays) {
+__global__ void __launch_bounds__(1024) k_bucket_prefix(const uint32_t *counts, uint32_t *bases, int narrays, uint32_t *total0) {
   __shared__ uint32_t s_tmp[1024];
   constexpr int PER = kBuckets / 1024;
   const int t = threadIdx.x;
@@ -717,12 +808,27 @@ __global__ void __launch_bounds__(1024) k_bucket_prefix(const uint32_t *counts, 
       __syncthreads();
     }
     uint32_t run = s_tmp[t] - sum;
+    if (a == 0 && total0 && t == 1023) *total0 = s_tmp[t];  // item count of the first array
     for (int q = 0; q < PER; ++q) {
       bases[a * kBuckets + PER * t + q] = run;
       run += c[q];
     }
     __syncthreads();
   }
+}
+
+// every per-call fill (status words, slot keys, bucket counters, head table) in ONE launch: each hipMemsetAsync is its
+// own ~2-7 us kernel, and an extraction call needs five of them
+struct InitArgs {
+  uint32_t *p[6];
+  uint32_t nw[6];  // 32-bit words
+  uint32_t val[6];
+};
+__global__ void __launch_bounds__(256) k_init(InitArgs I) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+#pragma unroll
+  for (int r = 0; r < 6; ++r)
+    if (i < I.nw[r]) I.p[r][i] = I.val[r];
 }
 
 template <bool SCATTER>
@@ -843,7 +949,7 @@ __global__ void __launch_bounds__(256) k_pt_bucket(const uint64_t *comp, const u
   }
 }
 
-int point_sort_runs(wc_ctx *ctx, const wc_points &pts, double vs, uint32_t *keys_out, uint32_t *idx_out, uint32_t *status) {
+int point_sort_runs(wc_ctx *ctx, const wc_points &pts, double vs, uint32_t *keys_out, uint32_t *idx_out, uint32_t *status, bool counts_cleared) {
   hipStream_t st = ctx->stream;
   const uint64_t n = pts.n;
   WC_TRY(wc_ensure(ctx, ctx->b_misc[1], n * 8));            // run composites (at most one per point)
@@ -851,10 +957,10 @@ int point_sort_runs(wc_ctx *ctx, const wc_points &pts, double vs, uint32_t *keys
   WC_TRY(wc_ensure(ctx, ctx->b_misc[3], n * 2));            // run lengths, indexed by the run's first point
   WC_TRY(wc_ensure(ctx, ctx->b_keys[0], n * 4));            // per-point keys
   uint32_t *counts = (uint32_t *)ctx->b_misc[2].p;
-  WC_HIP(ctx, hipMemsetAsync(counts, 0, 3 * kBuckets * 4, st));
+  if (!counts_cleared) WC_HIP(ctx, hipMemsetAsync(counts, 0, 3 * kBuckets * 4, st));
   const unsigned tiles = (unsigned)((n + kTile - 1) / kTile);
   k_pt_runs<false><<<tiles, 256, 0, st>>>(pts, vs, n, (uint32_t *)ctx->b_keys[0].p, counts, nullptr, nullptr, nullptr, status);
-  k_bucket_prefix<<<1, 1024, 0, st>>>(counts, counts + 3 * kBuckets, 2);
+  k_bucket_prefix<<<1, 1024, 0, st>>>(counts, counts + 3 * kBuckets, 2, nullptr);
   k_pt_runs<true><<<tiles, 256, 0, st>>>(pts, vs, n, (uint32_t *)ctx->b_keys[0].p, counts, counts + 2 * kBuckets,
                                         (uint64_t *)ctx->b_misc[1].p, (uint16_t *)ctx->b_misc[3].p, status);
   k_pt_bucket<<<kBuckets, 256, 0, st>>>((const uint64_t *)ctx->b_misc[1].p, counts, (const uint16_t *)ctx->b_misc[3].p, keys_out, idx_out,
@@ -865,14 +971,14 @@ int point_sort_runs(wc_ctx *ctx, const wc_points &pts, double vs, uint32_t *keys
 
 template <typename Src, bool POINTS>
 int bucket_sort(wc_ctx *ctx, const Src &src, uint64_t n, uint64_t *comp_buf, uint32_t *keys_out, uint32_t *idx_out, uint32_t *counts,
-                uint32_t *status, bool have_hist) {
+                uint32_t *status, bool have_hist, uint32_t *total_out = nullptr) {
   hipStream_t st = ctx->stream;
   const unsigned tiles = (unsigned)((n + kTile - 1) / kTile);
   if (!have_hist) {
     WC_HIP(ctx, hipMemsetAsync(counts, 0, 2 * kBuckets * 4, st));  // counts + cursors
     k_bucket_hist<Src><<<tiles, 256, 0, st>>>(src, n, counts, status);
   }
-  k_bucket_prefix<<<1, 1024, 0, st>>>(counts, counts + 2 * kBuckets, 1);
+  k_bucket_prefix<<<1, 1024, 0, st>>>(counts, counts + 2 * kBuckets, 1, total_out);
   k_bucket_scatter<Src><<<tiles, 256, 0, st>>>(src, n, counts, counts + kBuckets, comp_buf, status);
   k_bucket_sort<POINTS><<<kBuckets, 256, 0, st>>>(comp_buf, counts, keys_out, idx_out, status);
   WC_HIP(ctx, hipGetLastError());
@@ -936,13 +1042,8 @@ int run_pipeline(wc_ctx *ctx, const wc_points &pts, double t_lo, double t_hi, wc
     if (ctx->ex_prof) (void)hipEventRecord(ctx->ex_ev[i], st);
   };
   mark(0);
-  WC_HIP(ctx, hipMemsetAsync(status, 0, 64 * 4, st));
-  WC_HIP(ctx, hipMemsetAsync(ctx->b_slot_keys[0].p, 0xFF, total_slots * 8, st));
-  const bool fast_slots = fast && tbits <= 31 && total_slots < (1ull << 32);
-  if (fast_slots) {
-    WC_TRY(wc_ensure(ctx, ctx->b_misc[4], 3 * kBuckets * 4));
-    WC_HIP(ctx, hipMemsetAsync(ctx->b_misc[4].p, 0, 2 * kBuckets * 4, st));  // slot bucket counts (filled by k_roots) + cursors
-  }
+  const bool fast_slots = fast && tbits <= 31 && total_slots < (1ull << 31);
+  if (fast_slots) WC_TRY(wc_ensure(ctx, ctx->b_misc[4], 3 * kBuckets * 4));
   const unsigned g256 = (unsigned)((n + 255) / 256);
   // fast path (32-bit keys): bucket sort of (voxel key, index) composites; general path: rocPRIM radix sort
   const bool fast_pts = fast && sizeof(K) == 4;
@@ -950,9 +1051,23 @@ int run_pipeline(wc_ctx *ctx, const wc_points &pts, double t_lo, double t_hi, wc
     WC_TRY(wc_ensure(ctx, ctx->b_misc[1], std::max<uint64_t>(n, total_slots) * 8));
     WC_TRY(wc_ensure(ctx, ctx->b_misc[2], 5 * kBuckets * 4));
   }
+  const uint32_t nslots = (uint32_t)(n / (uint64_t)(P.min_points + 1) + 1);
+  {
+    InitArgs I{};
+    int r = 0;
+    auto fill = [&](void *p, uint64_t words, uint32_t v) { I.p[r] = (uint32_t *)p, I.nw[r] = (uint32_t)words, I.val[r] = v, ++r; };
+    fill(status, 64, 0u);
+    fill(ctx->b_slot_keys[0].p, total_slots * 2, 0xFFFFFFFFu);                  // slot keys: ~0 = no surfel in the slot
+    fill(ctx->b_misc[0].p, nslots, 0xFFFFFFFFu);                                // head slot table: ~0 = no live head
+    if (fast_slots) fill(ctx->b_misc[4].p, 2 * kBuckets, 0u);                   // slot bucket counts (filled by k_roots) + cursors
+    if (fast_pts) fill(ctx->b_misc[2].p, 3 * kBuckets, 0u);                     // point-sort run counts | point counts | cursors
+    uint32_t mx = 0;
+    for (int q = 0; q < r; ++q) mx = std::max(mx, I.nw[q]);
+    k_init<<<(mx + 255) / 256, 256, 0, st>>>(I);
+  }
   if (fast_pts) {
     mark(1);
-    WC_TRY(point_sort_runs(ctx, pts, E.vs, (uint32_t *)ctx->b_keys[1].p, (uint32_t *)ctx->b_vals[1].p, status));
+    WC_TRY(point_sort_runs(ctx, pts, E.vs, (uint32_t *)ctx->b_keys[1].p, (uint32_t *)ctx->b_vals[1].p, status, true));
   } else {
     k_keygen<K><<<g256, 256, 0, st>>>(pts, E.vs, (K *)ctx->b_keys[0].p, (uint32_t *)ctx->b_vals[0].p, status);
     mark(1);
@@ -975,15 +1090,27 @@ int run_pipeline(wc_ctx *ctx, const wc_points &pts, double t_lo, double t_hi, wc
   A.slot_counts = fast_slots ? (uint32_t *)ctx->b_misc[4].p : nullptr;
   A.slot_shift = tbits > 12 ? tbits - 12 : 0u;
   A.heads = (const uint32_t *)ctx->b_misc[0].p;
-  A.nslots = (uint32_t)(n / (uint64_t)(P.min_points + 1) + 1);
-  WC_HIP(ctx, hipMemsetAsync(ctx->b_misc[0].p, 0xFF, (size_t)A.nslots * 4, st));
+  A.nslots = nslots;
   k_heads<K><<<g256, 256, 0, st>>>((const K *)ctx->b_keys[1].p, n, P.min_points, (uint32_t *)ctx->b_misc[0].p);
-  k_roots<K><<<kRootsGrid, 64, 0, st>>>(A, (const K *)ctx->b_keys[1].p);
+  WC_TRY(wc_ensure(ctx, ctx->b_misc[5], (size_t)A.nslots * sizeof(SplitJob)));
+  A.split_jobs = (SplitJob *)ctx->b_misc[5].p;
+  A.prof = nullptr;
+#ifdef WC_PROF_ROOTS
+  WC_TRY(wc_ensure(ctx, ctx->b_misc[6], (size_t)A.nslots * 32));
+  WC_HIP(ctx, hipMemsetAsync(ctx->b_misc[6].p, 0, (size_t)A.nslots * 32, st));
+  A.prof = (uint32_t *)ctx->b_misc[6].p;
+#endif
+  WC_TRY(wc_ensure(ctx, ctx->b_misc[7], (size_t)A.nslots * (9 * kMom * 8 + 4)));
+  A.node_tot = (double *)ctx->b_misc[7].p;
+  A.root_ncand = (uint32_t *)(A.node_tot + (size_t)A.nslots * 9 * kMom);
+  k_roots<K, 1><<<kRootsGrid, 64, 0, st>>>(A, (const K *)ctx->b_keys[1].p);  // stream root + layer 1
+  k_roots<K, 3><<<kRootsGrid, 64, 0, st>>>(A, (const K *)ctx->b_keys[1].p);  // node tests + emission
+  k_roots<K, 2><<<kRoots2Grid, 64, 0, st>>>(A, (const K *)ctx->b_keys[1].p);  // layer 2 of the split nodes (rare)
   mark(3);
   if (fast_slots) {
     SlotSrc ssrc{(const uint64_t *)ctx->b_slot_keys[0].p, tbits > 12 ? tbits - 12 : 0u};
     WC_TRY((bucket_sort<SlotSrc, false>(ctx, ssrc, total_slots, (uint64_t *)ctx->b_misc[1].p, nullptr, (uint32_t *)ctx->b_slot_idx[1].p,
-                                        (uint32_t *)ctx->b_misc[4].p, status, true)));
+                                        (uint32_t *)ctx->b_misc[4].p, status, true, status)));  // status[0] = surfel count = histogram total
   } else {
     k_iota<<<(unsigned)((total_slots + 255) / 256), 256, 0, st>>>((uint32_t *)ctx->b_slot_idx[0].p, total_slots);
     WC_TRY(sort_pairs<uint64_t>(ctx, (uint64_t *)ctx->b_slot_keys[0].p, (uint64_t *)ctx->b_slot_keys[1].p,
@@ -1084,5 +1211,26 @@ extern "C" int wc_extract_stage_ms(wc_ctx *ctx, float *h_ms5) {
   if (!ctx || !h_ms5 || !ctx->ex_ev[0]) return WC_ERR_ARG;
   WC_HIP(ctx, hipEventSynchronize(ctx->ex_ev[5]));
   for (int i = 0; i < 5; ++i) WC_HIP(ctx, hipEventElapsedTime(&h_ms5[i], ctx->ex_ev[i], ctx->ex_ev[i + 1]));
+  return WC_OK;
+}
+
+extern "C" int wc_debug_status(wc_ctx *ctx, uint32_t *h_out64) {  // profiling aid: status words [0..16) + section timers
+  if (!ctx || !h_out64 || !ctx->b_status.p) return WC_ERR_ARG;
+  WC_HIP(ctx, hipMemcpy(h_out64, ctx->b_status.p, 64 * 4, hipMemcpyDeviceToHost));
+#ifdef WC_PROF_ROOTS
+  // average the per-root section timers into words [16, 24), number of timed roots in word 24
+  const size_t nslots = ctx->ex.pts.n / (size_t)(ctx->P.min_points + 1) + 1;
+  std::vector<uint32_t> rows(nslots * 8);
+  WC_HIP(ctx, hipMemcpy(rows.data(), ctx->b_misc[6].p, nslots * 32, hipMemcpyDeviceToHost));
+  double sum[8] = {0};
+  uint32_t cnt = 0;
+  for (size_t r = 0; r < nslots; ++r)
+    if (rows[r * 8 + 1]) {
+      ++cnt;
+      for (int i = 0; i < 8; ++i) sum[i] += rows[r * 8 + i];
+    }
+  for (int i = 0; i < 8; ++i) h_out64[16 + i] = cnt ? (uint32_t)(sum[i] / cnt) : 0;
+  h_out64[24] = cnt;
+#endif
   return WC_OK;
 }
