@@ -34,7 +34,6 @@ constexpr int kMom = 11;    // n, St, Sx, Sy, Sz, Sxx, Sxy, Sxz, Syy, Syz, Szz
 constexpr unsigned kRootsGrid = 256 * 16;  // wavefronts of the layer-0/1 pass (static work split; <= 128 VGPRs => all resident)
 constexpr unsigned kRoots2Grid = 256 * 4;  // wavefronts of the (rare) layer-2 pass
 constexpr int kBuckets = 4096;    // buckets of the composite sorts
-constexpr int kBucketCap = 4096;  // largest bucket the in-LDS bitonic sort takes
 constexpr int kTile = 4096;       // items per workgroup in the histogram / scatter passes
 constexpr uint32_t kFlagKeyRange = 1u, kFlagSlotOverflow = 2u, kFlagTimeRange = 4u, kFlagBucketOverflow = 8u;
 
@@ -169,6 +168,8 @@ struct RootsArgs {
   uint32_t *status;        // [0] emitted count, [1] flags
   uint32_t *slot_counts;   // bucket histogram of the surfel time keys (fast slot sort), or null
   uint32_t slot_shift;
+  uint64_t *slot_bins;          // [kBuckets][slot_bin_cap] (time key << 32 | slot) of the surfels of each time bucket
+  uint32_t slot_bin_cap;
   struct SplitJob *split_jobs;  // roots queued for the layer-2 pass; count in status[4]
   uint32_t *prof;               // WC_PROF_ROOTS builds: 8 section timers per head slot
   double *node_tot;             // [head slot][9][11] node totals of the layer-0/1 pass
@@ -214,7 +215,6 @@ template <typename K, int PHASE>
 __global__ void __launch_bounds__(64) k_roots(RootsArgs A, const K *__restrict__ keys) {
   constexpr int phase = (PHASE == 2) ? 2 : 1;       // octree pass: 1 = root + layer 1, 2 = layer 2
   constexpr bool do_stream = (PHASE != 3);          // PHASE 1: stream only; PHASE 3: node tests + emission only
-  constexpr bool do_emit = (PHASE != 1);            // PHASE 2: both (the rare layer-2 pass stays fused)
   constexpr int ntab = (phase == 1) ? 9 : 64;
   __shared__ double s_open[ntab * kMom];
   __shared__ double s_total[ntab * kMom];
@@ -570,8 +570,14 @@ __global__ void __launch_bounds__(64) k_roots(RootsArgs A, const K *__restrict__
         } else {
           key = ob - P.t_lo_bits;
         }
-        A.slot_keys[slot] = key;
-        if (A.slot_counts) atomicAdd(&A.slot_counts[min((uint32_t)(key >> A.slot_shift), (uint32_t)(kBuckets - 1))], 1u);
+        if (A.slot_counts) {  // fast slot order: drop the surfel into its time bucket right here (k_slot_emit sorts each bucket)
+          if (key >> 32) atomicOr(&A.status[1], kFlagTimeRange);
+          const uint32_t bkt = min((uint32_t)(key >> A.slot_shift), (uint32_t)(kBuckets - 1));
+          const uint32_t r = atomicAdd(&A.slot_counts[bkt], 1u);
+          if (r < A.slot_bin_cap) A.slot_bins[(size_t)bkt * A.slot_bin_cap + r] = (key << 32) | (uint64_t)(uint32_t)slot;
+        } else {
+          A.slot_keys[slot] = key;
+        }
         ok = true;
       }
       emitted += (uint32_t)__popcll(__ballot(ok));
@@ -619,15 +625,72 @@ __global__ void __launch_bounds__(256) k_gather(const uint32_t *__restrict__ sor
   }
 }
 
-// ---- bucket sort of 64-bit composites (group-by with a fixed order inside the group) -----------------------------------
-// Both sorts of the extraction only need "equal keys contiguous, ascending index inside a key".  Packing (key, index)
-// into one 64-bit composite makes ANY sort of the composites stable by construction, so the global pass can be an
-// unordered MSD scatter into 4096 buckets (per-tile LDS histograms, one global atomic per non-empty (tile, bucket)) and
-// each bucket is finished by a bitonic sort in LDS (4096 small buckets: bitonic cost grows as n log^2 n).  For the points
-// the bucket digit is built from the LOW bits of the voxel index (x&15, y&15, z&15): neighbouring voxels land in different buckets, so planar scenes do not overload one
-// bucket; the order of the voxels among each other is irrelevant (only grouping matters).  3 launches instead of
-// rocPRIM's ~20 (merge path) for 1 M pairs.  A bucket larger than kBucketCap raises a flag and the caller falls back
-// to the rocPRIM radix sort.
+// Fast slot order + gather in one launch.  The emission dropped every surfel into one of 4096 time buckets (a count and a
+// fixed-capacity bin per bucket), so what is left is: the exclusive prefix of the counts (every workgroup sums the counts
+// in front of its four buckets: 16 KB out of L2, cheaper than a separate scan launch), the order inside a bucket (rank by
+// counting, one wavefront per bucket, a handful of surfels each) and the 160-byte copy slot -> output, 16 B per lane.
+constexpr int kSlotBinMax = 512;
+__global__ void __launch_bounds__(256) k_slot_emit(const uint32_t *__restrict__ counts, const uint64_t *__restrict__ bins, uint32_t bin_cap,
+                                                  const wc_surfel *__restrict__ slots, const wc_surfel_id *__restrict__ slot_ids,
+                                                  uint32_t *status, wc_surfel *out, wc_surfel_id *out_ids, uint64_t cap) {
+  __shared__ uint64_t s_item[4][kSlotBinMax];
+  __shared__ uint32_t s_sorted[4][kSlotBinMax];
+  __shared__ uint32_t s_red[4];
+  if (status[1] & (kFlagBucketOverflow | kFlagKeyRange)) return;
+  const int t = threadIdx.x, w = t >> 6, lane = t & 63;
+  const uint32_t b0 = blockIdx.x * 4u;
+  uint32_t part = 0;
+  for (uint32_t i = t; i < b0; i += 256) part += counts[i];
+  for (int off = 32; off >= 1; off >>= 1) part += __shfl_xor(part, off);
+  if (lane == 0) s_red[w] = part;
+  __syncthreads();
+  uint32_t base = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+  const uint32_t c0 = counts[b0], c1 = counts[b0 + 1], c2 = counts[b0 + 2], c3 = counts[b0 + 3];
+  if (blockIdx.x == gridDim.x - 1 && t == 0) status[0] = base + c0 + c1 + c2 + c3;  // surfels emitted
+  base += (w > 0 ? c0 : 0u) + (w > 1 ? c1 : 0u) + (w > 2 ? c2 : 0u);
+  const uint32_t c = w == 0 ? c0 : (w == 1 ? c1 : (w == 2 ? c2 : c3));
+  if (c == 0) return;
+  if (c > bin_cap) {
+    if (lane == 0) atomicOr(&status[1], kFlagBucketOverflow);
+    return;
+  }
+  const uint64_t *bin = bins + (size_t)(b0 + w) * bin_cap;
+  for (uint32_t i = lane; i < c; i += 64) s_item[w][i] = bin[i];
+  __builtin_amdgcn_wave_barrier();
+  for (uint32_t i = lane; i < c; i += 64) {
+    const uint64_t mine = s_item[w][i];
+    uint32_t rank = 0;
+    for (uint32_t j = 0; j < c; ++j) rank += (s_item[w][j] < mine) ? 1u : 0u;  // composites are unique (slot index)
+    s_sorted[w][rank] = (uint32_t)mine;
+  }
+  __builtin_amdgcn_wave_barrier();
+  const int sub = lane / 10, piece = lane - sub * 10;  // six records per pass, ten 16-byte pieces per record
+  if (sub >= 6) return;
+  for (uint32_t r = sub; r < c; r += 6) {
+    const uint64_t o = (uint64_t)base + r;
+    if (o >= cap) break;
+    const uint32_t sl = s_sorted[w][r];
+    if (piece < 9)
+      ((double2 *)(out + o))[piece] = ((const double2 *)(slots + sl))[piece];
+    else if (out_ids)
+      *(uint4 *)(out_ids + o) = *(const uint4 *)(slot_ids + sl);
+  }
+}
+
+// ---- run-binned bucket sort of the points ---------------------------------------------------------------------------
+// The extraction only needs "points of one voxel contiguous, in time order".  A sweep is time ordered and a scan line
+// stays inside one 0.8 m voxel for many consecutive points, so the unit that is sorted is the RUN (maximal stretch of
+// consecutive points with one voxel key, cut at tile boundaries), not the point:
+//   k_pt_runs    the only pass over the AoS input: voxel keys of a tile, run heads, one (key rest | start index)
+//                composite per run dropped into the bin of its bucket (4096 buckets of fixed capacity, the slot claimed
+//                with one global atomic per non-empty (tile, bucket)), the run length stored next to the start index
+//   k_pt_bucket  one wavefront per bucket: exclusive prefix of the bucket point counts (summed in place, no scan launch),
+//                rank-by-counting of the bucket's runs, prefix of the run lengths, expansion into the per-point
+//                (key, index) arrays k_roots consumes, and the head slot table of the live root voxels
+// The bucket digit is built from the LOW bits of the voxel index (x&15, y&15, z&15): neighbouring voxels land in
+// different buckets, so planar scenes do not overload one bucket; the order of the voxels among each other is
+// irrelevant (only grouping matters).  2 launches instead of rocPRIM's ~20 (merge path) for 1 M pairs.  A bucket with
+// more runs than the bin capacity raises kFlagBucketOverflow and the caller falls back to the rocPRIM radix sort.
 
 __device__ __forceinline__ uint32_t key_digit(uint32_t key) {
   const uint32_t x = key & 1023u, y = (key >> 10) & 1023u, z = key >> 20;
@@ -643,134 +706,10 @@ __device__ __forceinline__ uint32_t key_join(uint32_t d, uint32_t r) {
   return x | (y << 10) | (z << 20);
 }
 
-struct PointSrc {  // composite = rest(voxel key) << 32 | point index
-  wc_points pts;
-  double vs;
-  __device__ __forceinline__ bool get(uint64_t i, uint32_t &digit, uint64_t &comp, uint32_t *status) const {
-    double x0, y0, z0, x, y, z;
-    load_xyz(pts, 0, x0, y0, z0);
-    load_xyz(pts, i, x, y, z);
-    int rx = vox(x, vs) - vox(x0, vs) + 512, ry = vox(y, vs) - vox(y0, vs) + 512, rz = vox(z, vs) - vox(z0, vs) + 512;
-    if ((unsigned)rx >= 1024u || (unsigned)ry >= 1024u || (unsigned)rz >= 1024u) {
-      atomicOr(&status[1], kFlagKeyRange);
-      rx = min(max(rx, 0), 1023), ry = min(max(ry, 0), 1023), rz = min(max(rz, 0), 1023);
-    }
-    const uint32_t key = (uint32_t)rx | ((uint32_t)ry << 10) | ((uint32_t)rz << 20);
-    digit = key_digit(key);
-    comp = ((uint64_t)key_rest(key) << 32) | (uint64_t)(uint32_t)i;
-    return true;
-  }
-};
-struct SlotSrc {  // composite = time key << 32 | slot index; empty slots (key = ~0) are dropped => compaction for free
-  const uint64_t *keys;
-  uint32_t shift;
-  __device__ __forceinline__ bool get(uint64_t i, uint32_t &digit, uint64_t &comp, uint32_t *status) const {
-    const uint64_t k = keys[i];
-    if (k == ~0ull) return false;
-    if (k >> 32) atomicOr(&status[1], kFlagTimeRange);
-    digit = min((uint32_t)(k >> shift), (uint32_t)(kBuckets - 1));
-    comp = (k << 32) | (uint64_t)(uint32_t)i;
-    return true;
-  }
-};
-
-template <typename Src>
-__global__ void __launch_bounds__(256) k_bucket_hist(Src src, uint64_t n, uint32_t *counts, uint32_t *status) {
-  __shared__ uint32_t s_h[kBuckets];
-  for (int b = threadIdx.x; b < kBuckets; b += 256) s_h[b] = 0;
-  __syncthreads();
-  const uint64_t t0 = (uint64_t)blockIdx.x * kTile;
-  for (int j = 0; j < kTile / 256; ++j) {
-    const uint64_t i = t0 + (uint64_t)j * 256 + threadIdx.x;
-    uint32_t d;
-    uint64_t c;
-    if (i < n && src.get(i, d, c, status)) atomicAdd(&s_h[d], 1u);
-  }
-  __syncthreads();
-  for (int b = threadIdx.x; b < kBuckets; b += 256)
-    if (s_h[b]) atomicAdd(&counts[b], s_h[b]);
-}
-
-template <typename Src>
-__global__ void __launch_bounds__(256) k_bucket_scatter(Src src, uint64_t n, const uint32_t *counts, uint32_t *cursor, uint64_t *comp_out,
-                                                       uint32_t *status) {
-  __shared__ uint32_t s_cnt[kBuckets];
-  const uint32_t *s_base = counts + 2 * kBuckets;  // written by k_bucket_prefix
-  for (int b = threadIdx.x; b < kBuckets; b += 256) s_cnt[b] = 0;
-  __syncthreads();
-  const uint64_t t0 = (uint64_t)blockIdx.x * kTile;
-  uint32_t dig[kTile / 256], rank[kTile / 256];
-  uint64_t comp[kTile / 256];
-#pragma unroll
-  for (int j = 0; j < kTile / 256; ++j) {
-    const uint64_t i = t0 + (uint64_t)j * 256 + threadIdx.x;
-    dig[j] = 0xFFFFFFFFu;
-    if (i < n && src.get(i, dig[j], comp[j], status))
-      rank[j] = atomicAdd(&s_cnt[dig[j]], 1u);
-    else
-      dig[j] = 0xFFFFFFFFu;
-  }
-  __syncthreads();
-  for (int b = threadIdx.x; b < kBuckets; b += 256) {
-    const uint32_t c = s_cnt[b];
-    s_cnt[b] = c ? atomicAdd(&cursor[b], c) : 0u;  // this tile's range inside bucket b
-  }
-  __syncthreads();
-#pragma unroll
-  for (int j = 0; j < kTile / 256; ++j)
-    if (dig[j] != 0xFFFFFFFFu) comp_out[(size_t)s_base[dig[j]] + s_cnt[dig[j]] + rank[j]] = comp[j];
-}
-
-// one workgroup per bucket: bitonic sort of the composites in LDS, then the (key, index) pair arrays the rest of the
-// pipeline consumes.  POINTS: key = voxel key rebuilt from (bucket digit, rest); otherwise only the index is written.
-template <bool POINTS>
-__global__ void __launch_bounds__(256) k_bucket_sort(const uint64_t *comp, const uint32_t *counts, uint32_t *keys_out, uint32_t *idx_out,
-                                                    uint32_t *status) {
-  __shared__ uint64_t s[kBucketCap];
-  const int b = blockIdx.x, t = threadIdx.x;
-  const uint32_t base = counts[2 * kBuckets + b], nb = counts[b];
-  if (nb == 0) return;
-  if (nb > (uint32_t)kBucketCap) {
-    if (t == 0) atomicOr(&status[1], kFlagBucketOverflow);
-    return;
-  }
-  uint32_t N = 64;
-  while (N < nb) N <<= 1;
-  for (uint32_t i = t; i < N; i += 256) s[i] = (i < nb) ? comp[(size_t)base + i] : ~0ull;
-  __syncthreads();
-  for (uint32_t k = 2; k <= N; k <<= 1)
-    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-      for (uint32_t p = t; p < N / 2; p += 256) {
-        const uint32_t i = 2 * p - (p & (j - 1));  // lower element of the pair (bit j clear)
-        const uint32_t l = i + j;
-        const uint64_t a = s[i], c = s[l];
-        const bool asc = (i & k) == 0;
-        if ((a > c) == asc) {
-          s[i] = c;
-          s[l] = a;
-        }
-      }
-      __syncthreads();
-    }
-  for (uint32_t i = t; i < nb; i += 256) {
-    const uint64_t c = s[i];
-    idx_out[(size_t)base + i] = (uint32_t)c;
-    if (POINTS) keys_out[(size_t)base + i] = key_join((uint32_t)b, (uint32_t)(c >> 32));
-  }
-}
-
-// ---- run-compressed bucket sort of the points -----------------------------------------------------------------------
-// A sweep is time ordered and a scan line stays inside one 0.8 m voxel for many consecutive points, so the unit that
-// is sorted is the RUN (maximal stretch of consecutive points with one voxel key, cut at tile boundaries), not the
-// point: k_pt_hist writes the per-point keys once (the only pass over the 48-byte AoS input), counts runs and points
-// per bucket; k_pt_scatter drops (key rest | start index) composites of the run heads into their buckets and the run
-// length next to the start index; k_pt_bucket sorts a bucket's runs and EXPANDS them into the per-point (key, index)
-// arrays k_heads / k_roots consume.  Points of one voxel end up contiguous and in time order (runs sorted by start).
-__device__ __forceinline__ uint32_t point_key(const wc_points &pts, double vs, uint64_t i, uint32_t *status) {
-  double x0, y0, z0, x, y, z;
-  load_xyz(pts, 0, x0, y0, z0);
+__device__ __forceinline__ uint32_t point_key(const wc_points &pts, double vs, uint64_t i, int k0x, int k0y, int k0z, uint32_t *status) {
+  double x, y, z;
   load_xyz(pts, i, x, y, z);
-  int rx = vox(x, vs) - vox(x0, vs) + 512, ry = vox(y, vs) - vox(y0, vs) + 512, rz = vox(z, vs) - vox(z0, vs) + 512;
+  int rx = vox(x, vs) - k0x + 512, ry = vox(y, vs) - k0y + 512, rz = vox(z, vs) - k0z + 512;
   if ((unsigned)rx >= 1024u || (unsigned)ry >= 1024u || (unsigned)rz >= 1024u) {
     atomicOr(&status[1], kFlagKeyRange);
     rx = min(max(rx, 0), 1023), ry = min(max(ry, 0), 1023), rz = min(max(rz, 0), 1023);
@@ -788,35 +727,6 @@ __device__ __forceinline__ uint32_t run_length(const unsigned long long *s_bits,
   return min(nxt, cnt) - i;
 }
 
-// exclusive prefixes of the per-bucket run and point counts (one small workgroup; every later workgroup just reads them)
-__global__ void __launch_bounds__(1024) k_bucket_prefix(const uint32_t *counts, uint32_t *bases, int narrays, uint32_t *total0) {
-  __shared__ uint32_t s_tmp[1024];
-  constexpr int PER = kBuckets / 1024;
-  const int t = threadIdx.x;
-  for (int a = 0; a < narrays; ++a) {
-    uint32_t c[PER], sum = 0;
-    for (int q = 0; q < PER; ++q) {
-      c[q] = counts[a * kBuckets + PER * t + q];
-      sum += c[q];
-    }
-    s_tmp[t] = sum;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-      const uint32_t v = (t >= off) ? s_tmp[t - off] : 0u;
-      __syncthreads();
-      s_tmp[t] += v;
-      __syncthreads();
-    }
-    uint32_t run = s_tmp[t] - sum;
-    if (a == 0 && total0 && t == 1023) *total0 = s_tmp[t];  // item count of the first array
-    for (int q = 0; q < PER; ++q) {
-      bases[a * kBuckets + PER * t + q] = run;
-      run += c[q];
-    }
-    __syncthreads();
-  }
-}
-
 // every per-call fill (status words, slot keys, bucket counters, head table) in ONE launch: each hipMemsetAsync is its
 // own ~2-7 us kernel, and an extraction call needs five of them
 struct InitArgs {
@@ -831,59 +741,50 @@ __global__ void __launch_bounds__(256) k_init(InitArgs I) {
     if (i < I.nw[r]) I.p[r][i] = I.val[r];
 }
 
-template <bool SCATTER>
-__global__ void __launch_bounds__(256) k_pt_runs(wc_points pts, double vs, uint64_t n, uint32_t *keys_raw, uint32_t *counts /*runs|pts*/,
-                                                uint32_t *cursor, uint64_t *comp_out, uint16_t *run_len, uint32_t *status) {
+// counts = run counts [kBuckets] | point counts [kBuckets]
+__global__ void __launch_bounds__(256) k_pt_runs(wc_points pts, double vs, uint64_t n, uint32_t *counts, uint64_t *bins, uint32_t bin_cap,
+                                                uint16_t *run_len, uint32_t *status) {
   __shared__ uint32_t s_key[kTile];
   __shared__ unsigned long long s_bits[kTile / 64];
   __shared__ uint32_t s_runs[kBuckets];
-  __shared__ uint32_t s_pts[SCATTER ? 1 : kBuckets];
+  __shared__ uint32_t s_pts[kBuckets];
   const int t = threadIdx.x;
   const uint64_t t0 = (uint64_t)blockIdx.x * kTile;
   const uint32_t cnt = (uint32_t)min((uint64_t)kTile, n - t0);
-  const uint32_t *bases = counts + 3 * kBuckets;  // written by k_bucket_prefix
   for (int b = t; b < kBuckets; b += 256) {
     s_runs[b] = 0;
-    if (!SCATTER) s_pts[b] = 0;
+    s_pts[b] = 0;
   }
   if (t < kTile / 64) s_bits[t] = 0ull;
-  for (uint32_t i = t; i < cnt; i += 256) {
-    uint32_t k;
-    if (SCATTER) {
-      k = keys_raw[t0 + i];
-    } else {
-      k = point_key(pts, vs, t0 + i, status);
-      keys_raw[t0 + i] = k;
-    }
-    s_key[i] = k;
-  }
+  double x0, y0, z0;
+  load_xyz(pts, 0, x0, y0, z0);
+  const int k0x = vox(x0, vs), k0y = vox(y0, vs), k0z = vox(z0, vs);
+  for (uint32_t i = t; i < cnt; i += 256) s_key[i] = point_key(pts, vs, t0 + i, k0x, k0y, k0z, status);
   __syncthreads();
   for (uint32_t i = t; i < cnt; i += 256)
     if (i == 0 || s_key[i] != s_key[i - 1]) atomicOr(&s_bits[i >> 6], 1ull << (i & 63));
   __syncthreads();
   uint32_t rank[kTile / 256];
+  uint16_t len[kTile / 256];
 #pragma unroll
   for (int j = 0; j < kTile / 256; ++j) {
     const uint32_t i = (uint32_t)j * 256 + t;
     rank[j] = 0xFFFFFFFFu;
     if (i < cnt && ((s_bits[i >> 6] >> (i & 63)) & 1ull)) {
       const uint32_t d = key_digit(s_key[i]);
+      const uint32_t l = run_length(s_bits, i, cnt);
+      len[j] = (uint16_t)l;
       rank[j] = atomicAdd(&s_runs[d], 1u);
-      if (!SCATTER) atomicAdd(&s_pts[d], run_length(s_bits, i, cnt));
+      atomicAdd(&s_pts[d], l);
     }
   }
   __syncthreads();
-  if (!SCATTER) {
-    for (int b = t; b < kBuckets; b += 256)
-      if (s_runs[b]) {
-        atomicAdd(&counts[b], s_runs[b]);
-        atomicAdd(&counts[kBuckets + b], s_pts[b]);
-      }
-    return;
-  }
   for (int b = t; b < kBuckets; b += 256) {
     const uint32_t c = s_runs[b];
-    s_runs[b] = c ? atomicAdd(&cursor[b], c) : 0u;
+    if (c) {
+      s_runs[b] = atomicAdd(&counts[b], c);  // this tile's range inside the bin of bucket b
+      atomicAdd(&counts[kBuckets + b], s_pts[b]);
+    }
   }
   __syncthreads();
 #pragma unroll
@@ -891,96 +792,120 @@ __global__ void __launch_bounds__(256) k_pt_runs(wc_points pts, double vs, uint6
     if (rank[j] == 0xFFFFFFFFu) continue;
     const uint32_t i = (uint32_t)j * 256 + t;
     const uint32_t k = s_key[i], d = key_digit(k);
-    comp_out[(size_t)bases[d] + s_runs[d] + rank[j]] = ((uint64_t)key_rest(k) << 32) | (uint64_t)(uint32_t)(t0 + i);
-    run_len[t0 + i] = (uint16_t)run_length(s_bits, i, cnt);
+    const uint32_t pos = s_runs[d] + rank[j];
+    if (pos < bin_cap) bins[(size_t)d * bin_cap + pos] = ((uint64_t)key_rest(k) << 32) | (uint64_t)(uint32_t)(t0 + i);
+    run_len[t0 + i] = len[j];
   }
 }
 
-// one workgroup per bucket: sort the bucket's runs (bitonic on the composites), then expand them to per-point output
-__global__ void __launch_bounds__(256) k_pt_bucket(const uint64_t *comp, const uint32_t *counts, const uint16_t *run_len, uint32_t *keys_out,
-                                                  uint32_t *idx_out, uint32_t *status) {
-  __shared__ uint64_t s[kBucketCap];
-  __shared__ uint32_t s_off[kBucketCap];
-  const int b = blockIdx.x, t = threadIdx.x;
-  const uint32_t rbase = counts[3 * kBuckets + b], pbase = counts[4 * kBuckets + b], nb = counts[b];
+// one wavefront per bucket (four per workgroup).  Dynamic LDS per wavefront: bin_cap x {unsorted composite, sorted
+// composite, output offset}.
+__global__ void __launch_bounds__(256) k_pt_bucket(const uint64_t *__restrict__ bins, uint32_t bin_cap, const uint32_t *__restrict__ counts,
+                                                  const uint16_t *__restrict__ run_len, uint32_t *keys_out, uint32_t *idx_out,
+                                                  uint32_t *head_slots, int min_points, uint32_t *status) {
+  extern __shared__ __align__(16) unsigned char s_dyn[];
+  __shared__ uint32_t s_red[4];
+  const int t = threadIdx.x, w = t >> 6, lane = t & 63;
+  uint64_t *s_a = (uint64_t *)s_dyn + (size_t)w * bin_cap;
+  uint64_t *s_b = (uint64_t *)s_dyn + (size_t)(4 + w) * bin_cap;
+  uint32_t *s_off = (uint32_t *)((uint64_t *)s_dyn + (size_t)8 * bin_cap) + (size_t)w * bin_cap;
+  const uint32_t b0 = blockIdx.x * 4u;
+  const uint32_t *pcounts = counts + kBuckets;
+  uint32_t part = 0;
+  for (uint32_t i = t; i < b0; i += 256) part += pcounts[i];
+  for (int off = 32; off >= 1; off >>= 1) part += __shfl_xor(part, off);
+  if (lane == 0) s_red[w] = part;
+  __syncthreads();
+  uint32_t pbase = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+  for (int j = 0; j < w; ++j) pbase += pcounts[b0 + j];
+  const uint32_t b = b0 + w, nb = counts[b], total = pcounts[b];
   if (nb == 0) return;
-  if (nb > (uint32_t)kBucketCap) {
-    if (t == 0) atomicOr(&status[1], kFlagBucketOverflow);
+  if (nb > bin_cap) {
+    if (lane == 0) atomicOr(&status[1], kFlagBucketOverflow);
     return;
   }
-  uint32_t N = 64;
-  while (N < nb) N <<= 1;
-  for (uint32_t i = t; i < N; i += 256) s[i] = (i < nb) ? comp[(size_t)rbase + i] : ~0ull;
-  __syncthreads();
-  for (uint32_t k = 2; k <= N; k <<= 1)
-    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-      for (uint32_t p = t; p < N / 2; p += 256) {
-        const uint32_t i = 2 * p - (p & (j - 1));
-        const uint32_t l = i + j;
-        const uint64_t a = s[i], c = s[l];
-        if ((a > c) == ((i & k) == 0)) {
-          s[i] = c;
-          s[l] = a;
-        }
-      }
-      __syncthreads();
+  const uint64_t *bin = bins + (size_t)b * bin_cap;
+  for (uint32_t i = lane; i < nb; i += 64) s_a[i] = bin[i];
+  __builtin_amdgcn_wave_barrier();
+  for (uint32_t i = lane; i < nb; i += 64) {  // rank by counting: composites are unique (start index)
+    const uint64_t mine = s_a[i];
+    uint32_t rank = 0;
+    for (uint32_t j = 0; j < nb; ++j) rank += (s_a[j] < mine) ? 1u : 0u;
+    s_b[rank] = mine;
+  }
+  __builtin_amdgcn_wave_barrier();
+  // exclusive prefix of the run lengths in sorted order -> offsets inside the bucket
+  uint32_t carry = 0;
+  for (uint32_t i0 = 0; i0 < nb; i0 += 64) {
+    const uint32_t i = i0 + lane;
+    const uint32_t l = (i < nb) ? (uint32_t)run_len[(uint32_t)s_b[i]] : 0u;
+    uint32_t inc = l;
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t v = __shfl_up(inc, off);
+      if (lane >= off) inc += v;
     }
-  // exclusive prefix of the run lengths (sorted order) -> output offsets
-  for (uint32_t i = t; i < N; i += 256) s_off[i] = (i < nb) ? (uint32_t)run_len[(uint32_t)s[i]] : 0u;
-  __syncthreads();
-  if (t == 0) {  // buckets hold a handful of runs on regular clouds; a serial scan of <= 4096 entries is the tail case
-    uint32_t run = 0;
-    for (uint32_t i = 0; i < nb; ++i) {
-      const uint32_t l = s_off[i];
-      s_off[i] = run;
-      run += l;
+    if (i < nb) s_off[i] = carry + inc - l;
+    carry += __shfl(inc, 63);
+  }
+  __builtin_amdgcn_wave_barrier();
+  // live root heads: a voxel segment with more than min_points points (InitOctoTree cc:129); two live heads are at least
+  // min_points + 1 positions apart, so slot = position / (min_points + 1) is collision free
+  for (uint32_t r = lane; r < nb; r += 64) {
+    const uint32_t rest = (uint32_t)(s_b[r] >> 32);
+    if (r > 0 && (uint32_t)(s_b[r - 1] >> 32) == rest) continue;
+    uint32_t r2 = r + 1;
+    while (r2 < nb && (uint32_t)(s_b[r2] >> 32) == rest) ++r2;
+    const uint32_t seg = (r2 < nb ? s_off[r2] : total) - s_off[r];
+    if (seg > (uint32_t)min_points) {
+      const uint32_t pos = pbase + s_off[r];
+      head_slots[pos / (uint32_t)(min_points + 1)] = pos;
     }
   }
-  __syncthreads();
-  const int lane = t & 63, wave = t >> 6;
-  for (uint32_t r = wave; r < nb; r += 4) {  // one wavefront per run: contiguous, coalesced expansion
-    const uint64_t c = s[r];
-    const uint32_t start = (uint32_t)c, len = run_len[start], key = key_join((uint32_t)b, (uint32_t)(c >> 32));
-    const size_t o = (size_t)pbase + s_off[r];
-    for (uint32_t j = lane; j < len; j += 64) {
-      keys_out[o + j] = key;
-      idx_out[o + j] = start + j;
+  // expansion, one lane per output point: binary search of the run that covers position j
+  for (uint32_t j = lane; j < total; j += 64) {
+    uint32_t lo = 0, hi = nb;  // last run with s_off <= j
+    while (hi - lo > 1) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (s_off[mid] <= j)
+        lo = mid;
+      else
+        hi = mid;
     }
+    const uint64_t c = s_b[lo];
+    keys_out[(size_t)pbase + j] = key_join(b, (uint32_t)(c >> 32));
+    idx_out[(size_t)pbase + j] = (uint32_t)c + (j - s_off[lo]);
   }
 }
 
-int point_sort_runs(wc_ctx *ctx, const wc_points &pts, double vs, uint32_t *keys_out, uint32_t *idx_out, uint32_t *status, bool counts_cleared) {
+constexpr uint32_t kPtBinMax = 1024;  // runs per bucket the in-LDS path takes (4 wavefronts x 20 B x 1024 = 80 KB of LDS)
+
+// bin capacity for n points: twice the mean a cloud without any run structure would produce, 64 at least
+inline uint32_t pt_bin_cap(uint64_t n) {
+  uint32_t cap = 64;
+  while (cap < kPtBinMax && (uint64_t)cap * kBuckets < 2 * n) cap *= 2;
+  return cap;
+}
+
+// counts (run counts | point counts) and the head slot table must be cleared by the caller
+int point_sort_runs(wc_ctx *ctx, const wc_points &pts, double vs, uint32_t *keys_out, uint32_t *idx_out, uint32_t *head_slots, int min_points,
+                    uint32_t *status) {
   hipStream_t st = ctx->stream;
   const uint64_t n = pts.n;
-  WC_TRY(wc_ensure(ctx, ctx->b_misc[1], n * 8));            // run composites (at most one per point)
-  WC_TRY(wc_ensure(ctx, ctx->b_misc[2], 5 * kBuckets * 4));  // run counts | point counts | cursors | run bases | point bases
-  WC_TRY(wc_ensure(ctx, ctx->b_misc[3], n * 2));            // run lengths, indexed by the run's first point
-  WC_TRY(wc_ensure(ctx, ctx->b_keys[0], n * 4));            // per-point keys
+  const uint32_t cap = pt_bin_cap(n);
+  WC_TRY(wc_ensure(ctx, ctx->b_misc[1], (uint64_t)kBuckets * cap * 8));  // run bins
+  WC_TRY(wc_ensure(ctx, ctx->b_misc[2], 2 * kBuckets * 4));             // run counts | point counts
+  WC_TRY(wc_ensure(ctx, ctx->b_misc[3], n * 2));                         // run lengths, indexed by the run's first point
   uint32_t *counts = (uint32_t *)ctx->b_misc[2].p;
-  if (!counts_cleared) WC_HIP(ctx, hipMemsetAsync(counts, 0, 3 * kBuckets * 4, st));
   const unsigned tiles = (unsigned)((n + kTile - 1) / kTile);
-  k_pt_runs<false><<<tiles, 256, 0, st>>>(pts, vs, n, (uint32_t *)ctx->b_keys[0].p, counts, nullptr, nullptr, nullptr, status);
-  k_bucket_prefix<<<1, 1024, 0, st>>>(counts, counts + 3 * kBuckets, 2, nullptr);
-  k_pt_runs<true><<<tiles, 256, 0, st>>>(pts, vs, n, (uint32_t *)ctx->b_keys[0].p, counts, counts + 2 * kBuckets,
-                                        (uint64_t *)ctx->b_misc[1].p, (uint16_t *)ctx->b_misc[3].p, status);
-  k_pt_bucket<<<kBuckets, 256, 0, st>>>((const uint64_t *)ctx->b_misc[1].p, counts, (const uint16_t *)ctx->b_misc[3].p, keys_out, idx_out,
-                                       status);
-  WC_HIP(ctx, hipGetLastError());
-  return WC_OK;
-}
-
-template <typename Src, bool POINTS>
-int bucket_sort(wc_ctx *ctx, const Src &src, uint64_t n, uint64_t *comp_buf, uint32_t *keys_out, uint32_t *idx_out, uint32_t *counts,
-                uint32_t *status, bool have_hist, uint32_t *total_out = nullptr) {
-  hipStream_t st = ctx->stream;
-  const unsigned tiles = (unsigned)((n + kTile - 1) / kTile);
-  if (!have_hist) {
-    WC_HIP(ctx, hipMemsetAsync(counts, 0, 2 * kBuckets * 4, st));  // counts + cursors
-    k_bucket_hist<Src><<<tiles, 256, 0, st>>>(src, n, counts, status);
+  const size_t lds = (size_t)4 * cap * 20;
+  static bool attr_set = false;
+  if (!attr_set) {
+    WC_HIP(ctx, hipFuncSetAttribute((const void *)k_pt_bucket, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * kPtBinMax * 20)));
+    attr_set = true;
   }
-  k_bucket_prefix<<<1, 1024, 0, st>>>(counts, counts + 2 * kBuckets, 1, total_out);
-  k_bucket_scatter<Src><<<tiles, 256, 0, st>>>(src, n, counts, counts + kBuckets, comp_buf, status);
-  k_bucket_sort<POINTS><<<kBuckets, 256, 0, st>>>(comp_buf, counts, keys_out, idx_out, status);
+  k_pt_runs<<<tiles, 256, 0, st>>>(pts, vs, n, counts, (uint64_t *)ctx->b_misc[1].p, cap, (uint16_t *)ctx->b_misc[3].p, status);
+  k_pt_bucket<<<kBuckets / 4, 256, lds, st>>>((const uint64_t *)ctx->b_misc[1].p, cap, counts, (const uint16_t *)ctx->b_misc[3].p, keys_out,
+                                             idx_out, head_slots, min_points, status);
   WC_HIP(ctx, hipGetLastError());
   return WC_OK;
 }
@@ -1043,13 +968,16 @@ int run_pipeline(wc_ctx *ctx, const wc_points &pts, double t_lo, double t_hi, wc
   };
   mark(0);
   const bool fast_slots = fast && tbits <= 31 && total_slots < (1ull << 31);
+  // capacity of a time bucket's bin: twice the count every bucket would get if EVERY slot held a surfel, 64 at least
+  uint32_t bin_cap = 64;
+  while (bin_cap < kSlotBinMax && (uint64_t)bin_cap * kBuckets < 2 * total_slots) bin_cap *= 2;
   if (fast_slots) WC_TRY(wc_ensure(ctx, ctx->b_misc[4], 3 * kBuckets * 4));
   const unsigned g256 = (unsigned)((n + 255) / 256);
   // fast path (32-bit keys): bucket sort of (voxel key, index) composites; general path: rocPRIM radix sort
   const bool fast_pts = fast && sizeof(K) == 4;
   if (fast_pts || fast_slots) {
-    WC_TRY(wc_ensure(ctx, ctx->b_misc[1], std::max<uint64_t>(n, total_slots) * 8));
-    WC_TRY(wc_ensure(ctx, ctx->b_misc[2], 5 * kBuckets * 4));
+    WC_TRY(wc_ensure(ctx, ctx->b_misc[1], (uint64_t)kBuckets * std::max(bin_cap, pt_bin_cap(n)) * 8));  // run bins, later slot bins
+    WC_TRY(wc_ensure(ctx, ctx->b_misc[2], 2 * kBuckets * 4));
   }
   const uint32_t nslots = (uint32_t)(n / (uint64_t)(P.min_points + 1) + 1);
   {
@@ -1057,17 +985,18 @@ int run_pipeline(wc_ctx *ctx, const wc_points &pts, double t_lo, double t_hi, wc
     int r = 0;
     auto fill = [&](void *p, uint64_t words, uint32_t v) { I.p[r] = (uint32_t *)p, I.nw[r] = (uint32_t)words, I.val[r] = v, ++r; };
     fill(status, 64, 0u);
-    fill(ctx->b_slot_keys[0].p, total_slots * 2, 0xFFFFFFFFu);                  // slot keys: ~0 = no surfel in the slot
+    if (!fast_slots) fill(ctx->b_slot_keys[0].p, total_slots * 2, 0xFFFFFFFFu);  // slot keys: ~0 = no surfel in the slot
     fill(ctx->b_misc[0].p, nslots, 0xFFFFFFFFu);                                // head slot table: ~0 = no live head
     if (fast_slots) fill(ctx->b_misc[4].p, 2 * kBuckets, 0u);                   // slot bucket counts (filled by k_roots) + cursors
-    if (fast_pts) fill(ctx->b_misc[2].p, 3 * kBuckets, 0u);                     // point-sort run counts | point counts | cursors
+    if (fast_pts) fill(ctx->b_misc[2].p, 2 * kBuckets, 0u);                     // point-sort run counts | point counts
     uint32_t mx = 0;
     for (int q = 0; q < r; ++q) mx = std::max(mx, I.nw[q]);
     k_init<<<(mx + 255) / 256, 256, 0, st>>>(I);
   }
   if (fast_pts) {
     mark(1);
-    WC_TRY(point_sort_runs(ctx, pts, E.vs, (uint32_t *)ctx->b_keys[1].p, (uint32_t *)ctx->b_vals[1].p, status, true));
+    WC_TRY(point_sort_runs(ctx, pts, E.vs, (uint32_t *)ctx->b_keys[1].p, (uint32_t *)ctx->b_vals[1].p, (uint32_t *)ctx->b_misc[0].p,
+                           P.min_points, status));  // also fills the head slot table
   } else {
     k_keygen<K><<<g256, 256, 0, st>>>(pts, E.vs, (K *)ctx->b_keys[0].p, (uint32_t *)ctx->b_vals[0].p, status);
     mark(1);
@@ -1089,9 +1018,11 @@ int run_pipeline(wc_ctx *ctx, const wc_points &pts, double t_lo, double t_hi, wc
   A.status = status;
   A.slot_counts = fast_slots ? (uint32_t *)ctx->b_misc[4].p : nullptr;
   A.slot_shift = tbits > 12 ? tbits - 12 : 0u;
+  A.slot_bins = (uint64_t *)ctx->b_misc[1].p;  // free again once the point sort is done
+  A.slot_bin_cap = bin_cap;
   A.heads = (const uint32_t *)ctx->b_misc[0].p;
   A.nslots = nslots;
-  k_heads<K><<<g256, 256, 0, st>>>((const K *)ctx->b_keys[1].p, n, P.min_points, (uint32_t *)ctx->b_misc[0].p);
+  if (!fast_pts) k_heads<K><<<g256, 256, 0, st>>>((const K *)ctx->b_keys[1].p, n, P.min_points, (uint32_t *)ctx->b_misc[0].p);
   WC_TRY(wc_ensure(ctx, ctx->b_misc[5], (size_t)A.nslots * sizeof(SplitJob)));
   A.split_jobs = (SplitJob *)ctx->b_misc[5].p;
   A.prof = nullptr;
@@ -1108,20 +1039,20 @@ int run_pipeline(wc_ctx *ctx, const wc_points &pts, double t_lo, double t_hi, wc
   k_roots<K, 2><<<kRoots2Grid, 64, 0, st>>>(A, (const K *)ctx->b_keys[1].p);  // layer 2 of the split nodes (rare)
   mark(3);
   if (fast_slots) {
-    SlotSrc ssrc{(const uint64_t *)ctx->b_slot_keys[0].p, tbits > 12 ? tbits - 12 : 0u};
-    WC_TRY((bucket_sort<SlotSrc, false>(ctx, ssrc, total_slots, (uint64_t *)ctx->b_misc[1].p, nullptr, (uint32_t *)ctx->b_slot_idx[1].p,
-                                        (uint32_t *)ctx->b_misc[4].p, status, true, status)));  // status[0] = surfel count = histogram total
+    k_slot_emit<<<kBuckets / 4, 256, 0, st>>>((const uint32_t *)ctx->b_misc[4].p, A.slot_bins, bin_cap, (const wc_surfel *)ctx->b_slots.p,
+                                             (const wc_surfel_id *)ctx->b_slot_ids.p, status, d_out, d_ids, cap);
+    mark(4);
   } else {
     k_iota<<<(unsigned)((total_slots + 255) / 256), 256, 0, st>>>((uint32_t *)ctx->b_slot_idx[0].p, total_slots);
     WC_TRY(sort_pairs<uint64_t>(ctx, (uint64_t *)ctx->b_slot_keys[0].p, (uint64_t *)ctx->b_slot_keys[1].p,
                                 (uint32_t *)ctx->b_slot_idx[0].p, (uint32_t *)ctx->b_slot_idx[1].p, total_slots,
                                 slot_end_bit));
+    mark(4);
+    const uint64_t gth = std::min<uint64_t>(total_slots, cap) * 10;
+    if (gth)
+      k_gather<<<(unsigned)((gth + 255) / 256), 256, 0, st>>>((const uint32_t *)ctx->b_slot_idx[1].p, (const wc_surfel *)ctx->b_slots.p,
+                                                             (const wc_surfel_id *)ctx->b_slot_ids.p, status, d_out, d_ids, cap);
   }
-  mark(4);
-  const uint64_t gth = std::min<uint64_t>(total_slots, cap) * 10;
-  if (gth)
-    k_gather<<<(unsigned)((gth + 255) / 256), 256, 0, st>>>((const uint32_t *)ctx->b_slot_idx[1].p, (const wc_surfel *)ctx->b_slots.p,
-                                                           (const wc_surfel_id *)ctx->b_slot_ids.p, status, d_out, d_ids, cap);
   mark(5);
   WC_HIP(ctx, hipMemcpyAsync(ctx->h_status, status, 8, hipMemcpyDeviceToHost, st));
   WC_HIP(ctx, hipGetLastError());
