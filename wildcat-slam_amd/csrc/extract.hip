@@ -32,6 +32,7 @@ namespace {
 
 constexpr int kMom = 11;    // n, St, Sx, Sy, Sz, Sxx, Sxy, Sxz, Syy, Syz, Szz
 constexpr unsigned kRootsGrid = 256 * 16;  // wavefronts of the layer-0/1 pass (static work split; <= 128 VGPRs => all resident)
+constexpr unsigned kEmitGrid = 256 * 8;   // wavefronts of the node-test + emission pass (three roots at a time each)
 constexpr unsigned kRoots2Grid = 256 * 4;  // wavefronts of the (rare) layer-2 pass
 constexpr int kBuckets = 4096;    // buckets of the composite sorts
 constexpr int kTile = 4096;       // items per workgroup in the histogram / scatter passes
@@ -176,6 +177,45 @@ struct RootsArgs {
   uint32_t *root_ncand;         // [head slot] candidates written by the layer-0/1 pass
 };
 
+// a candidate cluster that passed every gate becomes a surfel (ClusterSurfels' second loop, cc:54-64): normal towards the
+// view point, record + id into the candidate's slot, and the time key into the fast slot order (or the key array)
+__device__ __forceinline__ void emit_surfel(const RootsArgs &A, const Pca &rr, uint64_t slot, int layer, int nu, uint32_t ord, int kx, int ky,
+                                          int kz, float q0) {
+  const ExParams &P = A.P;
+  double nx = rr.nrm[0], ny = rr.nrm[1], nz = rr.nrm[2];
+  const double d = nx * (rr.c[0] - P.view[0]) + ny * (rr.c[1] - P.view[1]) + nz * (rr.c[2] - P.view[2]);
+  if (d < 0) nx = -nx, ny = -ny, nz = -nz;  // cc:59-61
+  const float ql = layer == 0 ? q0 : (layer == 1 ? q0 / 2 : (q0 / 2) / 2);
+  wc_surfel sf;
+  sf.t = rr.tmean;
+  sf.center[0] = rr.c[0], sf.center[1] = rr.c[1], sf.center[2] = rr.c[2];
+  for (int i = 0; i < 9; ++i) sf.cov[i] = rr.cov[i];
+  sf.normal[0] = nx, sf.normal[1] = ny, sf.normal[2] = nz;
+  sf.resolution = (double)(ql * 4);  // quarter_length_ * 4, float arithmetic (cc:307)
+  sf.sigma = sqrt(rr.ev[0]);
+  A.slots[slot] = sf;
+  uint32_t node = (uint32_t)layer;
+  if (layer == 1) node |= (uint32_t)(nu - 1) << 2;
+  if (layer == 2) node |= ((uint32_t)(nu >> 3) << 2) | ((uint32_t)(nu & 7) << 5);
+  A.slot_ids[slot] = wc_surfel_id{kx, ky, kz, node | (ord << 8)};
+  const uint64_t ob = ordered_bits(rr.tmean);
+  uint64_t key;
+  if (ob < P.t_lo_bits) {
+    atomicOr(&A.status[1], kFlagTimeRange);
+    key = 0;
+  } else {
+    key = ob - P.t_lo_bits;
+  }
+  if (A.slot_counts) {  // fast slot order: drop the surfel into its time bucket right here (k_slot_emit sorts each bucket)
+    if (key >> 32) atomicOr(&A.status[1], kFlagTimeRange);
+    const uint32_t bkt = min((uint32_t)(key >> A.slot_shift), (uint32_t)(kBuckets - 1));
+    const uint32_t r = atomicAdd(&A.slot_counts[bkt], 1u);
+    if (r < A.slot_bin_cap) A.slot_bins[(size_t)bkt * A.slot_bin_cap + r] = (key << 32) | (uint64_t)(uint32_t)slot;
+  } else {
+    A.slot_keys[slot] = key;
+  }
+}
+
 // Heads of the root-voxel segments that can emit anything (n > min_points, InitOctoTree cc:129).  Two live heads are at
 // least min_points + 1 positions apart, so slot = pos / (min_points + 1) is collision free: no atomics, no compaction
 // (a single append counter serialised at ~12 ns per live root: 46 us for 3.9 k roots).
@@ -213,8 +253,7 @@ struct SplitJob {  // a root whose layer-1 nodes need the layer-2 pass (k_roots<
 // at ~90 dequeues/us and cost more than it balanced.
 template <typename K, int PHASE>
 __global__ void __launch_bounds__(64) k_roots(RootsArgs A, const K *__restrict__ keys) {
-  constexpr int phase = (PHASE == 2) ? 2 : 1;       // octree pass: 1 = root + layer 1, 2 = layer 2
-  constexpr bool do_stream = (PHASE != 3);          // PHASE 1: stream only; PHASE 3: node tests + emission only
+  constexpr int phase = PHASE;  // octree pass: 1 = root + layer 1 (streaming only, k_roots_emit finishes it), 2 = layer 2 (fused)
   constexpr int ntab = (phase == 1) ? 9 : 64;
   __shared__ double s_open[ntab * kMom];
   __shared__ double s_total[ntab * kMom];
@@ -268,7 +307,6 @@ __global__ void __launch_bounds__(64) k_roots(RootsArgs A, const K *__restrict__
     unsigned long long split1 = 0;  // layer-1 octants that get split (tested, not a plane; cc:175-182)
     if (PHASE != 2) {
       head = __shfl(my_head, hb);
-      if (PHASE == 3) ncand = A.root_ncand[head / (uint64_t)(P.min_points + 1)];
     } else {
       const SplitJob job = A.split_jobs[it];
       head = job.head;
@@ -289,8 +327,8 @@ __global__ void __launch_bounds__(64) k_roots(RootsArgs A, const K *__restrict__
     const float q0 = P.vs_f / 4;  // quarter_length_ of the root (cc:207)
     const uint64_t slot_base = (head * (uint64_t)(P.max_layer + 1)) / (uint64_t)P.cluster_min;
 
-    const uint32_t cand_begin = (PHASE == 3) ? 0u : ncand;
-    if (do_stream) {
+    const uint32_t cand_begin = ncand;
+    {
     for (int i = lane; i < ntab * kMom; i += 64) {
       s_open[i] = 0.0;
       s_total[i] = 0.0;
@@ -476,7 +514,7 @@ __global__ void __launch_bounds__(64) k_roots(RootsArgs A, const K *__restrict__
       }
     }
     }
-    if (PHASE == 1) {  // hand the node totals and the candidate count to k_roots<K, 3> (tests + emission, full occupancy)
+    if (PHASE == 1) {  // hand the node totals and the candidate count to k_roots_emit (tests + emission)
       const uint64_t hs = head / (uint64_t)(P.min_points + 1);
       for (int i = lane; i < ntab * kMom; i += 64) A.node_tot[hs * (9 * kMom) + i] = s_total[i];
       if (lane == 0) A.root_ncand[hs] = ncand;
@@ -494,7 +532,6 @@ __global__ void __launch_bounds__(64) k_roots(RootsArgs A, const K *__restrict__
     //      above them the first candidates, so a root costs one eigen-solve latency instead of two ----
     const uint32_t ncap = (uint32_t)min((uint64_t)ncand, A.total_slots > slot_base ? A.total_slots - slot_base : 0);
     unsigned long long plane_mask = 0;
-    bool stop = false;
     for (uint32_t batch = 0;; ++batch) {
       // lane job: node test (first batch only) or candidate
       const bool node_lane = (batch == 0) && lane < ntab;
@@ -512,11 +549,9 @@ __global__ void __launch_bounds__(64) k_roots(RootsArgs A, const K *__restrict__
         bool exists = true;
         if (phase == 2) exists = (split1 >> (lane >> 3)) & 1ull;
         nu = lane;
-        const double *tot = (PHASE == 3) ? A.node_tot + (head / (uint64_t)(P.min_points + 1)) * (9 * kMom) + lane * kMom : nullptr;
-        const double cnt_n = (PHASE == 3) ? tot[0] : s_total[lane * kMom];
-        if (exists && cnt_n > (double)P.min_points) {
+        if (exists && s_total[lane * kMom] > (double)P.min_points) {
           have = true;
-          for (int i = 0; i < kMom; ++i) mom[i] = (PHASE == 3) ? tot[i] : s_total[lane * kMom + i];
+          for (int i = 0; i < kMom; ++i) mom[i] = s_total[lane * kMom + i];
         }
       } else if (cand_lane) {
         slot = slot_base + c;
@@ -534,58 +569,15 @@ __global__ void __launch_bounds__(64) k_roots(RootsArgs A, const K *__restrict__
       if (batch == 0) {
         const bool plane = node_lane && have && (rr.ev[0] < P.thr) && (rr.like > P.min_like);  // cc:106-111
         plane_mask = __ballot(plane);
-        if (phase == 1) {
-          const bool root_tested = __shfl((int)(node_lane && have), 0) != 0;
-          if (!root_tested) {
-            stop = true;  // n <= min_points: nothing below this root exists (cc:129)
-            break;
-          }
-          split1 = (P.max_layer >= 2) ? (__ballot(lane >= 1 && lane < 9 && have && !plane) >> 1) : 0ull;
-        }
       }
       bool ok = false;
       if (cand_lane && have && ((plane_mask >> nu) & 1ull) && !(rr.ev[0] > P.thr || rr.like < P.min_like)) {  // cc:54
-        double nx = rr.nrm[0], ny = rr.nrm[1], nz = rr.nrm[2];
-        const double d = nx * (rr.c[0] - P.view[0]) + ny * (rr.c[1] - P.view[1]) + nz * (rr.c[2] - P.view[2]);
-        if (d < 0) nx = -nx, ny = -ny, nz = -nz;  // cc:59-61
         const int layer = (phase == 2) ? 2 : (nu == 0 ? 0 : 1);
-        const float ql = layer == 0 ? q0 : (layer == 1 ? q0 / 2 : (q0 / 2) / 2);
-        wc_surfel sf;
-        sf.t = rr.tmean;
-        sf.center[0] = rr.c[0], sf.center[1] = rr.c[1], sf.center[2] = rr.c[2];
-        for (int i = 0; i < 9; ++i) sf.cov[i] = rr.cov[i];
-        sf.normal[0] = nx, sf.normal[1] = ny, sf.normal[2] = nz;
-        sf.resolution = (double)(ql * 4);  // quarter_length_ * 4, float arithmetic (cc:307)
-        sf.sigma = sqrt(rr.ev[0]);
-        A.slots[slot] = sf;
-        uint32_t node = (uint32_t)layer;
-        if (layer == 1) node |= (uint32_t)(nu - 1) << 2;
-        if (layer == 2) node |= ((uint32_t)(nu >> 3) << 2) | ((uint32_t)(nu & 7) << 5);
-        A.slot_ids[slot] = wc_surfel_id{kx, ky, kz, node | (ord << 8)};
-        const uint64_t ob = ordered_bits(rr.tmean);
-        uint64_t key;
-        if (ob < P.t_lo_bits) {
-          atomicOr(&A.status[1], kFlagTimeRange);
-          key = 0;
-        } else {
-          key = ob - P.t_lo_bits;
-        }
-        if (A.slot_counts) {  // fast slot order: drop the surfel into its time bucket right here (k_slot_emit sorts each bucket)
-          if (key >> 32) atomicOr(&A.status[1], kFlagTimeRange);
-          const uint32_t bkt = min((uint32_t)(key >> A.slot_shift), (uint32_t)(kBuckets - 1));
-          const uint32_t r = atomicAdd(&A.slot_counts[bkt], 1u);
-          if (r < A.slot_bin_cap) A.slot_bins[(size_t)bkt * A.slot_bin_cap + r] = (key << 32) | (uint64_t)(uint32_t)slot;
-        } else {
-          A.slot_keys[slot] = key;
-        }
+        emit_surfel(A, rr, slot, layer, nu, ord, kx, ky, kz, q0);
         ok = true;
       }
       emitted += (uint32_t)__popcll(__ballot(ok));
       WC_TICK(6);  // gates + surfel stores
-    }
-    if (PHASE == 3 && !stop && split1 != 0 && lane == 0) {  // layer-2 pass needed: queue the root for k_roots<K, 2>
-      const uint32_t q = atomicAdd(&A.status[4], 1u);
-      A.split_jobs[q] = SplitJob{(uint32_t)head, ncand, split1};
     }
     // the surfel count: with the slot histogram it is the histogram total (k_bucket_prefix); a per-root atomic on one
     // word serialises at ~12 ns per root once every wavefront reaches this point at the same time (47 us for 3.9 k roots)
@@ -596,6 +588,103 @@ __global__ void __launch_bounds__(64) k_roots(RootsArgs A, const K *__restrict__
 #endif
     __syncthreads();
    }
+  }
+}
+
+// Node tests + emission of the layer-0/1 pass, THREE roots per wavefront.  One root offers 9 node tests and a dozen or so
+// candidate clusters, i.e. ~20 of 64 lanes for an eigen-solve that costs ~13 k cycles of fp64 VALU issue: at one root per
+// wavefront the launch is VALU-issue bound on mostly idle lanes.  Lane = 21 * group + l; in the first batch l < 9 tests
+// node l (InitOctoTree / CutOctoTree gates, cc:129-138, :170-183) and l >= 9 takes candidate l - 9 (ClusterSurfels'
+// second loop, cc:32-64); later batches (rare) take 21 more candidates per group.
+template <typename K>
+__global__ void __launch_bounds__(64) k_roots_emit(RootsArgs A, const K *__restrict__ keys) {
+  constexpr int G = 21, NG = 3;
+  const int lane = threadIdx.x;
+  const ExParams &P = A.P;
+  constexpr int B = KeyTraits<K>::bits;
+  constexpr int half = 1 << (B - 1);
+  if (A.status[1] & (kFlagBucketOverflow | kFlagKeyRange)) return;
+  const int g = lane / G, l = lane - g * G;
+  double x0, y0, z0;
+  load_xyz(A.pts, 0, x0, y0, z0);
+  const int k0x = vox(x0, P.vs), k0y = vox(y0, P.vs), k0z = vox(z0, P.vs);
+  const float q0 = P.vs_f / 4;  // quarter_length_ of the root (cc:207)
+
+  const uint32_t per_wave = (A.nslots + gridDim.x - 1) / gridDim.x;
+  const uint32_t it_end = min((blockIdx.x + 1) * per_wave, A.nslots);
+  for (uint32_t it = blockIdx.x * per_wave; it < it_end; it += 64) {
+    const uint32_t my_head = (it + lane < it_end) ? A.heads[it + lane] : 0xFFFFFFFFu;
+    unsigned long long live_mask = __ballot(my_head != 0xFFFFFFFFu);
+    while (live_mask) {
+      int hb = -1;  // the live head this lane's group works on
+      for (int k = 0; k < NG; ++k) {
+        if (!live_mask) break;
+        const int bit = __ffsll((long long)live_mask) - 1;
+        live_mask &= live_mask - 1;
+        if (g == k) hb = bit;
+      }
+      const uint32_t head_or = __shfl(my_head, hb < 0 ? 0 : hb);
+      bool active = g < NG && hb >= 0;
+      const uint64_t head = active ? head_or : 0;
+      const uint64_t hs = head / (uint64_t)(P.min_points + 1);
+      const uint32_t ncand = active ? A.root_ncand[hs] : 0u;
+      const K rootkey = keys[head];
+      const int kx = (int)(rootkey & ((K(1) << B) - 1)) - half + k0x;
+      const int ky = (int)((rootkey >> B) & ((K(1) << B) - 1)) - half + k0y;
+      const int kz = (int)((rootkey >> (2 * B)) & ((K(1) << B) - 1)) - half + k0z;
+      const uint64_t slot_base = (head * (uint64_t)(P.max_layer + 1)) / (uint64_t)P.cluster_min;
+      const uint32_t ncap = (uint32_t)min((uint64_t)ncand, A.total_slots > slot_base ? A.total_slots - slot_base : 0);
+      uint32_t plane_mask = 0, split1 = 0, emitted = 0;
+      for (uint32_t batch = 0;; ++batch) {
+        const bool node_lane = active && batch == 0 && l < 9;
+        const uint32_t c = (batch == 0) ? (uint32_t)(l - 9) : (uint32_t)(G - 9) + (batch - 1) * G + (uint32_t)l;
+        const bool cand_lane = active && (batch > 0 || l >= 9) && c < ncap;
+        if (!__ballot(node_lane || cand_lane)) break;
+        double mom[kMom];
+        bool have = false;
+        int nu = 0;
+        uint32_t ord = 0;
+        uint64_t slot = 0;
+        if (node_lane) {
+          const double *tot = A.node_tot + hs * (9 * kMom) + l * kMom;
+          nu = l;
+          if (tot[0] > (double)P.min_points) {
+            have = true;
+            for (int i = 0; i < kMom; ++i) mom[i] = tot[i];
+          }
+        } else if (cand_lane) {
+          slot = slot_base + c;
+          const uint32_t meta = A.cand_meta[slot];
+          nu = (int)(meta & 0x7F);
+          ord = meta >> 8;
+          have = true;
+          for (int i = 0; i < kMom; ++i) mom[i] = A.cand[slot * kMom + i];
+        }
+        Pca rr;
+        if (have) pca_from_moments(mom, rr);
+        if (batch == 0) {
+          const bool plane = node_lane && have && (rr.ev[0] < P.thr) && (rr.like > P.min_like);  // cc:106-111
+          const int sh = (g < NG) ? g * G : 0;
+          plane_mask = (uint32_t)(__ballot(plane) >> sh) & 0x1FFu;
+          const bool root_tested = (__ballot(node_lane && have) >> sh) & 1ull;
+          if (!root_tested) active = false;  // n <= min_points: nothing below this root exists (cc:129)
+          const uint32_t nonplane = (uint32_t)(__ballot(node_lane && have && !plane) >> sh) & 0x1FFu;
+          split1 = (P.max_layer >= 2 && active) ? (nonplane >> 1) : 0u;  // tested layer-1 nodes that are not planes (cc:175-182)
+        }
+        bool ok = false;
+        if (cand_lane && active && have && ((plane_mask >> nu) & 1u) && !(rr.ev[0] > P.thr || rr.like < P.min_like)) {  // cc:54
+          emit_surfel(A, rr, slot, nu == 0 ? 0 : 1, nu, ord, kx, ky, kz, q0);
+          ok = true;
+        }
+        emitted += (uint32_t)__popcll(__ballot(ok));
+      }
+      if (active && l == 0 && split1 != 0) {  // layer-2 pass needed: queue the root for k_roots<K, 2>
+        const uint32_t q = atomicAdd(&A.status[4], 1u);
+        A.split_jobs[q] = SplitJob{(uint32_t)head, ncand, (unsigned long long)split1};
+      }
+      // without the slot histogram (general path) the surfel count is accumulated here
+      if (lane == 0 && emitted && !A.slot_counts) atomicAdd(&A.status[0], emitted);
+    }
   }
 }
 
@@ -706,17 +795,6 @@ __device__ __forceinline__ uint32_t key_join(uint32_t d, uint32_t r) {
   return x | (y << 10) | (z << 20);
 }
 
-__device__ __forceinline__ uint32_t point_key(const wc_points &pts, double vs, uint64_t i, int k0x, int k0y, int k0z, uint32_t *status) {
-  double x, y, z;
-  load_xyz(pts, i, x, y, z);
-  int rx = vox(x, vs) - k0x + 512, ry = vox(y, vs) - k0y + 512, rz = vox(z, vs) - k0z + 512;
-  if ((unsigned)rx >= 1024u || (unsigned)ry >= 1024u || (unsigned)rz >= 1024u) {
-    atomicOr(&status[1], kFlagKeyRange);
-    rx = min(max(rx, 0), 1023), ry = min(max(ry, 0), 1023), rz = min(max(rz, 0), 1023);
-  }
-  return (uint32_t)rx | ((uint32_t)ry << 10) | ((uint32_t)rz << 20);
-}
-
 // run heads of a tile held in s_key[0..cnt): bit i of the bitmap is set when point i starts a run; returns the run
 // length of head i (distance to the next head or to the end of the tile)
 __device__ __forceinline__ uint32_t run_length(const unsigned long long *s_bits, uint32_t i, uint32_t cnt) {
@@ -741,9 +819,21 @@ __global__ void __launch_bounds__(256) k_init(InitArgs I) {
     if (i < I.nw[r]) I.p[r][i] = I.val[r];
 }
 
-// counts = run counts [kBuckets] | point counts [kBuckets]
-__global__ void __launch_bounds__(256) k_pt_runs(wc_points pts, double vs, uint64_t n, uint32_t *counts, uint64_t *bins, uint32_t bin_cap,
-                                                uint16_t *run_len, uint32_t *status) {
+// run composite: key rest (18 bits) << 45 | start index (32 bits) << 13 | run length - 1 (13 bits): sorting the composites
+// sorts by (voxel, start), and the length rides along (no second array, no dependent gather in k_pt_bucket)
+__device__ __forceinline__ uint64_t run_comp(uint32_t rest, uint32_t start, uint32_t len) {
+  return ((uint64_t)rest << 45) | ((uint64_t)start << 13) | (uint64_t)(len - 1);
+}
+__device__ __forceinline__ uint32_t comp_rest(uint64_t c) { return (uint32_t)(c >> 45); }
+__device__ __forceinline__ uint32_t comp_start(uint64_t c) { return (uint32_t)(c >> 13); }
+__device__ __forceinline__ uint32_t comp_len(uint64_t c) { return ((uint32_t)c & 8191u) + 1u; }
+static_assert(kTile <= 8192, "run length field");
+
+// counts = run counts [kBuckets] | point counts [kBuckets].  1024 threads per 4096-point tile: one tile per CU is all a
+// 1 M-point sweep offers, so the latency hiding has to come from wavefronts of the same workgroup.
+constexpr int kRunThreads = 1024;
+__global__ void __launch_bounds__(kRunThreads) k_pt_runs(wc_points pts, double vs, uint64_t n, uint32_t *counts, uint64_t *bins,
+                                                        uint32_t bin_cap, uint32_t *status) {
   __shared__ uint32_t s_key[kTile];
   __shared__ unsigned long long s_bits[kTile / 64];
   __shared__ uint32_t s_runs[kBuckets];
@@ -751,35 +841,54 @@ __global__ void __launch_bounds__(256) k_pt_runs(wc_points pts, double vs, uint6
   const int t = threadIdx.x;
   const uint64_t t0 = (uint64_t)blockIdx.x * kTile;
   const uint32_t cnt = (uint32_t)min((uint64_t)kTile, n - t0);
-  for (int b = t; b < kBuckets; b += 256) {
+  double x0, y0, z0;
+  load_xyz(pts, 0, x0, y0, z0);
+  uint32_t key[kTile / kRunThreads];
+#pragma unroll
+  for (int j = 0; j < kTile / kRunThreads; ++j) {  // all loads of the tile in flight before anything waits on them
+    const uint32_t i = (uint32_t)j * kRunThreads + t;
+    key[j] = 0;
+    if (i < cnt) {
+      double x, y, z;
+      load_xyz(pts, t0 + i, x, y, z);
+      int rx = vox(x, vs) - vox(x0, vs) + 512, ry = vox(y, vs) - vox(y0, vs) + 512, rz = vox(z, vs) - vox(z0, vs) + 512;
+      if ((unsigned)rx >= 1024u || (unsigned)ry >= 1024u || (unsigned)rz >= 1024u) {
+        atomicOr(&status[1], kFlagKeyRange);
+        rx = min(max(rx, 0), 1023), ry = min(max(ry, 0), 1023), rz = min(max(rz, 0), 1023);
+      }
+      key[j] = (uint32_t)rx | ((uint32_t)ry << 10) | ((uint32_t)rz << 20);
+    }
+  }
+  for (int b = t; b < kBuckets; b += kRunThreads) {
     s_runs[b] = 0;
     s_pts[b] = 0;
   }
   if (t < kTile / 64) s_bits[t] = 0ull;
-  double x0, y0, z0;
-  load_xyz(pts, 0, x0, y0, z0);
-  const int k0x = vox(x0, vs), k0y = vox(y0, vs), k0z = vox(z0, vs);
-  for (uint32_t i = t; i < cnt; i += 256) s_key[i] = point_key(pts, vs, t0 + i, k0x, k0y, k0z, status);
-  __syncthreads();
-  for (uint32_t i = t; i < cnt; i += 256)
-    if (i == 0 || s_key[i] != s_key[i - 1]) atomicOr(&s_bits[i >> 6], 1ull << (i & 63));
-  __syncthreads();
-  uint32_t rank[kTile / 256];
-  uint16_t len[kTile / 256];
 #pragma unroll
-  for (int j = 0; j < kTile / 256; ++j) {
-    const uint32_t i = (uint32_t)j * 256 + t;
+  for (int j = 0; j < kTile / kRunThreads; ++j) s_key[j * kRunThreads + t] = key[j];
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < kTile / kRunThreads; ++j) {
+    const uint32_t i = (uint32_t)j * kRunThreads + t;
+    const bool headp = i < cnt && (i == 0 || key[j] != s_key[i - 1]);
+    const unsigned long long m = __ballot(headp);  // i is 64-aligned per wavefront: one bitmap word each
+    if ((t & 63) == 0) s_bits[i >> 6] = m;
+  }
+  __syncthreads();
+  uint32_t rank[kTile / kRunThreads], len[kTile / kRunThreads];
+#pragma unroll
+  for (int j = 0; j < kTile / kRunThreads; ++j) {
+    const uint32_t i = (uint32_t)j * kRunThreads + t;
     rank[j] = 0xFFFFFFFFu;
     if (i < cnt && ((s_bits[i >> 6] >> (i & 63)) & 1ull)) {
-      const uint32_t d = key_digit(s_key[i]);
-      const uint32_t l = run_length(s_bits, i, cnt);
-      len[j] = (uint16_t)l;
+      const uint32_t d = key_digit(key[j]);
+      len[j] = run_length(s_bits, i, cnt);
       rank[j] = atomicAdd(&s_runs[d], 1u);
-      atomicAdd(&s_pts[d], l);
+      atomicAdd(&s_pts[d], len[j]);
     }
   }
   __syncthreads();
-  for (int b = t; b < kBuckets; b += 256) {
+  for (int b = t; b < kBuckets; b += kRunThreads) {
     const uint32_t c = s_runs[b];
     if (c) {
       s_runs[b] = atomicAdd(&counts[b], c);  // this tile's range inside the bin of bucket b
@@ -788,44 +897,48 @@ __global__ void __launch_bounds__(256) k_pt_runs(wc_points pts, double vs, uint6
   }
   __syncthreads();
 #pragma unroll
-  for (int j = 0; j < kTile / 256; ++j) {
+  for (int j = 0; j < kTile / kRunThreads; ++j) {
     if (rank[j] == 0xFFFFFFFFu) continue;
-    const uint32_t i = (uint32_t)j * 256 + t;
-    const uint32_t k = s_key[i], d = key_digit(k);
+    const uint32_t i = (uint32_t)j * kRunThreads + t;
+    const uint32_t d = key_digit(key[j]);
     const uint32_t pos = s_runs[d] + rank[j];
-    if (pos < bin_cap) bins[(size_t)d * bin_cap + pos] = ((uint64_t)key_rest(k) << 32) | (uint64_t)(uint32_t)(t0 + i);
-    run_len[t0 + i] = len[j];
+    if (pos < bin_cap) bins[(size_t)d * bin_cap + pos] = run_comp(key_rest(key[j]), (uint32_t)(t0 + i), len[j]);
   }
 }
 
 // one wavefront per bucket (four per workgroup).  Dynamic LDS per wavefront: bin_cap x {unsorted composite, sorted
 // composite, output offset}.
 __global__ void __launch_bounds__(256) k_pt_bucket(const uint64_t *__restrict__ bins, uint32_t bin_cap, const uint32_t *__restrict__ counts,
-                                                  const uint16_t *__restrict__ run_len, uint32_t *keys_out, uint32_t *idx_out,
-                                                  uint32_t *head_slots, int min_points, uint32_t *status) {
+                                                  uint32_t *keys_out, uint32_t *idx_out, uint32_t *head_slots, int min_points,
+                                                  uint32_t *status) {
   extern __shared__ __align__(16) unsigned char s_dyn[];
   __shared__ uint32_t s_red[4];
   const int t = threadIdx.x, w = t >> 6, lane = t & 63;
   uint64_t *s_a = (uint64_t *)s_dyn + (size_t)w * bin_cap;
   uint64_t *s_b = (uint64_t *)s_dyn + (size_t)(4 + w) * bin_cap;
   uint32_t *s_off = (uint32_t *)((uint64_t *)s_dyn + (size_t)8 * bin_cap) + (size_t)w * bin_cap;
-  const uint32_t b0 = blockIdx.x * 4u;
+  const uint32_t b0 = blockIdx.x * 4u, b = b0 + w;
   const uint32_t *pcounts = counts + kBuckets;
+  // everything that comes from HBM / L2 is requested up front: the bucket's own counts, its first 64 runs, and this
+  // thread's share of the point counts in front of the workgroup's buckets
+  const uint32_t nb = counts[b], total = pcounts[b];
+  const uint64_t *bin = bins + (size_t)b * bin_cap;
+  const uint64_t first = ((uint32_t)lane < min(nb, bin_cap)) ? bin[lane] : 0ull;
   uint32_t part = 0;
   for (uint32_t i = t; i < b0; i += 256) part += pcounts[i];
+  uint32_t before = 0;  // points of the workgroup's buckets in front of this wavefront's
+  for (int j = 0; j < w; ++j) before += pcounts[b0 + j];
   for (int off = 32; off >= 1; off >>= 1) part += __shfl_xor(part, off);
   if (lane == 0) s_red[w] = part;
   __syncthreads();
-  uint32_t pbase = s_red[0] + s_red[1] + s_red[2] + s_red[3];
-  for (int j = 0; j < w; ++j) pbase += pcounts[b0 + j];
-  const uint32_t b = b0 + w, nb = counts[b], total = pcounts[b];
+  const uint32_t pbase = s_red[0] + s_red[1] + s_red[2] + s_red[3] + before;
   if (nb == 0) return;
   if (nb > bin_cap) {
     if (lane == 0) atomicOr(&status[1], kFlagBucketOverflow);
     return;
   }
-  const uint64_t *bin = bins + (size_t)b * bin_cap;
-  for (uint32_t i = lane; i < nb; i += 64) s_a[i] = bin[i];
+  if ((uint32_t)lane < nb) s_a[lane] = first;
+  for (uint32_t i = lane + 64; i < nb; i += 64) s_a[i] = bin[i];
   __builtin_amdgcn_wave_barrier();
   for (uint32_t i = lane; i < nb; i += 64) {  // rank by counting: composites are unique (start index)
     const uint64_t mine = s_a[i];
@@ -838,7 +951,7 @@ __global__ void __launch_bounds__(256) k_pt_bucket(const uint64_t *__restrict__ 
   uint32_t carry = 0;
   for (uint32_t i0 = 0; i0 < nb; i0 += 64) {
     const uint32_t i = i0 + lane;
-    const uint32_t l = (i < nb) ? (uint32_t)run_len[(uint32_t)s_b[i]] : 0u;
+    const uint32_t l = (i < nb) ? comp_len(s_b[i]) : 0u;
     uint32_t inc = l;
     for (int off = 1; off < 64; off <<= 1) {
       const uint32_t v = __shfl_up(inc, off);
@@ -851,10 +964,10 @@ __global__ void __launch_bounds__(256) k_pt_bucket(const uint64_t *__restrict__ 
   // live root heads: a voxel segment with more than min_points points (InitOctoTree cc:129); two live heads are at least
   // min_points + 1 positions apart, so slot = position / (min_points + 1) is collision free
   for (uint32_t r = lane; r < nb; r += 64) {
-    const uint32_t rest = (uint32_t)(s_b[r] >> 32);
-    if (r > 0 && (uint32_t)(s_b[r - 1] >> 32) == rest) continue;
+    const uint32_t rest = comp_rest(s_b[r]);
+    if (r > 0 && comp_rest(s_b[r - 1]) == rest) continue;
     uint32_t r2 = r + 1;
-    while (r2 < nb && (uint32_t)(s_b[r2] >> 32) == rest) ++r2;
+    while (r2 < nb && comp_rest(s_b[r2]) == rest) ++r2;
     const uint32_t seg = (r2 < nb ? s_off[r2] : total) - s_off[r];
     if (seg > (uint32_t)min_points) {
       const uint32_t pos = pbase + s_off[r];
@@ -872,8 +985,8 @@ __global__ void __launch_bounds__(256) k_pt_bucket(const uint64_t *__restrict__ 
         hi = mid;
     }
     const uint64_t c = s_b[lo];
-    keys_out[(size_t)pbase + j] = key_join(b, (uint32_t)(c >> 32));
-    idx_out[(size_t)pbase + j] = (uint32_t)c + (j - s_off[lo]);
+    keys_out[(size_t)pbase + j] = key_join(b, comp_rest(c));
+    idx_out[(size_t)pbase + j] = comp_start(c) + (j - s_off[lo]);
   }
 }
 
@@ -894,7 +1007,6 @@ int point_sort_runs(wc_ctx *ctx, const wc_points &pts, double vs, uint32_t *keys
   const uint32_t cap = pt_bin_cap(n);
   WC_TRY(wc_ensure(ctx, ctx->b_misc[1], (uint64_t)kBuckets * cap * 8));  // run bins
   WC_TRY(wc_ensure(ctx, ctx->b_misc[2], 2 * kBuckets * 4));             // run counts | point counts
-  WC_TRY(wc_ensure(ctx, ctx->b_misc[3], n * 2));                         // run lengths, indexed by the run's first point
   uint32_t *counts = (uint32_t *)ctx->b_misc[2].p;
   const unsigned tiles = (unsigned)((n + kTile - 1) / kTile);
   const size_t lds = (size_t)4 * cap * 20;
@@ -903,9 +1015,9 @@ int point_sort_runs(wc_ctx *ctx, const wc_points &pts, double vs, uint32_t *keys
     WC_HIP(ctx, hipFuncSetAttribute((const void *)k_pt_bucket, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * kPtBinMax * 20)));
     attr_set = true;
   }
-  k_pt_runs<<<tiles, 256, 0, st>>>(pts, vs, n, counts, (uint64_t *)ctx->b_misc[1].p, cap, (uint16_t *)ctx->b_misc[3].p, status);
-  k_pt_bucket<<<kBuckets / 4, 256, lds, st>>>((const uint64_t *)ctx->b_misc[1].p, cap, counts, (const uint16_t *)ctx->b_misc[3].p, keys_out,
-                                             idx_out, head_slots, min_points, status);
+  k_pt_runs<<<tiles, kRunThreads, 0, st>>>(pts, vs, n, counts, (uint64_t *)ctx->b_misc[1].p, cap, status);
+  k_pt_bucket<<<kBuckets / 4, 256, lds, st>>>((const uint64_t *)ctx->b_misc[1].p, cap, counts, keys_out, idx_out, head_slots, min_points,
+                                             status);
   WC_HIP(ctx, hipGetLastError());
   return WC_OK;
 }
@@ -1035,7 +1147,7 @@ int run_pipeline(wc_ctx *ctx, const wc_points &pts, double t_lo, double t_hi, wc
   A.node_tot = (double *)ctx->b_misc[7].p;
   A.root_ncand = (uint32_t *)(A.node_tot + (size_t)A.nslots * 9 * kMom);
   k_roots<K, 1><<<kRootsGrid, 64, 0, st>>>(A, (const K *)ctx->b_keys[1].p);  // stream root + layer 1
-  k_roots<K, 3><<<kRootsGrid, 64, 0, st>>>(A, (const K *)ctx->b_keys[1].p);  // node tests + emission
+  k_roots_emit<K><<<kEmitGrid, 64, 0, st>>>(A, (const K *)ctx->b_keys[1].p);  // node tests + emission
   k_roots<K, 2><<<kRoots2Grid, 64, 0, st>>>(A, (const K *)ctx->b_keys[1].p);  // layer 2 of the split nodes (rare)
   mark(3);
   if (fast_slots) {
