@@ -152,13 +152,47 @@ __device__ __forceinline__ void pca_from_moments(const double *m, Pca &r) {
   r.like = 2 * (r.ev[1] - r.ev[0]) / ((r.ev[0] + r.ev[1]) + r.ev[2]);
 }
 
+// ---- voxel key <-> (bucket digit, rest) and the run composites of the run-binned point sort (see k_pt_runs) ----
+__device__ __forceinline__ uint32_t key_digit(uint32_t key) {
+  const uint32_t x = key & 1023u, y = (key >> 10) & 1023u, z = key >> 20;
+  return (x & 15u) | ((y & 15u) << 4) | ((z & 15u) << 8);
+}
+__device__ __forceinline__ uint32_t key_rest(uint32_t key) {
+  const uint32_t x = key & 1023u, y = (key >> 10) & 1023u, z = key >> 20;
+  return (x >> 4) | ((y >> 4) << 6) | ((z >> 4) << 12);
+}
+__device__ __forceinline__ uint32_t key_join(uint32_t d, uint32_t r) {
+  const uint32_t x = (d & 15u) | ((r & 63u) << 4), y = ((d >> 4) & 15u) | (((r >> 6) & 63u) << 4),
+                 z = ((d >> 8) & 15u) | (((r >> 12) & 63u) << 4);
+  return x | (y << 10) | (z << 20);
+}
+
+// run composite: key rest (18 bits) << 45 | start index (32 bits) << 13 | run length - 1 (13 bits): sorting the composites
+// sorts by (voxel, start), and the length rides along (no second array, no dependent gather in k_pt_bucket)
+__device__ __forceinline__ uint64_t run_comp(uint32_t rest, uint32_t start, uint32_t len) {
+  return ((uint64_t)rest << 45) | ((uint64_t)start << 13) | (uint64_t)(len - 1);
+}
+__device__ __forceinline__ uint32_t comp_rest(uint64_t c) { return (uint32_t)(c >> 45); }
+__device__ __forceinline__ uint32_t comp_start(uint64_t c) { return (uint32_t)(c >> 13); }
+__device__ __forceinline__ uint32_t comp_len(uint64_t c) { return ((uint32_t)c & 8191u) + 1u; }
+static_assert(kTile <= 8192, "run length field");
+
+// a live root voxel (more than min_points points).  pos = rank of its first point in the voxel-sorted order (names the
+// head slot and the candidate slot range).  RUNS mode (run-binned point sort): the root's points are nr sorted runs
+// starting at runs[gidx], total points; otherwise they are keys/vals[pos ...] while the key stays the same.
+struct HeadRec {
+  uint32_t pos, gidx, nr, total;
+};
 struct SplitJob;
 struct RootsArgs {
   wc_points pts;
   ExParams P;
   uint64_t n;
   const uint32_t *vals;    // sorted point indices
-  const uint32_t *heads;   // head slot table: position of the live root head in slot pos / (min_points + 1), ~0 = none
+  const HeadRec *heads;    // head slot table: the live root whose first sorted position is pos sits in slot pos / (min_points + 1)
+  const uint64_t *runs;    // RUNS mode: the sorted run composites of every bucket, [kBuckets][run_cap]
+  const uint32_t *run_off; // RUNS mode: bucket-local point offset of every sorted run
+  uint32_t run_cap;
   uint32_t nslots;
   double *cand;            // [total_slots][11] candidate cluster moments
   uint32_t *cand_meta;     // [total_slots] local node | phase << 7 | ordinal << 8
@@ -220,12 +254,12 @@ __device__ __forceinline__ void emit_surfel(const RootsArgs &A, const Pca &rr, u
 // least min_points + 1 positions apart, so slot = pos / (min_points + 1) is collision free: no atomics, no compaction
 // (a single append counter serialised at ~12 ns per live root: 46 us for 3.9 k roots).
 template <typename K>
-__global__ void __launch_bounds__(256) k_heads(const K *__restrict__ keys, uint64_t n, int min_points, uint32_t *head_slots) {
+__global__ void __launch_bounds__(256) k_heads(const K *__restrict__ keys, uint64_t n, int min_points, HeadRec *head_slots) {
   const uint64_t pos = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (pos >= n) return;
   const K k = keys[pos];
   const bool live = (pos == 0 || keys[pos - 1] != k) && (pos + (uint64_t)min_points < n) && keys[pos + min_points] == k;
-  if (live) head_slots[pos / (uint64_t)(min_points + 1)] = (uint32_t)pos;
+  if (live) head_slots[pos / (uint64_t)(min_points + 1)] = HeadRec{(uint32_t)pos, 0u, 0u, 0u};
 }
 
 #ifdef WC_PROF_ROOTS
@@ -251,7 +285,7 @@ struct SplitJob {  // a root whose layer-1 nodes need the layer-2 pass (k_roots<
 // of the same code over the 64 layer-2 nodes (rare on regular scenes, so the common case keeps a 5 KB LDS footprint).
 // Static work assignment (every wavefront owns a contiguous run of head slots): a device-side dequeue word serialised
 // at ~90 dequeues/us and cost more than it balanced.
-template <typename K, int PHASE>
+template <typename K, int PHASE, bool RUNS>
 __global__ void __launch_bounds__(64) k_roots(RootsArgs A, const K *__restrict__ keys) {
   constexpr int phase = PHASE;  // octree pass: 1 = root + layer 1 (streaming only, k_roots_emit finishes it), 2 = layer 2 (fused)
   constexpr int ntab = (phase == 1) ? 9 : 64;
@@ -293,31 +327,73 @@ __global__ void __launch_bounds__(64) k_roots(RootsArgs A, const K *__restrict__
     it_step = gridDim.x;
   }
   for (; it < it_end; it += (PHASE != 2 ? 64u : it_step)) {
-   uint32_t my_head = 0xFFFFFFFFu;
+   HeadRec my_head{0xFFFFFFFFu, 0u, 0u, 0u};
    unsigned long long live_mask = 1ull;
    if (PHASE != 2) {
-     my_head = (it + lane < it_end) ? A.heads[it + lane] : 0xFFFFFFFFu;
-     live_mask = __ballot(my_head != 0xFFFFFFFFu);
+     if (it + lane < it_end) my_head = A.heads[it + lane];
+     live_mask = __ballot(my_head.pos != 0xFFFFFFFFu);
    }
    while (live_mask) {
     const int hb = __ffsll((long long)live_mask) - 1;
     live_mask &= live_mask - 1;
-    uint64_t head;
+    HeadRec hrec;
     uint32_t ncand = 0, emitted = 0;
     unsigned long long split1 = 0;  // layer-1 octants that get split (tested, not a plane; cc:175-182)
     if (PHASE != 2) {
-      head = __shfl(my_head, hb);
+      hrec = HeadRec{(uint32_t)__shfl((int)my_head.pos, hb), (uint32_t)__shfl((int)my_head.gidx, hb), (uint32_t)__shfl((int)my_head.nr, hb),
+                     (uint32_t)__shfl((int)my_head.total, hb)};
     } else {
       const SplitJob job = A.split_jobs[it];
-      head = job.head;
+      hrec = A.heads[job.head / (uint32_t)(P.min_points + 1)];
       ncand = job.ncand;
       split1 = job.split1;
     }
+    const uint64_t head = hrec.pos;
 #ifdef WC_PROF_ROOTS
     unsigned long long tick_ = __builtin_readcyclecounter();
     uint32_t prof_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
-    const K rootkey = keys[head];
+    // RUNS: lane r < 64 keeps run r of this root (start index, root-local offset) in registers
+    uint32_t r_start = 0, r_off = 0;
+    K rootkey;
+    if (RUNS) {
+      uint64_t comp = 0;
+      if ((uint32_t)lane < min(hrec.nr, 64u)) {
+        comp = A.runs[(size_t)hrec.gidx + lane];
+        r_off = A.run_off[(size_t)hrec.gidx + lane];
+      }
+      r_start = comp_start(comp);
+      r_off -= (uint32_t)__builtin_amdgcn_readfirstlane((int)r_off);
+      rootkey = (K)key_join(hrec.gidx / A.run_cap, (uint32_t)__builtin_amdgcn_readfirstlane((int)comp_rest(comp)));
+    } else {
+      rootkey = keys[head];
+    }
+    // index of the root's p-th point (time order)
+    // (called by all lanes: the register path broadcasts run descriptors with readlane)
+    auto point_index = [&](uint32_t pp, bool ok_lane) -> uint32_t {
+      if (!RUNS) return ok_lane ? A.vals[head + pp] : 0u;
+      if (hrec.nr <= 64u) {
+        uint32_t st = (uint32_t)__builtin_amdgcn_readfirstlane((int)r_start), o = 0;
+        for (uint32_t k = 1; k < hrec.nr; ++k) {
+          const uint32_t ok = (uint32_t)__builtin_amdgcn_readlane((int)r_off, (int)k);
+          const uint32_t sk = (uint32_t)__builtin_amdgcn_readlane((int)r_start, (int)k);
+          if (pp >= ok) st = sk, o = ok;
+        }
+        return st + (pp - o);
+      }
+      if (!ok_lane) return 0u;
+      const uint32_t *ro = A.run_off + hrec.gidx;  // many runs (unordered input): binary search in the offset table
+      const uint32_t o0 = ro[0];
+      uint32_t lo = 0, hi = hrec.nr;
+      while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (ro[mid] - o0 <= pp)
+          lo = mid;
+        else
+          hi = mid;
+      }
+      return comp_start(A.runs[(size_t)hrec.gidx + lo]) + (pp - (ro[lo] - o0));
+    };
 
     // absolute root voxel index and centre ((0.5 + k) * voxel_size, cc:208-210)
     const int kx = (int)(rootkey & ((K(1) << B) - 1)) - half + k0x;
@@ -344,11 +420,11 @@ __global__ void __launch_bounds__(64) k_roots(RootsArgs A, const K *__restrict__
     double a_open = 0.0, a_total = 0.0, last = 0.0;
 
     // ---- software-pipelined chunk loop: the next 64 points are in flight while the current ones stream ----
-    uint64_t pos = head + lane;
-    bool valid = pos < A.n && keys[pos] == rootkey;
+    uint32_t pp = lane;  // position inside the root
+    bool valid = RUNS ? (pp < hrec.total) : (head + pp < A.n && keys[head + pp] == rootkey);
     double px = 0, py = 0, pz = 0, pt = 0;
+    uint32_t idx = point_index(pp, valid);
     if (valid) {
-      const uint32_t idx = A.vals[pos];
       load_xyz(A.pts, idx, px, py, pz);
       pt = load_t(A.pts, idx);
     }
@@ -396,10 +472,10 @@ __global__ void __launch_bounds__(64) k_roots(RootsArgs A, const K *__restrict__
       // prefetch the next chunk
       bool nvalid_next = false;
       if (nvalid == 64) {
-        pos += 64;
-        nvalid_next = pos < A.n && keys[pos] == rootkey;
+        pp += 64;
+        nvalid_next = RUNS ? (pp < hrec.total) : (head + pp < A.n && keys[head + pp] == rootkey);
+        idx = point_index(pp, nvalid_next);
         if (nvalid_next) {
-          const uint32_t idx = A.vals[pos];
           load_xyz(A.pts, idx, px, py, pz);
           pt = load_t(A.pts, idx);
         }
@@ -596,7 +672,7 @@ __global__ void __launch_bounds__(64) k_roots(RootsArgs A, const K *__restrict__
 // wavefront the launch is VALU-issue bound on mostly idle lanes.  Lane = 21 * group + l; in the first batch l < 9 tests
 // node l (InitOctoTree / CutOctoTree gates, cc:129-138, :170-183) and l >= 9 takes candidate l - 9 (ClusterSurfels'
 // second loop, cc:32-64); later batches (rare) take 21 more candidates per group.
-template <typename K>
+template <typename K, bool RUNS>
 __global__ void __launch_bounds__(64) k_roots_emit(RootsArgs A, const K *__restrict__ keys) {
   constexpr int G = 21, NG = 3;
   const int lane = threadIdx.x;
@@ -613,8 +689,9 @@ __global__ void __launch_bounds__(64) k_roots_emit(RootsArgs A, const K *__restr
   const uint32_t per_wave = (A.nslots + gridDim.x - 1) / gridDim.x;
   const uint32_t it_end = min((blockIdx.x + 1) * per_wave, A.nslots);
   for (uint32_t it = blockIdx.x * per_wave; it < it_end; it += 64) {
-    const uint32_t my_head = (it + lane < it_end) ? A.heads[it + lane] : 0xFFFFFFFFu;
-    unsigned long long live_mask = __ballot(my_head != 0xFFFFFFFFu);
+    HeadRec my_head{0xFFFFFFFFu, 0u, 0u, 0u};
+    if (it + lane < it_end) my_head = A.heads[it + lane];
+    unsigned long long live_mask = __ballot(my_head.pos != 0xFFFFFFFFu);
     while (live_mask) {
       int hb = -1;  // the live head this lane's group works on
       for (int k = 0; k < NG; ++k) {
@@ -623,12 +700,19 @@ __global__ void __launch_bounds__(64) k_roots_emit(RootsArgs A, const K *__restr
         live_mask &= live_mask - 1;
         if (g == k) hb = bit;
       }
-      const uint32_t head_or = __shfl(my_head, hb < 0 ? 0 : hb);
+      const uint32_t head_or = (uint32_t)__shfl((int)my_head.pos, hb < 0 ? 0 : hb);
+      const uint32_t gidx_or = (uint32_t)__shfl((int)my_head.gidx, hb < 0 ? 0 : hb);
       bool active = g < NG && hb >= 0;
       const uint64_t head = active ? head_or : 0;
       const uint64_t hs = head / (uint64_t)(P.min_points + 1);
       const uint32_t ncand = active ? A.root_ncand[hs] : 0u;
-      const K rootkey = keys[head];
+      K rootkey;
+      if (RUNS) {
+        const uint32_t gidx = active ? gidx_or : 0u;
+        rootkey = (K)key_join(gidx / A.run_cap, comp_rest(A.runs[gidx]));
+      } else {
+        rootkey = keys[head];
+      }
       const int kx = (int)(rootkey & ((K(1) << B) - 1)) - half + k0x;
       const int ky = (int)((rootkey >> B) & ((K(1) << B) - 1)) - half + k0y;
       const int kz = (int)((rootkey >> (2 * B)) & ((K(1) << B) - 1)) - half + k0z;
@@ -781,20 +865,6 @@ __global__ void __launch_bounds__(256) k_slot_emit(const uint32_t *__restrict__ 
 // irrelevant (only grouping matters).  2 launches instead of rocPRIM's ~20 (merge path) for 1 M pairs.  A bucket with
 // more runs than the bin capacity raises kFlagBucketOverflow and the caller falls back to the rocPRIM radix sort.
 
-__device__ __forceinline__ uint32_t key_digit(uint32_t key) {
-  const uint32_t x = key & 1023u, y = (key >> 10) & 1023u, z = key >> 20;
-  return (x & 15u) | ((y & 15u) << 4) | ((z & 15u) << 8);
-}
-__device__ __forceinline__ uint32_t key_rest(uint32_t key) {
-  const uint32_t x = key & 1023u, y = (key >> 10) & 1023u, z = key >> 20;
-  return (x >> 4) | ((y >> 4) << 6) | ((z >> 4) << 12);
-}
-__device__ __forceinline__ uint32_t key_join(uint32_t d, uint32_t r) {
-  const uint32_t x = (d & 15u) | ((r & 63u) << 4), y = ((d >> 4) & 15u) | (((r >> 6) & 63u) << 4),
-                 z = ((d >> 8) & 15u) | (((r >> 12) & 63u) << 4);
-  return x | (y << 10) | (z << 20);
-}
-
 // run heads of a tile held in s_key[0..cnt): bit i of the bitmap is set when point i starts a run; returns the run
 // length of head i (distance to the next head or to the end of the tile)
 __device__ __forceinline__ uint32_t run_length(const unsigned long long *s_bits, uint32_t i, uint32_t cnt) {
@@ -818,16 +888,6 @@ __global__ void __launch_bounds__(256) k_init(InitArgs I) {
   for (int r = 0; r < 6; ++r)
     if (i < I.nw[r]) I.p[r][i] = I.val[r];
 }
-
-// run composite: key rest (18 bits) << 45 | start index (32 bits) << 13 | run length - 1 (13 bits): sorting the composites
-// sorts by (voxel, start), and the length rides along (no second array, no dependent gather in k_pt_bucket)
-__device__ __forceinline__ uint64_t run_comp(uint32_t rest, uint32_t start, uint32_t len) {
-  return ((uint64_t)rest << 45) | ((uint64_t)start << 13) | (uint64_t)(len - 1);
-}
-__device__ __forceinline__ uint32_t comp_rest(uint64_t c) { return (uint32_t)(c >> 45); }
-__device__ __forceinline__ uint32_t comp_start(uint64_t c) { return (uint32_t)(c >> 13); }
-__device__ __forceinline__ uint32_t comp_len(uint64_t c) { return ((uint32_t)c & 8191u) + 1u; }
-static_assert(kTile <= 8192, "run length field");
 
 // counts = run counts [kBuckets] | point counts [kBuckets].  1024 threads per 4096-point tile: one tile per CU is all a
 // 1 M-point sweep offers, so the latency hiding has to come from wavefronts of the same workgroup.
@@ -907,10 +967,9 @@ __global__ void __launch_bounds__(kRunThreads) k_pt_runs(wc_points pts, double v
 }
 
 // one wavefront per bucket (four per workgroup).  Dynamic LDS per wavefront: bin_cap x {unsorted composite, sorted
-// composite, output offset}.
-__global__ void __launch_bounds__(256) k_pt_bucket(const uint64_t *__restrict__ bins, uint32_t bin_cap, const uint32_t *__restrict__ counts,
-                                                  uint32_t *keys_out, uint32_t *idx_out, uint32_t *head_slots, int min_points,
-                                                  uint32_t *status) {
+// composite, point offset}.  Nothing is expanded to per-point arrays: the roots pass walks the runs itself.
+__global__ void __launch_bounds__(256) k_pt_bucket(uint64_t *bins, uint32_t bin_cap, const uint32_t *__restrict__ counts, uint32_t *run_off,
+                                                  HeadRec *head_slots, int min_points, uint32_t *status) {
   extern __shared__ __align__(16) unsigned char s_dyn[];
   __shared__ uint32_t s_red[4];
   const int t = threadIdx.x, w = t >> 6, lane = t & 63;
@@ -961,6 +1020,12 @@ __global__ void __launch_bounds__(256) k_pt_bucket(const uint64_t *__restrict__ 
     carry += __shfl(inc, 63);
   }
   __builtin_amdgcn_wave_barrier();
+  // the sorted runs go back in place (this wavefront owns the bin), their bucket-local point offsets next to them
+  uint64_t *bin_rw = bins + (size_t)b * bin_cap;
+  for (uint32_t r = lane; r < nb; r += 64) {
+    bin_rw[r] = s_b[r];
+    run_off[(size_t)b * bin_cap + r] = s_off[r];
+  }
   // live root heads: a voxel segment with more than min_points points (InitOctoTree cc:129); two live heads are at least
   // min_points + 1 positions apart, so slot = position / (min_points + 1) is collision free
   for (uint32_t r = lane; r < nb; r += 64) {
@@ -971,22 +1036,8 @@ __global__ void __launch_bounds__(256) k_pt_bucket(const uint64_t *__restrict__ 
     const uint32_t seg = (r2 < nb ? s_off[r2] : total) - s_off[r];
     if (seg > (uint32_t)min_points) {
       const uint32_t pos = pbase + s_off[r];
-      head_slots[pos / (uint32_t)(min_points + 1)] = pos;
+      head_slots[pos / (uint32_t)(min_points + 1)] = HeadRec{pos, b * bin_cap + r, r2 - r, seg};
     }
-  }
-  // expansion, one lane per output point: binary search of the run that covers position j
-  for (uint32_t j = lane; j < total; j += 64) {
-    uint32_t lo = 0, hi = nb;  // last run with s_off <= j
-    while (hi - lo > 1) {
-      const uint32_t mid = (lo + hi) >> 1;
-      if (s_off[mid] <= j)
-        lo = mid;
-      else
-        hi = mid;
-    }
-    const uint64_t c = s_b[lo];
-    keys_out[(size_t)pbase + j] = key_join(b, comp_rest(c));
-    idx_out[(size_t)pbase + j] = comp_start(c) + (j - s_off[lo]);
   }
 }
 
@@ -1000,13 +1051,15 @@ inline uint32_t pt_bin_cap(uint64_t n) {
 }
 
 // counts (run counts | point counts) and the head slot table must be cleared by the caller
-int point_sort_runs(wc_ctx *ctx, const wc_points &pts, double vs, uint32_t *keys_out, uint32_t *idx_out, uint32_t *head_slots, int min_points,
-                    uint32_t *status) {
+// counts (run counts | point counts) and the head slot table must be cleared by the caller.  Leaves the sorted runs in
+// b_misc[1], their point offsets in b_misc[3] and the live roots in the head slot table.
+int point_sort_runs(wc_ctx *ctx, const wc_points &pts, double vs, HeadRec *head_slots, int min_points, uint32_t *status) {
   hipStream_t st = ctx->stream;
   const uint64_t n = pts.n;
   const uint32_t cap = pt_bin_cap(n);
   WC_TRY(wc_ensure(ctx, ctx->b_misc[1], (uint64_t)kBuckets * cap * 8));  // run bins
   WC_TRY(wc_ensure(ctx, ctx->b_misc[2], 2 * kBuckets * 4));             // run counts | point counts
+  WC_TRY(wc_ensure(ctx, ctx->b_misc[3], (uint64_t)kBuckets * cap * 4));  // point offsets of the sorted runs
   uint32_t *counts = (uint32_t *)ctx->b_misc[2].p;
   const unsigned tiles = (unsigned)((n + kTile - 1) / kTile);
   const size_t lds = (size_t)4 * cap * 20;
@@ -1016,7 +1069,7 @@ int point_sort_runs(wc_ctx *ctx, const wc_points &pts, double vs, uint32_t *keys
     attr_set = true;
   }
   k_pt_runs<<<tiles, kRunThreads, 0, st>>>(pts, vs, n, counts, (uint64_t *)ctx->b_misc[1].p, cap, status);
-  k_pt_bucket<<<kBuckets / 4, 256, lds, st>>>((const uint64_t *)ctx->b_misc[1].p, cap, counts, keys_out, idx_out, head_slots, min_points,
+  k_pt_bucket<<<kBuckets / 4, 256, lds, st>>>((uint64_t *)ctx->b_misc[1].p, cap, counts, (uint32_t *)ctx->b_misc[3].p, head_slots, min_points,
                                              status);
   WC_HIP(ctx, hipGetLastError());
   return WC_OK;
@@ -1072,7 +1125,7 @@ int run_pipeline(wc_ctx *ctx, const wc_points &pts, double t_lo, double t_hi, wc
   WC_TRY(wc_ensure(ctx, ctx->b_slot_idx[0], total_slots * 4));
   WC_TRY(wc_ensure(ctx, ctx->b_slot_idx[1], total_slots * 4));
   WC_TRY(wc_ensure(ctx, ctx->b_status, 64 * 4));
-  WC_TRY(wc_ensure(ctx, ctx->b_misc[0], (n / (uint64_t)(P.min_points + 1) + 2) * 4));
+  WC_TRY(wc_ensure(ctx, ctx->b_misc[0], (n / (uint64_t)(P.min_points + 1) + 2) * sizeof(HeadRec)));
   uint32_t *status = (uint32_t *)ctx->b_status.p;
 
   auto mark = [&](int i) {
@@ -1088,7 +1141,7 @@ int run_pipeline(wc_ctx *ctx, const wc_points &pts, double t_lo, double t_hi, wc
   // fast path (32-bit keys): bucket sort of (voxel key, index) composites; general path: rocPRIM radix sort
   const bool fast_pts = fast && sizeof(K) == 4;
   if (fast_pts || fast_slots) {
-    WC_TRY(wc_ensure(ctx, ctx->b_misc[1], (uint64_t)kBuckets * std::max(bin_cap, pt_bin_cap(n)) * 8));  // run bins, later slot bins
+    WC_TRY(wc_ensure(ctx, ctx->b_slot_keys[1], (uint64_t)kBuckets * bin_cap * 8));  // slot bins (the general path's sort buffer)
     WC_TRY(wc_ensure(ctx, ctx->b_misc[2], 2 * kBuckets * 4));
   }
   const uint32_t nslots = (uint32_t)(n / (uint64_t)(P.min_points + 1) + 1);
@@ -1098,7 +1151,7 @@ int run_pipeline(wc_ctx *ctx, const wc_points &pts, double t_lo, double t_hi, wc
     auto fill = [&](void *p, uint64_t words, uint32_t v) { I.p[r] = (uint32_t *)p, I.nw[r] = (uint32_t)words, I.val[r] = v, ++r; };
     fill(status, 64, 0u);
     if (!fast_slots) fill(ctx->b_slot_keys[0].p, total_slots * 2, 0xFFFFFFFFu);  // slot keys: ~0 = no surfel in the slot
-    fill(ctx->b_misc[0].p, nslots, 0xFFFFFFFFu);                                // head slot table: ~0 = no live head
+    fill(ctx->b_misc[0].p, (uint64_t)nslots * 4, 0xFFFFFFFFu);                  // head slot table: pos = ~0 = no live head
     if (fast_slots) fill(ctx->b_misc[4].p, 2 * kBuckets, 0u);                   // slot bucket counts (filled by k_roots) + cursors
     if (fast_pts) fill(ctx->b_misc[2].p, 2 * kBuckets, 0u);                     // point-sort run counts | point counts
     uint32_t mx = 0;
@@ -1107,8 +1160,7 @@ int run_pipeline(wc_ctx *ctx, const wc_points &pts, double t_lo, double t_hi, wc
   }
   if (fast_pts) {
     mark(1);
-    WC_TRY(point_sort_runs(ctx, pts, E.vs, (uint32_t *)ctx->b_keys[1].p, (uint32_t *)ctx->b_vals[1].p, (uint32_t *)ctx->b_misc[0].p,
-                           P.min_points, status));  // also fills the head slot table
+    WC_TRY(point_sort_runs(ctx, pts, E.vs, (HeadRec *)ctx->b_misc[0].p, P.min_points, status));  // also fills the head slot table
   } else {
     k_keygen<K><<<g256, 256, 0, st>>>(pts, E.vs, (K *)ctx->b_keys[0].p, (uint32_t *)ctx->b_vals[0].p, status);
     mark(1);
@@ -1130,11 +1182,14 @@ int run_pipeline(wc_ctx *ctx, const wc_points &pts, double t_lo, double t_hi, wc
   A.status = status;
   A.slot_counts = fast_slots ? (uint32_t *)ctx->b_misc[4].p : nullptr;
   A.slot_shift = tbits > 12 ? tbits - 12 : 0u;
-  A.slot_bins = (uint64_t *)ctx->b_misc[1].p;  // free again once the point sort is done
+  A.slot_bins = (uint64_t *)ctx->b_slot_keys[1].p;
+  A.runs = (const uint64_t *)ctx->b_misc[1].p;
+  A.run_off = (const uint32_t *)ctx->b_misc[3].p;
+  A.run_cap = pt_bin_cap(n);
   A.slot_bin_cap = bin_cap;
-  A.heads = (const uint32_t *)ctx->b_misc[0].p;
+  A.heads = (const HeadRec *)ctx->b_misc[0].p;
   A.nslots = nslots;
-  if (!fast_pts) k_heads<K><<<g256, 256, 0, st>>>((const K *)ctx->b_keys[1].p, n, P.min_points, (uint32_t *)ctx->b_misc[0].p);
+  if (!fast_pts) k_heads<K><<<g256, 256, 0, st>>>((const K *)ctx->b_keys[1].p, n, P.min_points, (HeadRec *)ctx->b_misc[0].p);
   WC_TRY(wc_ensure(ctx, ctx->b_misc[5], (size_t)A.nslots * sizeof(SplitJob)));
   A.split_jobs = (SplitJob *)ctx->b_misc[5].p;
   A.prof = nullptr;
@@ -1146,9 +1201,18 @@ int run_pipeline(wc_ctx *ctx, const wc_points &pts, double t_lo, double t_hi, wc
   WC_TRY(wc_ensure(ctx, ctx->b_misc[7], (size_t)A.nslots * (9 * kMom * 8 + 4)));
   A.node_tot = (double *)ctx->b_misc[7].p;
   A.root_ncand = (uint32_t *)(A.node_tot + (size_t)A.nslots * 9 * kMom);
-  k_roots<K, 1><<<kRootsGrid, 64, 0, st>>>(A, (const K *)ctx->b_keys[1].p);  // stream root + layer 1
-  k_roots_emit<K><<<kEmitGrid, 64, 0, st>>>(A, (const K *)ctx->b_keys[1].p);  // node tests + emission
-  k_roots<K, 2><<<kRoots2Grid, 64, 0, st>>>(A, (const K *)ctx->b_keys[1].p);  // layer 2 of the split nodes (rare)
+  const K *skeys = (const K *)ctx->b_keys[1].p;  // sorted keys (general path only; the run path never expands them)
+  if (fast_pts) {
+    if constexpr (sizeof(K) == 4) {
+      k_roots<K, 1, true><<<kRootsGrid, 64, 0, st>>>(A, skeys);  // stream root + layer 1
+      k_roots_emit<K, true><<<kEmitGrid, 64, 0, st>>>(A, skeys);  // node tests + emission
+      k_roots<K, 2, true><<<kRoots2Grid, 64, 0, st>>>(A, skeys);  // layer 2 of the split nodes (rare)
+    }
+  } else {
+    k_roots<K, 1, false><<<kRootsGrid, 64, 0, st>>>(A, skeys);
+    k_roots_emit<K, false><<<kEmitGrid, 64, 0, st>>>(A, skeys);
+    k_roots<K, 2, false><<<kRoots2Grid, 64, 0, st>>>(A, skeys);
+  }
   mark(3);
   if (fast_slots) {
     k_slot_emit<<<kBuckets / 4, 256, 0, st>>>((const uint32_t *)ctx->b_misc[4].p, A.slot_bins, bin_cap, (const wc_surfel *)ctx->b_slots.p,
