@@ -117,8 +117,8 @@ def main():
     algo_bytes = 20 * n_pts + 144 * exp_surfels  # 20 B read per point + 144 B written per surfel
     dom_ms = stages[dom]
     achieved = algo_bytes / (dom_ms * 1e-3) / 1e9
-    kernel_names = {"roots": "k_roots", "point_sort": "rocprim radix sort (points)", "slot_sort": "rocprim radix sort (slots)",
-                    "keygen": "k_keygen", "gather": "k_gather"}
+    kernel_names = {"init": "k_init", "point_sort": "k_pt_runs + k_pt_bucket", "roots_stream": "k_roots<1>",
+                    "roots_emit": "k_roots_emit + k_roots<2>", "slot_order": "k_slot_emit"}
     roofline = {"bound": "hbm", "kernel": kernel_names[dom], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "algorithmic_bytes_per_launch": algo_bytes,
                 "avg_kernel_ms": round(dom_ms, 5),

@@ -108,3 +108,15 @@ def test_dense_voxels_overflow_fast_sort_and_fall_back(gpu, oracle):
     pts, _ = synth.g2_lattice(3, m=1100, span=4, seed=17)
     assert len(pts) == 3 * 8 * 1100
     _run(gpu, oracle, pts)
+
+
+def test_layer2_pass_after_a_sweep_without_splits(gpu, oracle):
+    # the layer-2 launch is skipped when the previous sweep queued no root for it; a sweep that does need it must then be
+    # completed by the finish() side (late layer-2 pass + second ordering), and the next regular sweep must be unaffected
+    regular, _ = synth.g2_lattice(300, m=32)
+    room = synth.g1_room(300_000)
+    _run(gpu, oracle, regular)
+    res, st = _run(gpu, oracle, room)
+    assert st.nodes_tested[2] > 0  # the room does reach layer 2
+    _run(gpu, oracle, regular)
+    _run(gpu, oracle, room)

@@ -41,6 +41,16 @@ struct wc_ctx {
     uint64_t cap;
     bool wide;
     bool general;
+    uint32_t last_splits = 256;  // roots the previous call queued for the layer-2 pass (sizes / gates that launch)
+    // the tail of the pipeline (layer-2 pass, surfel order, status read-back) is re-run by finish() when the call skipped
+    // the layer-2 launch and roots were queued for it after all
+    bool layer2_done = true;
+    int (*tail)(wc_ctx *, bool) = nullptr;
+    alignas(16) unsigned char roots_args[768];
+    uint64_t total_slots;
+    uint32_t bin_cap;
+    unsigned slot_end_bit;
+    bool fast_slots;
   } ex;
   wc_window_state *win = nullptr;
   // optional per-stage HIP events of the extraction pipeline (wc_extract_profile)

@@ -193,6 +193,8 @@ struct RootsArgs {
   const uint64_t *runs;    // RUNS mode: the sorted run composites of every bucket, [kBuckets][run_cap]
   const uint32_t *run_off; // RUNS mode: bucket-local point offset of every sorted run
   uint32_t run_cap;
+  const uint32_t *root_cnt;    // RUNS mode: live roots found by workgroup w of k_pt_bucket ...
+  const uint32_t *root_first;  // ... compacted into head table slots [root_first[w], root_first[w] + root_cnt[w])
   uint32_t nslots;
   double *cand;            // [total_slots][11] candidate cluster moments
   uint32_t *cand_meta;     // [total_slots] local node | phase << 7 | ordinal << 8
@@ -276,8 +278,54 @@ __global__ void __launch_bounds__(256) k_heads(const K *__restrict__ keys, uint6
 #endif
 
 struct SplitJob {  // a root whose layer-1 nodes need the layer-2 pass (k_roots<K, 2>)
-  uint32_t head, ncand;
+  uint32_t slot, ncand;  // head table slot of the root
   unsigned long long split1;
+};
+
+// RUNS mode work list: k_pt_bucket leaves the live roots of its workgroup w compacted in the head table (root_first /
+// root_cnt, kBuckets / 4 workgroups).  Every consumer wavefront scans the 1024 counts once (4 KB out of L2) and can then
+// turn a global root number into a head table slot: exactly one root (or three, k_roots_emit) per wavefront, instead
+// of whatever number of heads happens to fall into a fixed range of table slots (0, 1 or 2: the 2s set the kernel time).
+struct RootLocator {
+  static constexpr int PER = (kBuckets / 4) / 64;
+  uint32_t c[PER], f[PER];
+  uint32_t ex, total;
+  __device__ __forceinline__ void init(const RootsArgs &A, int lane) {
+    uint32_t sum = 0;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      c[k] = A.root_cnt[lane * PER + k];
+      f[k] = A.root_first[lane * PER + k];
+      sum += c[k];
+    }
+    uint32_t inc = sum;
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t v = __shfl_up(inc, off);
+      if (lane >= off) inc += v;
+    }
+    ex = inc - sum;
+    total = __shfl(inc, 63);
+  }
+  // head table slot of root number w (wavefront-uniform, w < total)
+  __device__ __forceinline__ uint32_t slot_of(const RootsArgs &A, uint32_t w) const {
+    const unsigned long long mask = __ballot(ex <= w);  // ex is non-decreasing over the lanes
+    const int owner = 63 - __clzll((long long)mask);
+    uint32_t rel = w - (uint32_t)__builtin_amdgcn_readlane((int)ex, owner);
+    uint32_t first = 0;
+    bool found = false;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {  // no early exit: everything stays in registers (no dependent load for root_first)
+      const uint32_t ck = (uint32_t)__builtin_amdgcn_readlane((int)c[k], owner);
+      const uint32_t fk = (uint32_t)__builtin_amdgcn_readlane((int)f[k], owner);
+      if (!found) {
+        if (rel < ck)
+          first = fk, found = true;
+        else
+          rel -= ck;
+      }
+    }
+    return first + rel;
+  }
 };
 
 // One wavefront per root voxel.  PHASE 1 streams the root + its eight layer-1 nodes (9 table rows); roots with layer-1
@@ -294,20 +342,22 @@ __global__ void __launch_bounds__(64) k_roots(RootsArgs A, const K *__restrict__
   __shared__ double s_last[ntab];
   __shared__ int s_cnt[ntab];
   __shared__ uint32_t s_ord[ntab];
-  __shared__ double s_stage[64 * 5];  // {1, t, x, y, z} of the staged chunk
+  __shared__ double s_prod[64 * kMom];  // the 11 moment terms {1, t, x, y, z, xx, xy, xz, yy, yz, zz} of every staged point
   __shared__ uint32_t s_code[64];
 
   const int lane = threadIdx.x;
   const ExParams &P = A.P;
   constexpr int B = KeyTraits<K>::bits;
   constexpr int half = 1 << (B - 1);
-  if (A.status[1] & (kFlagBucketOverflow | kFlagKeyRange)) return;  // the sort was abandoned: its outputs are not valid
+  const uint32_t njobs = (PHASE == 2) ? A.status[4] : 0u;
+  if (PHASE == 2 && blockIdx.x >= njobs) return;  // usually nothing is queued: leave before anything else is loaded
+  // (no status check: after a bin overflow the run structures are incomplete but consistent - the roots of the overflowed
+  // bucket are simply missing - and the host reruns the general path; a check would put one more dependent load in
+  // front of every wavefront)
 
-  // lane roles while streaming: lane = (level, moment); moment m = stage[ia] * stage[ib], stage = {1, t, x, y, z}
+  // lane roles while streaming: lane = (level, moment)
   const int Lq = lane / kMom;      // 0,1 used in phase 1; phase 2 uses lanes 0..10 only
   const int m = lane - Lq * kMom;
-  const int ia = (m <= 4) ? m : (m <= 7 ? 2 : (m <= 9 ? 3 : 4));
-  const int ib = (m <= 4) ? 0 : (m == 5 ? 2 : (m == 6 ? 3 : (m == 7 ? 4 : (m == 8 ? 3 : 4))));
   const int nlev = (phase == 1) ? (P.max_layer >= 1 ? 2 : 1) : 1;
   const bool act = lane < nlev * kMom;
 
@@ -315,39 +365,9 @@ __global__ void __launch_bounds__(64) k_roots(RootsArgs A, const K *__restrict__
   load_xyz(A.pts, 0, x0, y0, z0);
   const int k0x = vox(x0, P.vs), k0y = vox(y0, P.vs), k0z = vox(z0, P.vs);
 
-  // ---- work items of this wavefront ----
-  uint32_t it = 0, it_end = 0, it_step = 1;
-  if (PHASE != 2) {
-    const uint32_t per_wave = (A.nslots + gridDim.x - 1) / gridDim.x;
-    it = blockIdx.x * per_wave;
-    it_end = min((blockIdx.x + 1) * per_wave, A.nslots);
-  } else {
-    it = blockIdx.x;
-    it_end = A.status[4];
-    it_step = gridDim.x;
-  }
-  for (; it < it_end; it += (PHASE != 2 ? 64u : it_step)) {
-   HeadRec my_head{0xFFFFFFFFu, 0u, 0u, 0u};
-   unsigned long long live_mask = 1ull;
-   if (PHASE != 2) {
-     if (it + lane < it_end) my_head = A.heads[it + lane];
-     live_mask = __ballot(my_head.pos != 0xFFFFFFFFu);
-   }
-   while (live_mask) {
-    const int hb = __ffsll((long long)live_mask) - 1;
-    live_mask &= live_mask - 1;
-    HeadRec hrec;
-    uint32_t ncand = 0, emitted = 0;
-    unsigned long long split1 = 0;  // layer-1 octants that get split (tested, not a plane; cc:175-182)
-    if (PHASE != 2) {
-      hrec = HeadRec{(uint32_t)__shfl((int)my_head.pos, hb), (uint32_t)__shfl((int)my_head.gidx, hb), (uint32_t)__shfl((int)my_head.nr, hb),
-                     (uint32_t)__shfl((int)my_head.total, hb)};
-    } else {
-      const SplitJob job = A.split_jobs[it];
-      hrec = A.heads[job.head / (uint32_t)(P.min_points + 1)];
-      ncand = job.ncand;
-      split1 = job.split1;
-    }
+  // ---- one root: stream its points (PHASE 2: also test and emit) ----
+  auto do_root = [&](const HeadRec hrec, uint32_t tslot, uint32_t ncand, unsigned long long split1) {
+    uint32_t emitted = 0;
     const uint64_t head = hrec.pos;
 #ifdef WC_PROF_ROOTS
     unsigned long long tick_ = __builtin_readcyclecounter();
@@ -444,11 +464,11 @@ __global__ void __launch_bounds__(64) k_roots(RootsArgs A, const K *__restrict__
         const double c1z = cz + (double)((float)(2 * bz - 1) * q0);
         const int o1 = 4 * bx + 2 * by + bz;
         const int o2 = 4 * (px > c1x) + 2 * (py > c1y) + (pz > c1z);
-        s_stage[lane * 5 + 0] = 1.0;
-        s_stage[lane * 5 + 1] = pt;
-        s_stage[lane * 5 + 2] = px;
-        s_stage[lane * 5 + 3] = py;
-        s_stage[lane * 5 + 4] = pz;
+        // the moment terms are formed here, lane-parallel: the sequential pass below is bound by LDS reads (15 wavefronts
+        // per CU stream at once), and one 8-byte read per (point, moment) is half of what two factors would cost
+        double *pr = s_prod + lane * kMom;
+        pr[0] = 1.0, pr[1] = pt, pr[2] = px, pr[3] = py, pr[4] = pz;
+        pr[5] = px * px, pr[6] = px * py, pr[7] = px * pz, pr[8] = py * py, pr[9] = py * pz, pr[10] = pz * pz;
         s_code[lane] = (uint32_t)(o1 * 8 + o2);
         my_o1 = o1;
       }
@@ -492,22 +512,22 @@ __global__ void __launch_bounds__(64) k_roots(RootsArgs A, const K *__restrict__
             double ao = a_open, at = a_total;
 #pragma unroll 4
             for (int q = j; q < je; ++q) {
-              const double v = s_stage[q * 5 + ia] * s_stage[q * 5 + ib];
+              const double v = s_prod[q * kMom + m];
               ao += v;
               at += v;
             }
             a_open = ao;
             a_total = at;
             n_open += je - j;
-            last = s_stage[(je - 1) * 5 + 1];
+            last = s_prod[(je - 1) * kMom + 1];
           }
           j = je;
           if (j >= nvalid) break;
         }
         // ---- event point: full logic ----
         const uint32_t code = s_code[j];
-        const double t = s_stage[j * 5 + 1];
-        const double va = s_stage[j * 5 + ia], vb = s_stage[j * 5 + ib];
+        const double t = s_prod[j * kMom + 1];
+        const double v_ev = s_prod[j * kMom + m];
         ++j;
         if (phase == 2 && !((split1 >> (code >> 3)) & 1ull)) continue;  // parent layer-1 node is not split
         const int nu = (phase == 2) ? (int)code : (Lq == 0 ? 0 : 1 + (int)(code >> 3));
@@ -554,7 +574,7 @@ __global__ void __launch_bounds__(64) k_roots(RootsArgs A, const K *__restrict__
           }
         }
         if (act) {
-          const double v = va * vb;
+          const double v = v_ev;
           a_open += v;
           a_total += v;
           n_open += 1;
@@ -591,17 +611,20 @@ __global__ void __launch_bounds__(64) k_roots(RootsArgs A, const K *__restrict__
     }
     }
     if (PHASE == 1) {  // hand the node totals and the candidate count to k_roots_emit (tests + emission)
-      const uint64_t hs = head / (uint64_t)(P.min_points + 1);
-      for (int i = lane; i < ntab * kMom; i += 64) A.node_tot[hs * (9 * kMom) + i] = s_total[i];
-      if (lane == 0) A.root_ncand[hs] = ncand;
+      for (int i = lane; i < ntab * kMom; i += 64) A.node_tot[(size_t)tslot * (9 * kMom) + i] = s_total[i];
+      if (lane == 0) A.root_ncand[tslot] = ncand;
       WC_TICK(3);
+#ifdef WC_PROF_ROOTS
+      if (lane == 0 && A.prof)
+        for (int i = 0; i < 8; ++i) A.prof[(head / 21) * 8 + i] += prof_[i];
+#endif
       __syncthreads();
-      continue;
+      return;
     }
     __threadfence_block();
     __syncthreads();
     WC_TICK(3);  // write-back + open-cluster flush + fence
-    if (P.dbg & 2) continue;
+    if (P.dbg & 2) return;
 
     // ---- ONE pass of 3x3 PCAs for the node tests (InitOctoTree / CutOctoTree gates, cc:129-138, :170-183) and for
     //      the candidate clusters (ClusterSurfels' second loop, cc:32-64): lanes [0, ntab) take the nodes, the lanes
@@ -663,7 +686,34 @@ __global__ void __launch_bounds__(64) k_roots(RootsArgs A, const K *__restrict__
       for (int i = 0; i < 8; ++i) A.prof[(head / 21) * 8 + i] += prof_[i];
 #endif
     __syncthreads();
-   }
+  };
+
+  // ---- work items of this wavefront ----
+  if (PHASE == 2) {  // the queued split jobs, strided
+    for (uint32_t it = blockIdx.x; it < njobs; it += gridDim.x) {
+      const SplitJob job = A.split_jobs[it];
+      do_root(A.heads[job.slot], job.slot, job.ncand, job.split1);  // split1 = layer-1 octants that get split (cc:175-182)
+    }
+  } else if (RUNS) {  // compacted root list: one root per wavefront
+    RootLocator loc;
+    loc.init(A, lane);
+    for (uint32_t w = blockIdx.x; w < loc.total; w += gridDim.x) {
+      const uint32_t tslot = loc.slot_of(A, w);
+      do_root(A.heads[tslot], tslot, 0u, 0ull);
+    }
+  } else {  // sparse head table: every wavefront owns a contiguous range of slots
+    const uint32_t per_wave = (A.nslots + gridDim.x - 1) / gridDim.x;
+    const uint32_t it_end = min((blockIdx.x + 1) * per_wave, A.nslots);
+    for (uint32_t it = blockIdx.x * per_wave; it < it_end; it += 64) {
+      HeadRec my_head{0xFFFFFFFFu, 0u, 0u, 0u};
+      if (it + lane < it_end) my_head = A.heads[it + lane];
+      unsigned long long live_mask = __ballot(my_head.pos != 0xFFFFFFFFu);
+      while (live_mask) {
+        const int hb = __ffsll((long long)live_mask) - 1;
+        live_mask &= live_mask - 1;
+        do_root(HeadRec{(uint32_t)__shfl((int)my_head.pos, hb), 0u, 0u, 0u}, it + (uint32_t)hb, 0u, 0ull);
+      }
+    }
   }
 }
 
@@ -679,36 +729,23 @@ __global__ void __launch_bounds__(64) k_roots_emit(RootsArgs A, const K *__restr
   const ExParams &P = A.P;
   constexpr int B = KeyTraits<K>::bits;
   constexpr int half = 1 << (B - 1);
-  if (A.status[1] & (kFlagBucketOverflow | kFlagKeyRange)) return;
   const int g = lane / G, l = lane - g * G;
   double x0, y0, z0;
   load_xyz(A.pts, 0, x0, y0, z0);
   const int k0x = vox(x0, P.vs), k0y = vox(y0, P.vs), k0z = vox(z0, P.vs);
   const float q0 = P.vs_f / 4;  // quarter_length_ of the root (cc:207)
 
-  const uint32_t per_wave = (A.nslots + gridDim.x - 1) / gridDim.x;
-  const uint32_t it_end = min((blockIdx.x + 1) * per_wave, A.nslots);
-  for (uint32_t it = blockIdx.x * per_wave; it < it_end; it += 64) {
-    HeadRec my_head{0xFFFFFFFFu, 0u, 0u, 0u};
-    if (it + lane < it_end) my_head = A.heads[it + lane];
-    unsigned long long live_mask = __ballot(my_head.pos != 0xFFFFFFFFu);
-    while (live_mask) {
-      int hb = -1;  // the live head this lane's group works on
-      for (int k = 0; k < NG; ++k) {
-        if (!live_mask) break;
-        const int bit = __ffsll((long long)live_mask) - 1;
-        live_mask &= live_mask - 1;
-        if (g == k) hb = bit;
-      }
-      const uint32_t head_or = (uint32_t)__shfl((int)my_head.pos, hb < 0 ? 0 : hb);
-      const uint32_t gidx_or = (uint32_t)__shfl((int)my_head.gidx, hb < 0 ? 0 : hb);
-      bool active = g < NG && hb >= 0;
-      const uint64_t head = active ? head_or : 0;
-      const uint64_t hs = head / (uint64_t)(P.min_points + 1);
-      const uint32_t ncand = active ? A.root_ncand[hs] : 0u;
+  // one pass over up to NG roots; tslot = head table slot of this lane's group's root (~0: none)
+  auto do_roots = [&](uint32_t tslot) {
+      bool active = g < NG && tslot != 0xFFFFFFFFu;
+      HeadRec hrec{0u, 0u, 0u, 0u};
+      if (active) hrec = A.heads[tslot];
+      const uint64_t head = hrec.pos;
+      const uint32_t gidx_or = hrec.gidx;
+      const uint32_t ncand = active ? A.root_ncand[tslot] : 0u;  // side tables are indexed by table slot: no wait for hrec
       K rootkey;
       if (RUNS) {
-        const uint32_t gidx = active ? gidx_or : 0u;
+        const uint32_t gidx = gidx_or;
         rootkey = (K)key_join(gidx / A.run_cap, comp_rest(A.runs[gidx]));
       } else {
         rootkey = keys[head];
@@ -730,7 +767,7 @@ __global__ void __launch_bounds__(64) k_roots_emit(RootsArgs A, const K *__restr
         uint32_t ord = 0;
         uint64_t slot = 0;
         if (node_lane) {
-          const double *tot = A.node_tot + hs * (9 * kMom) + l * kMom;
+          const double *tot = A.node_tot + (size_t)tslot * (9 * kMom) + l * kMom;
           nu = l;
           if (tot[0] > (double)P.min_points) {
             have = true;
@@ -764,10 +801,40 @@ __global__ void __launch_bounds__(64) k_roots_emit(RootsArgs A, const K *__restr
       }
       if (active && l == 0 && split1 != 0) {  // layer-2 pass needed: queue the root for k_roots<K, 2>
         const uint32_t q = atomicAdd(&A.status[4], 1u);
-        A.split_jobs[q] = SplitJob{(uint32_t)head, ncand, (unsigned long long)split1};
+        A.split_jobs[q] = SplitJob{tslot, ncand, (unsigned long long)split1};
       }
       // without the slot histogram (general path) the surfel count is accumulated here
       if (lane == 0 && emitted && !A.slot_counts) atomicAdd(&A.status[0], emitted);
+  };
+
+  if (RUNS) {  // compacted root list: roots 3 w .. 3 w + 2
+    RootLocator loc;
+    loc.init(A, lane);
+    for (uint32_t w0 = blockIdx.x * NG; w0 < loc.total; w0 += gridDim.x * NG) {
+      uint32_t tslot = 0xFFFFFFFFu;
+      for (int k = 0; k < NG; ++k)
+        if (w0 + k < loc.total) {
+          const uint32_t sl = loc.slot_of(A, w0 + k);
+          if (g == k) tslot = sl;
+        }
+      do_roots(tslot);
+    }
+  } else {  // sparse head table: every wavefront owns a contiguous range of slots
+    const uint32_t per_wave = (A.nslots + gridDim.x - 1) / gridDim.x;
+    const uint32_t it_end = min((blockIdx.x + 1) * per_wave, A.nslots);
+    for (uint32_t it = blockIdx.x * per_wave; it < it_end; it += 64) {
+      const uint32_t my_pos = (it + lane < it_end) ? A.heads[it + lane].pos : 0xFFFFFFFFu;
+      unsigned long long live_mask = __ballot(my_pos != 0xFFFFFFFFu);
+      while (live_mask) {
+        uint32_t tslot = 0xFFFFFFFFu;
+        for (int k = 0; k < NG; ++k) {
+          if (!live_mask) break;
+          const int bit = __ffsll((long long)live_mask) - 1;
+          live_mask &= live_mask - 1;
+          if (g == k) tslot = it + (uint32_t)bit;
+        }
+        do_roots(tslot);
+      }
     }
   }
 }
@@ -809,7 +876,6 @@ __global__ void __launch_bounds__(256) k_slot_emit(const uint32_t *__restrict__ 
   __shared__ uint64_t s_item[4][kSlotBinMax];
   __shared__ uint32_t s_sorted[4][kSlotBinMax];
   __shared__ uint32_t s_red[4];
-  if (status[1] & (kFlagBucketOverflow | kFlagKeyRange)) return;
   const int t = threadIdx.x, w = t >> 6, lane = t & 63;
   const uint32_t b0 = blockIdx.x * 4u;
   uint32_t part = 0;
@@ -968,10 +1034,15 @@ __global__ void __launch_bounds__(kRunThreads) k_pt_runs(wc_points pts, double v
 
 // one wavefront per bucket (four per workgroup).  Dynamic LDS per wavefront: bin_cap x {unsorted composite, sorted
 // composite, point offset}.  Nothing is expanded to per-point arrays: the roots pass walks the runs itself.
+// The live roots (voxel segments with more than min_points points, InitOctoTree cc:129) of the workgroup go into the head
+// table COMPACTED from slot first = (points in front of the workgroup) / (min_points + 1): live root i of the workgroup
+// starts at least (min_points + 1) i points behind the workgroup's first point, so first + i never reaches the range of the
+// next workgroup - a dense work list without a global counter (root_first / root_cnt per workgroup).
 __global__ void __launch_bounds__(256) k_pt_bucket(uint64_t *bins, uint32_t bin_cap, const uint32_t *__restrict__ counts, uint32_t *run_off,
-                                                  HeadRec *head_slots, int min_points, uint32_t *status) {
+                                                  HeadRec *head_slots, uint32_t *root_cnt, uint32_t *root_first, int min_points,
+                                                  uint32_t *status) {
   extern __shared__ __align__(16) unsigned char s_dyn[];
-  __shared__ uint32_t s_red[4];
+  __shared__ uint32_t s_red[4], s_live[4];
   const int t = threadIdx.x, w = t >> 6, lane = t & 63;
   uint64_t *s_a = (uint64_t *)s_dyn + (size_t)w * bin_cap;
   uint64_t *s_b = (uint64_t *)s_dyn + (size_t)(4 + w) * bin_cap;
@@ -980,8 +1051,9 @@ __global__ void __launch_bounds__(256) k_pt_bucket(uint64_t *bins, uint32_t bin_
   const uint32_t *pcounts = counts + kBuckets;
   // everything that comes from HBM / L2 is requested up front: the bucket's own counts, its first 64 runs, and this
   // thread's share of the point counts in front of the workgroup's buckets
-  const uint32_t nb = counts[b], total = pcounts[b];
-  const uint64_t *bin = bins + (size_t)b * bin_cap;
+  uint32_t nb = counts[b];
+  const uint32_t total = pcounts[b];
+  uint64_t *bin = bins + (size_t)b * bin_cap;
   const uint64_t first = ((uint32_t)lane < min(nb, bin_cap)) ? bin[lane] : 0ull;
   uint32_t part = 0;
   for (uint32_t i = t; i < b0; i += 256) part += pcounts[i];
@@ -989,12 +1061,9 @@ __global__ void __launch_bounds__(256) k_pt_bucket(uint64_t *bins, uint32_t bin_
   for (int j = 0; j < w; ++j) before += pcounts[b0 + j];
   for (int off = 32; off >= 1; off >>= 1) part += __shfl_xor(part, off);
   if (lane == 0) s_red[w] = part;
-  __syncthreads();
-  const uint32_t pbase = s_red[0] + s_red[1] + s_red[2] + s_red[3] + before;
-  if (nb == 0) return;
   if (nb > bin_cap) {
     if (lane == 0) atomicOr(&status[1], kFlagBucketOverflow);
-    return;
+    nb = 0;  // the caller reruns the general path
   }
   if ((uint32_t)lane < nb) s_a[lane] = first;
   for (uint32_t i = lane + 64; i < nb; i += 64) s_a[i] = bin[i];
@@ -1021,23 +1090,47 @@ __global__ void __launch_bounds__(256) k_pt_bucket(uint64_t *bins, uint32_t bin_
   }
   __builtin_amdgcn_wave_barrier();
   // the sorted runs go back in place (this wavefront owns the bin), their bucket-local point offsets next to them
-  uint64_t *bin_rw = bins + (size_t)b * bin_cap;
   for (uint32_t r = lane; r < nb; r += 64) {
-    bin_rw[r] = s_b[r];
+    bin[r] = s_b[r];
     run_off[(size_t)b * bin_cap + r] = s_off[r];
   }
-  // live root heads: a voxel segment with more than min_points points (InitOctoTree cc:129); two live heads are at least
-  // min_points + 1 positions apart, so slot = position / (min_points + 1) is collision free
-  for (uint32_t r = lane; r < nb; r += 64) {
+  // live roots, pass 1: count
+  auto live_root = [&](uint32_t r, uint32_t &r2, uint32_t &seg) -> bool {
+    if (r >= nb) return false;
     const uint32_t rest = comp_rest(s_b[r]);
-    if (r > 0 && comp_rest(s_b[r - 1]) == rest) continue;
-    uint32_t r2 = r + 1;
+    if (r > 0 && comp_rest(s_b[r - 1]) == rest) return false;
+    r2 = r + 1;
     while (r2 < nb && comp_rest(s_b[r2]) == rest) ++r2;
-    const uint32_t seg = (r2 < nb ? s_off[r2] : total) - s_off[r];
-    if (seg > (uint32_t)min_points) {
-      const uint32_t pos = pbase + s_off[r];
-      head_slots[pos / (uint32_t)(min_points + 1)] = HeadRec{pos, b * bin_cap + r, r2 - r, seg};
+    seg = (r2 < nb ? s_off[r2] : total) - s_off[r];
+    return seg > (uint32_t)min_points;
+  };
+  uint32_t nlive = 0;
+  for (uint32_t r0 = 0; r0 < nb; r0 += 64) {
+    uint32_t r2, seg;
+    nlive += (uint32_t)__popcll(__ballot(live_root(r0 + lane, r2, seg)));
+  }
+  if (lane == 0) s_live[w] = nlive;
+  __syncthreads();
+  const uint32_t pbase0 = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+  const uint32_t pbase = pbase0 + before;
+  const uint32_t first_slot = pbase0 / (uint32_t)(min_points + 1);
+  uint32_t lbase = 0;
+  for (int j = 0; j < w; ++j) lbase += s_live[j];
+  if (t == 0) {
+    root_cnt[blockIdx.x] = s_live[0] + s_live[1] + s_live[2] + s_live[3];
+    root_first[blockIdx.x] = first_slot;
+  }
+  // pass 2: write the records
+  for (uint32_t r0 = 0; r0 < nb; r0 += 64) {
+    const uint32_t r = r0 + lane;
+    uint32_t r2 = 0, seg = 0;
+    const bool live = live_root(r, r2, seg);
+    const unsigned long long m = __ballot(live);
+    if (live) {
+      const uint32_t i = lbase + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+      head_slots[first_slot + i] = HeadRec{pbase + s_off[r], b * bin_cap + r, r2 - r, seg};
     }
+    lbase += (uint32_t)__popcll(m);
   }
 }
 
@@ -1058,7 +1151,7 @@ int point_sort_runs(wc_ctx *ctx, const wc_points &pts, double vs, HeadRec *head_
   const uint64_t n = pts.n;
   const uint32_t cap = pt_bin_cap(n);
   WC_TRY(wc_ensure(ctx, ctx->b_misc[1], (uint64_t)kBuckets * cap * 8));  // run bins
-  WC_TRY(wc_ensure(ctx, ctx->b_misc[2], 2 * kBuckets * 4));             // run counts | point counts
+  WC_TRY(wc_ensure(ctx, ctx->b_misc[2], (2 * kBuckets + 2 * (kBuckets / 4)) * 4));  // run counts | point counts | root_cnt | root_first
   WC_TRY(wc_ensure(ctx, ctx->b_misc[3], (uint64_t)kBuckets * cap * 4));  // point offsets of the sorted runs
   uint32_t *counts = (uint32_t *)ctx->b_misc[2].p;
   const unsigned tiles = (unsigned)((n + kTile - 1) / kTile);
@@ -1069,8 +1162,8 @@ int point_sort_runs(wc_ctx *ctx, const wc_points &pts, double vs, HeadRec *head_
     attr_set = true;
   }
   k_pt_runs<<<tiles, kRunThreads, 0, st>>>(pts, vs, n, counts, (uint64_t *)ctx->b_misc[1].p, cap, status);
-  k_pt_bucket<<<kBuckets / 4, 256, lds, st>>>((uint64_t *)ctx->b_misc[1].p, cap, counts, (uint32_t *)ctx->b_misc[3].p, head_slots, min_points,
-                                             status);
+  k_pt_bucket<<<kBuckets / 4, 256, lds, st>>>((uint64_t *)ctx->b_misc[1].p, cap, counts, (uint32_t *)ctx->b_misc[3].p, head_slots,
+                                             counts + 2 * kBuckets, counts + 2 * kBuckets + kBuckets / 4, min_points, status);
   WC_HIP(ctx, hipGetLastError());
   return WC_OK;
 }
@@ -1085,6 +1178,44 @@ int sort_pairs(wc_ctx *ctx, K *kin, K *kout, uint32_t *vin, uint32_t *vout, size
   WC_TRY(wc_ensure(ctx, ctx->b_sorttmp, tmp));
   tmp = ctx->b_sorttmp.cap;
   WC_HIP(ctx, rocprim::radix_sort_pairs<cfg>(ctx->b_sorttmp.p, tmp, kin, kout, vin, vout, n, 0u, end_bit, ctx->stream));
+  return WC_OK;
+}
+
+// layer-2 pass of the queued roots (optional), time order + gather of the surfels, status read-back
+template <typename K, bool RUNS>
+int pipeline_tail(wc_ctx *ctx, bool layer2) {
+  hipStream_t st = ctx->stream;
+  RootsArgs A;
+  memcpy(&A, ctx->ex.roots_args, sizeof(A));
+  uint32_t *status = A.status;
+  wc_surfel *d_out = ctx->ex.d_out;
+  wc_surfel_id *d_ids = ctx->ex.d_ids;
+  const uint64_t cap = ctx->ex.cap, total_slots = ctx->ex.total_slots;
+  auto mark = [&](int i) {
+    if (ctx->ex_prof) (void)hipEventRecord(ctx->ex_ev[i], st);
+  };
+  if (layer2) {
+    const unsigned grid2 = std::min(kRoots2Grid, std::max(64u, ctx->ex.last_splits));  // sized by the previous call's queue
+    k_roots<K, 2, RUNS><<<grid2, 64, 0, st>>>(A, (const K *)ctx->b_keys[1].p);
+  }
+  ctx->ex.layer2_done = layer2;
+  mark(4);
+  if (ctx->ex.fast_slots) {
+    k_slot_emit<<<kBuckets / 4, 256, 0, st>>>((const uint32_t *)ctx->b_misc[4].p, A.slot_bins, ctx->ex.bin_cap, (const wc_surfel *)ctx->b_slots.p,
+                                             (const wc_surfel_id *)ctx->b_slot_ids.p, status, d_out, d_ids, cap);
+  } else {
+    k_iota<<<(unsigned)((total_slots + 255) / 256), 256, 0, st>>>((uint32_t *)ctx->b_slot_idx[0].p, total_slots);
+    WC_TRY(sort_pairs<uint64_t>(ctx, (uint64_t *)ctx->b_slot_keys[0].p, (uint64_t *)ctx->b_slot_keys[1].p,
+                                (uint32_t *)ctx->b_slot_idx[0].p, (uint32_t *)ctx->b_slot_idx[1].p, total_slots,
+                                ctx->ex.slot_end_bit));
+    const uint64_t gth = std::min<uint64_t>(total_slots, cap) * 10;
+    if (gth)
+      k_gather<<<(unsigned)((gth + 255) / 256), 256, 0, st>>>((const uint32_t *)ctx->b_slot_idx[1].p, (const wc_surfel *)ctx->b_slots.p,
+                                                             (const wc_surfel_id *)ctx->b_slot_ids.p, status, d_out, d_ids, cap);
+  }
+  mark(5);
+  WC_HIP(ctx, hipMemcpyAsync(ctx->h_status, status, 32, hipMemcpyDeviceToHost, st));
+  WC_HIP(ctx, hipGetLastError());
   return WC_OK;
 }
 
@@ -1142,7 +1273,7 @@ int run_pipeline(wc_ctx *ctx, const wc_points &pts, double t_lo, double t_hi, wc
   const bool fast_pts = fast && sizeof(K) == 4;
   if (fast_pts || fast_slots) {
     WC_TRY(wc_ensure(ctx, ctx->b_slot_keys[1], (uint64_t)kBuckets * bin_cap * 8));  // slot bins (the general path's sort buffer)
-    WC_TRY(wc_ensure(ctx, ctx->b_misc[2], 2 * kBuckets * 4));
+    WC_TRY(wc_ensure(ctx, ctx->b_misc[2], (2 * kBuckets + 2 * (kBuckets / 4)) * 4));
   }
   const uint32_t nslots = (uint32_t)(n / (uint64_t)(P.min_points + 1) + 1);
   {
@@ -1151,23 +1282,21 @@ int run_pipeline(wc_ctx *ctx, const wc_points &pts, double t_lo, double t_hi, wc
     auto fill = [&](void *p, uint64_t words, uint32_t v) { I.p[r] = (uint32_t *)p, I.nw[r] = (uint32_t)words, I.val[r] = v, ++r; };
     fill(status, 64, 0u);
     if (!fast_slots) fill(ctx->b_slot_keys[0].p, total_slots * 2, 0xFFFFFFFFu);  // slot keys: ~0 = no surfel in the slot
-    fill(ctx->b_misc[0].p, (uint64_t)nslots * 4, 0xFFFFFFFFu);                  // head slot table: pos = ~0 = no live head
+    if (!fast_pts) fill(ctx->b_misc[0].p, (uint64_t)nslots * 4, 0xFFFFFFFFu);   // sparse head slot table: pos = ~0 = no live head
     if (fast_slots) fill(ctx->b_misc[4].p, 2 * kBuckets, 0u);                   // slot bucket counts (filled by k_roots) + cursors
     if (fast_pts) fill(ctx->b_misc[2].p, 2 * kBuckets, 0u);                     // point-sort run counts | point counts
     uint32_t mx = 0;
     for (int q = 0; q < r; ++q) mx = std::max(mx, I.nw[q]);
     k_init<<<(mx + 255) / 256, 256, 0, st>>>(I);
   }
+  mark(1);
   if (fast_pts) {
-    mark(1);
     WC_TRY(point_sort_runs(ctx, pts, E.vs, (HeadRec *)ctx->b_misc[0].p, P.min_points, status));  // also fills the head slot table
   } else {
     k_keygen<K><<<g256, 256, 0, st>>>(pts, E.vs, (K *)ctx->b_keys[0].p, (uint32_t *)ctx->b_vals[0].p, status);
-    mark(1);
     WC_TRY(sort_pairs<K>(ctx, (K *)ctx->b_keys[0].p, (K *)ctx->b_keys[1].p, (uint32_t *)ctx->b_vals[0].p,
                          (uint32_t *)ctx->b_vals[1].p, n, 3 * KeyTraits<K>::bits));
   }
-  mark(2);
   RootsArgs A;
   A.pts = pts;
   A.P = E;
@@ -1186,10 +1315,13 @@ int run_pipeline(wc_ctx *ctx, const wc_points &pts, double t_lo, double t_hi, wc
   A.runs = (const uint64_t *)ctx->b_misc[1].p;
   A.run_off = (const uint32_t *)ctx->b_misc[3].p;
   A.run_cap = pt_bin_cap(n);
+  A.root_cnt = (const uint32_t *)ctx->b_misc[2].p + 2 * kBuckets;
+  A.root_first = A.root_cnt + kBuckets / 4;
   A.slot_bin_cap = bin_cap;
   A.heads = (const HeadRec *)ctx->b_misc[0].p;
   A.nslots = nslots;
   if (!fast_pts) k_heads<K><<<g256, 256, 0, st>>>((const K *)ctx->b_keys[1].p, n, P.min_points, (HeadRec *)ctx->b_misc[0].p);
+  mark(2);
   WC_TRY(wc_ensure(ctx, ctx->b_misc[5], (size_t)A.nslots * sizeof(SplitJob)));
   A.split_jobs = (SplitJob *)ctx->b_misc[5].p;
   A.prof = nullptr;
@@ -1205,34 +1337,25 @@ int run_pipeline(wc_ctx *ctx, const wc_points &pts, double t_lo, double t_hi, wc
   if (fast_pts) {
     if constexpr (sizeof(K) == 4) {
       k_roots<K, 1, true><<<kRootsGrid, 64, 0, st>>>(A, skeys);  // stream root + layer 1
+      mark(3);
       k_roots_emit<K, true><<<kEmitGrid, 64, 0, st>>>(A, skeys);  // node tests + emission
-      k_roots<K, 2, true><<<kRoots2Grid, 64, 0, st>>>(A, skeys);  // layer 2 of the split nodes (rare)
     }
   } else {
     k_roots<K, 1, false><<<kRootsGrid, 64, 0, st>>>(A, skeys);
+    mark(3);
     k_roots_emit<K, false><<<kEmitGrid, 64, 0, st>>>(A, skeys);
-    k_roots<K, 2, false><<<kRoots2Grid, 64, 0, st>>>(A, skeys);
   }
-  mark(3);
-  if (fast_slots) {
-    k_slot_emit<<<kBuckets / 4, 256, 0, st>>>((const uint32_t *)ctx->b_misc[4].p, A.slot_bins, bin_cap, (const wc_surfel *)ctx->b_slots.p,
-                                             (const wc_surfel_id *)ctx->b_slot_ids.p, status, d_out, d_ids, cap);
-    mark(4);
-  } else {
-    k_iota<<<(unsigned)((total_slots + 255) / 256), 256, 0, st>>>((uint32_t *)ctx->b_slot_idx[0].p, total_slots);
-    WC_TRY(sort_pairs<uint64_t>(ctx, (uint64_t *)ctx->b_slot_keys[0].p, (uint64_t *)ctx->b_slot_keys[1].p,
-                                (uint32_t *)ctx->b_slot_idx[0].p, (uint32_t *)ctx->b_slot_idx[1].p, total_slots,
-                                slot_end_bit));
-    mark(4);
-    const uint64_t gth = std::min<uint64_t>(total_slots, cap) * 10;
-    if (gth)
-      k_gather<<<(unsigned)((gth + 255) / 256), 256, 0, st>>>((const uint32_t *)ctx->b_slot_idx[1].p, (const wc_surfel *)ctx->b_slots.p,
-                                                             (const wc_surfel_id *)ctx->b_slot_ids.p, status, d_out, d_ids, cap);
-  }
-  mark(5);
-  WC_HIP(ctx, hipMemcpyAsync(ctx->h_status, status, 8, hipMemcpyDeviceToHost, st));
-  WC_HIP(ctx, hipGetLastError());
-  return WC_OK;
+  static_assert(sizeof(RootsArgs) <= sizeof(ctx->ex.roots_args), "ctx.h: roots_args too small");
+  memcpy(ctx->ex.roots_args, &A, sizeof(A));
+  ctx->ex.total_slots = total_slots;
+  ctx->ex.bin_cap = bin_cap;
+  ctx->ex.slot_end_bit = slot_end_bit;
+  ctx->ex.fast_slots = fast_slots;
+  ctx->ex.tail = fast_pts ? &pipeline_tail<K, (sizeof(K) == 4)> : &pipeline_tail<K, false>;
+  // On regular scenes no root is queued for the layer-2 pass, and even an idle launch of it costs ~4.5 us: it is skipped
+  // when the previous call queued nothing (consecutive sweeps look alike); finish() runs the tail again if that guess
+  // was wrong.
+  return ctx->ex.tail(ctx, ctx->ex.last_splits > 0);
 }
 
 }  // namespace
@@ -1290,7 +1413,13 @@ extern "C" int wc_extract_surfels_finish(wc_ctx *ctx, uint64_t *h_n_out) {
     WC_TRY(run_pipeline<uint64_t>(ctx, ctx->ex.pts, ctx->ex.t_lo, ctx->ex.t_hi, ctx->ex.d_out, ctx->ex.d_ids, ctx->ex.cap, false));
     WC_HIP(ctx, hipStreamSynchronize(ctx->stream));
   }
+  if (!ctx->ex.layer2_done && ctx->h_status[4] > 0 && ctx->ex.tail) {  // roots were queued for the skipped layer-2 pass
+    ctx->ex.last_splits = ctx->h_status[4];
+    WC_TRY(ctx->ex.tail(ctx, true));
+    WC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
   const uint32_t flags = ctx->h_status[1];
+  ctx->ex.last_splits = ctx->h_status[4];
   if (h_n_out) *h_n_out = ctx->h_status[0];
   if (flags & kFlagKeyRange) return wc_fail(ctx, WC_ERR_ARG, "point cloud extent exceeds 2^20 root voxels");
   if (flags & kFlagSlotOverflow) return wc_fail(ctx, WC_ERR_HIP, "internal: candidate slot overflow");

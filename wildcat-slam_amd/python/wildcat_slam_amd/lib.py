@@ -165,7 +165,7 @@ class Context:
     def extract_stage_ms(self):
         ms = (C.c_float * 5)()
         self._ck(self.lib.wc_extract_stage_ms(self.h, ms))
-        return dict(zip(("keygen", "point_sort", "roots", "slot_sort", "gather"), [float(v) for v in ms]))
+        return dict(zip(("init", "point_sort", "roots_stream", "roots_emit", "slot_order"), [float(v) for v in ms]))
 
     def extract_surfels(self, points, hint=True, cap=None):
         """host convenience: upload POINT array, extract, download -> (surfels, ids)"""
