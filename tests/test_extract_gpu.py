@@ -120,3 +120,23 @@ def test_layer2_pass_after_a_sweep_without_splits(gpu, oracle):
     assert st.nodes_tested[2] > 0  # the room does reach layer 2
     _run(gpu, oracle, regular)
     _run(gpu, oracle, room)
+
+
+def test_wide_time_hint_overflows_time_bins_and_falls_back(gpu, oracle):
+    # a time hint a thousand times wider than the sweep puts every surfel into one of the 4096 time bins: the bin overflows and
+    # the call is completed with the radix sort of the slot keys
+    pts, _ = synth.g2_lattice(300, m=32)
+    t0, t1 = float(pts["time"][0]), float(pts["time"][-1])
+    _run(gpu, oracle, pts, hint=(t0 - 1.0, t1 + 2000.0))
+    _run(gpu, oracle, pts)
+
+
+def test_unordered_sweep_uses_radix_path_and_stays_there(gpu, oracle):
+    # spinning multi-beam order (consecutive points come from different beams): no run structure, bins overflow; the calls that
+    # follow start on the radix-sort path directly and must give the same result
+    room = synth.g1_room(400_000, seed=11)
+    for _ in range(3):
+        _run(gpu, oracle, room)
+    regular, _ = synth.g2_lattice(200, m=32)
+    for _ in range(18):  # long enough for the fast path to be tried again
+        _run(gpu, oracle, regular)

@@ -35,8 +35,8 @@ constexpr unsigned kRootsGrid = 256 * 16;  // wavefronts of the layer-0/1 pass (
 constexpr unsigned kEmitGrid = 256 * 8;   // wavefronts of the node-test + emission pass (three roots at a time each)
 constexpr unsigned kRoots2Grid = 256 * 4;  // wavefronts of the (rare) layer-2 pass
 constexpr int kBuckets = 4096;    // buckets of the composite sorts
-constexpr int kTile = 4096;       // items per workgroup in the histogram / scatter passes
-constexpr uint32_t kFlagKeyRange = 1u, kFlagSlotOverflow = 2u, kFlagTimeRange = 4u, kFlagBucketOverflow = 8u;
+constexpr int kTile = 2048;       // points per workgroup of k_pt_runs
+constexpr uint32_t kFlagKeyRange = 1u, kFlagSlotOverflow = 2u, kFlagTimeRange = 4u, kFlagBucketOverflow = 8u, kFlagSlotBinOverflow = 16u;
 
 struct ExParams {
   double vs;           // (double)voxel_size
@@ -890,7 +890,7 @@ __global__ void __launch_bounds__(256) k_slot_emit(const uint32_t *__restrict__ 
   const uint32_t c = w == 0 ? c0 : (w == 1 ? c1 : (w == 2 ? c2 : c3));
   if (c == 0) return;
   if (c > bin_cap) {
-    if (lane == 0) atomicOr(&status[1], kFlagBucketOverflow);
+    if (lane == 0) atomicOr(&status[1], kFlagSlotBinOverflow);
     return;
   }
   const uint64_t *bin = bins + (size_t)(b0 + w) * bin_cap;
@@ -957,7 +957,7 @@ __global__ void __launch_bounds__(256) k_init(InitArgs I) {
 
 // counts = run counts [kBuckets] | point counts [kBuckets].  1024 threads per 4096-point tile: one tile per CU is all a
 // 1 M-point sweep offers, so the latency hiding has to come from wavefronts of the same workgroup.
-constexpr int kRunThreads = 1024;
+constexpr int kRunThreads = 512;
 __global__ void __launch_bounds__(kRunThreads) k_pt_runs(wc_points pts, double vs, uint64_t n, uint32_t *counts, uint64_t *bins,
                                                         uint32_t bin_cap, uint32_t *status) {
   __shared__ uint32_t s_key[kTile];
@@ -1221,7 +1221,7 @@ int pipeline_tail(wc_ctx *ctx, bool layer2) {
 
 template <typename K>
 int run_pipeline(wc_ctx *ctx, const wc_points &pts, double t_lo, double t_hi, wc_surfel *d_out, wc_surfel_id *d_ids,
-                 uint64_t cap, bool fast) {
+                 uint64_t cap, bool fast, bool fast_order) {
   const wc_params &P = ctx->P;
   const uint64_t n = pts.n;
   hipStream_t st = ctx->stream;
@@ -1263,7 +1263,7 @@ int run_pipeline(wc_ctx *ctx, const wc_points &pts, double t_lo, double t_hi, wc
     if (ctx->ex_prof) (void)hipEventRecord(ctx->ex_ev[i], st);
   };
   mark(0);
-  const bool fast_slots = fast && tbits <= 31 && total_slots < (1ull << 31);
+  const bool fast_slots = fast_order && tbits <= 31 && total_slots < (1ull << 31);
   // capacity of a time bucket's bin: twice the count every bucket would get if EVERY slot held a surfel, 64 at least
   uint32_t bin_cap = 64;
   while (bin_cap < kSlotBinMax && (uint64_t)bin_cap * kBuckets < 2 * total_slots) bin_cap *= 2;
@@ -1391,8 +1391,12 @@ extern "C" int wc_extract_surfels_enqueue(wc_ctx *ctx, const wc_points *pts, dou
   }
   ctx->ex.t_lo = t_lo;
   ctx->ex.t_hi = t_hi;
-  ctx->ex.general = false;
-  return run_pipeline<uint32_t>(ctx, *pts, t_lo, t_hi, d_out, d_ids, cap, getenv("WC_NO_BUCKET_SORT") == nullptr);
+  // after a bin overflow of the run-binned point sort (very many points in few voxels, or points in no spatial order)
+  // the next calls go to the radix-sort path directly; the fast path is tried again every 16th call
+  ctx->ex.general = ctx->ex.general_calls > 0 || getenv("WC_NO_BUCKET_SORT") != nullptr;
+  if (ctx->ex.general_calls > 0) --ctx->ex.general_calls;
+  ctx->ex.order_general = false;
+  return run_pipeline<uint32_t>(ctx, *pts, t_lo, t_hi, d_out, d_ids, cap, !ctx->ex.general, true);
 }
 
 extern "C" int wc_extract_surfels_finish(wc_ctx *ctx, uint64_t *h_n_out) {
@@ -1402,15 +1406,25 @@ extern "C" int wc_extract_surfels_finish(wc_ctx *ctx, uint64_t *h_n_out) {
   if (ctx->ex.pts.n == 0) return WC_OK;
   WC_HIP(ctx, hipStreamSynchronize(ctx->stream));
   if ((ctx->h_status[1] & kFlagBucketOverflow) && !(ctx->h_status[1] & kFlagKeyRange) && !ctx->ex.general) {
-    // a bucket of the fast sort overflowed (very many points in few voxels): redo with the general radix sort
+    // a bin of the run-binned point sort overflowed: redo with the general radix sort
     ctx->ex.general = true;
-    WC_TRY(run_pipeline<uint32_t>(ctx, ctx->ex.pts, ctx->ex.t_lo, ctx->ex.t_hi, ctx->ex.d_out, ctx->ex.d_ids, ctx->ex.cap, false));
+    ctx->ex.general_calls = 15;
+    WC_TRY(run_pipeline<uint32_t>(ctx, ctx->ex.pts, ctx->ex.t_lo, ctx->ex.t_hi, ctx->ex.d_out, ctx->ex.d_ids, ctx->ex.cap, false, true));
     WC_HIP(ctx, hipStreamSynchronize(ctx->stream));
   }
   if ((ctx->h_status[1] & kFlagKeyRange) && !ctx->ex.wide) {
     // the sweep spans more than +-512 root voxels around its first point: redo with 21-bit-per-axis keys
     ctx->ex.wide = true;
-    WC_TRY(run_pipeline<uint64_t>(ctx, ctx->ex.pts, ctx->ex.t_lo, ctx->ex.t_hi, ctx->ex.d_out, ctx->ex.d_ids, ctx->ex.cap, false));
+    WC_TRY(run_pipeline<uint64_t>(ctx, ctx->ex.pts, ctx->ex.t_lo, ctx->ex.t_hi, ctx->ex.d_out, ctx->ex.d_ids, ctx->ex.cap, false, true));
+    WC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  if ((ctx->h_status[1] & kFlagSlotBinOverflow) && !ctx->ex.order_general) {
+    // very many surfels inside one 1/4096 of the sweep's time span: redo with the radix sort of the slot keys
+    ctx->ex.order_general = true;
+    if (ctx->ex.wide)
+      WC_TRY(run_pipeline<uint64_t>(ctx, ctx->ex.pts, ctx->ex.t_lo, ctx->ex.t_hi, ctx->ex.d_out, ctx->ex.d_ids, ctx->ex.cap, false, false));
+    else
+      WC_TRY(run_pipeline<uint32_t>(ctx, ctx->ex.pts, ctx->ex.t_lo, ctx->ex.t_hi, ctx->ex.d_out, ctx->ex.d_ids, ctx->ex.cap, !ctx->ex.general, false));
     WC_HIP(ctx, hipStreamSynchronize(ctx->stream));
   }
   if (!ctx->ex.layer2_done && ctx->h_status[4] > 0 && ctx->ex.tail) {  // roots were queued for the skipped layer-2 pass

@@ -168,13 +168,16 @@ class Context:
         return dict(zip(("init", "point_sort", "roots_stream", "roots_emit", "slot_order"), [float(v) for v in ms]))
 
     def extract_surfels(self, points, hint=True, cap=None):
-        """host convenience: upload POINT array, extract, download -> (surfels, ids)"""
+        """host convenience: upload POINT array, extract, download -> (surfels, ids).  hint: True = the sweep's own time range,
+        False = none (the library reads it back), (t_lo, t_hi) = explicit range"""
         n = len(points)
         cap = cap or max(1024, (3 * n) // 20 + 1)
         d_pts = self.to_device(points) if n else self.alloc(48)
         d_out, d_ids = self.alloc(cap * 144), self.alloc(cap * 16)
         desc = self.points_desc(d_pts, n)
-        if hint and n:
+        if isinstance(hint, tuple):
+            t_lo, t_hi = hint
+        elif hint and n:
             t_lo, t_hi = float(points["time"][0]), float(points["time"][-1])
         else:
             t_lo, t_hi = 1.0, 0.0
