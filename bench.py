@@ -117,10 +117,10 @@ def main():
     algo_bytes = 20 * n_pts + 144 * exp_surfels  # 20 B read per point + 144 B written per surfel
     dom_ms = stages[dom]
     achieved = algo_bytes / (dom_ms * 1e-3) / 1e9
-    kernel_names = {"init": "k_init", "point_sort": "k_pt_runs + k_pt_bucket", "roots_stream": "k_roots<1>",
-                    "roots_emit": "k_roots_emit + k_roots<2>", "slot_order": "k_slot_emit"}
+    kernel_names = {"init": "k_init", "point_sort": "k_pt_runs + k_pt_bucket", "roots_stream": "k_roots<unsigned int, 1, true>",
+                    "roots_emit": "k_roots_emit<unsigned int, true>", "slot_order": "k_slot_emit"}
     roofline = {"bound": "hbm", "kernel": kernel_names[dom], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "algorithmic_bytes_per_launch": algo_bytes,
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(kernel_names[dom]), "algorithmic_bytes_per_launch": algo_bytes,
                 "avg_kernel_ms": round(dom_ms, 5),
                 "whole_pipeline_frac": round(algo_bytes / (sum(stages.values()) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
 
@@ -169,6 +169,26 @@ def main():
     ctx.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` (reads x2-corrected + writes) from the newest committed PMC summary
+    (profiles/<tag>_pmc.json, written by profiles/summarize.py from separate rocprofv3 --pmc passes); None if absent."""
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")))
+    if not files:
+        return None
+    try:
+        ks = json.load(open(files[-1]))["kernels"]
+    except Exception:
+        return None
+    tot = 0
+    for name in kernel.split(" + "):
+        if name not in ks:
+            return None
+        tot += ks[name]["read_bytes_per_launch"] + ks[name]["write_bytes_per_launch"]
+    return tot
 
 
 def bench_window(ctx, args, world, rank, dev, torch, dist):

@@ -52,10 +52,16 @@ with open(os.path.join(out, f"{tag}_pmc.md"), "w") as f:
         for r in csv.DictReader(open(p)):
             if r["Counter_Name"] == ctr:
                 vals[short(r["Kernel_Name"])][ctr].append(float(r["Counter_Value"]))
+    traffic = {}
     for k, v in sorted(vals.items(), key=lambda kv: -sum(kv[1]["FETCH_SIZE"] or [0])):
         fe = sum(v["FETCH_SIZE"]) / max(1, len(v["FETCH_SIZE"]))
         wr = sum(v["WRITE_SIZE"]) / max(1, len(v["WRITE_SIZE"]))
         f.write(f"| `{k}` | {len(v['FETCH_SIZE'])} | {fe:.0f} | {2 * fe * 1024 / 1e6:.1f} | {wr:.0f} | {wr * 1024 / 1e6:.1f} |\n")
+        traffic[k] = {"read_bytes_per_launch": round(2 * fe * 1024), "write_bytes_per_launch": round(wr * 1024),
+                      "launches_sampled": len(v["FETCH_SIZE"])}
+# per-kernel HBM traffic (x2-corrected reads + writes) for bench.py's roofline.traffic field
+json.dump({"source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, profiles/collect.sh {tag}; reads x2 (gfx950 correction)",
+           "kernels": traffic}, open(os.path.join(out, f"{tag}_pmc.json"), "w"), indent=1)
 bj = os.path.join(src, "bench.json")
 if os.path.exists(bj):
     line = [l for l in open(bj) if l.startswith("{")][-1]
