@@ -648,65 +648,117 @@ __device__ __forceinline__ double readlane_d(double v, int src_lane) {  // src_l
   return __longlong_as_double(((long long)hi << 32) | (long long)(unsigned int)lo);
 }
 
-__device__ __forceinline__ bool factor_inv32_regs(double (*sB)[kNB + 1], double (*sXi)[kNB + 1]) {
-  const int lane = threadIdx.x & 63;
-  const int r = lane & 31;
-  const bool upper = lane >= 32;
-  double a[kNB];
-#pragma unroll
-  for (int c = 0; c < kNB; ++c) a[c] = upper ? (c == r ? 1.0 : 0.0) : sB[r][c];
-  double my_inv = 0.0;
+// 32x32 diagonal block: L (Cholesky) and L^-1, by the whole workgroup (256 threads), in LDS, in EIGHT block steps of four
+// columns instead of 32 single-column steps: what bounds this routine is the number of dependent LDS round trips and
+// barriers on the pivot chain, not arithmetic (a single-wavefront version with one step per column measured 13-28 us
+// per block, register resident or not).  Per block step every thread factors and inverts the 4x4 pivot block
+// redundantly in registers (no communication), 32 threads solve their row of the 4-column panel, 32 threads form the
+// four new rows of L^-1 (forward substitution on 4-row blocks, one column each), then everybody applies the rank-4 update.
+// in: sB rows 0..31 (lower part).  out: sB = L (lower, zeros above), sXi = L^-1.  Returns false on a non-positive pivot.
+__device__ __forceinline__ double rsqrt_nr(double a) {
+  double inv = __builtin_amdgcn_rsq(a);
+  inv = inv * (1.5 - 0.5 * a * inv * inv);
+  inv = inv * (1.5 - 0.5 * a * inv * inv);
+  return inv;
+}
+
+__device__ __forceinline__ bool factor_inv32_blk(double (*sB)[kNB + 1], double (*sXi)[kNB + 1]) {
+  const int tid = threadIdx.x;
+  for (int e = tid; e < kNB * kNB; e += 256) sXi[e / kNB][e % kNB] = 0.0;
   bool ok = true;
-#pragma unroll
-  for (int j = 0; j < kNB; ++j) {
-    const double ajj = readlane_d(a[j], j);
-    if (!(ajj > 0.0)) ok = false;
-    double inv = __builtin_amdgcn_rsq(ajj);
-    inv = inv * (1.5 - 0.5 * ajj * inv * inv);
-    inv = inv * (1.5 - 0.5 * ajj * inv * inv);
-    if (r == j) my_inv = inv;
-    const double lj = a[j] * inv;            // lower lanes: L[r][j]
-    if (!upper) a[j] = lj;
-    const double lrj = __shfl(lj, r);        // upper lane 32+r fetches L[r][j] from lane r
-    const double multL = upper ? 0.0 : lj;
-    const double multU = (upper && r > j) ? lrj * inv : 0.0;
-#pragma unroll
-    for (int c = 0; c < kNB; ++c) {
-      if (c > j) {
-        const double lcj = readlane_d(lj, c);  // L[c][j]
-        a[c] -= multL * lcj;                   // trailing update of the block (rows r >= c are the meaningful ones)
+  __syncthreads();
+  for (int j0 = 0; j0 < kNB; j0 += 4) {
+    // ---- 4x4 pivot block: factor + inverse, every thread on its own ----
+    const double p00 = sB[j0][j0], p10 = sB[j0 + 1][j0], p11 = sB[j0 + 1][j0 + 1], p20 = sB[j0 + 2][j0], p21 = sB[j0 + 2][j0 + 1],
+                 p22 = sB[j0 + 2][j0 + 2], p30 = sB[j0 + 3][j0], p31 = sB[j0 + 3][j0 + 1], p32 = sB[j0 + 3][j0 + 2],
+                 p33 = sB[j0 + 3][j0 + 3];
+    const double i00 = rsqrt_nr(p00);
+    const double l00 = p00 * i00, l10 = p10 * i00, l20 = p20 * i00, l30 = p30 * i00;
+    const double d1 = p11 - l10 * l10;
+    const double i11 = rsqrt_nr(d1);
+    const double l11 = d1 * i11, l21 = (p21 - l20 * l10) * i11, l31 = (p31 - l30 * l10) * i11;
+    const double d2 = p22 - l20 * l20 - l21 * l21;
+    const double i22 = rsqrt_nr(d2);
+    const double l22 = d2 * i22, l32 = (p32 - l30 * l20 - l31 * l21) * i22;
+    const double d3 = p33 - l30 * l30 - l31 * l31 - l32 * l32;
+    const double i33 = rsqrt_nr(d3);
+    const double l33 = d3 * i33;
+    if (!(p00 > 0.0 && d1 > 0.0 && d2 > 0.0 && d3 > 0.0)) ok = false;
+    const double i10 = -(l10 * i00) * i11;
+    const double i21 = -(l21 * i11) * i22;
+    const double i20 = -(l20 * i00 + l21 * i10) * i22;
+    const double i32 = -(l32 * i22) * i33;
+    const double i31 = -(l31 * i11 + l32 * i21) * i33;
+    const double i30 = -(l30 * i00 + l31 * i10 + l32 * i20) * i33;
+    __syncthreads();  // everybody has read the pivot block before its rows are overwritten
+    if (tid < kNB) {
+      // ---- the 4-column panel: row r of L = row r of A times Lp^-T; the pivot rows become Lp ----
+      const int r = tid;
+      if (r >= j0 + 4) {
+        const double v0 = sB[r][j0], v1 = sB[r][j0 + 1], v2 = sB[r][j0 + 2], v3 = sB[r][j0 + 3];
+        sB[r][j0] = v0 * i00;
+        sB[r][j0 + 1] = v0 * i10 + v1 * i11;
+        sB[r][j0 + 2] = v0 * i20 + v1 * i21 + v2 * i22;
+        sB[r][j0 + 3] = v0 * i30 + v1 * i31 + v2 * i32 + v3 * i33;
+      } else if (r >= j0) {
+        const int a = r - j0;
+        sB[r][j0] = a == 0 ? l00 : (a == 1 ? l10 : (a == 2 ? l20 : l30));
+        sB[r][j0 + 1] = a == 0 ? 0.0 : (a == 1 ? l11 : (a == 2 ? l21 : l31));
+        sB[r][j0 + 2] = a <= 1 ? 0.0 : (a == 2 ? l22 : l32);
+        sB[r][j0 + 3] = a <= 2 ? 0.0 : l33;
       } else {
-        const double bjc = readlane_d(a[c], 32 + j);  // unscaled row j of the inverse-in-progress
-        a[c] -= multU * bjc;                   // forward elimination applied to the identity
+        sB[r][j0] = sB[r][j0 + 1] = sB[r][j0 + 2] = sB[r][j0 + 3] = 0.0;  // above the diagonal
       }
+    } else if (tid < 2 * kNB) {
+      // ---- rows j0..j0+3 of X = L^-1, column c: w = e - L[rows][0..j0) X[0..j0)[c], then X[rows][c] = Lp^-1 w ----
+      // (the rows of L left of the pivot block are final since the earlier block steps)
+      const int c = tid - kNB;
+      double w0 = (c == j0) ? 1.0 : 0.0, w1 = (c == j0 + 1) ? 1.0 : 0.0, w2 = (c == j0 + 2) ? 1.0 : 0.0, w3 = (c == j0 + 3) ? 1.0 : 0.0;
+      for (int m2 = 0; m2 < j0; ++m2) {
+        const double x = sXi[m2][c];
+        w0 -= sB[j0][m2] * x;
+        w1 -= sB[j0 + 1][m2] * x;
+        w2 -= sB[j0 + 2][m2] * x;
+        w3 -= sB[j0 + 3][m2] * x;
+      }
+      sXi[j0][c] = i00 * w0;
+      sXi[j0 + 1][c] = i10 * w0 + i11 * w1;
+      sXi[j0 + 2][c] = i20 * w0 + i21 * w1 + i22 * w2;
+      sXi[j0 + 3][c] = i30 * w0 + i31 * w1 + i32 * w2 + i33 * w3;
     }
-  }
-#pragma unroll
-  for (int c = 0; c < kNB; ++c) {
-    if (upper)
-      sXi[r][c] = (c <= r) ? a[c] * my_inv : 0.0;
-    else
-      sB[r][c] = (c <= r) ? a[c] : 0.0;
+    __syncthreads();
+    // ---- rank-4 update of the trailing lower triangle ----
+    for (int e = tid; e < kNB * kNB; e += 256) {
+      const int r = e / kNB, c = e % kNB;
+      if (c >= j0 + 4 && c <= r)
+        sB[r][c] -= sB[r][j0] * sB[c][j0] + sB[r][j0 + 1] * sB[c][j0 + 1] + sB[r][j0 + 2] * sB[c][j0 + 2] + sB[r][j0 + 3] * sB[c][j0 + 3];
+    }
+    __syncthreads();
   }
   return ok;
 }
 
-__global__ void __launch_bounds__(64) k_chol_first(const double *A, int ld, double *Lmat, double *Linv, int *fail) {
+__global__ void __launch_bounds__(256) k_chol_first(const double *A, int ld, double *Lmat, double *Linv, int *fail) {
   __shared__ double sB[kNB][kNB + 1];
   __shared__ double sXi[kNB][kNB + 1];
-  for (int e = threadIdx.x; e < kNB * kNB; e += 64) sB[e / kNB][e % kNB] = A[(size_t)(e / kNB) * ld + e % kNB];
+  for (int e = threadIdx.x; e < kNB * kNB; e += 256) sB[e / kNB][e % kNB] = A[(size_t)(e / kNB) * ld + e % kNB];
   __syncthreads();
-  if (!factor_inv32_regs(sB, sXi)) {
+  if (!factor_inv32_blk(sB, sXi)) {
     if (threadIdx.x == 0) atomicOr(fail, 1);
   }
   __syncthreads();
-  for (int e = threadIdx.x; e < kNB * kNB; e += 64) {
+  for (int e = threadIdx.x; e < kNB * kNB; e += 256) {
     const int r = e / kNB, c = e % kNB;
     Lmat[(size_t)r * ld + c] = sB[r][c];
     Linv[e] = sXi[r][c];
   }
 }
 
+#ifdef WC_PROF_CHOL  // -DWC_PROF_CHOL: phase timers of the lead tile (the critical path of the factorisation), printed at step 20
+#define WC_CT(i) ct_[i] = clock64()
+#else
+#define WC_CT(i)
+#endif
 __global__ void __launch_bounds__(256) k_chol_step(double *A, int ld, int k, int nblk, double *Lmat, double *Linv, int *fail) {
   __shared__ double sA[64][kNB + 1];
   __shared__ double sLi[64][kNB + 1];
@@ -714,7 +766,12 @@ __global__ void __launch_bounds__(256) k_chol_step(double *A, int ld, int k, int
   __shared__ double sX[kNB][kNB + 1];
   const int ti = blockIdx.y, tj = blockIdx.x;
   if (tj > ti) return;
+#ifdef WC_PROF_CHOL
+  long long ct_[8];
+#endif
+  WC_CT(0);
   if (*fail) return;
+  WC_CT(1);
   const int tid = threadIdx.x;
   const int nrow = nblk * kNB;
   const int first = (k + 1) * kNB;
@@ -723,14 +780,19 @@ __global__ void __launch_bounds__(256) k_chol_step(double *A, int ld, int k, int
   // L_kk^-1 was left behind by the previous launch (tile (0,0) factors and inverts the next diagonal block in registers)
   for (int e = tid; e < kNB * kNB; e += 256) sX[e / kNB][e % kNB] = Linv[(size_t)k * kNB * kNB + e];
   // L rows of this tile's row range: Li = A[row0.., panel] * Linv^T
-  for (int e = tid; e < 64 * kNB; e += 256) {
-    const int r = e / kNB, c = e % kNB;
-    sA[r][c] = (row0 + r < nrow) ? A[(size_t)(row0 + r) * ld + pc + c] : 0.0;
+#pragma unroll
+  for (int e0 = 0; e0 < 64 * kNB; e0 += 256) {
+    const int e = e0 + tid, r = e / kNB, c = e % kNB;
+    const bool in = row0 + r < nrow;
+    const double v = A[(size_t)(in ? row0 + r : first) * ld + pc + c];
+    sA[r][c] = in ? v : 0.0;
   }
   __syncthreads();
+  WC_CT(2);
   {
     const int r = tid >> 2, c0 = (tid & 3) * 8;
     double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll 4
     for (int m2 = 0; m2 < kNB; ++m2) {
       const double a = sA[r][m2];
 #pragma unroll
@@ -745,13 +807,17 @@ __global__ void __launch_bounds__(256) k_chol_step(double *A, int ld, int k, int
   }
   __syncthreads();
   if (ti != tj) {
-    for (int e = tid; e < 64 * kNB; e += 256) {
-      const int r = e / kNB, c = e % kNB;
-      sA[r][c] = (col0 + r < nrow) ? A[(size_t)(col0 + r) * ld + pc + c] : 0.0;
+#pragma unroll
+    for (int e0 = 0; e0 < 64 * kNB; e0 += 256) {
+      const int e = e0 + tid, r = e / kNB, c = e % kNB;
+      const bool in = col0 + r < nrow;
+      const double v = A[(size_t)(in ? col0 + r : first) * ld + pc + c];
+      sA[r][c] = in ? v : 0.0;
     }
     __syncthreads();
     const int r = tid >> 2, c0 = (tid & 3) * 8;
     double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll 4
     for (int m2 = 0; m2 < kNB; ++m2) {
       const double a = sA[r][m2];
 #pragma unroll
@@ -763,9 +829,11 @@ __global__ void __launch_bounds__(256) k_chol_step(double *A, int ld, int k, int
     for (int e = tid; e < 64 * kNB; e += 256) sLj[e / kNB][e % kNB] = sLi[e / kNB][e % kNB];
   }
   __syncthreads();
+  WC_CT(3);
   // trailing update of this tile: A_ij -= Li Lj^T, 4x4 outputs per thread
   const int tr = (tid / 16) * 4, tc = (tid % 16) * 4;
   double acc[4][4] = {{0}};
+#pragma unroll 4
   for (int m2 = 0; m2 < kNB; ++m2) {
     double a[4], b[4];
 #pragma unroll
@@ -778,24 +846,42 @@ __global__ void __launch_bounds__(256) k_chol_step(double *A, int ld, int k, int
 #pragma unroll
       for (int q = 0; q < 4; ++q) acc[p][q] += a[p] * b[q];
   }
+  WC_CT(4);
   const bool lead = (ti == 0 && tj == 0);
+  // all 16 loads first, then the stores: written as one read-modify-write per element the stores order the later
+  // loads behind them (same array) and a tile pays 16 dependent HBM/L2 round trips (17 us of a 42 us step, measured)
+  double old[4][4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int r = row0 + tr + p, c = col0 + tc + q;
+      const bool in = r < nrow && c <= r;  // unconditional load from a clamped address: a guarded load is a branch per element
+      old[p][q] = A[in ? (size_t)r * ld + c : (size_t)first * ld + first];
+    }
 #pragma unroll
   for (int p = 0; p < 4; ++p)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int r = row0 + tr + p, c = col0 + tc + q;
       if (r < nrow && c <= r) {
-        const double v = A[(size_t)r * ld + c] - acc[p][q];
+        const double v = old[p][q] - acc[p][q];
         A[(size_t)r * ld + c] = v;
         if (lead && tr + p < kNB && tc + q < kNB) sA[tr + p][tc + q] = v;  // next diagonal block (lower part)
       }
     }
   if (!lead) return;
+  WC_CT(5);
   // look-ahead: factor + invert the next diagonal block right away (one wavefront, register resident)
   __syncthreads();
-  bool ok = true;
-  if (tid < 64) ok = factor_inv32_regs(sA, sLi);  // rows 0..31 of sA hold the block; the inverse lands in sLi
+  const bool ok = factor_inv32_blk(sA, sLi);  // rows 0..31 of sA hold the block; the inverse lands in sLi
   __syncthreads();
+  WC_CT(6);
+#ifdef WC_PROF_CHOL
+  if (tid == 0 && k == 20)
+    printf("chol step 20, lead tile, shader clocks: fail-check %lld loads %lld trsm %lld mac %lld rmw %lld factor %lld\n", ct_[1] - ct_[0], ct_[2] - ct_[1],
+           ct_[3] - ct_[2], ct_[4] - ct_[3], ct_[5] - ct_[4], ct_[6] - ct_[5]);
+#endif
   if (tid == 0 && !ok) atomicOr(fail, 1);
   for (int e = tid; e < kNB * kNB; e += 256) {
     const int r = e / kNB, c = e % kNB;
@@ -1300,7 +1386,7 @@ extern "C" int wc_window_solve(wc_ctx *ctx, double *h_x_inout, wc_solve_summary 
         dim3 grid((np + 255) / 256, np);
         k_damp<<<grid, 256, 0, st>>>(H, g, scale, n, np, ld, radius, A, diag);
       }
-      k_chol_first<<<1, 64, 0, st>>>(A, ld, Lmat, (double *)W->Linv.p, fail);
+      k_chol_first<<<1, 256, 0, st>>>(A, ld, Lmat, (double *)W->Linv.p, fail);
       for (int k = 0; k + 1 < nblk; ++k) {
         const int tiles = ((nblk - k - 1) * kNB + 63) / 64;
         k_chol_step<<<dim3(tiles, tiles), 256, 0, st>>>(A, ld, k, nblk, Lmat, (double *)W->Linv.p, fail);
