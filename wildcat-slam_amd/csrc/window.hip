@@ -655,16 +655,19 @@ __device__ __forceinline__ double readlane_d(double v, int src_lane) {  // src_l
 // redundantly in registers (no communication), 32 threads solve their row of the 4-column panel, 32 threads form the
 // four new rows of L^-1 (forward substitution on 4-row blocks, one column each), then everybody applies the rank-4 update.
 // in: sB rows 0..31 (lower part).  out: sB = L (lower, zeros above), sXi = L^-1.  Returns false on a non-positive pivot.
+using f64x4 = __attribute__((ext_vector_type(4))) double;
+
 __device__ __forceinline__ double rsqrt_nr(double a) {
-  double inv = __builtin_amdgcn_rsq(a);
-  inv = inv * (1.5 - 0.5 * a * inv * inv);
-  inv = inv * (1.5 - 0.5 * a * inv * inv);
+  double inv = __builtin_amdgcn_rsq(a);  // ~2^-26 relative; one Newton step squares that, the second is insurance the
+  inv = inv * (1.5 - 0.5 * a * inv * inv);  // pivot chain cannot afford (every dependent fp64 op costs ~25-30 clk here)
   return inv;
 }
 
 __device__ __forceinline__ bool factor_inv32_blk(double (*sB)[kNB + 1], double (*sXi)[kNB + 1]) {
   const int tid = threadIdx.x;
-  for (int e = tid; e < kNB * kNB; e += 256) sXi[e / kNB][e % kNB] = 0.0;
+  // sXi starts as the identity: rows below the current block step hold W = E - L X (right-looking substitution), rows
+  // at or above it the finished rows of X = L^-1
+  for (int e = tid; e < kNB * kNB; e += 256) sXi[e / kNB][e % kNB] = (e / kNB == e % kNB) ? 1.0 : 0.0;
   bool ok = true;
   __syncthreads();
   for (int j0 = 0; j0 < kNB; j0 += 4) {
@@ -710,28 +713,23 @@ __device__ __forceinline__ bool factor_inv32_blk(double (*sB)[kNB + 1], double (
         sB[r][j0] = sB[r][j0 + 1] = sB[r][j0 + 2] = sB[r][j0 + 3] = 0.0;  // above the diagonal
       }
     } else if (tid < 2 * kNB) {
-      // ---- rows j0..j0+3 of X = L^-1, column c: w = e - L[rows][0..j0) X[0..j0)[c], then X[rows][c] = Lp^-1 w ----
-      // (the rows of L left of the pivot block are final since the earlier block steps)
+      // ---- rows j0..j0+3 of X = Lp^-1 times the same rows of W, one column per thread (columns right of the block: zero) ----
       const int c = tid - kNB;
-      double w0 = (c == j0) ? 1.0 : 0.0, w1 = (c == j0 + 1) ? 1.0 : 0.0, w2 = (c == j0 + 2) ? 1.0 : 0.0, w3 = (c == j0 + 3) ? 1.0 : 0.0;
-      for (int m2 = 0; m2 < j0; ++m2) {
-        const double x = sXi[m2][c];
-        w0 -= sB[j0][m2] * x;
-        w1 -= sB[j0 + 1][m2] * x;
-        w2 -= sB[j0 + 2][m2] * x;
-        w3 -= sB[j0 + 3][m2] * x;
-      }
+      const double w0 = sXi[j0][c], w1 = sXi[j0 + 1][c], w2 = sXi[j0 + 2][c], w3 = sXi[j0 + 3][c];
       sXi[j0][c] = i00 * w0;
       sXi[j0 + 1][c] = i10 * w0 + i11 * w1;
       sXi[j0 + 2][c] = i20 * w0 + i21 * w1 + i22 * w2;
       sXi[j0 + 3][c] = i30 * w0 + i31 * w1 + i32 * w2 + i33 * w3;
     }
     __syncthreads();
-    // ---- rank-4 update of the trailing lower triangle ----
+    // ---- rank-4 updates: the trailing lower triangle of the block, and W below the block step (columns 0..j0+3) ----
     for (int e = tid; e < kNB * kNB; e += 256) {
       const int r = e / kNB, c = e % kNB;
-      if (c >= j0 + 4 && c <= r)
-        sB[r][c] -= sB[r][j0] * sB[c][j0] + sB[r][j0 + 1] * sB[c][j0 + 1] + sB[r][j0 + 2] * sB[c][j0 + 2] + sB[r][j0 + 3] * sB[c][j0 + 3];
+      if (r >= j0 + 4) {
+        const double a0 = sB[r][j0], a1 = sB[r][j0 + 1], a2 = sB[r][j0 + 2], a3 = sB[r][j0 + 3];
+        if (c >= j0 + 4 && c <= r) sB[r][c] -= a0 * sB[c][j0] + a1 * sB[c][j0 + 1] + a2 * sB[c][j0 + 2] + a3 * sB[c][j0 + 3];
+        if (c < j0 + 4) sXi[r][c] -= a0 * sXi[j0][c] + a1 * sXi[j0 + 1][c] + a2 * sXi[j0 + 2][c] + a3 * sXi[j0 + 3][c];
+      }
     }
     __syncthreads();
   }
@@ -789,20 +787,29 @@ __global__ void __launch_bounds__(256) k_chol_step(double *A, int ld, int k, int
   }
   __syncthreads();
   WC_CT(2);
-  {
-    const int r = tid >> 2, c0 = (tid & 3) * 8;
-    double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll 4
-    for (int m2 = 0; m2 < kNB; ++m2) {
-      const double a = sA[r][m2];
+  // The two small GEMMs of a tile run on the fp64 matrix cores: v_mfma_f64_16x16x4 takes A[i = l & 15][k = l >> 4] and
+  // B[k = l >> 4][j = l & 15] as ONE double per lane, i.e. one LDS read per lane feeds 16 x 16 x 4 products; the scalar
+  // loops (9 LDS reads per 8 products, 8 per 16) were LDS-bandwidth bound at 3.4 us each.  fp64 MFMA runs at the fp64 vector
+  // rate - the gain is operand reuse.  Wavefront w owns rows 16 w .. 16 w + 15 of the tile.
+  const int w = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+  {  // Li = A[rows, panel] * Linv^T  (64 x 32, K = 32)
+    f64x4 t0 = {0.0, 0.0, 0.0, 0.0}, t1 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-      for (int q = 0; q < 8; ++q) acc[q] += a * sX[c0 + q][m2];
+    for (int ks = 0; ks < kNB / 4; ++ks) {
+      const double a = sA[16 * w + li][4 * ks + lk];
+      t0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, sX[li][4 * ks + lk], t0, 0, 0, 0);
+      t1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, sX[16 + li][4 * ks + lk], t1, 0, 0, 0);
     }
+    // D layout of the fp64 form: register r of lane l is element (row = (l >> 4) + 4 r, col = l & 15)
 #pragma unroll
-    for (int q = 0; q < 8; ++q) sLi[r][c0 + q] = acc[q];
-    if (tj == 0 && row0 + r < nrow) {
-#pragma unroll
-      for (int q = 0; q < 8; ++q) Lmat[(size_t)(row0 + r) * ld + pc + c0 + q] = acc[q];
+    for (int r4 = 0; r4 < 4; ++r4) {
+      const int r = 16 * w + lk + 4 * r4;
+      sLi[r][li] = t0[r4];
+      sLi[r][16 + li] = t1[r4];
+      if (tj == 0 && row0 + r < nrow) {
+        Lmat[(size_t)(row0 + r) * ld + pc + li] = t0[r4];
+        Lmat[(size_t)(row0 + r) * ld + pc + 16 + li] = t1[r4];
+      }
     }
   }
   __syncthreads();
@@ -815,59 +822,57 @@ __global__ void __launch_bounds__(256) k_chol_step(double *A, int ld, int k, int
       sA[r][c] = in ? v : 0.0;
     }
     __syncthreads();
-    const int r = tid >> 2, c0 = (tid & 3) * 8;
-    double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll 4
-    for (int m2 = 0; m2 < kNB; ++m2) {
-      const double a = sA[r][m2];
+    f64x4 t0 = {0.0, 0.0, 0.0, 0.0}, t1 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-      for (int q = 0; q < 8; ++q) acc[q] += a * sX[c0 + q][m2];
+    for (int ks = 0; ks < kNB / 4; ++ks) {
+      const double a = sA[16 * w + li][4 * ks + lk];
+      t0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, sX[li][4 * ks + lk], t0, 0, 0, 0);
+      t1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, sX[16 + li][4 * ks + lk], t1, 0, 0, 0);
     }
 #pragma unroll
-    for (int q = 0; q < 8; ++q) sLj[r][c0 + q] = acc[q];
+    for (int r4 = 0; r4 < 4; ++r4) {
+      sLj[16 * w + lk + 4 * r4][li] = t0[r4];
+      sLj[16 * w + lk + 4 * r4][16 + li] = t1[r4];
+    }
   } else {
     for (int e = tid; e < 64 * kNB; e += 256) sLj[e / kNB][e % kNB] = sLi[e / kNB][e % kNB];
   }
+  // the tile's old values: requested before the update GEMM so that the round trip hides behind it.  Unconditional
+  // loads from clamped addresses (a guarded load is a branch per element), all of them before the first store (a store to
+  // the same array orders every later load behind it: 16 dependent round trips, 17 us of a 42 us step, measured)
+  double old[4][4];
+#pragma unroll
+  for (int tq = 0; tq < 4; ++tq)
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) {
+      const int r = row0 + 16 * w + lk + 4 * r4, c = col0 + 16 * tq + li;
+      const bool in = r < nrow && c <= r;
+      old[tq][r4] = A[in ? (size_t)r * ld + c : (size_t)first * ld + first];
+    }
   __syncthreads();
   WC_CT(3);
-  // trailing update of this tile: A_ij -= Li Lj^T, 4x4 outputs per thread
-  const int tr = (tid / 16) * 4, tc = (tid % 16) * 4;
-  double acc[4][4] = {{0}};
-#pragma unroll 4
-  for (int m2 = 0; m2 < kNB; ++m2) {
-    double a[4], b[4];
+  // trailing update of this tile: A_ij -= Li Lj^T (64 x 64, K = 32)
+  f64x4 acc[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      a[q] = sLi[tr + q][m2];
-      b[q] = sLj[tc + q][m2];
-    }
+  for (int tq = 0; tq < 4; ++tq) acc[tq] = f64x4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int p = 0; p < 4; ++p)
+  for (int ks = 0; ks < kNB / 4; ++ks) {
+    const double a = sLi[16 * w + li][4 * ks + lk];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) acc[p][q] += a[p] * b[q];
+    for (int tq = 0; tq < 4; ++tq) acc[tq] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, sLj[16 * tq + li][4 * ks + lk], acc[tq], 0, 0, 0);
   }
   WC_CT(4);
   const bool lead = (ti == 0 && tj == 0);
-  // all 16 loads first, then the stores: written as one read-modify-write per element the stores order the later
-  // loads behind them (same array) and a tile pays 16 dependent HBM/L2 round trips (17 us of a 42 us step, measured)
-  double old[4][4];
 #pragma unroll
-  for (int p = 0; p < 4; ++p)
+  for (int tq = 0; tq < 4; ++tq)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int r = row0 + tr + p, c = col0 + tc + q;
-      const bool in = r < nrow && c <= r;  // unconditional load from a clamped address: a guarded load is a branch per element
-      old[p][q] = A[in ? (size_t)r * ld + c : (size_t)first * ld + first];
-    }
-#pragma unroll
-  for (int p = 0; p < 4; ++p)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int r = row0 + tr + p, c = col0 + tc + q;
+    for (int r4 = 0; r4 < 4; ++r4) {
+      const int rl = 16 * w + lk + 4 * r4, cl = 16 * tq + li;
+      const int r = row0 + rl, c = col0 + cl;
       if (r < nrow && c <= r) {
-        const double v = old[p][q] - acc[p][q];
+        const double v = old[tq][r4] - acc[tq][r4];
         A[(size_t)r * ld + c] = v;
-        if (lead && tr + p < kNB && tc + q < kNB) sA[tr + p][tc + q] = v;  // next diagonal block (lower part)
+        if (lead && rl < kNB && cl < kNB) sA[rl][cl] = v;  // next diagonal block (lower part)
       }
     }
   if (!lead) return;
