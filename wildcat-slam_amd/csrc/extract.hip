@@ -717,6 +717,373 @@ __global__ void __launch_bounds__(64) k_roots(RootsArgs A, const K *__restrict__
   }
 }
 
+// ---- streaming for sweeps WITHOUT run structure (the radix-sort path) --------------------------------------------------
+// A spinning multi-beam lidar interleaves its beams: consecutive points of a voxel come from different octants, so in
+// k_roots above almost every point is an "event" (the cached layer-1 accumulators go through LDS, ~350 clk per point)
+// and the largest voxel of the sweep (thousands of points, one wavefront) sets the kernel time.  Here every accumulator
+// lives in a register for the whole root: lanes 0..10 carry the 11 moment sums of the LEVEL node (PHASE 1: the root;
+// PHASE 2: unused), lanes 11..54 those of the eight CHILD nodes of the pass (PHASE 1: the layer-1 octants; PHASE 2:
+// the layer-2 children of ONE split octant per pass over the points): four lane groups of 11, child s in register bank
+// A and child s + 4 in bank B.  A point costs one LDS read and two to four EXEC-masked fp64 adds whatever its octant is;
+// which lanes add is decided on the scalar unit from ballot masks formed once per 64-point chunk.  Same sums in the same
+// order as k_roots, hence the same bits.
+__device__ __forceinline__ double readlane_d(double v, int src_lane) {  // src_lane must be wave-uniform: v_readlane_b32 x2
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
+  return __hiloint2double(hi, lo);
+}
+
+// a += v, b += v on the lanes of `mask` only, as two EXEC-masked adds (the wavefront is fully active around it)
+__device__ __forceinline__ void masked_add2(double &a, double &b, double v, unsigned long long mask_in) {
+  // the mask is wave-uniform by construction (ballots, scalar shifts); readfirstlane pins it to SGPRs where the compiler's
+  // uniformity analysis gives up (it folds away where the value already is scalar)
+  const unsigned long long mask = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(mask_in >> 32)) << 32) |
+                                  (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)mask_in);
+  unsigned long long saved;
+  asm volatile(
+      "s_mov_b64 %0, exec\n\t"
+      "s_mov_b64 exec, %4\n\t"
+      "v_add_f64 %1, %1, %3\n\t"
+      "v_add_f64 %2, %2, %3\n\t"
+      "s_mov_b64 exec, %0"
+      : "=&s"(saved), "+v"(a), "+v"(b)
+      : "v"(v), "s"(mask));
+}
+
+// both banks of a point in one block: (a0, a1) += v on the lanes of mask_a, (b0, b1) += v on the lanes of mask_b
+__device__ __forceinline__ void masked_add4(double &a0, double &a1, double &b0, double &b1, double v, unsigned long long mask_a,
+                                            unsigned long long mask_b) {
+  unsigned long long saved;
+  asm volatile(
+      "s_mov_b64 %0, exec\n\t"
+      "s_mov_b64 exec, %6\n\t"
+      "v_add_f64 %1, %1, %5\n\t"
+      "v_add_f64 %2, %2, %5\n\t"
+      "s_mov_b64 exec, %7\n\t"
+      "v_add_f64 %3, %3, %5\n\t"
+      "v_add_f64 %4, %4, %5\n\t"
+      "s_mov_b64 exec, %0"
+      : "=&s"(saved), "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1)
+      : "v"(v), "s"(mask_a), "s"(mask_b));
+}
+__device__ __forceinline__ unsigned long long readlane_u64(uint32_t lo, uint32_t hi, int src_lane) {
+  return ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)hi, src_lane) << 32) |
+         (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)lo, src_lane);
+}
+
+template <typename K, int PHASE>
+__global__ void __launch_bounds__(64) k_roots_banks(RootsArgs A, const K *__restrict__ keys) {
+  constexpr int phase = PHASE;
+  constexpr int ntab = (phase == 1) ? 9 : 64;
+  __shared__ double s_total[(PHASE == 2) ? 64 * kMom : 1];  // PHASE 2: totals of the 64 layer-2 nodes for the fused tests
+  __shared__ double s_prod[64 * kMom];                      // the 11 moment terms of every staged point
+  const int lane = threadIdx.x;
+  const ExParams &P = A.P;
+  constexpr int B = KeyTraits<K>::bits;
+  constexpr int half = 1 << (B - 1);
+  const uint32_t njobs = (PHASE == 2) ? A.status[4] : 0u;
+  if (PHASE == 2 && blockIdx.x >= njobs) return;
+
+  const bool is_lvl = (PHASE == 1) && lane < kMom;
+  const int l1 = lane - kMom;
+  const int my_slot = (lane >= kMom && lane < 5 * kMom) ? l1 / kMom : 7;  // 7: no child group
+  const int m = is_lvl ? lane : (my_slot < 4 ? l1 - my_slot * kMom : 0);
+  const bool use_children = (PHASE == 2) || P.max_layer >= 1;
+  const unsigned long long lvl_mask = (PHASE == 1) ? ((1ull << kMom) - 1ull) : 0ull;
+
+  double x0, y0, z0;
+  load_xyz(A.pts, 0, x0, y0, z0);
+  const int k0x = vox(x0, P.vs), k0y = vox(y0, P.vs), k0z = vox(z0, P.vs);
+
+  auto do_root = [&](const uint64_t head, uint32_t tslot, uint32_t ncand, unsigned long long split1) __attribute__((always_inline)) {
+    uint32_t emitted = 0;
+    const K rootkey = keys[head];
+    const int kx = (int)(rootkey & ((K(1) << B) - 1)) - half + k0x;
+    const int ky = (int)((rootkey >> B) & ((K(1) << B) - 1)) - half + k0y;
+    const int kz = (int)((rootkey >> (2 * B)) & ((K(1) << B) - 1)) - half + k0z;
+    const double cx = (0.5 + kx) * P.vs_f, cy = (0.5 + ky) * P.vs_f, cz = (0.5 + kz) * P.vs_f;
+    const float q0 = P.vs_f / 4;  // quarter_length_ of the root (cc:207)
+    const uint64_t slot_base = (head * (uint64_t)(P.max_layer + 1)) / (uint64_t)P.cluster_min;
+    const uint32_t cand_begin = ncand;
+
+    // a temporal cluster of node nu ends (ClusterSurfels' first loop, cc:22-29): clusters with fewer than cluster_min points
+    // are dropped (cc:33), the others become candidates; `cnt_lane` is the m = 0 lane of the node (its sum is the count).
+    // (The sums are passed by value: a reference bound to bank A in one call and bank B in another turns into a pointer
+    // select after inlining and drags the sums into scratch memory.)
+    auto end_cluster = [&](bool lanes, int nu, double ao, uint32_t ord, int cnt_lane) __attribute__((always_inline)) {
+      const int cnt = (int)readlane_d(ao, cnt_lane);
+      if (cnt >= P.cluster_min) {
+        const uint64_t slot = slot_base + ncand;
+        if (slot < A.total_slots) {
+          if (lanes) {
+            A.cand[slot * kMom + m] = ao;
+            if (m == 0) A.cand_meta[slot] = (uint32_t)nu | ((uint32_t)(phase - 1) << 7) | (ord << 8);
+          }
+        } else if (lane == 0) {
+          atomicOr(&A.status[1], kFlagSlotOverflow);
+        }
+        ++ncand;
+      }
+    };
+
+    // ---- one pass over the root's points.  so < 0 (PHASE 1): every point feeds the level node and the child o1;
+    //      so >= 0 (PHASE 2): only the points of layer-1 octant so, child = their layer-2 octant o2.
+    //      (The sums are locals of the lambda, returned by value: captured by reference they would stay memory objects.) ----
+    struct Totals {
+      double a, b;
+    };
+    auto stream_pass = [&](const int so) __attribute__((always_inline)) -> Totals {
+      double aoA = 0.0, atA = 0.0, aoB = 0.0, atB = 0.0;  // open-cluster / node-total sums, banks A and B
+      uint32_t ordA = 0, ordB = 0;                        // cluster ordinals of the nodes this lane feeds
+      double carry_t = 0.0;   // lane o < 8: time of the last point of child o so far
+      bool carry_has = false;
+      double prev_t = 0.0;    // time of the previous point of the level node
+      bool have_prev = false;
+      // two-stage software pipeline over the 64-point chunks: (key, index) of chunk c + 2 and the points of chunk c + 1
+      // are in flight while chunk c is processed, so no step of the dependent chain key -> index -> point is waited for
+      // inside the loop (the loads are unconditional from clamped positions; validity is decided when they are used)
+      uint64_t pos = head + lane;
+      const uint64_t last = A.n - 1;
+      K kcur = keys[min(pos, last)];
+      uint32_t icur = A.vals[min(pos, last)];
+      K knext = keys[min(pos + 64, last)];
+      uint32_t inext = A.vals[min(pos + 64, last)];
+      bool valid = pos < A.n && kcur == rootkey;
+      double px = 0, py = 0, pz = 0, pt = 0;
+      if (valid) {
+        load_xyz(A.pts, icur, px, py, pz);
+        pt = load_t(A.pts, icur);
+      }
+      while (true) {
+        const int nvalid = __popcll(__ballot(valid));  // valid lanes are a prefix: keys are sorted
+        if (nvalid == 0) break;
+        __builtin_amdgcn_wave_barrier();
+        int node = 0;
+        bool in = false;
+        if (valid) {
+          // octant = 4*[x>cx] + 2*[y>cy] + [z>cz] (strict >, cc:147-158); child centre = centre +- quarter (cc:163-165)
+          const int bx = px > cx, by = py > cy, bz = pz > cz;
+          const int o1 = 4 * bx + 2 * by + bz;
+          if (so < 0) {
+            node = o1;
+            in = true;
+          } else {
+            const double c1x = cx + (double)((float)(2 * bx - 1) * q0);
+            const double c1y = cy + (double)((float)(2 * by - 1) * q0);
+            const double c1z = cz + (double)((float)(2 * bz - 1) * q0);
+            node = 4 * (px > c1x) + 2 * (py > c1y) + (pz > c1z);
+            in = (o1 == so);
+          }
+          double *pr = s_prod + lane * kMom;
+          pr[0] = 1.0, pr[1] = pt, pr[2] = px, pr[3] = py, pr[4] = pz;
+          pr[5] = px * px, pr[6] = px * py, pr[7] = px * pz, pr[8] = py * py, pr[9] = py * pz, pr[10] = pz * pz;
+        }
+        // cluster boundaries, lane-parallel: a new cluster starts at a point whose gap to the previous point OF THE SAME
+        // NODE exceeds cluster_gap (cc:24).  Predecessor inside the chunk: highest lower lane with the same child.
+        const unsigned long long IN = __ballot(in);
+        unsigned long long mymask = 0, lanemask = 0;  // lanemask: for lane o < 8 the points of child o (carry update)
+#pragma unroll
+        for (int o = 0; o < 8; ++o) {
+          const unsigned long long mo = __ballot(in && node == o);
+          if (node == o) mymask = mo;
+          if (lane == o) lanemask = mo;
+        }
+        const unsigned long long below = mymask & ((1ull << lane) - 1ull);
+        const int pred = below ? 63 - __clzll((long long)below) : 0;
+        const double t_in = __shfl(pt, pred);
+        const double t_ca = __shfl(carry_t, node);
+        const bool has_ca = __shfl((int)carry_has, node) != 0;
+        const bool g1 = in && (below ? (pt - t_in > P.gap) : (has_ca && pt - t_ca > P.gap));
+        const unsigned long long G1 = use_children ? __ballot(g1) : 0ull;
+        unsigned long long G0 = 0;
+        if (PHASE == 1) {
+          double t_pv = __shfl_up(pt, 1);
+          bool has_pv = true;
+          if (lane == 0) t_pv = prev_t, has_pv = have_prev;
+          G0 = __ballot(valid && has_pv && (pt - t_pv > P.gap));
+          prev_t = __shfl(pt, nvalid - 1);
+          have_prev = true;
+        }
+        {  // carries for the next chunk
+          const int hi = lanemask ? 63 - __clzll((long long)lanemask) : 0;
+          const double t_hi = __shfl(pt, hi);
+          if (lane < 8 && lanemask) carry_t = t_hi, carry_has = true;
+        }
+        // lane q: the two EXEC masks of point q - the lanes that add it into bank A (level node | child group, children
+        // 0..3) and into bank B (child group, children 4..7); the loop below fetches them with four v_readlane
+        unsigned long long kid = (in && use_children) ? (((1ull << kMom) - 1ull) << (kMom + kMom * (node & 3))) : 0ull;
+        const unsigned long long mB = (node & 4) ? kid : 0ull;
+        const unsigned long long mA = ((PHASE == 1 && valid) ? lvl_mask : 0ull) | ((node & 4) ? 0ull : kid);
+        const uint32_t mAlo = (uint32_t)mA, mAhi = (uint32_t)(mA >> 32), mBlo = (uint32_t)mB, mBhi = (uint32_t)(mB >> 32);
+        const int code = node;
+        __builtin_amdgcn_wave_barrier();
+        // the next chunk's points (their key / index arrived during the previous chunk), and key / index of the one after
+        bool nvalid_next = false;
+        if (nvalid == 64) {
+          pos += 64;
+          nvalid_next = pos < A.n && knext == rootkey;
+          if (nvalid_next) {
+            load_xyz(A.pts, inext, px, py, pz);
+            pt = load_t(A.pts, inext);
+          }
+          knext = keys[min(pos + 64, last)];
+          inext = A.vals[min(pos + 64, last)];
+        }
+
+        // ---- the sequential pass: time order.  Points between two cluster ends run through a branch-free body: four
+        //      v_readlane for the masks, one LDS read, four EXEC-masked adds ----
+        const unsigned long long GE = G0 | G1;
+        unsigned long long todo = (PHASE == 1) ? ((nvalid == 64) ? ~0ull : ((1ull << nvalid) - 1ull)) : IN;
+        if (P.dbg & 1) todo = 0;  // WC_DEBUG_SKIP=1: profiling experiments only
+        while (todo) {
+          const unsigned long long evs = GE & todo;
+          unsigned long long seg = evs ? (todo & ((evs & (0ull - evs)) - 1ull)) : todo;  // the points in front of the next cluster end
+          todo &= ~seg;
+          while (seg) {
+            const int j0 = __ffsll((long long)seg) - 1;
+            seg &= seg - 1;
+            const bool h1 = seg != 0;
+            const int j1 = h1 ? __ffsll((long long)seg) - 1 : j0;
+            seg &= seg - 1;
+            const bool h2 = seg != 0;
+            const int j2 = h2 ? __ffsll((long long)seg) - 1 : j0;
+            seg &= seg - 1;
+            const bool h3 = seg != 0;
+            const int j3 = h3 ? __ffsll((long long)seg) - 1 : j0;
+            seg &= seg - 1;
+            const double v0 = s_prod[j0 * kMom + m], v1 = s_prod[j1 * kMom + m], v2 = s_prod[j2 * kMom + m], v3 = s_prod[j3 * kMom + m];
+            masked_add4(aoA, atA, aoB, atB, v0, readlane_u64(mAlo, mAhi, j0), readlane_u64(mBlo, mBhi, j0));
+            // (masks of a missing point are forced to zero: nothing is added)
+            masked_add4(aoA, atA, aoB, atB, v1, h1 ? readlane_u64(mAlo, mAhi, j1) : 0ull, h1 ? readlane_u64(mBlo, mBhi, j1) : 0ull);
+            masked_add4(aoA, atA, aoB, atB, v2, h2 ? readlane_u64(mAlo, mAhi, j2) : 0ull, h2 ? readlane_u64(mBlo, mBhi, j2) : 0ull);
+            masked_add4(aoA, atA, aoB, atB, v3, h3 ? readlane_u64(mAlo, mAhi, j3) : 0ull, h3 ? readlane_u64(mBlo, mBhi, j3) : 0ull);
+          }
+          if (evs) {  // a cluster ends in front of point j: close it, then add the point
+            const int j = __ffsll((long long)evs) - 1;
+            todo &= ~(1ull << j);
+            const int c = __builtin_amdgcn_readlane(code, j);
+            const int cs = c & 3;
+            const bool bankB = (c >> 2) != 0;
+            if (PHASE == 1 && ((G0 >> j) & 1ull)) {
+              end_cluster(is_lvl, 0, aoA, ordA, 0);
+              if (is_lvl) aoA = 0.0, ordA += 1;
+            }
+            if ((G1 >> j) & 1ull) {
+              const int nu = (PHASE == 1) ? 1 + c : so * 8 + c;
+              const bool mine = (my_slot == cs);
+              if (bankB) {
+                end_cluster(mine, nu, aoB, ordB, kMom + kMom * cs);
+                if (mine) aoB = 0.0, ordB += 1;
+              } else {
+                end_cluster(mine, nu, aoA, ordA, kMom + kMom * cs);
+                if (mine) aoA = 0.0, ordA += 1;
+              }
+            }
+            masked_add4(aoA, atA, aoB, atB, s_prod[j * kMom + m], readlane_u64(mAlo, mAhi, j), readlane_u64(mBlo, mBhi, j));
+          }
+        }
+        if (nvalid < 64) break;
+        valid = nvalid_next;
+      }
+      // still-open clusters become candidates too (end of ClusterSurfels' first loop), node order
+      if (PHASE == 1) end_cluster(is_lvl, 0, aoA, ordA, 0);
+      if (use_children) {
+        for (int o = 0; o < 4; ++o) end_cluster(my_slot == o, (PHASE == 1) ? 1 + o : so * 8 + o, aoA, ordA, kMom + kMom * o);
+        for (int o = 0; o < 4; ++o) end_cluster(my_slot == o, (PHASE == 1) ? 5 + o : so * 8 + 4 + o, aoB, ordB, kMom + kMom * o);
+      }
+      return Totals{atA, atB};
+    };
+
+    if (PHASE == 1) {
+      const Totals t1 = stream_pass(-1);
+      double *tot = A.node_tot + (size_t)tslot * (9 * kMom);
+      if (is_lvl) tot[m] = t1.a;
+      if (my_slot < 4) {
+        tot[(1 + my_slot) * kMom + m] = t1.a;
+        tot[(5 + my_slot) * kMom + m] = t1.b;
+      }
+      if (lane == 0) A.root_ncand[tslot] = ncand;
+      __builtin_amdgcn_wave_barrier();
+      return;
+    }
+    for (int so = 0; so < 8; ++so) {
+      if (!((split1 >> so) & 1ull)) continue;  // only the split layer-1 octants have layer-2 nodes
+      const Totals tt = stream_pass(so);
+      if (my_slot < 4) {
+        s_total[(so * 8 + my_slot) * kMom + m] = tt.a;
+        s_total[(so * 8 + my_slot + 4) * kMom + m] = tt.b;
+      }
+    }
+    __threadfence_block();
+    __syncthreads();
+    // ---- node tests of the 64 layer-2 nodes + their candidate clusters, one batch of 3x3 PCAs (as in k_roots<K, 2>) ----
+    const uint32_t ncap = (uint32_t)min((uint64_t)ncand, A.total_slots > slot_base ? A.total_slots - slot_base : 0);
+    unsigned long long plane_mask = 0;
+    for (uint32_t batch = 0;; ++batch) {
+      const bool node_lane = (batch == 0) && lane < ntab;
+      const int cand_lane0 = (batch == 0) ? ntab : 0;
+      const uint32_t cbase = cand_begin + (batch == 0 ? 0u : (uint32_t)(64 - ntab) + (batch - 1) * 64u);
+      const uint32_t c = cbase + (uint32_t)(lane - cand_lane0);
+      const bool cand_lane = lane >= cand_lane0 && c < ncap;
+      if (batch > 0 && cbase >= ncap) break;
+      double mom[kMom];
+      bool have = false;
+      int nu = 0;
+      uint32_t ord = 0;
+      uint64_t slot = 0;
+      if (node_lane) {
+        const bool exists = (split1 >> (lane >> 3)) & 1ull;
+        nu = lane;
+        if (exists && s_total[lane * kMom] > (double)P.min_points) {
+          have = true;
+          for (int i = 0; i < kMom; ++i) mom[i] = s_total[lane * kMom + i];
+        }
+      } else if (cand_lane) {
+        slot = slot_base + c;
+        const uint32_t meta = A.cand_meta[slot];
+        nu = (int)(meta & 0x7F);
+        ord = meta >> 8;
+        have = true;
+        for (int i = 0; i < kMom; ++i) mom[i] = A.cand[slot * kMom + i];
+      }
+      Pca rr;
+      if (have) pca_from_moments(mom, rr);
+      if (batch == 0) {
+        const bool plane = node_lane && have && (rr.ev[0] < P.thr) && (rr.like > P.min_like);  // cc:106-111
+        plane_mask = __ballot(plane);
+      }
+      bool ok = false;
+      if (cand_lane && have && ((plane_mask >> nu) & 1ull) && !(rr.ev[0] > P.thr || rr.like < P.min_like)) {  // cc:54
+        emit_surfel(A, rr, slot, 2, nu, ord, kx, ky, kz, q0);
+        ok = true;
+      }
+      emitted += (uint32_t)__popcll(__ballot(ok));
+    }
+    if (lane == 0 && emitted && !A.slot_counts) atomicAdd(&A.status[0], emitted);
+    __syncthreads();
+  };
+
+  // ---- work items of this wavefront ----
+  if (PHASE == 2) {  // the queued split jobs, strided
+    for (uint32_t it = blockIdx.x; it < njobs; it += gridDim.x) {
+      const SplitJob job = A.split_jobs[it];
+      do_root(A.heads[job.slot].pos, job.slot, job.ncand, job.split1);
+    }
+  } else {  // sparse head table: every wavefront owns a contiguous range of slots
+    const uint32_t per_wave = (A.nslots + gridDim.x - 1) / gridDim.x;
+    const uint32_t it_end = min((blockIdx.x + 1) * per_wave, A.nslots);
+    for (uint32_t it = blockIdx.x * per_wave; it < it_end; it += 64) {
+      const uint32_t my_pos = (it + lane < it_end) ? A.heads[it + lane].pos : 0xFFFFFFFFu;
+      unsigned long long live_mask = __ballot(my_pos != 0xFFFFFFFFu);
+      while (live_mask) {
+        const int hb = __ffsll((long long)live_mask) - 1;
+        live_mask &= live_mask - 1;
+        do_root((uint32_t)__shfl((int)my_pos, hb), it + (uint32_t)hb, 0u, 0ull);
+      }
+    }
+  }
+}
+
 // Node tests + emission of the layer-0/1 pass, THREE roots per wavefront.  One root offers 9 node tests and a dozen or so
 // candidate clusters, i.e. ~20 of 64 lanes for an eigen-solve that costs ~13 k cycles of fp64 VALU issue: at one root per
 // wavefront the launch is VALU-issue bound on mostly idle lanes.  Lane = 21 * group + l; in the first batch l < 9 tests
@@ -1196,7 +1563,10 @@ int pipeline_tail(wc_ctx *ctx, bool layer2) {
   };
   if (layer2) {
     const unsigned grid2 = std::min(kRoots2Grid, std::max(64u, ctx->ex.last_splits));  // sized by the previous call's queue
-    k_roots<K, 2, RUNS><<<grid2, 64, 0, st>>>(A, (const K *)ctx->b_keys[1].p);
+    if constexpr (RUNS)
+      k_roots<K, 2, true><<<grid2, 64, 0, st>>>(A, (const K *)ctx->b_keys[1].p);
+    else
+      k_roots_banks<K, 2><<<grid2, 64, 0, st>>>(A, (const K *)ctx->b_keys[1].p);
   }
   ctx->ex.layer2_done = layer2;
   mark(4);
@@ -1341,7 +1711,7 @@ int run_pipeline(wc_ctx *ctx, const wc_points &pts, double t_lo, double t_hi, wc
       k_roots_emit<K, true><<<kEmitGrid, 64, 0, st>>>(A, skeys);  // node tests + emission
     }
   } else {
-    k_roots<K, 1, false><<<kRootsGrid, 64, 0, st>>>(A, skeys);
+    k_roots_banks<K, 1><<<kRootsGrid, 64, 0, st>>>(A, skeys);  // order-independent streaming (no run structure on this path)
     mark(3);
     k_roots_emit<K, false><<<kEmitGrid, 64, 0, st>>>(A, skeys);
   }
