@@ -46,7 +46,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 or world > 1:
+    force_dist = os.environ.get("WC_BENCH_FORCE_DIST") == "1"  # exercise the RCCL plumbing on one GPU (world size 1)
+    if args.gpus > 1 or world > 1 or force_dist:
         assert world == args.gpus, f"launch with torch.distributed.run --nproc-per-node {args.gpus}"
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -167,7 +168,7 @@ def main():
     if rank == 0:
         print(json.dumps(result))
     ctx.close()
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 
@@ -218,7 +219,7 @@ def bench_window(ctx, args, world, rank, dev, torch, dist):
         def __init__(self, ptr):
             self.ptr = ptr
 
-    if world > 1:
+    if world > 1 or os.environ.get("WC_BENCH_FORCE_DIST") == "1":
         ctx.window_set_allreduce(wdist.make_allreduce(torch, dist, dev))
     ctx.window_build(d_surf, d_pose, _Off(d_pairs.ptr + 8 * lo_b), cnt_b, w["imu"] if rank == 0 else None, w["sample_times"], w["grav"],
                      False, d_fs, d_fp, _Off(d_pf.ptr + 8 * lo_u), cnt_u)

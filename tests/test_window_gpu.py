@@ -113,3 +113,80 @@ def test_window_errors(gpu, oracle):
     with pytest.raises(lib.WildcatError) as e:  # sample states do not bracket the surfels: CHECKs at cc:259-265
         gpu.window_build(d_surf, d_pose, gpu.to_device(ok), 1, None, w["sample_times"][:3], w["grav"], True)
     assert e.value.code == 2
+
+
+def test_two_rank_sharded_solve_on_one_gpu(gpu, oracle):
+    """The multi-GPU scheme of SURVEY 8(e) with both 'ranks' on one device: two contexts, each with a contiguous half of
+    the correspondences (IMU factors on rank 0 only, unknowns replicated), the all-reduce callback of the C-ABI summing the
+    packed {H, g, cost} buffers through host memory in lock step (threads + barrier stand in for RCCL).  Both ranks must
+    end at the same point, take the same number of iterations and agree with the unsharded solve."""
+    import threading
+
+    from wildcat_slam_amd import dist as wdist
+    from wildcat_slam_amd import lib
+
+    w = synth.surfel_window(4, 400, seed=23, fixed_patches=200)
+    params = oracle.default_params()
+    pairs = oracle.match(w["surf"], w["pose"], w["surf"], w["pose"], True, params)
+    pf = oracle.match(w["surf"], w["pose"], w["fix_surf"], w["fix_pose"], False, params)
+    ns = len(w["sample_times"])
+    x0 = np.zeros(12 * ns)
+
+    def build(ctx, lo_b, cnt_b, lo_u, cnt_u, with_imu):
+        ctx.set_params(params)
+        keep = [ctx.to_device(w["surf"]), ctx.to_device(w["pose"]), ctx.to_device(pairs[lo_b:lo_b + cnt_b]),
+                ctx.to_device(w["fix_surf"]), ctx.to_device(w["fix_pose"]), ctx.to_device(pf[lo_u:lo_u + cnt_u])]
+        ctx.window_build(keep[0], keep[1], keep[2], cnt_b, w["imu"] if with_imu else None, w["sample_times"], w["grav"], True,
+                         keep[3], keep[4], keep[5], cnt_u)
+        return keep
+
+    # reference: everything on one context
+    keep_all = build(gpu, 0, len(pairs), 0, len(pf), True)
+    x_ref, s_ref, _ = gpu.window_solve(x0)
+
+    world = 2
+    ctxs = [lib.Context(0) for _ in range(world)]
+    bar = threading.Barrier(world)
+    stage = [None] * world
+    calls = [0] * world
+
+    def make_cb(r):
+        def cb(ptr, count):  # device pointer of this rank's buffer
+            host = ctxs[r].download_raw(ptr, count * 8).view(np.float64).copy()
+            stage[r] = host
+            bar.wait()
+            total = stage[0] + stage[1]  # fixed order: bitwise the same on both ranks
+            bar.wait()
+            ctxs[r].upload_raw(ptr, total)
+            calls[r] += 1
+
+        return cb
+
+    results = [None] * world
+    errors = []
+
+    def run(r):
+        try:
+            lo_b, cnt_b = wdist.shard_range(len(pairs), r, world)
+            lo_u, cnt_u = wdist.shard_range(len(pf), r, world)
+            keep = build(ctxs[r], lo_b, cnt_b, lo_u, cnt_u, r == 0)
+            ctxs[r].window_set_allreduce(make_cb(r))
+            results[r] = ctxs[r].window_solve(x0) + (keep,)
+        except Exception as e:  # pragma: no cover
+            errors.append(e)
+            bar.abort()
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=120)
+    assert not errors, errors
+    (x_a, s_a, _, _), (x_b, s_b, _, _) = results
+    assert calls[0] == calls[1] and calls[0] > 0
+    assert np.array_equal(x_a, x_b), "ranks diverged"
+    assert s_a.iterations == s_b.iterations == s_ref.iterations
+    assert _rel(x_a, x_ref) < 1e-6
+    for c in ctxs:
+        c.close()
+    del keep_all

@@ -130,6 +130,16 @@ class Context:
     def sync(self):
         self._ck(self.lib.wc_sync(self.h))
 
+    def download_raw(self, d_ptr, nbytes):
+        """bytes at a raw device pointer (e.g. the buffer handed to an all-reduce callback) -> uint8 array"""
+        out = np.zeros(int(nbytes), np.uint8)
+        self._ck(self.lib.wc_d2h(self.h, R.ptr(out), C.c_void_p(d_ptr), C.c_size_t(out.nbytes)))
+        return out
+
+    def upload_raw(self, d_ptr, arr):
+        arr = np.ascontiguousarray(arr)
+        self._ck(self.lib.wc_h2d(self.h, C.c_void_p(d_ptr), R.ptr(arr), C.c_size_t(arr.nbytes)))
+
     def timer_start(self):
         self._ck(self.lib.wc_timer_start(self.h))
 
