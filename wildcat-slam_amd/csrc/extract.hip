@@ -85,6 +85,19 @@ struct KeyTraits<uint64_t> {
   static constexpr int bits = 21;
 };
 
+// Flags and the final counts reach the host without a copy kernel: status words [8, 9] hold the device-visible address of
+// the context's pinned host mailbox (written by k_init); a flag is raised in HBM (for the kernels that test it) AND as a
+// plain store of 1 into mailbox word 8 + log2(flag) (idempotent, no PCIe atomic); k_slot_emit leaves the surfel count and
+// the layer-2 queue length in mailbox words 0 and 4.  The 32-byte hipMemcpyAsync this replaces was a 4 us blit kernel.
+__device__ __forceinline__ uint32_t *host_mailbox(const uint32_t *status) {
+  return (uint32_t *)(((unsigned long long)status[9] << 32) | (unsigned long long)status[8]);
+}
+__device__ __forceinline__ void raise_flag(uint32_t *status, uint32_t flag) {
+  atomicOr(&status[1], flag);
+  uint32_t *hm = host_mailbox(status);
+  if (hm) hm[8 + (__ffs((int)flag) - 1)] = 1u;
+}
+
 template <typename K>
 __global__ void __launch_bounds__(256) k_keygen(wc_points pts, double vs, K *keys, uint32_t *vals, uint32_t *status) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -98,7 +111,7 @@ __global__ void __launch_bounds__(256) k_keygen(wc_points pts, double vs, K *key
   int ry = vox(y, vs) - vox(y0, vs) + half;
   int rz = vox(z, vs) - vox(z0, vs) + half;
   if ((unsigned)rx >= (unsigned)(2 * half) || (unsigned)ry >= (unsigned)(2 * half) || (unsigned)rz >= (unsigned)(2 * half)) {
-    atomicOr(&status[1], kFlagKeyRange);
+    raise_flag(status, kFlagKeyRange);
     rx = min(max(rx, 0), 2 * half - 1);
     ry = min(max(ry, 0), 2 * half - 1);
     rz = min(max(rz, 0), 2 * half - 1);
@@ -237,13 +250,13 @@ __device__ __forceinline__ void emit_surfel(const RootsArgs &A, const Pca &rr, u
   const uint64_t ob = ordered_bits(rr.tmean);
   uint64_t key;
   if (ob < P.t_lo_bits) {
-    atomicOr(&A.status[1], kFlagTimeRange);
+    raise_flag(A.status, kFlagTimeRange);
     key = 0;
   } else {
     key = ob - P.t_lo_bits;
   }
   if (A.slot_counts) {  // fast slot order: drop the surfel into its time bucket right here (k_slot_emit sorts each bucket)
-    if (key >> 32) atomicOr(&A.status[1], kFlagTimeRange);
+    if (key >> 32) raise_flag(A.status, kFlagTimeRange);
     const uint32_t bkt = min((uint32_t)(key >> A.slot_shift), (uint32_t)(kBuckets - 1));
     const uint32_t r = atomicAdd(&A.slot_counts[bkt], 1u);
     if (r < A.slot_bin_cap) A.slot_bins[(size_t)bkt * A.slot_bin_cap + r] = (key << 32) | (uint64_t)(uint32_t)slot;
@@ -562,7 +575,7 @@ __global__ void __launch_bounds__(64) k_roots(RootsArgs A, const K *__restrict__
                   if (m == 0) A.cand_meta[slot] = (uint32_t)nu | ((uint32_t)(phase - 1) << 7) | (s_ord[nu] << 8);
                 }
               } else if (lane == 0) {
-                atomicOr(&A.status[1], kFlagSlotOverflow);
+                raise_flag(A.status, kFlagSlotOverflow);
               }
               ++ncand;
             }
@@ -604,7 +617,7 @@ __global__ void __launch_bounds__(64) k_roots(RootsArgs A, const K *__restrict__
           if (lane < kMom) A.cand[slot * kMom + lane] = s_open[nu * kMom + lane];
           if (lane == 0) A.cand_meta[slot] = (uint32_t)nu | ((uint32_t)(phase - 1) << 7) | (s_ord[nu] << 8);
         } else if (lane == 0) {
-          atomicOr(&A.status[1], kFlagSlotOverflow);
+          raise_flag(A.status, kFlagSlotOverflow);
         }
         ++ncand;
       }
@@ -820,7 +833,7 @@ __global__ void __launch_bounds__(64) k_roots_banks(RootsArgs A, const K *__rest
             if (m == 0) A.cand_meta[slot] = (uint32_t)nu | ((uint32_t)(phase - 1) << 7) | (ord << 8);
           }
         } else if (lane == 0) {
-          atomicOr(&A.status[1], kFlagSlotOverflow);
+          raise_flag(A.status, kFlagSlotOverflow);
         }
         ++ncand;
       }
@@ -1252,12 +1265,19 @@ __global__ void __launch_bounds__(256) k_slot_emit(const uint32_t *__restrict__ 
   __syncthreads();
   uint32_t base = s_red[0] + s_red[1] + s_red[2] + s_red[3];
   const uint32_t c0 = counts[b0], c1 = counts[b0 + 1], c2 = counts[b0 + 2], c3 = counts[b0 + 3];
-  if (blockIdx.x == gridDim.x - 1 && t == 0) status[0] = base + c0 + c1 + c2 + c3;  // surfels emitted
+  if (blockIdx.x == gridDim.x - 1 && t == 0) {
+    status[0] = base + c0 + c1 + c2 + c3;  // surfels emitted
+    uint32_t *hm = host_mailbox(status);
+    if (hm) {
+      hm[0] = base + c0 + c1 + c2 + c3;
+      hm[4] = status[4];  // roots queued for the layer-2 pass (every emitting kernel has finished)
+    }
+  }
   base += (w > 0 ? c0 : 0u) + (w > 1 ? c1 : 0u) + (w > 2 ? c2 : 0u);
   const uint32_t c = w == 0 ? c0 : (w == 1 ? c1 : (w == 2 ? c2 : c3));
   if (c == 0) return;
   if (c > bin_cap) {
-    if (lane == 0) atomicOr(&status[1], kFlagSlotBinOverflow);
+    if (lane == 0) raise_flag(status, kFlagSlotBinOverflow);
     return;
   }
   const uint64_t *bin = bins + (size_t)(b0 + w) * bin_cap;
@@ -1311,14 +1331,14 @@ __device__ __forceinline__ uint32_t run_length(const unsigned long long *s_bits,
 // every per-call fill (status words, slot keys, bucket counters, head table) in ONE launch: each hipMemsetAsync is its
 // own ~2-7 us kernel, and an extraction call needs five of them
 struct InitArgs {
-  uint32_t *p[6];
-  uint32_t nw[6];  // 32-bit words
-  uint32_t val[6];
+  uint32_t *p[8];
+  uint32_t nw[8];  // 32-bit words
+  uint32_t val[8];
 };
 __global__ void __launch_bounds__(256) k_init(InitArgs I) {
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
 #pragma unroll
-  for (int r = 0; r < 6; ++r)
+  for (int r = 0; r < 8; ++r)
     if (i < I.nw[r]) I.p[r][i] = I.val[r];
 }
 
@@ -1346,7 +1366,7 @@ __global__ void __launch_bounds__(kRunThreads) k_pt_runs(wc_points pts, double v
       load_xyz(pts, t0 + i, x, y, z);
       int rx = vox(x, vs) - vox(x0, vs) + 512, ry = vox(y, vs) - vox(y0, vs) + 512, rz = vox(z, vs) - vox(z0, vs) + 512;
       if ((unsigned)rx >= 1024u || (unsigned)ry >= 1024u || (unsigned)rz >= 1024u) {
-        atomicOr(&status[1], kFlagKeyRange);
+        raise_flag(status, kFlagKeyRange);
         rx = min(max(rx, 0), 1023), ry = min(max(ry, 0), 1023), rz = min(max(rz, 0), 1023);
       }
       key[j] = (uint32_t)rx | ((uint32_t)ry << 10) | ((uint32_t)rz << 20);
@@ -1429,7 +1449,7 @@ __global__ void __launch_bounds__(256) k_pt_bucket(uint64_t *bins, uint32_t bin_
   for (int off = 32; off >= 1; off >>= 1) part += __shfl_xor(part, off);
   if (lane == 0) s_red[w] = part;
   if (nb > bin_cap) {
-    if (lane == 0) atomicOr(&status[1], kFlagBucketOverflow);
+    if (lane == 0) raise_flag(status, kFlagBucketOverflow);
     nb = 0;  // the caller reruns the general path
   }
   if ((uint32_t)lane < nb) s_a[lane] = first;
@@ -1584,7 +1604,8 @@ int pipeline_tail(wc_ctx *ctx, bool layer2) {
                                                              (const wc_surfel_id *)ctx->b_slot_ids.p, status, d_out, d_ids, cap);
   }
   mark(5);
-  WC_HIP(ctx, hipMemcpyAsync(ctx->h_status, status, 32, hipMemcpyDeviceToHost, st));
+  // the time-bin path leaves count, queue length and flags in the pinned mailbox itself (k_slot_emit, raise_flag)
+  if (!ctx->ex.fast_slots) WC_HIP(ctx, hipMemcpyAsync(ctx->h_status, status, 32, hipMemcpyDeviceToHost, st));
   WC_HIP(ctx, hipGetLastError());
   return WC_OK;
 }
@@ -1650,7 +1671,16 @@ int run_pipeline(wc_ctx *ctx, const wc_points &pts, double t_lo, double t_hi, wc
     InitArgs I{};
     int r = 0;
     auto fill = [&](void *p, uint64_t words, uint32_t v) { I.p[r] = (uint32_t *)p, I.nw[r] = (uint32_t)words, I.val[r] = v, ++r; };
-    fill(status, 64, 0u);
+    fill(status, 8, 0u);
+    fill(status + 10, 54, 0u);
+    {  // address of the pinned host mailbox into status words [8, 9]
+      void *dp = nullptr;
+      if (hipHostGetDevicePointer(&dp, ctx->h_status, 0) != hipSuccess) dp = nullptr;
+      const unsigned long long a = (unsigned long long)dp;
+      fill(status + 8, 1, (uint32_t)a);
+      fill(status + 9, 1, (uint32_t)(a >> 32));
+    }
+    for (int q = 0; q < 16; ++q) ctx->h_status[q] = 0;
     if (!fast_slots) fill(ctx->b_slot_keys[0].p, total_slots * 2, 0xFFFFFFFFu);  // slot keys: ~0 = no surfel in the slot
     if (!fast_pts) fill(ctx->b_misc[0].p, (uint64_t)nslots * 4, 0xFFFFFFFFu);   // sparse head slot table: pos = ~0 = no live head
     if (fast_slots) fill(ctx->b_misc[4].p, 2 * kBuckets, 0u);                   // slot bucket counts (filled by k_roots) + cursors
@@ -1749,7 +1779,7 @@ extern "C" int wc_extract_surfels_enqueue(wc_ctx *ctx, const wc_points *pts, dou
   ctx->ex.d_ids = d_ids;
   ctx->ex.cap = cap;
   ctx->ex.wide = false;
-  ctx->h_status[0] = ctx->h_status[1] = 0;
+  for (int q = 0; q < 16; ++q) ctx->h_status[q] = 0;
   if (pts->n == 0) return WC_OK;
   if (t_lo > t_hi) {  // no hint: read the first and last timestamp back (input is time ordered)
     WC_HIP(ctx, hipMemcpyAsync(&ctx->h_mail[0], pts->time, 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -1774,19 +1804,25 @@ extern "C" int wc_extract_surfels_finish(wc_ctx *ctx, uint64_t *h_n_out) {
   ctx->ex.active = false;
   if (h_n_out) *h_n_out = 0;
   if (ctx->ex.pts.n == 0) return WC_OK;
-  WC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  auto wait = [&]() -> int {  // stream done; fold the mailbox flag words (raise_flag) into h_status[1]
+    WC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < 5; ++i)
+      if (ctx->h_status[8 + i]) ctx->h_status[1] |= 1u << i;
+    return WC_OK;
+  };
+  WC_TRY(wait());
   if ((ctx->h_status[1] & kFlagBucketOverflow) && !(ctx->h_status[1] & kFlagKeyRange) && !ctx->ex.general) {
     // a bin of the run-binned point sort overflowed: redo with the general radix sort
     ctx->ex.general = true;
     ctx->ex.general_calls = 15;
     WC_TRY(run_pipeline<uint32_t>(ctx, ctx->ex.pts, ctx->ex.t_lo, ctx->ex.t_hi, ctx->ex.d_out, ctx->ex.d_ids, ctx->ex.cap, false, true));
-    WC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    WC_TRY(wait());
   }
   if ((ctx->h_status[1] & kFlagKeyRange) && !ctx->ex.wide) {
     // the sweep spans more than +-512 root voxels around its first point: redo with 21-bit-per-axis keys
     ctx->ex.wide = true;
     WC_TRY(run_pipeline<uint64_t>(ctx, ctx->ex.pts, ctx->ex.t_lo, ctx->ex.t_hi, ctx->ex.d_out, ctx->ex.d_ids, ctx->ex.cap, false, true));
-    WC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    WC_TRY(wait());
   }
   if ((ctx->h_status[1] & kFlagSlotBinOverflow) && !ctx->ex.order_general) {
     // very many surfels inside one 1/4096 of the sweep's time span: redo with the radix sort of the slot keys
@@ -1795,12 +1831,12 @@ extern "C" int wc_extract_surfels_finish(wc_ctx *ctx, uint64_t *h_n_out) {
       WC_TRY(run_pipeline<uint64_t>(ctx, ctx->ex.pts, ctx->ex.t_lo, ctx->ex.t_hi, ctx->ex.d_out, ctx->ex.d_ids, ctx->ex.cap, false, false));
     else
       WC_TRY(run_pipeline<uint32_t>(ctx, ctx->ex.pts, ctx->ex.t_lo, ctx->ex.t_hi, ctx->ex.d_out, ctx->ex.d_ids, ctx->ex.cap, !ctx->ex.general, false));
-    WC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    WC_TRY(wait());
   }
   if (!ctx->ex.layer2_done && ctx->h_status[4] > 0 && ctx->ex.tail) {  // roots were queued for the skipped layer-2 pass
     ctx->ex.last_splits = ctx->h_status[4];
     WC_TRY(ctx->ex.tail(ctx, true));
-    WC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    WC_TRY(wait());
   }
   const uint32_t flags = ctx->h_status[1];
   ctx->ex.last_splits = ctx->h_status[4];
