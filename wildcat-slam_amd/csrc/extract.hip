@@ -952,6 +952,21 @@ __global__ void __launch_bounds__(64) k_roots_banks(RootsArgs A, const K *__rest
           const unsigned long long evs = GE & todo;
           unsigned long long seg = evs ? (todo & ((evs & (0ull - evs)) - 1ull)) : todo;  // the points in front of the next cluster end
           todo &= ~seg;
+          if (PHASE == 1 && seg) {  // every point is in the pass: the segment is a contiguous range, a counted loop does it
+            int j = __ffsll((long long)seg) - 1;
+            const int je = j + __popcll(seg);
+            seg = 0;
+            for (; j + 4 <= je; j += 4) {
+              const double v0 = s_prod[j * kMom + m], v1 = s_prod[(j + 1) * kMom + m], v2 = s_prod[(j + 2) * kMom + m],
+                           v3 = s_prod[(j + 3) * kMom + m];
+              masked_add4(aoA, atA, aoB, atB, v0, readlane_u64(mAlo, mAhi, j), readlane_u64(mBlo, mBhi, j));
+              masked_add4(aoA, atA, aoB, atB, v1, readlane_u64(mAlo, mAhi, j + 1), readlane_u64(mBlo, mBhi, j + 1));
+              masked_add4(aoA, atA, aoB, atB, v2, readlane_u64(mAlo, mAhi, j + 2), readlane_u64(mBlo, mBhi, j + 2));
+              masked_add4(aoA, atA, aoB, atB, v3, readlane_u64(mAlo, mAhi, j + 3), readlane_u64(mBlo, mBhi, j + 3));
+            }
+            for (; j < je; ++j)
+              masked_add4(aoA, atA, aoB, atB, s_prod[j * kMom + m], readlane_u64(mAlo, mAhi, j), readlane_u64(mBlo, mBhi, j));
+          }
           while (seg) {
             const int j0 = __ffsll((long long)seg) - 1;
             seg &= seg - 1;
