@@ -3,21 +3,24 @@
 // everything beneath it (BuildVoxelMap :186-220, InitOctoTree :128-140, CutOctoTree :142-184, InitPlane :82-126,
 // ExtractSurfelInfo :304-314, ClusterSurfels :12-65).  Decision rules: SURVEY.md Appendix A.
 //
-// Pipeline (all on one stream, no host synchronisation until the count is read back):
-//   1. k_keygen      point -> root-voxel key relative to the voxel of point 0 (floor(p / (double)0.8f), true fp64
-//                    division), 10 bits per axis (21 in the wide fallback); value = point index
-//   2. radix sort    stable LSD sort of (key, index): points of one root voxel become one contiguous segment that is
-//                    still in time order (the input is time ordered) — the order ClusterSurfels relies on (cc:22-29)
-//   3. k_roots       one wavefront per segment.  Lanes are (level, moment) pairs: 3 octree levels x 11 running
-//                    moments {n, St, Sx, Sy, Sz, Sxx, Sxy, Sxz, Syy, Syz, Szz}.  Points are streamed in time order
-//                    through LDS-resident per-node accumulators, so every sum is formed in exactly the order the
-//                    reference forms it (bit-identical moments => bit-identical gate decisions).  Node totals feed
-//                    the planarity test, open-cluster sums are flushed to candidate slots when the gap rule fires.
-//                    At the end of the segment: node tests (3x3 Jacobi eigensolve per lane), then one lane per
-//                    candidate cluster does the cluster PCA, the gates, the view-point flip and writes the surfel.
-//   4. radix sort    of the surfel slots by timestamp (compacts and orders, surfel_extraction.cc:334)
-//   5. k_gather      slot -> caller's output buffer
-// The path is HBM/latency bound (20 B read per point, 144 B written per surfel, SURVEY §8(d)); no MFMA.
+// Pipeline of one sweep (all on one stream, no host synchronisation until wc_extract_surfels_finish):
+//   0. k_init        every per-call fill in one launch (status words, bucket / bin counters, mailbox address)
+//   1. k_pt_runs     the only pass over the AoS input: root-voxel key relative to the voxel of point 0
+//                    (floor(p / (double)0.8f), true fp64 division; 10 bits per axis, 21 in the wide fallback), RUNS of
+//                    consecutive points with one key, one composite per run into the bin of its bucket (4096 buckets)
+//   2. k_pt_bucket   per bucket: sorted runs (voxel, start) + point offsets + the compacted work list of live roots
+//   3. k_roots<1>    one wavefront per root voxel, lanes = (level, moment): the root's points are streamed IN TIME ORDER
+//                    through per-node accumulators, so every sum is formed in exactly the order the reference forms it
+//                    (bit-identical moments => bit-identical gate decisions); open-cluster sums become candidate
+//                    slots when the gap rule fires (ClusterSurfels, cc:22-29)
+//   4. k_roots_emit  three roots per wavefront: node tests + candidate clusters as ONE batch of 3x3 Jacobi PCAs, gates,
+//                    view-point flip, surfel into its slot, time key into its time bin; roots whose layer-1 nodes
+//                    split are queued
+//   5. k_roots<2>    layer 2 of the queued roots (launched only if the previous sweep needed it)
+//   6. k_slot_emit   time order (surfel_extraction.cc:334) + copy slot -> caller's buffer, count to the host mailbox
+// Fallbacks, chosen by finish() from the flags: radix-sort path (k_keygen + rocPRIM + k_heads + k_roots_banks) for
+// sweeps without run structure or with overfull bins, 21-bit keys for wide sweeps, radix sort of the slot keys.
+// The path is HBM/latency bound (20 B read per point, 144 B written per surfel, SURVEY 8(d)); no MFMA.
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
@@ -28,7 +31,6 @@
 #include "dmath.h"
 
 namespace {
-
 
 constexpr int kMom = 11;    // n, St, Sx, Sy, Sz, Sxx, Sxy, Sxz, Syy, Syz, Szz
 constexpr unsigned kRootsGrid = 256 * 16;  // wavefronts of the layer-0/1 pass (static work split; <= 128 VGPRs => all resident)
