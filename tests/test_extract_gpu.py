@@ -140,3 +140,16 @@ def test_unordered_sweep_uses_radix_path_and_stays_there(gpu, oracle):
     regular, _ = synth.g2_lattice(200, m=32)
     for _ in range(18):  # long enough for the fast path to be tried again
         _run(gpu, oracle, regular)
+
+
+def test_unordered_small_sweep_stays_on_the_run_binned_path(gpu, oracle):
+    # firing-order sweep small enough for the run bins (one run per point, buckets of a few hundred runs: in-wave bitonic sort,
+    # LDS capacity grown on demand); the first call streams with k_roots (binary search in the run offsets), the following
+    # ones with k_roots_banks (run statistics of the previous sweep) - all of them must agree with the oracle
+    room = synth.g1_room(60_000, seed=5)
+    for _ in range(3):
+        _run(gpu, oracle, room)
+    regular, _ = synth.g2_lattice(150, m=32)
+    for _ in range(2):  # back to a sweep with run structure
+        _run(gpu, oracle, regular)
+    _run(gpu, oracle, synth.g1_room(120_000, seed=6))

@@ -43,6 +43,8 @@ struct wc_ctx {
     bool general;
     bool order_general = false;  // this call orders the surfels with the radix sort (a time bin overflowed)
     int general_calls = 0;       // upcoming calls that start on the radix-sort path right away
+    uint32_t lds_cap = 256;      // runs per bucket k_pt_bucket sorts in LDS (256 / 512 / 1024, grows with the data)
+    bool unordered = false;      // the previous sweep had (almost) no run structure: stream with k_roots_banks
     uint32_t last_splits = 256;  // roots the previous call queued for the layer-2 pass (sizes / gates that launch)
     // the tail of the pipeline (layer-2 pass, surfel order, status read-back) is re-run by finish() when the call skipped
     // the layer-2 launch and roots were queued for it after all

@@ -38,7 +38,7 @@ constexpr unsigned kEmitGrid = 256 * 8;   // wavefronts of the node-test + emiss
 constexpr unsigned kRoots2Grid = 256 * 4;  // wavefronts of the (rare) layer-2 pass
 constexpr int kBuckets = 4096;    // buckets of the composite sorts
 constexpr int kTile = 2048;       // points per workgroup of k_pt_runs
-constexpr uint32_t kFlagKeyRange = 1u, kFlagSlotOverflow = 2u, kFlagTimeRange = 4u, kFlagBucketOverflow = 8u, kFlagSlotBinOverflow = 16u;
+constexpr uint32_t kFlagKeyRange = 1u, kFlagSlotOverflow = 2u, kFlagTimeRange = 4u, kFlagBucketOverflow = 8u, kFlagSlotBinOverflow = 16u, kFlagLdsOverflow = 32u;
 
 struct ExParams {
   double vs;           // (double)voxel_size
@@ -786,7 +786,7 @@ __device__ __forceinline__ unsigned long long readlane_u64(uint32_t lo, uint32_t
          (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)lo, src_lane);
 }
 
-template <typename K, int PHASE>
+template <typename K, int PHASE, bool RUNS>
 __global__ void __launch_bounds__(64) k_roots_banks(RootsArgs A, const K *__restrict__ keys) {
   constexpr int phase = PHASE;
   constexpr int ntab = (phase == 1) ? 9 : 64;
@@ -810,9 +810,27 @@ __global__ void __launch_bounds__(64) k_roots_banks(RootsArgs A, const K *__rest
   load_xyz(A.pts, 0, x0, y0, z0);
   const int k0x = vox(x0, P.vs), k0y = vox(y0, P.vs), k0z = vox(z0, P.vs);
 
-  auto do_root = [&](const uint64_t head, uint32_t tslot, uint32_t ncand, unsigned long long split1) __attribute__((always_inline)) {
+  auto do_root = [&](const HeadRec hrec, uint32_t tslot, uint32_t ncand, unsigned long long split1) __attribute__((always_inline)) {
     uint32_t emitted = 0;
-    const K rootkey = keys[head];
+    const uint64_t head = hrec.pos;
+    // RUNS: the root's points are hrec.nr sorted runs starting at runs[hrec.gidx] (a sweep without run structure: one run
+    // per point, so point p of the root is simply run p; otherwise a binary search in the run offsets)
+    const K rootkey = RUNS ? (K)key_join(hrec.gidx / A.run_cap, comp_rest(A.runs[hrec.gidx])) : keys[head];
+    const bool unit_runs = RUNS && hrec.nr == hrec.total;
+    const uint32_t off0 = (RUNS && !unit_runs) ? A.run_off[hrec.gidx] : 0u;
+    auto run_point = [&](uint32_t pp) __attribute__((always_inline)) -> uint32_t {  // RUNS: index of the root's pp-th point, pp < total
+      if (unit_runs) return comp_start(A.runs[(size_t)hrec.gidx + pp]);
+      const uint32_t *ro = A.run_off + hrec.gidx;
+      uint32_t lo = 0, hi = hrec.nr;
+      while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (ro[mid] - off0 <= pp)
+          lo = mid;
+        else
+          hi = mid;
+      }
+      return comp_start(A.runs[(size_t)hrec.gidx + lo]) + (pp - (ro[lo] - off0));
+    };
     const int kx = (int)(rootkey & ((K(1) << B) - 1)) - half + k0x;
     const int ky = (int)((rootkey >> B) & ((K(1) << B) - 1)) - half + k0y;
     const int kz = (int)((rootkey >> (2 * B)) & ((K(1) << B) - 1)) - half + k0z;
@@ -857,13 +875,22 @@ __global__ void __launch_bounds__(64) k_roots_banks(RootsArgs A, const K *__rest
       // two-stage software pipeline over the 64-point chunks: (key, index) of chunk c + 2 and the points of chunk c + 1
       // are in flight while chunk c is processed, so no step of the dependent chain key -> index -> point is waited for
       // inside the loop (the loads are unconditional from clamped positions; validity is decided when they are used)
-      uint64_t pos = head + lane;
+      uint64_t pos = head + lane;  // (RUNS: only pos - head, the position inside the root, is used)
       const uint64_t last = A.n - 1;
-      K kcur = keys[min(pos, last)];
-      uint32_t icur = A.vals[min(pos, last)];
-      K knext = keys[min(pos + 64, last)];
-      uint32_t inext = A.vals[min(pos + 64, last)];
-      bool valid = pos < A.n && kcur == rootkey;
+      K kcur = 0, knext = 0;
+      uint32_t icur, inext;
+      bool valid;
+      if (RUNS) {
+        valid = (uint32_t)lane < hrec.total;
+        icur = valid ? run_point((uint32_t)lane) : 0u;
+        inext = ((uint32_t)lane + 64u < hrec.total) ? run_point((uint32_t)lane + 64u) : 0u;
+      } else {
+        kcur = keys[min(pos, last)];
+        icur = A.vals[min(pos, last)];
+        knext = keys[min(pos + 64, last)];
+        inext = A.vals[min(pos + 64, last)];
+        valid = pos < A.n && kcur == rootkey;
+      }
       double px = 0, py = 0, pz = 0, pt = 0;
       if (valid) {
         load_xyz(A.pts, icur, px, py, pz);
@@ -936,13 +963,18 @@ __global__ void __launch_bounds__(64) k_roots_banks(RootsArgs A, const K *__rest
         bool nvalid_next = false;
         if (nvalid == 64) {
           pos += 64;
-          nvalid_next = pos < A.n && knext == rootkey;
+          nvalid_next = RUNS ? ((uint32_t)(pos - head) < hrec.total) : (pos < A.n && knext == rootkey);
           if (nvalid_next) {
             load_xyz(A.pts, inext, px, py, pz);
             pt = load_t(A.pts, inext);
           }
-          knext = keys[min(pos + 64, last)];
-          inext = A.vals[min(pos + 64, last)];
+          if (RUNS) {
+            const uint32_t pn = (uint32_t)(pos - head) + 64u;
+            inext = (pn < hrec.total) ? run_point(pn) : 0u;
+          } else {
+            knext = keys[min(pos + 64, last)];
+            inext = A.vals[min(pos + 64, last)];
+          }
         }
 
         // ---- the sequential pass: time order.  Points between two cluster ends run through a branch-free body: four
@@ -1097,7 +1129,14 @@ __global__ void __launch_bounds__(64) k_roots_banks(RootsArgs A, const K *__rest
   if (PHASE == 2) {  // the queued split jobs, strided
     for (uint32_t it = blockIdx.x; it < njobs; it += gridDim.x) {
       const SplitJob job = A.split_jobs[it];
-      do_root(A.heads[job.slot].pos, job.slot, job.ncand, job.split1);
+      do_root(A.heads[job.slot], job.slot, job.ncand, job.split1);
+    }
+  } else if (RUNS) {  // compacted root list: one root per wavefront
+    RootLocator loc;
+    loc.init(A, lane);
+    for (uint32_t w = blockIdx.x; w < loc.total; w += gridDim.x) {
+      const uint32_t tslot = loc.slot_of(A, w);
+      do_root(A.heads[tslot], tslot, 0u, 0ull);
     }
   } else {  // sparse head table: every wavefront owns a contiguous range of slots
     const uint32_t per_wave = (A.nslots + gridDim.x - 1) / gridDim.x;
@@ -1108,7 +1147,7 @@ __global__ void __launch_bounds__(64) k_roots_banks(RootsArgs A, const K *__rest
       while (live_mask) {
         const int hb = __ffsll((long long)live_mask) - 1;
         live_mask &= live_mask - 1;
-        do_root((uint32_t)__shfl((int)my_pos, hb), it + (uint32_t)hb, 0u, 0ull);
+        do_root(HeadRec{(uint32_t)__shfl((int)my_pos, hb), 0u, 0u, 0u}, it + (uint32_t)hb, 0u, 0ull);
       }
     }
   }
@@ -1288,6 +1327,7 @@ __global__ void __launch_bounds__(256) k_slot_emit(const uint32_t *__restrict__ 
     if (hm) {
       hm[0] = base + c0 + c1 + c2 + c3;
       hm[4] = status[4];  // roots queued for the layer-2 pass (every emitting kernel has finished)
+      hm[5] = status[5];  // runs of the sweep (run-binned sort only): tells the host whether the input has run structure
     }
   }
   base += (w > 0 ? c0 : 0u) + (w > 1 ? c1 : 0u) + (w > 2 ? c2 : 0u);
@@ -1436,21 +1476,23 @@ __global__ void __launch_bounds__(kRunThreads) k_pt_runs(wc_points pts, double v
   }
 }
 
-// one wavefront per bucket (four per workgroup).  Dynamic LDS per wavefront: bin_cap x {unsorted composite, sorted
-// composite, point offset}.  Nothing is expanded to per-point arrays: the roots pass walks the runs itself.
+// one wavefront per bucket (four per workgroup).  Dynamic LDS per wavefront: lds_cap x {composite, composite, point
+// offset}.  Nothing is expanded to per-point arrays: the roots pass walks the runs itself.  Buckets with up to 64 runs
+// (time-ordered sweeps: a handful) are ranked by counting; larger ones (sweeps without run structure: one run per point)
+// by a bitonic sort inside the wavefront, in LDS, no barriers.
 // The live roots (voxel segments with more than min_points points, InitOctoTree cc:129) of the workgroup go into the head
 // table COMPACTED from slot first = (points in front of the workgroup) / (min_points + 1): live root i of the workgroup
 // starts at least (min_points + 1) i points behind the workgroup's first point, so first + i never reaches the range of the
 // next workgroup - a dense work list without a global counter (root_first / root_cnt per workgroup).
-__global__ void __launch_bounds__(256) k_pt_bucket(uint64_t *bins, uint32_t bin_cap, const uint32_t *__restrict__ counts, uint32_t *run_off,
-                                                  HeadRec *head_slots, uint32_t *root_cnt, uint32_t *root_first, int min_points,
-                                                  uint32_t *status) {
+__global__ void __launch_bounds__(256) k_pt_bucket(uint64_t *bins, uint32_t bin_cap, uint32_t lds_cap, const uint32_t *__restrict__ counts,
+                                                  uint32_t *run_off, HeadRec *head_slots, uint32_t *root_cnt, uint32_t *root_first,
+                                                  int min_points, uint32_t *status) {
   extern __shared__ __align__(16) unsigned char s_dyn[];
   __shared__ uint32_t s_red[4], s_live[4];
   const int t = threadIdx.x, w = t >> 6, lane = t & 63;
-  uint64_t *s_a = (uint64_t *)s_dyn + (size_t)w * bin_cap;
-  uint64_t *s_b = (uint64_t *)s_dyn + (size_t)(4 + w) * bin_cap;
-  uint32_t *s_off = (uint32_t *)((uint64_t *)s_dyn + (size_t)8 * bin_cap) + (size_t)w * bin_cap;
+  uint64_t *s_a = (uint64_t *)s_dyn + (size_t)w * lds_cap;
+  uint64_t *s_b = (uint64_t *)s_dyn + (size_t)(4 + w) * lds_cap;
+  uint32_t *s_off = (uint32_t *)((uint64_t *)s_dyn + (size_t)8 * lds_cap) + (size_t)w * lds_cap;
   const uint32_t b0 = blockIdx.x * 4u, b = b0 + w;
   const uint32_t *pcounts = counts + kBuckets;
   // everything that comes from HBM / L2 is requested up front: the bucket's own counts, its first 64 runs, and this
@@ -1459,59 +1501,88 @@ __global__ void __launch_bounds__(256) k_pt_bucket(uint64_t *bins, uint32_t bin_
   const uint32_t total = pcounts[b];
   uint64_t *bin = bins + (size_t)b * bin_cap;
   const uint64_t first = ((uint32_t)lane < min(nb, bin_cap)) ? bin[lane] : 0ull;
-  uint32_t part = 0;
+  uint32_t part = 0, runs_part = 0;
   for (uint32_t i = t; i < b0; i += 256) part += pcounts[i];
+  if (blockIdx.x == gridDim.x - 1)
+    for (uint32_t i = t; i < kBuckets; i += 256) runs_part += counts[i];  // run total of the sweep (statistics for the host)
   uint32_t before = 0;  // points of the workgroup's buckets in front of this wavefront's
   for (int j = 0; j < w; ++j) before += pcounts[b0 + j];
   for (int off = 32; off >= 1; off >>= 1) part += __shfl_xor(part, off);
   if (lane == 0) s_red[w] = part;
-  if (nb > bin_cap) {
-    if (lane == 0) raise_flag(status, kFlagBucketOverflow);
-    nb = 0;  // the caller reruns the general path
+  if (blockIdx.x == gridDim.x - 1) {
+    for (int off = 32; off >= 1; off >>= 1) runs_part += __shfl_xor(runs_part, off);
+    if (lane == 0) atomicAdd(&status[5], runs_part);
   }
-  if ((uint32_t)lane < nb) s_a[lane] = first;
-  for (uint32_t i = lane + 64; i < nb; i += 64) s_a[i] = bin[i];
-  __builtin_amdgcn_wave_barrier();
-  for (uint32_t i = lane; i < nb; i += 64) {  // rank by counting: composites are unique (start index)
-    const uint64_t mine = s_a[i];
-    uint32_t rank = 0;
-    for (uint32_t j = 0; j < nb; ++j) rank += (s_a[j] < mine) ? 1u : 0u;
-    s_b[rank] = mine;
+  if (nb > bin_cap || nb > lds_cap) {
+    if (lane == 0) raise_flag(status, nb > bin_cap ? kFlagBucketOverflow : kFlagLdsOverflow);
+    nb = 0;  // the caller reruns with a larger LDS capacity or on the general path
+  }
+  if (nb <= 64) {
+    if ((uint32_t)lane < nb) s_a[lane] = first;
+    __builtin_amdgcn_wave_barrier();
+    if ((uint32_t)lane < nb) {  // rank by counting: composites are unique (start index)
+      uint32_t rank = 0;
+      for (uint32_t j = 0; j < nb; ++j) rank += (s_a[j] < first) ? 1u : 0u;
+      s_b[rank] = first;
+    }
+  } else {
+    uint32_t N = 128;
+    while (N < nb) N <<= 1;
+    s_b[lane] = first;
+    for (uint32_t i = lane + 64; i < N; i += 64) s_b[i] = (i < nb) ? bin[i] : ~0ull;
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t k = 2; k <= N; k <<= 1)
+      for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+        for (uint32_t p = lane; p < N / 2; p += 64) {
+          const uint32_t i = 2 * p - (p & (j - 1)), l = i + j;
+          const uint64_t x = s_b[i], y = s_b[l];
+          if ((x > y) == ((i & k) == 0)) {
+            s_b[i] = y;
+            s_b[l] = x;
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
   }
   __builtin_amdgcn_wave_barrier();
-  // exclusive prefix of the run lengths in sorted order -> offsets inside the bucket
+  // exclusive prefix of the run lengths in sorted order -> offsets inside the bucket; sorted runs back in place
   uint32_t carry = 0;
   for (uint32_t i0 = 0; i0 < nb; i0 += 64) {
     const uint32_t i = i0 + lane;
-    const uint32_t l = (i < nb) ? comp_len(s_b[i]) : 0u;
+    const uint64_t c = (i < nb) ? s_b[i] : 0ull;
+    const uint32_t l = (i < nb) ? comp_len(c) : 0u;
     uint32_t inc = l;
     for (int off = 1; off < 64; off <<= 1) {
       const uint32_t v = __shfl_up(inc, off);
       if (lane >= off) inc += v;
     }
-    if (i < nb) s_off[i] = carry + inc - l;
+    if (i < nb) {
+      s_off[i] = carry + inc - l;
+      bin[i] = c;
+      run_off[(size_t)b * bin_cap + i] = carry + inc - l;
+    }
     carry += __shfl(inc, 63);
   }
   __builtin_amdgcn_wave_barrier();
-  // the sorted runs go back in place (this wavefront owns the bin), their bucket-local point offsets next to them
-  for (uint32_t r = lane; r < nb; r += 64) {
-    bin[r] = s_b[r];
-    run_off[(size_t)b * bin_cap + r] = s_off[r];
-  }
-  // live roots, pass 1: count
-  auto live_root = [&](uint32_t r, uint32_t &r2, uint32_t &seg) -> bool {
-    if (r >= nb) return false;
-    const uint32_t rest = comp_rest(s_b[r]);
-    if (r > 0 && comp_rest(s_b[r - 1]) == rest) return false;
-    r2 = r + 1;
-    while (r2 < nb && comp_rest(s_b[r2]) == rest) ++r2;
-    seg = (r2 < nb ? s_off[r2] : total) - s_off[r];
-    return seg > (uint32_t)min_points;
-  };
-  uint32_t nlive = 0;
-  for (uint32_t r0 = 0; r0 < nb; r0 += 64) {
-    uint32_t r2, seg;
-    nlive += (uint32_t)__popcll(__ballot(live_root(r0 + lane, r2, seg)));
+  // live roots: voxel segments (runs with one key rest) with more than min_points points.  Chunks of 64 runs from the END,
+  // so that the start of the next segment is known when a segment head is looked at; the live ones are listed in LDS
+  // (the unsorted-composite array is free now) as head | end << 16.
+  uint32_t *s_list = (uint32_t *)s_a;
+  uint32_t nlive = 0, next_head = nb;
+  for (int i0 = (int)((nb + 63) / 64) * 64 - 64; i0 >= 0; i0 -= 64) {
+    const uint32_t r = (uint32_t)i0 + lane;
+    const bool in = r < nb;
+    const uint32_t rest = in ? comp_rest(s_b[r]) : 0u;
+    const bool head = in && (r == 0 || comp_rest(s_b[r - 1]) != rest);
+    const unsigned long long hm = __ballot(head);
+    const unsigned long long above = (lane == 63) ? 0ull : (hm >> (lane + 1));
+    const uint32_t r2 = above ? r + (uint32_t)__ffsll((long long)above) : next_head;  // first run of the next segment
+    const uint32_t seg = (r2 < nb ? s_off[min(r2, nb - 1)] : total) - (in ? s_off[r] : 0u);
+    const bool live = head && seg > (uint32_t)min_points;
+    const unsigned long long lm = __ballot(live);
+    if (live) s_list[nlive + (uint32_t)__popcll(lm & ((1ull << lane) - 1ull))] = r | (r2 << 16);
+    nlive += (uint32_t)__popcll(lm);
+    if (hm) next_head = (uint32_t)i0 + (uint32_t)__ffsll((long long)hm) - 1u;
   }
   if (lane == 0) s_live[w] = nlive;
   __syncthreads();
@@ -1524,49 +1595,44 @@ __global__ void __launch_bounds__(256) k_pt_bucket(uint64_t *bins, uint32_t bin_
     root_cnt[blockIdx.x] = s_live[0] + s_live[1] + s_live[2] + s_live[3];
     root_first[blockIdx.x] = first_slot;
   }
-  // pass 2: write the records
-  for (uint32_t r0 = 0; r0 < nb; r0 += 64) {
-    const uint32_t r = r0 + lane;
-    uint32_t r2 = 0, seg = 0;
-    const bool live = live_root(r, r2, seg);
-    const unsigned long long m = __ballot(live);
-    if (live) {
-      const uint32_t i = lbase + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-      head_slots[first_slot + i] = HeadRec{pbase + s_off[r], b * bin_cap + r, r2 - r, seg};
-    }
-    lbase += (uint32_t)__popcll(m);
+  for (uint32_t k = lane; k < nlive; k += 64) {
+    const uint32_t r = s_list[k] & 0xFFFFu, r2 = s_list[k] >> 16;
+    const uint32_t seg = (r2 < nb ? s_off[r2] : total) - s_off[r];
+    head_slots[first_slot + lbase + k] = HeadRec{pbase + s_off[r], b * bin_cap + r, r2 - r, seg};
   }
 }
 
 constexpr uint32_t kPtBinMax = 1024;  // runs per bucket the in-LDS path takes (4 wavefronts x 20 B x 1024 = 80 KB of LDS)
 
-// bin capacity for n points: twice the mean a cloud without any run structure would produce, 64 at least
+// bin capacity for n points: 32 x the mean a cloud without any run structure would produce (voxel occupancy is heavy
+// tailed: a room sweep of 64 k points has buckets of 280 runs at a mean of 16), 64 at least
 inline uint32_t pt_bin_cap(uint64_t n) {
   uint32_t cap = 64;
-  while (cap < kPtBinMax && (uint64_t)cap * kBuckets < 2 * n) cap *= 2;
+  while (cap < kPtBinMax && (uint64_t)cap * kBuckets < 32 * n) cap *= 2;
   return cap;
 }
 
-// counts (run counts | point counts) and the head slot table must be cleared by the caller
-// counts (run counts | point counts) and the head slot table must be cleared by the caller.  Leaves the sorted runs in
-// b_misc[1], their point offsets in b_misc[3] and the live roots in the head slot table.
+// counts (run counts | point counts) and status must be cleared by the caller.  Leaves the sorted runs in b_misc[1], their
+// point offsets in b_misc[3] and the live roots in the head slot table.  The LDS capacity per bucket (ctx->ex.lds_cap:
+// 256, 512 or 1024 runs) follows the data: a bucket above it raises kFlagLdsOverflow and the call is repeated one size up.
 int point_sort_runs(wc_ctx *ctx, const wc_points &pts, double vs, HeadRec *head_slots, int min_points, uint32_t *status) {
   hipStream_t st = ctx->stream;
   const uint64_t n = pts.n;
   const uint32_t cap = pt_bin_cap(n);
+  const uint32_t lds_cap = std::min(cap, std::max(64u, ctx->ex.lds_cap));
   WC_TRY(wc_ensure(ctx, ctx->b_misc[1], (uint64_t)kBuckets * cap * 8));  // run bins
   WC_TRY(wc_ensure(ctx, ctx->b_misc[2], (2 * kBuckets + 2 * (kBuckets / 4)) * 4));  // run counts | point counts | root_cnt | root_first
   WC_TRY(wc_ensure(ctx, ctx->b_misc[3], (uint64_t)kBuckets * cap * 4));  // point offsets of the sorted runs
   uint32_t *counts = (uint32_t *)ctx->b_misc[2].p;
   const unsigned tiles = (unsigned)((n + kTile - 1) / kTile);
-  const size_t lds = (size_t)4 * cap * 20;
+  const size_t lds = (size_t)4 * lds_cap * 20;
   static bool attr_set = false;
   if (!attr_set) {
     WC_HIP(ctx, hipFuncSetAttribute((const void *)k_pt_bucket, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * kPtBinMax * 20)));
     attr_set = true;
   }
   k_pt_runs<<<tiles, kRunThreads, 0, st>>>(pts, vs, n, counts, (uint64_t *)ctx->b_misc[1].p, cap, status);
-  k_pt_bucket<<<kBuckets / 4, 256, lds, st>>>((uint64_t *)ctx->b_misc[1].p, cap, counts, (uint32_t *)ctx->b_misc[3].p, head_slots,
+  k_pt_bucket<<<kBuckets / 4, 256, lds, st>>>((uint64_t *)ctx->b_misc[1].p, cap, lds_cap, counts, (uint32_t *)ctx->b_misc[3].p, head_slots,
                                              counts + 2 * kBuckets, counts + 2 * kBuckets + kBuckets / 4, min_points, status);
   WC_HIP(ctx, hipGetLastError());
   return WC_OK;
@@ -1600,10 +1666,14 @@ int pipeline_tail(wc_ctx *ctx, bool layer2) {
   };
   if (layer2) {
     const unsigned grid2 = std::min(kRoots2Grid, std::max(64u, ctx->ex.last_splits));  // sized by the previous call's queue
-    if constexpr (RUNS)
-      k_roots<K, 2, true><<<grid2, 64, 0, st>>>(A, (const K *)ctx->b_keys[1].p);
-    else
-      k_roots_banks<K, 2><<<grid2, 64, 0, st>>>(A, (const K *)ctx->b_keys[1].p);
+    if constexpr (RUNS) {
+      if (ctx->ex.unordered)
+        k_roots_banks<K, 2, true><<<grid2, 64, 0, st>>>(A, (const K *)ctx->b_keys[1].p);
+      else
+        k_roots<K, 2, true><<<grid2, 64, 0, st>>>(A, (const K *)ctx->b_keys[1].p);
+    } else {
+      k_roots_banks<K, 2, false><<<grid2, 64, 0, st>>>(A, (const K *)ctx->b_keys[1].p);
+    }
   }
   ctx->ex.layer2_done = layer2;
   mark(4);
@@ -1753,12 +1823,15 @@ int run_pipeline(wc_ctx *ctx, const wc_points &pts, double t_lo, double t_hi, wc
   const K *skeys = (const K *)ctx->b_keys[1].p;  // sorted keys (general path only; the run path never expands them)
   if (fast_pts) {
     if constexpr (sizeof(K) == 4) {
-      k_roots<K, 1, true><<<kRootsGrid, 64, 0, st>>>(A, skeys);  // stream root + layer 1
+      if (ctx->ex.unordered)  // the previous sweep had no run structure: order-independent streaming
+        k_roots_banks<K, 1, true><<<kRootsGrid, 64, 0, st>>>(A, skeys);
+      else
+        k_roots<K, 1, true><<<kRootsGrid, 64, 0, st>>>(A, skeys);  // stream root + layer 1
       mark(3);
       k_roots_emit<K, true><<<kEmitGrid, 64, 0, st>>>(A, skeys);  // node tests + emission
     }
   } else {
-    k_roots_banks<K, 1><<<kRootsGrid, 64, 0, st>>>(A, skeys);  // order-independent streaming (no run structure on this path)
+    k_roots_banks<K, 1, false><<<kRootsGrid, 64, 0, st>>>(A, skeys);  // order-independent streaming (no run structure on this path)
     mark(3);
     k_roots_emit<K, false><<<kEmitGrid, 64, 0, st>>>(A, skeys);
   }
@@ -1823,11 +1896,19 @@ extern "C" int wc_extract_surfels_finish(wc_ctx *ctx, uint64_t *h_n_out) {
   if (ctx->ex.pts.n == 0) return WC_OK;
   auto wait = [&]() -> int {  // stream done; fold the mailbox flag words (raise_flag) into h_status[1]
     WC_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    for (int i = 0; i < 5; ++i)
+    for (int i = 0; i < 6; ++i)
       if (ctx->h_status[8 + i]) ctx->h_status[1] |= 1u << i;
     return WC_OK;
   };
   WC_TRY(wait());
+  // a bucket had more runs than the LDS capacity of k_pt_bucket (but fits its bin): repeat one capacity up (sticky)
+  while ((ctx->h_status[1] & kFlagLdsOverflow) && !(ctx->h_status[1] & (kFlagBucketOverflow | kFlagKeyRange)) && !ctx->ex.general &&
+         ctx->ex.lds_cap < kPtBinMax) {
+    ctx->ex.lds_cap *= 2;
+    WC_TRY(run_pipeline<uint32_t>(ctx, ctx->ex.pts, ctx->ex.t_lo, ctx->ex.t_hi, ctx->ex.d_out, ctx->ex.d_ids, ctx->ex.cap, true, true));
+    WC_TRY(wait());
+  }
+  if ((ctx->h_status[1] & kFlagLdsOverflow) && !ctx->ex.general) ctx->h_status[1] |= kFlagBucketOverflow;  // still too large
   if ((ctx->h_status[1] & kFlagBucketOverflow) && !(ctx->h_status[1] & kFlagKeyRange) && !ctx->ex.general) {
     // a bin of the run-binned point sort overflowed: redo with the general radix sort
     ctx->ex.general = true;
@@ -1857,6 +1938,9 @@ extern "C" int wc_extract_surfels_finish(wc_ctx *ctx, uint64_t *h_n_out) {
   }
   const uint32_t flags = ctx->h_status[1];
   ctx->ex.last_splits = ctx->h_status[4];
+  // run statistics of the run-binned sort: fewer than four points per run on average = no run structure (a spinning
+  // multi-beam sensor in firing order): the next sweep streams with k_roots_banks right away
+  if (!ctx->ex.general && !ctx->ex.wide && ctx->h_status[5] > 0) ctx->ex.unordered = (uint64_t)ctx->h_status[5] * 4 > ctx->ex.pts.n;
   if (h_n_out) *h_n_out = ctx->h_status[0];
   if (flags & kFlagKeyRange) return wc_fail(ctx, WC_ERR_ARG, "point cloud extent exceeds 2^20 root voxels");
   if (flags & kFlagSlotOverflow) return wc_fail(ctx, WC_ERR_HIP, "internal: candidate slot overflow");
