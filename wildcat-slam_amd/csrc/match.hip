@@ -34,7 +34,7 @@ struct MatchParams {
   double org[3];        // grid origin (scaled units)
   int dim[3];           // cells per axis (<= 1024)
   const uint32_t *cell_start;  // dense per-cell [start, end) into the sorted targets, or null (binary search fallback)
-  const uint32_t *cell_end;
+
 };
 
 __device__ __forceinline__ void feature6(const wc_surfel &s, const wc_pose &p, double cs, double as, double f[6], V3 &cw, V3 &nw) {
@@ -87,14 +87,19 @@ __global__ void __launch_bounds__(256) k_cell_keys(const double *feat, uint32_t 
   vals[i] = i;
 }
 
-// dense cell table: first / one-past-last sorted target of every non-empty cell (empty cells keep start = end = 0)
-__global__ void __launch_bounds__(256) k_cell_table(const uint32_t *skeys, uint32_t n, MatchParams M, uint32_t *cell_start, uint32_t *cell_end) {
+// dense cell table: cell_first[c] = number of sorted targets in cells < c (a lower bound for EVERY cell, empty ones
+// included), so that a run of cells along x - contiguous in the sorted order - is ONE range [first[c0], first[c1 + 1]):
+// two table reads per row of a shell instead of two per cell.  The table is pre-filled with n (cells behind the last
+// target); the thread of the first target of a cell fills the gap since the previous non-empty cell.
+__global__ void __launch_bounds__(256) k_cell_table(const uint32_t *skeys, uint32_t n, MatchParams M, uint32_t *cell_first) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const uint32_t k = skeys[i];
-  const size_t c = (size_t)(k & 1023u) + (size_t)M.dim[0] * ((size_t)((k >> 10) & 1023u) + (size_t)M.dim[1] * (size_t)(k >> 20));
-  if (i == 0 || skeys[i - 1] != k) cell_start[c] = i;
-  if (i == n - 1 || skeys[i + 1] != k) cell_end[c] = i + 1;
+  if (i > 0 && skeys[i - 1] == k) return;
+  auto cell_of = [&](uint32_t key) { return (size_t)(key & 1023u) + (size_t)M.dim[0] * ((size_t)((key >> 10) & 1023u) + (size_t)M.dim[1] * (size_t)(key >> 20)); };
+  const size_t c = cell_of(k);
+  size_t c0 = (i == 0) ? 0 : cell_of(skeys[i - 1]) + 1;
+  for (; c0 <= c; ++c0) cell_first[c0] = i;
 }
 
 __global__ void __launch_bounds__(256) k_sorted_feat(const double *feat, const uint32_t *sorted_idx, uint32_t n, double *sfeat) {
@@ -145,9 +150,13 @@ struct TopK {
 template <int K>
 __global__ void __launch_bounds__(128) k_knn_gate(const wc_surfel *q_surf, const wc_pose *q_pose, uint32_t nq, const double *sfeat,
                                                  const uint32_t *skeys, const uint32_t *sorig, const double *tworld, uint32_t nt,
-                                                 MatchParams M, uint32_t *gated, uint32_t *knn_idx, double *knn_d2) {
-  const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
-  if (q >= nq) return;
+                                                 MatchParams M, uint32_t *gated, uint32_t *knn_idx, double *knn_d2,
+                                                 const uint32_t *__restrict__ qorder) {
+  // qorder: the queries in the order of their grid cell (same-set matching: the sorted target permutation).  Neighbouring
+  // threads then scan the same cell ranges: their feature loads hit the same cache lines and their trip counts agree.
+  const uint32_t qi = blockIdx.x * blockDim.x + threadIdx.x;
+  if (qi >= nq) return;
+  const uint32_t q = qorder ? qorder[qi] : qi;
   double f[6];
   V3 cq, nq_w;
   feature6(q_surf[q], q_pose[q], M.cs, M.as, f, cq, nq_w);
@@ -183,15 +192,14 @@ __global__ void __launch_bounds__(128) k_knn_gate(const wc_surfel *q_surf, const
           if (x0 > x1) continue;
           uint32_t b, e;
           const size_t row = (size_t)M.dim[0] * ((size_t)y + (size_t)M.dim[1] * (size_t)z);
-          for (int x = x0; x <= x1; ++x) {
-            if (M.cell_start) {
-              b = M.cell_start[row + x];
-              e = M.cell_end[row + x];
-            } else {  // binary-search fallback: the whole x-run at once
+          {
+            if (M.cell_start) {  // the x-run of cells is one contiguous range of sorted targets
+              b = M.cell_start[row + x0];
+              e = M.cell_start[row + x1 + 1];
+            } else {  // binary-search fallback
               const uint32_t base = ((uint32_t)y << 10) | ((uint32_t)z << 20);
               b = lower_bound_u32(skeys, nt, base | (uint32_t)x0);
               e = lower_bound_u32(skeys, nt, (base | (uint32_t)x1) + 1u);
-              x = x1;
             }
             for (uint32_t i = b; i < e; ++i) {
               const double *p = sfeat + (size_t)i * 6;
@@ -341,18 +349,17 @@ extern "C" int wc_match(wc_ctx *ctx, const wc_surfel *d_q_surf, const wc_pose *d
   }
   k_sorted_feat<<<(nt + 255) / 256, 256, 0, st>>>((const double *)b_feat.p, v1, nt, (double *)b_sfeat.p);
   const size_t ncell = (size_t)M.dim[0] * M.dim[1] * M.dim[2];
-  M.cell_start = M.cell_end = nullptr;
+  M.cell_start = nullptr;
   if (ncell <= (1u << 24)) {  // dense [start, end) table (<= 128 MB); larger grids fall back to binary searches
-    WC_TRY(wc_ensure(ctx, ctx->b_misc[0], ncell * 8));
-    WC_HIP(ctx, hipMemsetAsync(ctx->b_misc[0].p, 0, ncell * 8, st));
+    WC_TRY(wc_ensure(ctx, ctx->b_misc[0], (ncell + 1) * 4));
+    WC_HIP(ctx, hipMemsetD32Async((hipDeviceptr_t)ctx->b_misc[0].p, (int)nt, ncell + 1, st));
     M.cell_start = (const uint32_t *)ctx->b_misc[0].p;
-    M.cell_end = M.cell_start + ncell;
-    k_cell_table<<<(nt + 255) / 256, 256, 0, st>>>(k1, nt, M, (uint32_t *)ctx->b_misc[0].p, (uint32_t *)ctx->b_misc[0].p + ncell);
+    k_cell_table<<<(nt + 255) / 256, 256, 0, st>>>(k1, nt, M, (uint32_t *)ctx->b_misc[0].p);
   }
   // 3. exact k-NN + gates
 #define WC_KNN_LAUNCH(KK)                                                                                                        \
   k_knn_gate<KK><<<(nq + 127) / 128, 128, 0, st>>>(d_q_surf, d_q_pose, nq, (const double *)b_sfeat.p, k1, v1, (const double *)b_world.p, \
-                                                  nt, M, (uint32_t *)b_gated.p, d_knn_idx, d_knn_d2)
+                                                  nt, M, (uint32_t *)b_gated.p, d_knn_idx, d_knn_d2, same_set ? v1 : nullptr)
   switch (P.knn_k) {  // the reference's k = 10 gets its own instantiation (top-k in 30 registers)
     case 10: WC_KNN_LAUNCH(10); break;
     case 1: WC_KNN_LAUNCH(1); break;
