@@ -101,10 +101,28 @@ __device__ __forceinline__ void surfel_side(const double *xl, const double *xr, 
                                             V3 &rotated_plus_t, double j[6], bool want_jac) {
   const V3 r = (1 - f) * ld3(xl) + f * ld3(xr);
   const V3 t = (1 - f) * ld3(xl + 3) + f * ld3(xr + 3);
-  const Q4 E = so3_exp(r);
+  // Exp(r) and Jr(r) from ONE sincos of the half angle (sin th = 2 s c, 1 - cos th = 2 s^2): evaluating so3_exp and so3_Jr
+  // separately costs four fp64 sin / cos per side, and this kernel is bound by exactly that arithmetic (fp64 vector rate),
+  // not by its 136 B per record.  Differs from the separate calls by a few ulp.
+  const double th2 = dot(r, r);
+  Q4 E;
+  M3 Jr;
+  if (th2 < 1e-10 * 1e-10) {
+    E = so3_exp(r);
+    Jr = m3_identity();
+  } else {
+    const double th = sqrt(th2), ith = 1.0 / th;
+    double sh, ch;
+    sincos(0.5 * th, &sh, &ch);
+    const double imag = sh * ith;
+    E = Q4{ch, imag * r.x, imag * r.y, imag * r.z};
+    const V3 an = (-ith) * r;  // unit axis of -r (Jr(r) = Jl(-r), utils.h:46-58)
+    const double sn = 2.0 * sh * ch * ith, omc = 2.0 * sh * sh * ith;
+    Jr = sn * m3_identity() + (1 - sn) * outer(an, an) + omc * hat(an);
+  }
   rotated_plus_t = qrot(E, a) + t;
   if (want_jac) {
-    const M3 T = (qmat(E) * hat(a)) * so3_Jr(r);
+    const M3 T = (qmat(E) * hat(a)) * Jr;
     const V3 row = vecmat(wn, T);
     j[0] = sign * row.x, j[1] = sign * row.y, j[2] = sign * row.z;
     j[3] = -sign * wn.x, j[4] = -sign * wn.y, j[5] = -sign * wn.z;
@@ -140,20 +158,22 @@ __device__ __forceinline__ void eval_binary(const WinParams &wp, const double *r
   cost = 0.5 * cauchy(wp.cauchy_b, r * r, sc);
   r_out = r * sc;
   if (!v) return;
-  for (int i = 0; i < 24; ++i) v[i] = 0.0;
   const int mode = (sp2l > sp1l + 1) ? 0 : (sp2l == sp1l + 1 ? 1 : 2);
-  // local slots of (sp1l, sp1r, sp2l, sp2r) among the distinct blocks (DispatchPtr, cost_functor.h:216-229)
-  const int s2l = mode == 0 ? 2 : (mode == 1 ? 1 : 0), s2r = s2l + 1;
-  if (wp.quirks) {  // four plain assignments, later write wins (Q1)
-    for (int c = 0; c < 6; ++c) v[0 * 6 + c] = j1[c] * (1 - f1);
-    for (int c = 0; c < 6; ++c) v[1 * 6 + c] = j1[c] * f1;
-    for (int c = 0; c < 6; ++c) v[s2l * 6 + c] = j2[c] * (1 - f2);
-    for (int c = 0; c < 6; ++c) v[s2r * 6 + c] = j2[c] * f2;
-  } else {
-    for (int c = 0; c < 6; ++c) v[0 * 6 + c] += j1[c] * (1 - f1);
-    for (int c = 0; c < 6; ++c) v[1 * 6 + c] += j1[c] * f1;
-    for (int c = 0; c < 6; ++c) v[s2l * 6 + c] += j2[c] * (1 - f2);
-    for (int c = 0; c < 6; ++c) v[s2r * 6 + c] += j2[c] * f2;
+  // local slots of (sp1l, sp1r, sp2l, sp2r) among the distinct blocks (DispatchPtr, cost_functor.h:216-229): side 1 sits
+  // in slots 0 / 1, side 2 in 2 / 3 (mode 0), 1 / 2 (mode 1) or 0 / 1 (mode 2).  Written with static indices and selects:
+  // indexing v[] with the slot number puts the whole row into scratch memory (208 B per lane).
+#pragma unroll
+  for (int c = 0; c < 6; ++c) {
+    const double a1 = j1[c] * (1 - f1), b1 = j1[c] * f1, a2v = j2[c] * (1 - f2), b2v = j2[c] * f2;
+    if (wp.quirks) {  // four plain assignments, later write wins (Q1)
+      v[c] = (mode == 2) ? a2v : a1;
+      v[6 + c] = (mode == 2) ? b2v : (mode == 1 ? a2v : b1);
+    } else {
+      v[c] = a1 + ((mode == 2) ? a2v : 0.0);
+      v[6 + c] = b1 + ((mode == 2) ? b2v : (mode == 1 ? a2v : 0.0));
+    }
+    v[12 + c] = (mode == 0) ? a2v : (mode == 1 ? b2v : 0.0);
+    v[18 + c] = (mode == 0) ? b2v : 0.0;
   }
   for (int i = 0; i < 24; ++i) v[i] *= sc;
 }
@@ -362,14 +382,24 @@ __global__ void __launch_bounds__(256) k_seg_heads(const uint32_t *keys, uint32_
 }
 
 // ---- assembly: one workgroup per piece ------------------------------------------------------------------------------
-// Phase A: thread k evaluates record k of the piece (residual + W-wide Jacobian row) into LDS.
-// Phase B: threads own OUTPUT entries of the packed upper triangle of [J r]^T [J r] ((W+1)(W+2)/2 values; the corner
-//          (W,W) carries the piece's cost instead of sum r^2) and loop over the records: fixed order, no atomics.
+// Phase A: thread k evaluates record k of the piece (residual + W-wide Jacobian row) into LDS (row k of V = [J r]).
+// Phase B: the Gram matrix V^T V ((W+1)^2, packed upper triangle; the corner (W,W) carries the piece's cost instead of
+//          sum r^2) in 4x4 register blocks: thread = (block of the upper block triangle, slice of the records); per
+//          record it reads 8 values and does 16 products.  One thread per output entry (2 LDS reads per product) made
+//          this phase LDS-bandwidth bound at ~190 us per linearisation; an fp64-MFMA variant is no faster (fp64 MFMA has
+//          the vector rate and a 25-wide Gram wastes 58 % of 32x32 tiles).  The slices are added in fixed order: no
+//          atomics, bitwise reproducible.
 template <int W, bool UNARY>
 __global__ void __launch_bounds__(kPiece) k_lin_surfel(WinParams wp, const Piece *pieces, const double *rec, const uint32_t *keys,
                                                       uint32_t nrec, const double *x, double *partial) {
   constexpr int T = W + 1;
-  __shared__ double sV[kPiece * T];
+  constexpr int NB = (T + 3) / 4;            // 4-column blocks of V
+  constexpr int NBLK = NB * (NB + 1) / 2;    // blocks (bi <= bj) of the Gram matrix
+  constexpr int NS = kPiece / NBLK;          // record slices
+  constexpr int SL = (kPiece + NS - 1) / NS; // records per slice
+  constexpr int VSZ = kPiece * T + 4;        // + 4: the padded columns of the last block read past the last row
+  constexpr int PSZ = NS * NBLK * 16;
+  __shared__ double sV[VSZ > PSZ ? VSZ : PSZ];  // V, later the per-slice partial blocks
   __shared__ double sC[kPiece];
   const Piece pc = pieces[blockIdx.x];
   const int tid = threadIdx.x;
@@ -384,6 +414,44 @@ __global__ void __launch_bounds__(kPiece) k_lin_surfel(WinParams wp, const Piece
     for (int i = 0; i < W; ++i) sV[tid * T + i] = v[i];
     sV[tid * T + W] = r;
     sC[tid] = c;
+  } else {
+#pragma unroll
+    for (int i = 0; i < T; ++i) sV[tid * T + i] = 0.0;  // records past the end of the piece contribute nothing
+    sC[tid] = 0.0;
+  }
+  if (tid < 4) sV[kPiece * T + tid] = 0.0;
+  __syncthreads();
+  double acc[4][4] = {{0.0}};
+  const int blk = tid % NBLK, slice = tid / NBLK;
+  int bi = 0, remb = blk;
+  while (remb >= NB - bi) {
+    remb -= NB - bi;
+    ++bi;
+  }
+  const int bj = bi + remb;
+  if (slice < NS) {
+    // columns past T (last block) belong to the next record: their products are masked out below
+    const int k0 = slice * SL, k1 = min(k0 + SL, kPiece);
+    const double *pi = sV + 4 * bi, *pj = sV + 4 * bj;
+    for (int k = k0; k < k1; ++k) {
+      double a[4], c4[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        a[q] = pi[k * T + q];
+        c4[q] = pj[k * T + q];
+      }
+#pragma unroll
+      for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[p][q] += a[p] * c4[q];
+    }
+  }
+  __syncthreads();  // everybody is done with V: its storage takes the partial blocks
+  if (slice < NS) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) sV[(slice * NBLK + blk) * 16 + p * 4 + q] = acc[p][q];
   }
   __syncthreads();
   constexpr int NOUT = T * (T + 1) / 2;
@@ -394,13 +462,18 @@ __global__ void __launch_bounds__(kPiece) k_lin_surfel(WinParams wp, const Piece
       ++i;
     }
     const int j = i + rem;
-    double acc = 0.0;
+    double out = 0.0;
     if (i == W) {
-      for (uint32_t k = 0; k < pc.count; ++k) acc += sC[k];
+      double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+      for (uint32_t k = 0; k < kPiece; k += 4) a0 += sC[k], a1 += sC[k + 1], a2 += sC[k + 2], a3 += sC[k + 3];
+      out = (a0 + a1) + (a2 + a3);
     } else {
-      for (uint32_t k = 0; k < pc.count; ++k) acc += sV[k * T + i] * sV[k * T + j];
+      const int ti = i >> 2, tj = j >> 2;
+      const int q = ti * NB - ti * (ti - 1) / 2 + (tj - ti);  // index of block (ti, tj) in the ti <= tj enumeration
+      const int off = q * 16 + (i & 3) * 4 + (j & 3);
+      for (int sl = 0; sl < NS; ++sl) out += sV[sl * NBLK * 16 + off];
     }
-    partial[pc.part_off + e] = acc;
+    partial[pc.part_off + e] = out;
   }
 }
 
