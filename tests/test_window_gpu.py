@@ -190,3 +190,38 @@ def test_two_rank_sharded_solve_on_one_gpu(gpu, oracle):
     for c in ctxs:
         c.close()
     del keep_all
+
+
+def test_c3_window_size_independent_properties(gpu):
+    """BASELINE config C3 (5-scan window, 200 k surfels) at full size, where the oracle would take minutes: properties that
+    hold at any size.  Correspondences from the GPU matcher; the normal equations are symmetric with a positive diagonal,
+    bitwise reproducible, the gradient of the gauge-fixed position block is zero, the LM run decreases the cost and ends at a
+    point where the gradient is much smaller than at the start; every pair is (older, newer)."""
+    w = synth.surfel_window(5, 40_000, seed=31, fixed_patches=20_000)
+    n_s = len(w["surf"])
+    d_surf, d_pose = gpu.to_device(w["surf"]), gpu.to_device(w["pose"])
+    d_fs, d_fp = gpu.to_device(w["fix_surf"]), gpu.to_device(w["fix_pose"])
+    d_pairs, d_pf = gpu.alloc(8 * n_s), gpu.alloc(8 * n_s)
+    n_b = gpu.match_device(d_surf, d_pose, n_s, d_surf, d_pose, n_s, True, d_pairs, n_s)
+    n_u = gpu.match_device(d_surf, d_pose, n_s, d_fs, d_fp, len(w["fix_surf"]), False, d_pf, n_s)
+    assert n_b > n_s // 2 and n_u > 0
+    pairs = d_pairs.download(R.PAIR, n_b)
+    t = w["surf"]["t"]
+    assert np.all(t[pairs["first"]] < t[pairs["second"]])  # (older, newer), knn_surfel_matcher.cc:40-44
+    assert len(np.unique(pairs.view(np.uint64))) == n_b   # no duplicate pair
+    gpu.window_build(d_surf, d_pose, d_pairs, n_b, w["imu"], w["sample_times"], w["grav"], True, d_fs, d_fp, d_pf, n_u)
+    ns = len(w["sample_times"])
+    x0 = np.zeros(12 * ns)
+    H, g, c0 = gpu.window_linearize(x0)
+    H2, g2, c02 = gpu.window_linearize(x0)
+    assert np.array_equal(H, H2) and np.array_equal(g, g2) and c0 == c02  # fixed reduction order
+    assert np.array_equal(H, H.T)
+    d = np.diag(H)
+    assert np.all(d[6:] > 0)                 # every free unknown is constrained
+    assert np.all(g[3:6] == 0) and np.all(H[3:6, :] == 0)  # SubsetParameterization(12, {3,4,5}) on the first sample (cc:556-560)
+    x, s, _ = gpu.window_solve(x0)
+    assert s.iterations >= 1 and s.final_cost < s.initial_cost
+    assert abs(s.initial_cost - c0) <= 1e-9 * c0
+    _, g_end, c_end = gpu.window_linearize(x)
+    assert abs(c_end - s.final_cost) <= 1e-9 * c_end
+    assert np.abs(g_end).max() < 1e-2 * np.abs(g).max()
