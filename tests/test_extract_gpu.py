@@ -153,3 +153,34 @@ def test_unordered_small_sweep_stays_on_the_run_binned_path(gpu, oracle):
     for _ in range(2):  # back to a sweep with run structure
         _run(gpu, oracle, regular)
     _run(gpu, oracle, synth.g1_room(120_000, seed=6))
+
+
+@pytest.mark.parametrize("override", [
+    dict(max_layer=1),                                  # no layer-2 pass at all
+    dict(max_layer=0),                                  # root voxels only
+    dict(min_points=8, cluster_min_points=8),           # denser head table / more candidate slots per point
+    dict(cluster_gap=2e-4),                             # many temporal clusters per node (every scan line its own)
+    dict(voxel_size=0.5, planer_threshold=0.02),        # other grid, other gate
+    dict(view_point=(3.0, -2.0, 1.0), min_plane_likeness=0.3),
+])
+def test_non_default_parameters(gpu, oracle, override):
+    """the reference hard-codes BuildVoxelMap(..., 0.8, 2, {20,...}, 0.01, 0.1) (surfel_extraction.cc:327); the kernels take
+    them as parameters, so other values must agree with the oracle as well - on a sweep with run structure and on one in
+    firing order"""
+    params = oracle.default_params()
+    for k, v in override.items():
+        if k == "view_point":
+            for i in range(3):
+                params.view_point[i] = v[i]
+        else:
+            setattr(params, k, v)
+    gpu.set_params(params)
+    try:
+        for pts in (synth.g2_lattice(120, m=40)[0], synth.g1_room(90_000, seed=13)):
+            s_ref, id_ref, st = oracle.extract_surfels(pts, params)
+            s_gpu, id_gpu = gpu.extract_surfels(pts)
+            assert len(s_gpu) == len(s_ref) == st.surfels
+            if len(s_ref):
+                helpers.check_surfels(s_gpu, id_gpu, s_ref, id_ref, tol=1e-6, t_tol=1e-5)
+    finally:
+        gpu.set_params(oracle.default_params())
