@@ -161,7 +161,7 @@ def main():
 
     if not args.no_window:
         try:
-            result["window"] = bench_window(ctx, args, world, rank, dev, torch, dist)
+            result["window"] = bench_window(ctx, args, world, rank, dev, torch, dist, cpu=(rank == 0 and world == 1 and not args.no_cpu_baseline))
         except Exception as e:  # the headline line must survive a failure of the extra section
             result["window"] = {"error": repr(e)}
 
@@ -192,7 +192,7 @@ def pmc_traffic(kernel):
     return tot
 
 
-def bench_window(ctx, args, world, rank, dev, torch, dist):
+def bench_window(ctx, args, world, rank, dev, torch, dist, cpu=False):
     """LM ("GN") iterations per second on a C4-like window: `scans` sweeps x `patches` surfels, binary + unary surfel
     factors + IMU factors, correspondences from the GPU matcher.  With N > 1 the correspondences are sharded over the
     ranks (unknowns replicated) and every linearisation ends in ONE RCCL all-reduce of the packed {H, g, cost}."""
@@ -253,6 +253,32 @@ def bench_window(ctx, args, world, rank, dev, torch, dist):
                               "frac": round(algo / (lin_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "algorithmic_bytes_per_linearisation": algo},
         "match_s": round(t_match, 4), "match_surfels_per_s": round(2 * n_s / t_match, 1), "generate_s": round(t_gen, 2),
     }
+    if cpu:
+        # CPU baseline of the LM step: the single-thread oracle (oracle/window.cc + oracle/match.cc) on a BOUNDED sample - the
+        # same 20-sweep window geometry (same 127 sample states / 1524 unknowns, same IMU factors) with 1/20 of the surfels
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import pyoracle  # test infrastructure, used here ONLY as the timed CPU baseline
+
+        frac = 20
+        ws = synth.surfel_window(args.window_scans, max(1, args.window_patches // frac), seed=synth.SEED + 7,
+                                 fixed_patches=max(1, args.window_patches // frac))
+        prm = pyoracle.default_params()
+        t1 = time.perf_counter()
+        pb = pyoracle.match(ws["surf"], ws["pose"], ws["surf"], ws["pose"], True, prm)
+        pu = pyoracle.match(ws["surf"], ws["pose"], ws["fix_surf"], ws["fix_pose"], False, prm)
+        t_cm = time.perf_counter() - t1
+        Wc = pyoracle.Window(ws["sample_times"], ws["grav"], False, prm)
+        Wc.add_binary(ws["surf"], ws["pose"], pb)
+        Wc.add_unary(ws["fix_surf"], ws["fix_pose"], ws["surf"], ws["pose"], pu)
+        Wc.add_imu(ws["imu"])
+        t1 = time.perf_counter()
+        _, sc, _ = Wc.solve(np.zeros(12 * len(ws["sample_times"])))
+        t_cs = time.perf_counter() - t1
+        out["cpu_baseline"] = {
+            "value": round(max(1, sc.iterations) / t_cs, 3), "unit": "LM iterations/s", "cores": 1, "kind": "port",
+            "sample": "same window geometry with 1/%d of the surfels (%d surfels, %d + %d surfel factors, %d unknowns): %d LM iterations in %.1f s; "
+                      "matcher %.0f surfels/s" % (frac, len(ws["surf"]), len(pb), len(pu), 12 * len(ws["sample_times"]), sc.iterations, t_cs,
+                                                   2 * len(ws["surf"]) / t_cm)}
     return out
 
 
