@@ -33,7 +33,7 @@
 namespace {
 
 constexpr int kMom = 11;    // n, St, Sx, Sy, Sz, Sxx, Sxy, Sxz, Syy, Syz, Szz
-constexpr unsigned kRootsGrid = 256 * 16;  // wavefronts of the layer-0/1 pass (static work split; <= 128 VGPRs => all resident)
+constexpr unsigned kRootsGrid = 256 * 16;  // wavefronts of the layer-0/1 pass (one root each from the dense work list; all resident)
 constexpr unsigned kEmitGrid = 256 * 8;   // wavefronts of the node-test + emission pass (three roots at a time each)
 constexpr unsigned kRoots2Grid = 256 * 4;  // wavefronts of the (rare) layer-2 pass
 constexpr int kBuckets = 4096;    // buckets of the composite sorts
@@ -343,11 +343,13 @@ struct RootLocator {
   }
 };
 
-// One wavefront per root voxel.  PHASE 1 streams the root + its eight layer-1 nodes (9 table rows); roots with layer-1
-// nodes that were tested and are not planes (CutOctoTree recursion, cc:175-182) are queued for PHASE 2, a second launch
-// of the same code over the 64 layer-2 nodes (rare on regular scenes, so the common case keeps a 5 KB LDS footprint).
-// Static work assignment (every wavefront owns a contiguous run of head slots): a device-side dequeue word serialised
-// at ~90 dequeues/us and cost more than it balanced.
+// One wavefront per root voxel.  PHASE 1 streams the root + its eight layer-1 nodes (9 table rows) and leaves node totals
+// and candidate clusters to k_roots_emit; roots with layer-1 nodes that were tested and are not planes (CutOctoTree
+// recursion, cc:175-182) are queued for PHASE 2, a second launch of the same streaming code over the 64 layer-2 nodes with
+// the tests and the emission fused in (rare on regular scenes, so the common case keeps a 7 KB LDS footprint).
+// Work assignment: RUNS mode takes root number blockIdx.x of the dense work list (RootLocator); the radix-sort path scans a
+// fixed range of the sparse head table.  (A device-side dequeue word serialised at ~90 dequeues/us and cost more than it
+// balanced.)
 template <typename K, int PHASE, bool RUNS>
 __global__ void __launch_bounds__(64) k_roots(RootsArgs A, const K *__restrict__ keys) {
   constexpr int phase = PHASE;  // octree pass: 1 = root + layer 1 (streaming only, k_roots_emit finishes it), 2 = layer 2 (fused)
@@ -693,7 +695,7 @@ __global__ void __launch_bounds__(64) k_roots(RootsArgs A, const K *__restrict__
       emitted += (uint32_t)__popcll(__ballot(ok));
       WC_TICK(6);  // gates + surfel stores
     }
-    // the surfel count: with the slot histogram it is the histogram total (k_bucket_prefix); a per-root atomic on one
+    // the surfel count: with the time bins it is the total of the bin counts (k_slot_emit); a per-root atomic on one
     // word serialises at ~12 ns per root once every wavefront reaches this point at the same time (47 us for 3.9 k roots)
     if (lane == 0 && emitted && !A.slot_counts) atomicAdd(&A.status[0], emitted);
 #ifdef WC_PROF_ROOTS
