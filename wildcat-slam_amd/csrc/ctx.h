@@ -26,6 +26,7 @@ struct wc_ctx {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   std::string err;
   // scratch buffers (device), grown on demand and kept for the lifetime of the ctx
+  wc_buf b_ex_ctrl;  // the extraction's control block (status words, bucket / bin counters): never shared, cleared ahead of time
   wc_buf b_keys[2], b_vals[2], b_sorttmp, b_slots, b_slot_ids, b_slot_keys[2], b_slot_idx[2], b_cand, b_cand_meta,
       b_status, b_misc[8];
   // pinned host mailbox
@@ -48,6 +49,7 @@ struct wc_ctx {
     uint32_t last_splits = 256;  // roots the previous call queued for the layer-2 pass (sizes / gates that launch)
     // the tail of the pipeline (layer-2 pass, surfel order, status read-back) is re-run by finish() when the call skipped
     // the layer-2 launch and roots were queued for it after all
+    bool precleared = false;     // the control block has been cleared (on the stream) by the previous finish()
     bool layer2_done = true;
     int (*tail)(wc_ctx *, bool) = nullptr;
     alignas(16) unsigned char roots_args[768];

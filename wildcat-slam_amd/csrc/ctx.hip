@@ -88,7 +88,8 @@ extern "C" void wc_ctx_destroy(wc_ctx *ctx) {
   wc_window_free(ctx);
   wc_buf *all[] = {&ctx->b_keys[0],      &ctx->b_keys[1],     &ctx->b_vals[0],     &ctx->b_vals[1],      &ctx->b_sorttmp,
                    &ctx->b_slots,        &ctx->b_slot_ids,    &ctx->b_slot_keys[0], &ctx->b_slot_keys[1], &ctx->b_slot_idx[0],
-                   &ctx->b_slot_idx[1],  &ctx->b_cand,        &ctx->b_cand_meta,   &ctx->b_status};
+                   &ctx->b_slot_idx[1],  &ctx->b_cand,        &ctx->b_cand_meta,   &ctx->b_status,
+                   &ctx->b_ex_ctrl};
   for (wc_buf *b : all)
     if (b->p) (void)hipFree(b->p);
   for (wc_buf &b : ctx->b_misc)

@@ -1614,6 +1614,31 @@ inline uint32_t pt_bin_cap(uint64_t n) {
   return cap;
 }
 
+// The extraction's control block (its own buffer: the other entry points of the library never touch it, so it can be
+// cleared ahead of time): status words | run counts, point counts | root_cnt, root_first | time-bin counts.
+constexpr uint32_t kCtrlStatus = 0, kCtrlCounts = 64, kCtrlRoots = kCtrlCounts + 2 * kBuckets, kCtrlBins = kCtrlRoots + 2 * (kBuckets / 4),
+                   kCtrlWords = kCtrlBins + kBuckets;
+
+// clears the control block and stores the mailbox address (status words [8, 9]); used in front of a call, or - the usual
+// case - by finish() for the NEXT call: run ahead of time it hides behind the host's turn-around between two sweeps
+// instead of being the first, 3 us long, kernel of the sweep with a 4 us submission gap behind it.
+int clear_ctrl(wc_ctx *ctx) {
+  WC_TRY(wc_ensure(ctx, ctx->b_ex_ctrl, kCtrlWords * 4));
+  uint32_t *ctrl = (uint32_t *)ctx->b_ex_ctrl.p;
+  InitArgs I{};
+  void *dp = nullptr;
+  if (hipHostGetDevicePointer(&dp, ctx->h_status, 0) != hipSuccess) dp = nullptr;
+  const unsigned long long a = (unsigned long long)dp;
+  I.p[0] = ctrl, I.nw[0] = 8, I.val[0] = 0u;
+  I.p[1] = ctrl + 10, I.nw[1] = kCtrlRoots - 10, I.val[1] = 0u;  // rest of the status words, run / point counts
+  I.p[2] = ctrl + 8, I.nw[2] = 1, I.val[2] = (uint32_t)a;
+  I.p[3] = ctrl + 9, I.nw[3] = 1, I.val[3] = (uint32_t)(a >> 32);
+  I.p[4] = ctrl + kCtrlBins, I.nw[4] = kBuckets, I.val[4] = 0u;
+  k_init<<<(kCtrlRoots + 255) / 256, 256, 0, ctx->stream>>>(I);
+  WC_HIP(ctx, hipGetLastError());
+  return WC_OK;
+}
+
 // counts (run counts | point counts) and status must be cleared by the caller.  Leaves the sorted runs in b_misc[1], their
 // point offsets in b_misc[3] and the live roots in the head slot table.  The LDS capacity per bucket (ctx->ex.lds_cap:
 // 256, 512 or 1024 runs) follows the data: a bucket above it raises kFlagLdsOverflow and the call is repeated one size up.
@@ -1623,9 +1648,8 @@ int point_sort_runs(wc_ctx *ctx, const wc_points &pts, double vs, HeadRec *head_
   const uint32_t cap = pt_bin_cap(n);
   const uint32_t lds_cap = std::min(cap, std::max(64u, ctx->ex.lds_cap));
   WC_TRY(wc_ensure(ctx, ctx->b_misc[1], (uint64_t)kBuckets * cap * 8));  // run bins
-  WC_TRY(wc_ensure(ctx, ctx->b_misc[2], (2 * kBuckets + 2 * (kBuckets / 4)) * 4));  // run counts | point counts | root_cnt | root_first
   WC_TRY(wc_ensure(ctx, ctx->b_misc[3], (uint64_t)kBuckets * cap * 4));  // point offsets of the sorted runs
-  uint32_t *counts = (uint32_t *)ctx->b_misc[2].p;
+  uint32_t *counts = (uint32_t *)ctx->b_ex_ctrl.p + kCtrlCounts;  // run counts | point counts | root_cnt | root_first
   const unsigned tiles = (unsigned)((n + kTile - 1) / kTile);
   const size_t lds = (size_t)4 * lds_cap * 20;
   static bool attr_set = false;
@@ -1680,7 +1704,7 @@ int pipeline_tail(wc_ctx *ctx, bool layer2) {
   ctx->ex.layer2_done = layer2;
   mark(4);
   if (ctx->ex.fast_slots) {
-    k_slot_emit<<<kBuckets / 4, 256, 0, st>>>((const uint32_t *)ctx->b_misc[4].p, A.slot_bins, ctx->ex.bin_cap, (const wc_surfel *)ctx->b_slots.p,
+    k_slot_emit<<<kBuckets / 4, 256, 0, st>>>((const uint32_t *)ctx->b_ex_ctrl.p + kCtrlBins, A.slot_bins, ctx->ex.bin_cap, (const wc_surfel *)ctx->b_slots.p,
                                              (const wc_surfel_id *)ctx->b_slot_ids.p, status, d_out, d_ids, cap);
   } else {
     k_iota<<<(unsigned)((total_slots + 255) / 256), 256, 0, st>>>((uint32_t *)ctx->b_slot_idx[0].p, total_slots);
@@ -1735,9 +1759,13 @@ int run_pipeline(wc_ctx *ctx, const wc_points &pts, double t_lo, double t_hi, wc
   WC_TRY(wc_ensure(ctx, ctx->b_slot_keys[1], total_slots * 8));
   WC_TRY(wc_ensure(ctx, ctx->b_slot_idx[0], total_slots * 4));
   WC_TRY(wc_ensure(ctx, ctx->b_slot_idx[1], total_slots * 4));
-  WC_TRY(wc_ensure(ctx, ctx->b_status, 64 * 4));
   WC_TRY(wc_ensure(ctx, ctx->b_misc[0], (n / (uint64_t)(P.min_points + 1) + 2) * sizeof(HeadRec)));
-  uint32_t *status = (uint32_t *)ctx->b_status.p;
+  // the control block: cleared ahead of time by the previous finish() (see clear_ctrl) or right here
+  const bool precleared = ctx->ex.precleared && ctx->b_ex_ctrl.p;
+  ctx->ex.precleared = false;
+  if (!precleared) WC_TRY(clear_ctrl(ctx));
+  for (int q = 0; q < 16; ++q) ctx->h_status[q] = 0;
+  uint32_t *status = (uint32_t *)ctx->b_ex_ctrl.p + kCtrlStatus;
 
   auto mark = [&](int i) {
     if (ctx->ex_prof) (void)hipEventRecord(ctx->ex_ev[i], st);
@@ -1747,33 +1775,19 @@ int run_pipeline(wc_ctx *ctx, const wc_points &pts, double t_lo, double t_hi, wc
   // capacity of a time bucket's bin: twice the count every bucket would get if EVERY slot held a surfel, 64 at least
   uint32_t bin_cap = 64;
   while (bin_cap < kSlotBinMax && (uint64_t)bin_cap * kBuckets < 2 * total_slots) bin_cap *= 2;
-  if (fast_slots) WC_TRY(wc_ensure(ctx, ctx->b_misc[4], 3 * kBuckets * 4));
   const unsigned g256 = (unsigned)((n + 255) / 256);
   // fast path (32-bit keys): bucket sort of (voxel key, index) composites; general path: rocPRIM radix sort
   const bool fast_pts = fast && sizeof(K) == 4;
   if (fast_pts || fast_slots) {
     WC_TRY(wc_ensure(ctx, ctx->b_slot_keys[1], (uint64_t)kBuckets * bin_cap * 8));  // slot bins (the general path's sort buffer)
-    WC_TRY(wc_ensure(ctx, ctx->b_misc[2], (2 * kBuckets + 2 * (kBuckets / 4)) * 4));
   }
   const uint32_t nslots = (uint32_t)(n / (uint64_t)(P.min_points + 1) + 1);
-  {
+  if (!fast_slots || !fast_pts) {  // the large fills of the radix-sort paths
     InitArgs I{};
     int r = 0;
     auto fill = [&](void *p, uint64_t words, uint32_t v) { I.p[r] = (uint32_t *)p, I.nw[r] = (uint32_t)words, I.val[r] = v, ++r; };
-    fill(status, 8, 0u);
-    fill(status + 10, 54, 0u);
-    {  // address of the pinned host mailbox into status words [8, 9]
-      void *dp = nullptr;
-      if (hipHostGetDevicePointer(&dp, ctx->h_status, 0) != hipSuccess) dp = nullptr;
-      const unsigned long long a = (unsigned long long)dp;
-      fill(status + 8, 1, (uint32_t)a);
-      fill(status + 9, 1, (uint32_t)(a >> 32));
-    }
-    for (int q = 0; q < 16; ++q) ctx->h_status[q] = 0;
     if (!fast_slots) fill(ctx->b_slot_keys[0].p, total_slots * 2, 0xFFFFFFFFu);  // slot keys: ~0 = no surfel in the slot
     if (!fast_pts) fill(ctx->b_misc[0].p, (uint64_t)nslots * 4, 0xFFFFFFFFu);   // sparse head slot table: pos = ~0 = no live head
-    if (fast_slots) fill(ctx->b_misc[4].p, 2 * kBuckets, 0u);                   // slot bucket counts (filled by k_roots) + cursors
-    if (fast_pts) fill(ctx->b_misc[2].p, 2 * kBuckets, 0u);                     // point-sort run counts | point counts
     uint32_t mx = 0;
     for (int q = 0; q < r; ++q) mx = std::max(mx, I.nw[q]);
     k_init<<<(mx + 255) / 256, 256, 0, st>>>(I);
@@ -1798,13 +1812,13 @@ int run_pipeline(wc_ctx *ctx, const wc_points &pts, double t_lo, double t_hi, wc
   A.slot_keys = (uint64_t *)ctx->b_slot_keys[0].p;
   A.total_slots = total_slots;
   A.status = status;
-  A.slot_counts = fast_slots ? (uint32_t *)ctx->b_misc[4].p : nullptr;
+  A.slot_counts = fast_slots ? (uint32_t *)ctx->b_ex_ctrl.p + kCtrlBins : nullptr;
   A.slot_shift = tbits > 12 ? tbits - 12 : 0u;
   A.slot_bins = (uint64_t *)ctx->b_slot_keys[1].p;
   A.runs = (const uint64_t *)ctx->b_misc[1].p;
   A.run_off = (const uint32_t *)ctx->b_misc[3].p;
   A.run_cap = pt_bin_cap(n);
-  A.root_cnt = (const uint32_t *)ctx->b_misc[2].p + 2 * kBuckets;
+  A.root_cnt = (const uint32_t *)ctx->b_ex_ctrl.p + kCtrlRoots;
   A.root_first = A.root_cnt + kBuckets / 4;
   A.slot_bin_cap = bin_cap;
   A.heads = (const HeadRec *)ctx->b_misc[0].p;
@@ -1939,16 +1953,19 @@ extern "C" int wc_extract_surfels_finish(wc_ctx *ctx, uint64_t *h_n_out) {
     WC_TRY(wait());
   }
   const uint32_t flags = ctx->h_status[1];
+  const uint32_t n_out = ctx->h_status[0];
   ctx->ex.last_splits = ctx->h_status[4];
   // run statistics of the run-binned sort: fewer than four points per run on average = no run structure (a spinning
   // multi-beam sensor in firing order): the next sweep streams with k_roots_banks right away
   if (!ctx->ex.general && !ctx->ex.wide && ctx->h_status[5] > 0) ctx->ex.unordered = (uint64_t)ctx->h_status[5] * 4 > ctx->ex.pts.n;
-  if (h_n_out) *h_n_out = ctx->h_status[0];
+  if (h_n_out) *h_n_out = n_out;
+  // the control block of the NEXT call is cleared now, asynchronously: it runs while the host turns around
+  if (clear_ctrl(ctx) == WC_OK) ctx->ex.precleared = true;
   if (flags & kFlagKeyRange) return wc_fail(ctx, WC_ERR_ARG, "point cloud extent exceeds 2^20 root voxels");
   if (flags & kFlagSlotOverflow) return wc_fail(ctx, WC_ERR_HIP, "internal: candidate slot overflow");
   if (flags & kFlagTimeRange) return wc_fail(ctx, WC_ERR_ARG, "surfel timestamp below the t_lo hint");
-  if (ctx->h_status[0] > ctx->ex.cap) return wc_fail(ctx, WC_ERR_CAPACITY, "output capacity %llu < %u surfels",
-                                                      (unsigned long long)ctx->ex.cap, ctx->h_status[0]);
+  if (n_out > ctx->ex.cap) return wc_fail(ctx, WC_ERR_CAPACITY, "output capacity %llu < %u surfels",
+                                          (unsigned long long)ctx->ex.cap, n_out);
   return WC_OK;
 }
 
@@ -1974,8 +1991,9 @@ extern "C" int wc_extract_stage_ms(wc_ctx *ctx, float *h_ms5) {
 }
 
 extern "C" int wc_debug_status(wc_ctx *ctx, uint32_t *h_out64) {  // profiling aid: status words [0..16) + section timers
-  if (!ctx || !h_out64 || !ctx->b_status.p) return WC_ERR_ARG;
-  WC_HIP(ctx, hipMemcpy(h_out64, ctx->b_status.p, 64 * 4, hipMemcpyDeviceToHost));
+  if (!ctx || !h_out64 || !ctx->b_ex_ctrl.p) return WC_ERR_ARG;
+  // (the device copy has been cleared for the next call already: words 0..15 come from the host mailbox of the last call)
+  for (int i = 0; i < 64; ++i) h_out64[i] = i < 16 ? ctx->h_status[i] : 0u;
 #ifdef WC_PROF_ROOTS
   // average the per-root section timers into words [16, 24), number of timed roots in word 24
   const size_t nslots = ctx->ex.pts.n / (size_t)(ctx->P.min_points + 1) + 1;

@@ -305,7 +305,7 @@ void LidarOdometry::UpdateImuPoses() {
   CubicBSpline rot_interp(ts, rc), pos_interp(ts, pc);
   long first = -1, last = -1;
   for (size_t i = 0; i < imu_states_.size(); ++i) {
-    V3 r, p;
+    V3 r{0, 0, 0}, p{0, 0, 0};
     const bool ok = rot_interp.Interp(imu_states_[i].t, r);
     const bool ok2 = pos_interp.Interp(imu_states_[i].t, p);
     WC_CHECK(ok == ok2);
