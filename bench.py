@@ -109,7 +109,9 @@ def main():
     # bound kernels leaves idle is filled by the other sweep.  Reported next to the headline, never as `value`.
     pipelined = None
     try:
-        F = max(2, args.in_flight)
+        if args.in_flight < 2:
+            raise RuntimeError("skipped (--in-flight < 2)")
+        F = args.in_flight
         ring = [(ctx, out_p, ids_p, None)]
         for _ in range(F - 1):
             c2 = lib.Context(local_rank)

@@ -9,9 +9,9 @@ O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 python $R/bench.py --steps 200 --warmup 20 > $O/bench.json 2> $O/bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o b -- python $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline > $O/trace.log 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o b -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --window-scans 4 --window-patches 50000 > $O/pmc_fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o b -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --window-scans 4 --window-patches 50000 > $O/pmc_write.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o b -- python $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline --in-flight 1 > $O/trace.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o b -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --in-flight 1 --window-scans 4 --window-patches 50000 > $O/pmc_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o b -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --in-flight 1 --window-scans 4 --window-patches 50000 > $O/pmc_write.log 2>&1
 rm -f $O/*/b_kernel_trace.csv.bak
 ls $O $O/trace | head -20
 tail -1 $O/bench.json | cut -c1-300
