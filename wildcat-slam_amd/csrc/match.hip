@@ -164,7 +164,7 @@ struct TopK {
 
 // exact k-NN + gates.  gated[q][j] = j-th neighbour passing the first three gates (kNone-terminated).
 template <int K>
-__global__ void __launch_bounds__(128) k_knn_gate(const wc_surfel *q_surf, const wc_pose *q_pose, uint32_t nq, const double *sfeat,
+__global__ void __launch_bounds__(128, 4) k_knn_gate(const wc_surfel *q_surf, const wc_pose *q_pose, uint32_t nq, const double *sfeat,
                                                  const uint32_t *skeys, const uint32_t *sorig, const double *tworld, uint32_t nt,
                                                  MatchParams M, uint32_t *gated, uint32_t *knn_idx, double *knn_d2,
                                                  const uint32_t *__restrict__ qorder) {
