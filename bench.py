@@ -77,9 +77,11 @@ def main():
 
     out_p, ids_p = _Ptr(d_out.data_ptr()), _Ptr(d_ids.data_ptr())
 
+    enq, fin = ctx.prepare_extract(desc, out_p, ids_p, cap, t_lo, t_hi)  # ctypes argument objects built once
+
     def step():
-        ctx.extract_enqueue(desc, out_p, ids_p, cap, t_lo, t_hi)
-        return ctx.extract_finish()
+        enq()
+        return fin()
 
     for _ in range(args.warmup):
         n_s = step()
