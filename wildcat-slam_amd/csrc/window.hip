@@ -732,8 +732,8 @@ using f64x4 = __attribute__((ext_vector_type(4))) double;
 
 __device__ __forceinline__ double rsqrt_nr(double a) {
   double inv = __builtin_amdgcn_rsq(a);  // ~2^-26 relative; one Newton step squares that, the second is insurance the
-  inv = inv * (1.5 - 0.5 * a * inv * inv);  // pivot chain cannot afford (every dependent fp64 op costs ~25-30 clk here)
-  return inv;
+  const double h = 0.5 * inv;             // pivot chain cannot afford (every dependent fp64 op costs ~25-30 clk here)
+  return fma(h, fma(-a * inv, inv, 1.0), inv);  // inv + inv/2 (1 - a inv^2)
 }
 
 __device__ __forceinline__ bool factor_inv32_blk(double (*sB)[kNB + 1], double (*sXi)[kNB + 1]) {
@@ -748,15 +748,17 @@ __device__ __forceinline__ bool factor_inv32_blk(double (*sB)[kNB + 1], double (
     const double p00 = sB[j0][j0], p10 = sB[j0 + 1][j0], p11 = sB[j0 + 1][j0 + 1], p20 = sB[j0 + 2][j0], p21 = sB[j0 + 2][j0 + 1],
                  p22 = sB[j0 + 2][j0 + 2], p30 = sB[j0 + 3][j0], p31 = sB[j0 + 3][j0 + 1], p32 = sB[j0 + 3][j0 + 2],
                  p33 = sB[j0 + 3][j0 + 3];
+    // (explicit fma: this chain of dependent fp64 operations is the critical path of the whole factorisation, and the
+    // solve is compared with the oracle at 1e-6, not bit for bit)
     const double i00 = rsqrt_nr(p00);
     const double l00 = p00 * i00, l10 = p10 * i00, l20 = p20 * i00, l30 = p30 * i00;
-    const double d1 = p11 - l10 * l10;
+    const double d1 = fma(-l10, l10, p11);
     const double i11 = rsqrt_nr(d1);
-    const double l11 = d1 * i11, l21 = (p21 - l20 * l10) * i11, l31 = (p31 - l30 * l10) * i11;
-    const double d2 = p22 - l20 * l20 - l21 * l21;
+    const double l11 = d1 * i11, l21 = fma(-l20, l10, p21) * i11, l31 = fma(-l30, l10, p31) * i11;
+    const double d2 = fma(-l21, l21, fma(-l20, l20, p22));
     const double i22 = rsqrt_nr(d2);
-    const double l22 = d2 * i22, l32 = (p32 - l30 * l20 - l31 * l21) * i22;
-    const double d3 = p33 - l30 * l30 - l31 * l31 - l32 * l32;
+    const double l22 = d2 * i22, l32 = fma(-l31, l21, fma(-l30, l20, p32)) * i22;
+    const double d3 = fma(-l32, l32, fma(-l31, l31, fma(-l30, l30, p33)));
     const double i33 = rsqrt_nr(d3);
     const double l33 = d3 * i33;
     if (!(p00 > 0.0 && d1 > 0.0 && d2 > 0.0 && d3 > 0.0)) ok = false;
@@ -766,9 +768,9 @@ __device__ __forceinline__ bool factor_inv32_blk(double (*sB)[kNB + 1], double (
     const double i32 = -(l32 * i22) * i33;
     const double i31 = -(l31 * i11 + l32 * i21) * i33;
     const double i30 = -(l30 * i00 + l31 * i10 + l32 * i20) * i33;
-    __syncthreads();  // everybody has read the pivot block before its rows are overwritten
+    // (no barrier here: the pivot block is only overwritten after the next barrier, see below)
     if (tid < kNB) {
-      // ---- the 4-column panel: row r of L = row r of A times Lp^-T; the pivot rows become Lp ----
+      // ---- the 4-column panel: row r of L = row r of A times Lp^-T ----
       const int r = tid;
       if (r >= j0 + 4) {
         const double v0 = sB[r][j0], v1 = sB[r][j0 + 1], v2 = sB[r][j0 + 2], v3 = sB[r][j0 + 3];
@@ -776,13 +778,7 @@ __device__ __forceinline__ bool factor_inv32_blk(double (*sB)[kNB + 1], double (
         sB[r][j0 + 1] = v0 * i10 + v1 * i11;
         sB[r][j0 + 2] = v0 * i20 + v1 * i21 + v2 * i22;
         sB[r][j0 + 3] = v0 * i30 + v1 * i31 + v2 * i32 + v3 * i33;
-      } else if (r >= j0) {
-        const int a = r - j0;
-        sB[r][j0] = a == 0 ? l00 : (a == 1 ? l10 : (a == 2 ? l20 : l30));
-        sB[r][j0 + 1] = a == 0 ? 0.0 : (a == 1 ? l11 : (a == 2 ? l21 : l31));
-        sB[r][j0 + 2] = a <= 1 ? 0.0 : (a == 2 ? l22 : l32);
-        sB[r][j0 + 3] = a <= 2 ? 0.0 : l33;
-      } else {
+      } else if (r < j0) {
         sB[r][j0] = sB[r][j0 + 1] = sB[r][j0 + 2] = sB[r][j0 + 3] = 0.0;  // above the diagonal
       }
     } else if (tid < 2 * kNB) {
@@ -795,14 +791,19 @@ __device__ __forceinline__ bool factor_inv32_blk(double (*sB)[kNB + 1], double (
       sXi[j0 + 3][c] = i30 * w0 + i31 * w1 + i32 * w2 + i33 * w3;
     }
     __syncthreads();
+    if (tid >= j0 && tid < j0 + 4) {  // the pivot rows become Lp (every thread has its own copy of Lp by now)
+      const int r = tid, a = r - j0;
+      sB[r][j0] = a == 0 ? l00 : (a == 1 ? l10 : (a == 2 ? l20 : l30));
+      sB[r][j0 + 1] = a == 0 ? 0.0 : (a == 1 ? l11 : (a == 2 ? l21 : l31));
+      sB[r][j0 + 2] = a <= 1 ? 0.0 : (a == 2 ? l22 : l32);
+      sB[r][j0 + 3] = a <= 2 ? 0.0 : l33;
+    }
     // ---- rank-4 updates: the trailing lower triangle of the block, and W below the block step (columns 0..j0+3) ----
-    for (int e = tid; e < kNB * kNB; e += 256) {
-      const int r = e / kNB, c = e % kNB;
-      if (r >= j0 + 4) {
-        const double a0 = sB[r][j0], a1 = sB[r][j0 + 1], a2 = sB[r][j0 + 2], a3 = sB[r][j0 + 3];
-        if (c >= j0 + 4 && c <= r) sB[r][c] -= a0 * sB[c][j0] + a1 * sB[c][j0 + 1] + a2 * sB[c][j0 + 2] + a3 * sB[c][j0 + 3];
-        if (c < j0 + 4) sXi[r][c] -= a0 * sXi[j0][c] + a1 * sXi[j0 + 1][c] + a2 * sXi[j0 + 2][c] + a3 * sXi[j0 + 3][c];
-      }
+    for (int e = tid; e < (kNB - j0 - 4) * kNB; e += 256) {  // rows below the pivot block only
+      const int r = j0 + 4 + e / kNB, c = e % kNB;
+      const double a0 = sB[r][j0], a1 = sB[r][j0 + 1], a2 = sB[r][j0 + 2], a3 = sB[r][j0 + 3];
+      if (c >= j0 + 4 && c <= r) sB[r][c] -= a0 * sB[c][j0] + a1 * sB[c][j0 + 1] + a2 * sB[c][j0 + 2] + a3 * sB[c][j0 + 3];
+      if (c < j0 + 4) sXi[r][c] -= a0 * sXi[j0][c] + a1 * sXi[j0 + 1][c] + a2 * sXi[j0 + 2][c] + a3 * sXi[j0 + 3][c];
     }
     __syncthreads();
   }
