@@ -95,36 +95,63 @@ namespace {
 // ---- device-side factor arithmetic ---------------------------------------------------------------------------------
 __device__ __forceinline__ V3 ld3(const double *p) { return mk3(p[0], p[1], p[2]); }
 
+// Explicitly fused helpers for the factor evaluation (the file is built with -ffp-contract=off for the gate decisions of
+// the extraction; here the results are held to 1e-10 relative, and the fp64 instruction count is what bounds phase A).
+__device__ __forceinline__ double dotf(V3 a, V3 b) { return fma(a.x, b.x, fma(a.y, b.y, a.z * b.z)); }
+__device__ __forceinline__ V3 crossf(V3 a, V3 b) {
+  return mk3(fma(a.y, b.z, -(a.z * b.y)), fma(a.z, b.x, -(a.x * b.z)), fma(a.x, b.y, -(a.y * b.x)));
+}
+__device__ __forceinline__ V3 lerp3(const double *l, const double *r, double g, double f) {
+  return mk3(fma(f, r[0], g * l[0]), fma(f, r[1], g * l[1]), fma(f, r[2], g * l[2]));
+}
+// unit quaternion (w, u): R v = v + w t + u x t with t = 2 u x v;  R^T v = v - w t + u x t
+__device__ __forceinline__ V3 qrotf(double w, V3 u, V3 v) {
+  V3 t = crossf(u, v);
+  t = t + t;
+  const V3 ut = crossf(u, t);
+  return mk3(fma(w, t.x, v.x) + ut.x, fma(w, t.y, v.y) + ut.y, fma(w, t.z, v.z) + ut.z);
+}
+__device__ __forceinline__ double rsqrt_nr(double a);
+
 // one surfel side: correction interpolated between two sample blocks (cost_functor.h:124-136), rotated lever arm
 // and, if wanted, the 1x6 Jacobian w.r.t. the interpolated (rot_cor, pos_cor)  (cost_functor.h:147-150, :162-165)
 __device__ __forceinline__ void surfel_side(const double *xl, const double *xr, double f, V3 a, V3 wn, double sign,
                                             V3 &rotated_plus_t, double j[6], bool want_jac) {
-  const V3 r = (1 - f) * ld3(xl) + f * ld3(xr);
-  const V3 t = (1 - f) * ld3(xl + 3) + f * ld3(xr + 3);
+  const double g = 1 - f;
+  const V3 r = lerp3(xl, xr, g, f);
+  const V3 t = lerp3(xl + 3, xr + 3, g, f);
   // Exp(r) and Jr(r) from ONE sincos of the half angle (sin th = 2 s c, 1 - cos th = 2 s^2): evaluating so3_exp and so3_Jr
   // separately costs four fp64 sin / cos per side, and this kernel is bound by exactly that arithmetic (fp64 vector rate),
-  // not by its 136 B per record.  Differs from the separate calls by a few ulp.
-  const double th2 = dot(r, r);
-  Q4 E;
-  M3 Jr;
-  if (th2 < 1e-10 * 1e-10) {
-    E = so3_exp(r);
-    Jr = m3_identity();
+  // not by its 136 B per record.  The Jacobian row  wn^T Exp(r) Hat(a) Jr(r)  is evaluated right to left as vectors
+  // (u = Exp(r)^T wn, v = u x a, row = sn v + (1 - sn)(v . an) an + omc (v x an)) instead of two 3x3 matrix products:
+  // a third of the operations.  Differs from the matrix form by a few ulp.
+  const double th2 = dotf(r, r);
+  double qw, sn, omc, ith;
+  V3 qu;
+  if (th2 < 1e-10 * 1e-10) {  // Jr = I (utils.h:47), Exp by its series (so3.hpp:705-712)
+    const Q4 E = so3_exp(r);
+    qw = E.w, qu = mk3(E.x, E.y, E.z);
+    sn = 1.0, omc = 0.0, ith = 0.0;
   } else {
-    const double th = sqrt(th2), ith = 1.0 / th;
+    ith = rsqrt_nr(th2);
+    const double th = th2 * ith;
     double sh, ch;
     sincos(0.5 * th, &sh, &ch);
     const double imag = sh * ith;
-    E = Q4{ch, imag * r.x, imag * r.y, imag * r.z};
-    const V3 an = (-ith) * r;  // unit axis of -r (Jr(r) = Jl(-r), utils.h:46-58)
-    const double sn = 2.0 * sh * ch * ith, omc = 2.0 * sh * sh * ith;
-    Jr = sn * m3_identity() + (1 - sn) * outer(an, an) + omc * hat(an);
+    qw = ch, qu = imag * r;
+    const double s2 = (sh + sh) * ith;
+    sn = s2 * ch, omc = s2 * sh;
   }
-  rotated_plus_t = qrot(E, a) + t;
+  rotated_plus_t = qrotf(qw, qu, a) + t;
   if (want_jac) {
-    const M3 T = (qmat(E) * hat(a)) * Jr;
-    const V3 row = vecmat(wn, T);
-    j[0] = sign * row.x, j[1] = sign * row.y, j[2] = sign * row.z;
+    const V3 an = (-ith) * r;  // unit axis of -r (Jr(r) = Jl(-r), utils.h:46-58)
+    const V3 u = qrotf(-qw, qu, wn);
+    const V3 v = crossf(u, a);
+    const V3 c = crossf(v, an);
+    const double k = (1 - sn) * dotf(v, an);
+    j[0] = sign * fma(sn, v.x, fma(k, an.x, omc * c.x));
+    j[1] = sign * fma(sn, v.y, fma(k, an.y, omc * c.y));
+    j[2] = sign * fma(sn, v.z, fma(k, an.z, omc * c.z));
     j[3] = -sign * wn.x, j[4] = -sign * wn.y, j[5] = -sign * wn.z;
   }
 }
@@ -153,7 +180,7 @@ __device__ __forceinline__ void eval_binary(const WinParams &wp, const double *r
   double j1[6], j2[6];
   surfel_side(x + 12 * sp1l, x + 12 * (sp1l + 1), f1, a1, wn, -1.0, s1, j1, v != nullptr);
   surfel_side(x + 12 * sp2l, x + 12 * (sp2l + 1), f2, a2, wn, +1.0, s2, j2, v != nullptr);
-  double r = w * dot(n, (s1 + dp) - s2);  // cost_functor.h:140
+  double r = w * dotf(n, (s1 + dp) - s2);  // cost_functor.h:140
   double sc;
   cost = 0.5 * cauchy(wp.cauchy_b, r * r, sc);
   r_out = r * sc;
@@ -162,9 +189,10 @@ __device__ __forceinline__ void eval_binary(const WinParams &wp, const double *r
   // local slots of (sp1l, sp1r, sp2l, sp2r) among the distinct blocks (DispatchPtr, cost_functor.h:216-229): side 1 sits
   // in slots 0 / 1, side 2 in 2 / 3 (mode 0), 1 / 2 (mode 1) or 0 / 1 (mode 2).  Written with static indices and selects:
   // indexing v[] with the slot number puts the whole row into scratch memory (208 B per lane).
+  const double w1l = sc * (1 - f1), w1r = sc * f1, w2l = sc * (1 - f2), w2r = sc * f2;  // corrector folded in
 #pragma unroll
   for (int c = 0; c < 6; ++c) {
-    const double a1 = j1[c] * (1 - f1), b1 = j1[c] * f1, a2v = j2[c] * (1 - f2), b2v = j2[c] * f2;
+    const double a1 = j1[c] * w1l, b1 = j1[c] * w1r, a2v = j2[c] * w2l, b2v = j2[c] * w2r;
     if (wp.quirks) {  // four plain assignments, later write wins (Q1)
       v[c] = (mode == 2) ? a2v : a1;
       v[6 + c] = (mode == 2) ? b2v : (mode == 1 ? a2v : b1);
@@ -175,7 +203,6 @@ __device__ __forceinline__ void eval_binary(const WinParams &wp, const double *r
     v[12 + c] = (mode == 0) ? a2v : (mode == 1 ? b2v : 0.0);
     v[18 + c] = (mode == 0) ? b2v : 0.0;
   }
-  for (int i = 0; i < 24; ++i) v[i] *= sc;
 }
 
 __device__ __forceinline__ void eval_unary(const WinParams &wp, const double *rec, uint32_t nu, uint32_t k, uint32_t key,
@@ -190,14 +217,15 @@ __device__ __forceinline__ void eval_unary(const WinParams &wp, const double *re
   V3 s2;
   double j2[6];
   surfel_side(x + 12 * sp2l, x + 12 * (sp2l + 1), f2, a2, wn, +1.0, s2, j2, v != nullptr);
-  double r = w * dot(n, d - s2);  // cost_functor.h:39
+  double r = w * dotf(n, d - s2);  // cost_functor.h:39
   double sc;
   cost = 0.5 * cauchy(wp.cauchy_b, r * r, sc);
   r_out = r * sc;
   if (!v) return;
+  const double wl = sc * (1 - f2), wr = sc * f2;
   for (int c = 0; c < 6; ++c) {
-    v[c] = j2[c] * (1 - f2) * sc;
-    v[6 + c] = j2[c] * f2 * sc;
+    v[c] = j2[c] * wl;
+    v[6 + c] = j2[c] * wr;
   }
 }
 
@@ -396,31 +424,39 @@ __global__ void __launch_bounds__(kPiece) k_lin_surfel(WinParams wp, const Piece
   constexpr int NB = (T + 3) / 4;            // 4-column blocks of V
   constexpr int NBLK = NB * (NB + 1) / 2;    // blocks (bi <= bj) of the Gram matrix
   constexpr int NS = kPiece / NBLK;          // record slices
-  constexpr int SL = (kPiece + NS - 1) / NS; // records per slice
   constexpr int VSZ = kPiece * T + 4;        // + 4: the padded columns of the last block read past the last row
   constexpr int PSZ = NS * NBLK * 16;
   __shared__ double sV[VSZ > PSZ ? VSZ : PSZ];  // V, later the per-slice partial blocks
-  __shared__ double sC[kPiece];
+  __shared__ double sC[kPiece / 64];
   const Piece pc = pieces[blockIdx.x];
   const int tid = threadIdx.x;
+#ifdef WC_PROF_LIN
+  long long lt_[6];
+  lt_[0] = clock64();
+#endif
+  double c = 0.0;
   if (tid < (int)pc.count) {
-    double v[W], r, c;
+    double v[W], r;
     const uint32_t k = pc.begin + tid;
     if (UNARY)
-      eval_unary(wp, rec, nrec, k, keys[k], x, r, c, v);
+      eval_unary(wp, rec, nrec, k, pc.key, x, r, c, v);  // one key per piece: the sample blocks are wave-uniform
     else
-      eval_binary(wp, rec, nrec, k, keys[k], x, r, c, v);
+      eval_binary(wp, rec, nrec, k, pc.key, x, r, c, v);
 #pragma unroll
     for (int i = 0; i < W; ++i) sV[tid * T + i] = v[i];
     sV[tid * T + W] = r;
-    sC[tid] = c;
-  } else {
-#pragma unroll
-    for (int i = 0; i < T; ++i) sV[tid * T + i] = 0.0;  // records past the end of the piece contribute nothing
-    sC[tid] = 0.0;
   }
-  if (tid < 4) sV[kPiece * T + tid] = 0.0;
+  // cost of the piece: fixed shuffle tree per wavefront, the four wavefront sums are added in the tail
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) c += __shfl_down(c, d, 64);
+  if ((tid & 63) == 0) sC[tid >> 6] = c;
+#ifdef WC_PROF_LIN
+  lt_[1] = clock64();
+#endif
   __syncthreads();
+#ifdef WC_PROF_LIN
+  lt_[2] = clock64();
+#endif
   double acc[4][4] = {{0.0}};
   const int blk = tid % NBLK, slice = tid / NBLK;
   int bi = 0, remb = blk;
@@ -430,8 +466,10 @@ __global__ void __launch_bounds__(kPiece) k_lin_surfel(WinParams wp, const Piece
   }
   const int bj = bi + remb;
   if (slice < NS) {
-    // columns past T (last block) belong to the next record: their products are masked out below
-    const int k0 = slice * SL, k1 = min(k0 + SL, kPiece);
+    // the slices partition the piece's records [0, count); columns past T (last block) belong to the next record (or, for
+    // the last record, to unwritten storage): those products land in accumulator entries that are never read
+    const int sl = ((int)pc.count + NS - 1) / NS;
+    const int k0 = slice * sl, k1 = min(k0 + sl, (int)pc.count);
     const double *pi = sV + 4 * bi, *pj = sV + 4 * bj;
     for (int k = k0; k < k1; ++k) {
       double a[4], c4[4];
@@ -443,9 +481,12 @@ __global__ void __launch_bounds__(kPiece) k_lin_surfel(WinParams wp, const Piece
 #pragma unroll
       for (int p = 0; p < 4; ++p)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) acc[p][q] += a[p] * c4[q];
+        for (int q = 0; q < 4; ++q) acc[p][q] = fma(a[p], c4[q], acc[p][q]);
     }
   }
+#ifdef WC_PROF_LIN
+  lt_[3] = clock64();
+#endif
   __syncthreads();  // everybody is done with V: its storage takes the partial blocks
   if (slice < NS) {
 #pragma unroll
@@ -464,9 +505,7 @@ __global__ void __launch_bounds__(kPiece) k_lin_surfel(WinParams wp, const Piece
     const int j = i + rem;
     double out = 0.0;
     if (i == W) {
-      double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-      for (uint32_t k = 0; k < kPiece; k += 4) a0 += sC[k], a1 += sC[k + 1], a2 += sC[k + 2], a3 += sC[k + 3];
-      out = (a0 + a1) + (a2 + a3);
+      out = (sC[0] + sC[1]) + (sC[2] + sC[3]);
     } else {
       const int ti = i >> 2, tj = j >> 2;
       const int q = ti * NB - ti * (ti - 1) / 2 + (tj - ti);  // index of block (ti, tj) in the ti <= tj enumeration
@@ -475,6 +514,12 @@ __global__ void __launch_bounds__(kPiece) k_lin_surfel(WinParams wp, const Piece
     }
     partial[pc.part_off + e] = out;
   }
+#ifdef WC_PROF_LIN
+  lt_[4] = clock64();
+  if (tid == 0 && (blockIdx.x % 997) == 500)
+    printf("lin W=%d blk %u count %u: A %lld sync %lld B %lld tail %lld total %lld\n", W, blockIdx.x, pc.count, lt_[1] - lt_[0],
+           lt_[2] - lt_[1], lt_[3] - lt_[2], lt_[4] - lt_[3], lt_[4] - lt_[0]);
+#endif
 }
 
 // IMU factors of one sample interval: <= kImuMax factors x 12 residual rows, 36-wide Jacobian
@@ -516,99 +561,165 @@ __global__ void __launch_bounds__(256) k_lin_imu(WinParams wp, const Piece *piec
   }
 }
 
-// gather the piece partials into the dense normal equations: one workgroup per 12x12 block pair (I <= J).
-// G groups of 144 threads stride over the pair's source list (diagonal-band pairs have hundreds of sources, the rest
-// at most four); the group partial sums are combined in fixed order, so the result is bitwise reproducible.
-template <int G>
-__global__ void __launch_bounds__(144 * G) k_gather_H(const Src *src, const uint32_t *src_begin, const double *partial, int ns,
-                                                     int fix_first, const uint32_t *pair_list, double *H) {
-  __shared__ double sred[G][144];
-  const int pid = pair_list ? (int)pair_list[blockIdx.x] : (int)blockIdx.x;
-  // invert pid = I*ns - I(I-1)/2 + (J-I)
-  int I = 0, rem = pid;
-  while (rem >= ns - I) {
-    rem -= ns - I;
-    ++I;
-  }
-  const int J = I + rem;
-  const int grp = threadIdx.x / 144, e = threadIdx.x % 144;
-  const int u = e / 12, v = e % 12;
+// Gather of the piece partials into the dense normal equations, g and the cost: ONE launch with four roles by workgroup
+// index (four dependent launches of latency-bound kernels cost 110 us per linearisation; run side by side they cost what
+// the longest role does).  Workgroup = 7 groups of 144 threads (one thread per entry of a 12x12 block pair):
+//   heavy  - block pairs with more than kHeavySrc sources (the diagonal band, hundreds each): one pair per workgroup, the
+//            groups stride over the source list, partial sums combined in fixed order;
+//   light  - the other pairs (at most a few sources): one pair per group;
+//   g      - one sample block per workgroup, 16 groups of 12 lanes stride over the block's source list;
+//   cost   - the last workgroup adds the cost slots of all partials.
+// Every source costs two dependent loads (descriptor, value): four sources are in flight per thread, added in list order
+// (bitwise reproducible, no atomics).
+constexpr int kGG = 7;
+struct GatherArgs {
+  const Src *src;
+  const uint32_t *src_begin;
+  const GSrc *gsrc;
+  const uint32_t *gsrc_begin;
+  const Piece *pieces;
+  const uint32_t *heavy;
+  const double *partial;
+  double *H, *g, *cost;
+  uint32_t nheavy, npairs, npieces, nb_pieces, nu_pieces;
+  int ns, fix_first;
+};
+
+template <int STRIDE>
+__device__ __forceinline__ double gather_pair_sum(const Src *src, const double *partial, uint32_t s0, uint32_t eend, int u, int v) {
   double acc = 0.0;
-  const uint32_t b = src_begin[pid], eend = src_begin[pid + 1];
-  if (G == 1 && eend - b > kHeavySrc) return;  // long source lists are handled by the 7-group launch
-  for (uint32_t s = b + grp; s < eend; s += G) {
-    const Src sr = src[s];
-    if (u < sr.w && v < sr.w) {
+  for (uint32_t s = s0; s < eend; s += 4 * STRIDE) {
+    double val[4];
+    bool ok[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const uint32_t sq = s + q * STRIDE;
+      const bool live = sq < eend;
+      const Src sr = src[live ? sq : s];
+      ok[q] = live && u < sr.w && v < sr.w;
       uint32_t r = sr.p * sr.w + u, c = sr.q * sr.w + v;
       if (r > c) {
         const uint32_t t = r;
         r = c, c = t;
       }
-      acc += partial[sr.part_off + tri_index(r, c, sr.T)];
+      val[q] = partial[sr.part_off + (ok[q] ? tri_index(r, c, sr.T) : 0u)];
     }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (ok[q]) acc += val[q];
   }
-  if (G > 1) {
-    sred[grp][e] = acc;
-    __syncthreads();
-    if (grp != 0) return;
-    acc = 0.0;
-    for (int q = 0; q < G; ++q) acc += sred[q][e];
-  }
-  const int n = 12 * ns;
-  const int gi = I * 12 + u, gj = J * 12 + v;
-  if (fix_first && ((gi >= 3 && gi < 6) || (gj >= 3 && gj < 6))) acc = 0.0;  // SubsetParameterization(12,{3,4,5})
-  H[(size_t)gi * n + gj] = acc;
-  H[(size_t)gj * n + gi] = acc;
+  return acc;
 }
 
-// g = J^T r: one workgroup per sample block, 16 groups of 12 lanes stride over the block's source list
-__global__ void __launch_bounds__(192) k_gather_g(const GSrc *gsrc, const uint32_t *gsrc_begin, const double *partial, int fix_first,
-                                                 double *g) {
-  __shared__ double sred[16][12];
-  const int I = blockIdx.x, grp = threadIdx.x / 12, u = threadIdx.x % 12;
-  double acc = 0.0;
-  for (uint32_t s = gsrc_begin[I] + grp; s < gsrc_begin[I + 1]; s += 16) {
-    const GSrc sr = gsrc[s];
-    if (u < sr.w) acc += partial[sr.part_off + tri_index(sr.p * sr.w + u, sr.T - 1, sr.T)];
-  }
-  sred[grp][u] = acc;
-  __syncthreads();
-  if (grp != 0) return;
-  acc = 0.0;
-  for (int q = 0; q < 16; ++q) acc += sred[q][u];
-  const int gi = I * 12 + u;
-  if (fix_first && gi >= 3 && gi < 6) acc = 0.0;
-  g[gi] = acc;
-}
-
-// deterministic sum of the cost slots of all partials (+ max |g| over the active columns) -> mailbox
-__global__ void __launch_bounds__(1024) k_cost_sum(const Piece *pieces, uint32_t npieces, uint32_t nb_pieces, uint32_t nu_pieces,
-                                                  const double *partial, const double *g, int n, double *mail, int slot) {
-  __shared__ double s[1024];
+__global__ void __launch_bounds__(144 * kGG) k_gather(GatherArgs a) {
+  __shared__ double sred[kGG * 144];
   const int tid = threadIdx.x;
-  double acc = 0.0;
-  for (uint32_t p = tid; p < npieces; p += 1024) {
-    const uint32_t T = p < nb_pieces ? 25 : (p < nb_pieces + nu_pieces ? 13 : 37);
-    acc += partial[pieces[p].part_off + T * (T + 1) / 2 - 1];
-  }
-  s[tid] = acc;
-  __syncthreads();
-  for (int st = 512; st > 0; st >>= 1) {
-    if (tid < st) s[tid] += s[tid + st];
-    __syncthreads();
-  }
-  if (tid == 0) mail[slot] = s[0];
-  __syncthreads();
-  if (g) {
-    double mx = 0.0;
-    for (int i = tid; i < n; i += 1024) mx = fmax(mx, fabs(g[i]));
-    s[tid] = mx;
-    __syncthreads();
-    for (int st = 512; st > 0; st >>= 1) {
-      if (tid < st) s[tid] = fmax(s[tid], s[tid + st]);
-      __syncthreads();
+  const uint32_t nlight = (a.npairs + kGG - 1) / kGG;
+  uint32_t blk = blockIdx.x;
+  if (blk < a.nheavy + nlight) {
+    const bool heavy = blk < a.nheavy;
+    const int grp = tid / 144, e = tid % 144;
+    const int u = e / 12, v = e % 12;
+    const uint32_t pid = heavy ? a.heavy[blk] : (blk - a.nheavy) * kGG + grp;
+    double acc = 0.0;
+    bool write = false;
+    if (pid < a.npairs) {
+      const uint32_t b = a.src_begin[pid], eend = a.src_begin[pid + 1];
+      if (heavy) {
+        acc = gather_pair_sum<kGG>(a.src, a.partial, b + grp, eend, u, v);
+      } else if (eend - b <= kHeavySrc) {
+        acc = gather_pair_sum<1>(a.src, a.partial, b, eend, u, v);
+        write = true;
+      }
     }
-    if (tid == 0) mail[slot + 1] = s[0];
+    if (heavy) {
+      sred[grp * 144 + e] = acc;
+      __syncthreads();
+      if (grp == 0) {
+        acc = 0.0;
+        for (int q = 0; q < kGG; ++q) acc += sred[q * 144 + e];
+        write = true;
+      }
+    }
+    if (!write) return;
+    // invert pid = I*ns - I(I-1)/2 + (J-I)
+    const int ns = a.ns;
+    const float f = 2.f * ns + 1.f;
+    int I = (int)((f - sqrtf(fmaxf(f * f - 8.f * (float)pid, 0.f))) * 0.5f);
+    I = max(0, min(I, ns - 1));
+    while (I > 0 && (uint32_t)(I * ns - I * (I - 1) / 2) > pid) --I;
+    while ((uint32_t)((I + 1) * ns - (I + 1) * I / 2) <= pid) ++I;
+    const int J = I + (int)(pid - (uint32_t)(I * ns - I * (I - 1) / 2));
+    const int n = 12 * ns;
+    const int gi = I * 12 + u, gj = J * 12 + v;
+    if (a.fix_first && ((gi >= 3 && gi < 6) || (gj >= 3 && gj < 6))) acc = 0.0;  // SubsetParameterization(12,{3,4,5})
+    a.H[(size_t)gi * n + gj] = acc;
+    a.H[(size_t)gj * n + gi] = acc;
+    return;
+  }
+  blk -= a.nheavy + nlight;
+  if (blk < (uint32_t)a.ns) {  // g = J^T r of sample block blk
+    const int I = (int)blk, grp = tid / 12, u = tid % 12;
+    double acc = 0.0;
+    if (tid < 192) {
+      const uint32_t eend = a.gsrc_begin[I + 1];
+      for (uint32_t s = a.gsrc_begin[I] + grp; s < eend; s += 64) {
+        double val[4];
+        bool ok[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const uint32_t sq = s + q * 16;
+          const bool live = sq < eend;
+          const GSrc sr = a.gsrc[live ? sq : s];
+          ok[q] = live && u < sr.w;
+          val[q] = a.partial[sr.part_off + (ok[q] ? tri_index(sr.p * sr.w + u, sr.T - 1, sr.T) : 0u)];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (ok[q]) acc += val[q];
+      }
+      sred[tid] = acc;
+    }
+    __syncthreads();
+    if (tid >= 12) return;
+    acc = 0.0;
+    for (int q = 0; q < 16; ++q) acc += sred[q * 12 + u];
+    const int gi = I * 12 + u;
+    if (a.fix_first && gi >= 3 && gi < 6) acc = 0.0;
+    a.g[gi] = acc;
+    return;
+  }
+  {  // cost: deterministic sum of the cost slots of all partials
+    constexpr int NT = 144 * kGG;
+    double acc = 0.0;
+    for (uint32_t p0 = tid; p0 < a.npieces; p0 += 4 * NT) {
+      double val[4];
+      bool ok[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const uint32_t p = p0 + q * NT;
+        ok[q] = p < a.npieces;
+        const uint32_t pp = ok[q] ? p : p0;
+        const uint32_t T = pp < a.nb_pieces ? 25 : (pp < a.nb_pieces + a.nu_pieces ? 13 : 37);
+        val[q] = a.partial[a.pieces[pp].part_off + T * (T + 1) / 2 - 1];
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (ok[q]) acc += val[q];
+    }
+    sred[tid] = acc;
+    __syncthreads();
+    if (tid < 16) {  // 1008 = 16 x 63
+      double t = 0.0;
+      for (int q = 0; q < 63; ++q) t += sred[tid * 63 + q];
+      sred[tid * 63] = t;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      double t = 0.0;
+      for (int q = 0; q < 16; ++q) t += sred[q * 63];
+      a.cost[0] = t;
+    }
   }
 }
 
@@ -1334,14 +1445,14 @@ int enqueue_linearize(wc_ctx *ctx, wc_window_state *W, const double *d_x, int ma
   if (W->npiece_i)
     k_lin_imu<<<W->npiece_i, 256, 0, st>>>(W->wp, pcs + W->npiece_b + W->npiece_u, (const ImuRec *)W->irec.p, d_x,
                                           (const double *)W->times_d.p, partial);
-  k_gather_H<1><<<W->npairs, 144, 0, st>>>((const Src *)W->src.p, (const uint32_t *)W->src_begin.p, partial, W->ns, W->wp.fix_first,
-                                          nullptr, lin_H(W));
-  if (W->nheavy)  // block pairs with long source lists (the diagonal band): 7 thread groups split each list
-    k_gather_H<7><<<W->nheavy, 144 * 7, 0, st>>>((const Src *)W->src.p, (const uint32_t *)W->src_begin.p, partial, W->ns,
-                                                W->wp.fix_first, (const uint32_t *)W->heavy.p, lin_H(W));
-  k_gather_g<<<W->ns, 192, 0, st>>>((const GSrc *)W->gsrc.p, (const uint32_t *)W->gsrc_begin.p, partial, W->wp.fix_first, lin_g(W));
-  k_cost_sum<<<1, 1024, 0, st>>>(pcs, W->npiece_b + W->npiece_u + W->npiece_i, W->npiece_b, W->npiece_u, partial, nullptr, W->n,
-                                lin_cost(W), 0);
+  GatherArgs ga;
+  ga.src = (const Src *)W->src.p, ga.src_begin = (const uint32_t *)W->src_begin.p;
+  ga.gsrc = (const GSrc *)W->gsrc.p, ga.gsrc_begin = (const uint32_t *)W->gsrc_begin.p;
+  ga.pieces = pcs, ga.heavy = (const uint32_t *)W->heavy.p, ga.partial = partial;
+  ga.H = lin_H(W), ga.g = lin_g(W), ga.cost = lin_cost(W);
+  ga.nheavy = W->nheavy, ga.npairs = W->npairs, ga.npieces = W->npiece_b + W->npiece_u + W->npiece_i;
+  ga.nb_pieces = W->npiece_b, ga.nu_pieces = W->npiece_u, ga.ns = W->ns, ga.fix_first = W->wp.fix_first;
+  k_gather<<<W->nheavy + (W->npairs + kGG - 1) / kGG + W->ns + 1, 144 * kGG, 0, st>>>(ga);
   WC_HIP(ctx, hipGetLastError());
   WC_TRY(do_allreduce(ctx, W, lin_H(W), lin_count(W)));  // the ONE collective of a linearisation
   k_post_reduce<<<1, 1024, 0, st>>>(lin_g(W), lin_cost(W), W->n, (double *)W->mail.p, mail_slot);
