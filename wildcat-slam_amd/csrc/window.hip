@@ -1080,39 +1080,93 @@ __global__ void __launch_bounds__(256) k_chol_step(double *A, int ld, int k, int
   }
 }
 
-// back substitution L^T y = z (z = row n of the factored augmented matrix), right-looking over 32-wide blocks from
-// last to first in ONE workgroup: y_k = Linv_kk^T z_k (32x32 products + column sums), then z_j -= L[block k rows][j] . y_k
-// for every j left of it (row-contiguous, coalesced reads of L; 32 independent loads per thread).
-__global__ void __launch_bounds__(1024) k_chol_back(const double *A, int ld, int n, const double *Linv, double *y) {
-  __shared__ double sz[4096];
+// workgroup barrier that only waits for this wavefront's LDS traffic: __syncthreads() also drains the outstanding global
+// loads (vmcnt(0)), which would serialise the prefetches below with the dependent chain
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// back substitution L^T y = z (z = row n of the factored augmented matrix), right-looking over 32-wide blocks from last to
+// first.  One workgroup doing all of it is bound by a single CU's load rate (it reads all of L: 9.4 MB at ~50 GB/s =
+// 0.19 ms at n = 1536), so the block rows are cut into chunks of kBackChunk: k_chol_back_chunk solves inside a chunk (one
+// workgroup, reads only the chunk's diagonal triangle), k_chol_back_gemv then removes the chunk's y from every z left
+// of it, one workgroup per 32 columns.  Inside the chunk: y_k = Linv_kk^T z_k (32x32 products + column sums), then
+// z_j -= L[block k rows][j] . y_k for the chunk's j left of block k; L and Linv of a step do not depend on y and are
+// loaded before the step's first barrier.
+constexpr int kBackChunk = 8;
+__global__ void __launch_bounds__(1024) k_chol_back_chunk(const double *A, int ld, int n, const double *Linv, const double *zsrc,
+                                                         double *y, int lo_blk, int hi_blk) {
+  __shared__ double sz[kBackChunk * kNB];
   __shared__ double sP[kNB][kNB + 1];
+  __shared__ double sQ[4][kBackChunk * kNB];
   __shared__ double syk[kNB];
   const int tid = threadIdx.x, m = tid >> 5, c = tid & 31;
-  const int nblk = (n + kNB - 1) / kNB;
-  for (int i = tid; i < nblk * kNB; i += 1024) sz[i] = (i < n) ? A[(size_t)n * ld + i] : 0.0;
-  __syncthreads();
-  for (int kb = nblk - 1; kb >= 0; --kb) {
-    sP[m][c] = (m >= c) ? Linv[(size_t)kb * kNB * kNB + tid] * sz[kb * kNB + m] : 0.0;  // Linv[m][c] z[m]
-    __syncthreads();
+  const int base = lo_blk * kNB, span = (hi_blk - lo_blk) * kNB;
+  if (tid < span) sz[tid] = (base + tid < n) ? zsrc[base + tid] : 0.0;
+  lds_barrier();
+  for (int kb = hi_blk - 1; kb >= lo_blk; --kb) {
+    const int loc = (kb - lo_blk) * kNB;  // local index of block kb's first row = number of chunk columns left of it
+    const int rows = min(kNB, n - kb * kNB);
+    const double li = Linv[(size_t)kb * kNB * kNB + tid];
+    // thread = (column j < loc, quarter of the block's rows): 8 independent loads, the quarters are added in fixed order
+    const bool upd = tid < 4 * loc;
+    const int j = upd ? tid % loc : 0, qr = upd ? tid / loc : 0;
+    double lv[8];
+    {
+      const double *col = A + (size_t)(kb * kNB + qr * 8) * ld + base + j;
+#pragma unroll
+      for (int rr = 0; rr < 8; ++rr) lv[rr] = (upd && qr * 8 + rr < rows) ? col[(size_t)rr * ld] : 0.0;
+    }
+    sP[m][c] = (m >= c) ? li * sz[loc + m] : 0.0;  // Linv[m][c] z[m]
+    lds_barrier();
     if (tid < kNB) {
       double acc = 0.0;
 #pragma unroll
       for (int q = 0; q < kNB; ++q) acc += sP[q][tid];
-      syk[tid] = (kb * kNB + tid < n) ? acc : 0.0;
+      acc = (kb * kNB + tid < n) ? acc : 0.0;
+      syk[tid] = acc;
+      sz[loc + tid] = acc;
     }
-    __syncthreads();
-    if (tid < kNB) sz[kb * kNB + tid] = syk[tid];
-    const int rows = min(kNB, n - kb * kNB);
-    for (int j = tid; j < kb * kNB; j += 1024) {
+    lds_barrier();
+    if (upd) {
       double acc = 0.0;
-      const double *col = A + (size_t)kb * kNB * ld + j;
-#pragma unroll 8
-      for (int rr = 0; rr < rows; ++rr) acc += col[(size_t)rr * ld] * syk[rr];
-      sz[j] -= acc;
+#pragma unroll
+      for (int rr = 0; rr < 8; ++rr) acc += lv[rr] * syk[qr * 8 + rr];
+      sQ[qr][j] = acc;
     }
-    __syncthreads();
+    lds_barrier();
+    if (tid < loc) sz[tid] -= (sQ[0][tid] + sQ[1][tid]) + (sQ[2][tid] + sQ[3][tid]);
+    lds_barrier();
   }
-  for (int i = tid; i < n; i += 1024) y[i] = sz[i];
+  if (tid < span && base + tid < n) y[base + tid] = sz[tid];
+}
+
+// y[j] = zsrc[j] - sum_{r in chunk} L[r][j] y[r] for the 32 columns j of this workgroup (all left of the chunk):
+// thread = (column, 1/32 slice of the chunk's rows); slice sums combined in fixed order
+__global__ void __launch_bounds__(1024) k_chol_back_gemv(const double *A, int ld, int n, const double *zsrc, double *y, int lo_blk,
+                                                        int hi_blk) {
+  __shared__ double sP[kNB][kNB + 1];
+  const int tid = threadIdx.x, sl = tid >> 5, c = tid & 31;
+  const int j = blockIdx.x * kNB + c;
+  const int per = hi_blk - lo_blk;  // rows per slice ((hi - lo) * 32 rows / 32 slices), <= kBackChunk
+  const int r0 = lo_blk * kNB + sl * per;
+  double lv[kBackChunk], yv[kBackChunk];
+#pragma unroll
+  for (int q = 0; q < kBackChunk; ++q) {
+    const bool ok = q < per && r0 + q < n;
+    lv[q] = ok ? A[(size_t)(r0 + q) * ld + j] : 0.0;
+    yv[q] = ok ? y[r0 + q] : 0.0;
+  }
+  double acc = 0.0;
+#pragma unroll
+  for (int q = 0; q < kBackChunk; ++q) acc += lv[q] * yv[q];
+  sP[sl][c] = acc;
+  __syncthreads();
+  if (tid < kNB) {
+    double t = 0.0;
+#pragma unroll
+    for (int q = 0; q < kNB; ++q) t += sP[q][tid];
+    const int jj = blockIdx.x * kNB + tid;
+    y[jj] = zsrc[jj] - t;
+  }
 }
 
 // candidate point and the scalars the trust-region logic needs:
@@ -1581,7 +1635,16 @@ extern "C" int wc_window_solve(wc_ctx *ctx, double *h_x_inout, wc_solve_summary 
         const int tiles = ((nblk - k - 1) * kNB + 63) / 64;
         k_chol_step<<<dim3(tiles, tiles), 256, 0, st>>>(A, ld, k, nblk, Lmat, (double *)W->Linv.p, fail);
       }
-      k_chol_back<<<1, 1024, 0, st>>>(Lmat, ld, n, (const double *)W->Linv.p, y);
+      {  // back substitution, chunk by chunk from the last block row
+        const double *zsrc = Lmat + (size_t)n * ld;
+        for (int hi = (n + kNB - 1) / kNB; hi > 0;) {
+          const int lo = std::max(0, hi - kBackChunk);
+          k_chol_back_chunk<<<1, 1024, 0, st>>>(Lmat, ld, n, (const double *)W->Linv.p, zsrc, y, lo, hi);
+          if (lo > 0) k_chol_back_gemv<<<lo, 1024, 0, st>>>(Lmat, ld, n, zsrc, y, lo, hi);
+          zsrc = y;
+          hi = lo;
+        }
+      }
       k_step<<<1, 1024, 0, st>>>(x, y, scale, g, diag, n, xc, mail);
       WC_TRY(enqueue_evaluate(ctx, W, xc, nullptr, 5));
       WC_HIP(ctx, hipGetLastError());
