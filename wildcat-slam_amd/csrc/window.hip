@@ -942,24 +942,102 @@ __global__ void __launch_bounds__(256) k_chol_first(const double *A, int ld, dou
 #else
 #define WC_CT(i)
 #endif
+// Lead workgroup of a step (see k_chol_step): L rows of the next diagonal block, its trailing update, factor + inverse.
+// sP: panel rows of the block, later L^-1 of the block; sXk: L_kk^-1; sD: old diagonal block -> updated -> L; sL: the
+// block's rows of L (panel solve).  The four arrays alias the tile path's LDS (two workgroups per CU stay resident).
+__device__ __forceinline__ void chol_lead(const double *A, int ld, int k, int nblk, double *Lmat, double *Linv, int *fail,
+                                          double (*sP)[kNB + 1], double (*sXk)[kNB + 1], double (*sD)[kNB + 1],
+                                          double (*sL)[kNB + 1]) {
+#ifdef WC_PROF_CHOL
+  long long ct_[8];
+#endif
+  WC_CT(0);
+  const int tid = threadIdx.x;
+  const int first = (k + 1) * kNB;
+  const size_t pc = (size_t)k * kNB;
+  const int failed = *fail;
+#pragma unroll
+  for (int e0 = 0; e0 < kNB * kNB; e0 += 256) {
+    const int e = e0 + tid, r = e / kNB, c = e % kNB;
+    sXk[r][c] = Linv[(size_t)k * kNB * kNB + e];
+    sP[r][c] = A[(size_t)(first + r) * ld + pc + c];
+    sD[r][c] = A[(size_t)(first + r) * ld + first + (c <= r ? c : r)];
+  }
+  __syncthreads();
+  WC_CT(1);
+  if (failed) return;
+  const int w = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+  const int rt = w >> 1, ct = w & 1;  // wavefront = one 16 x 16 tile of the 32 x 32 block
+  {
+    f64x4 t = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int ks = 0; ks < kNB / 4; ++ks)
+      t = __builtin_amdgcn_mfma_f64_16x16x4f64(sP[16 * rt + li][4 * ks + lk], sXk[16 * ct + li][4 * ks + lk], t, 0, 0, 0);
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) sL[16 * rt + lk + 4 * r4][16 * ct + li] = t[r4];
+  }
+  __syncthreads();
+  WC_CT(2);
+  {
+    f64x4 t = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int ks = 0; ks < kNB / 4; ++ks)
+      t = __builtin_amdgcn_mfma_f64_16x16x4f64(sL[16 * rt + li][4 * ks + lk], sL[16 * ct + li][4 * ks + lk], t, 0, 0, 0);
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) sD[16 * rt + lk + 4 * r4][16 * ct + li] -= t[r4];
+  }
+  __syncthreads();
+  WC_CT(3);
+  const bool ok = factor_inv32_blk(sD, sP);  // in: lower part of sD; out: sD = L, sP = L^-1
+  __syncthreads();
+  WC_CT(4);
+#ifdef WC_PROF_CHOL
+  if (tid == 0 && k == 20)
+    printf("chol step 20, lead workgroup, shader clocks: loads %lld trsm %lld update %lld factor %lld\n", ct_[1] - ct_[0], ct_[2] - ct_[1],
+           ct_[3] - ct_[2], ct_[4] - ct_[3]);
+#endif
+  if (tid == 0 && !ok) atomicOr(fail, 1);
+  for (int e = tid; e < kNB * kNB; e += 256) {
+    const int r = e / kNB, c = e % kNB;
+    Lmat[(size_t)(first + r) * ld + first + c] = sD[r][c];
+    Linv[(size_t)(k + 1) * kNB * kNB + e] = sP[r][c];
+  }
+}
+
 __global__ void __launch_bounds__(256) k_chol_step(double *A, int ld, int k, int nblk, double *Lmat, double *Linv, int *fail) {
   __shared__ double sA[64][kNB + 1];
   __shared__ double sLi[64][kNB + 1];
   __shared__ double sLj[64][kNB + 1];
   __shared__ double sX[kNB][kNB + 1];
-  const int ti = blockIdx.y, tj = blockIdx.x;
+  // row 0 of the grid holds the lead workgroup (x == 0): the critical path of the factorisation.  It redoes the 32 x 32
+  // corner of tile (0, 0) - panel solve of the next diagonal block's rows, its update - and factors + inverts that block
+  // right away; a quarter of a tile's matrix-core work (fp64 MFMA runs at the vector rate: 64 clk per 16x16x4) and no
+  // write-back stand between the launch and the factor.
+  if (blockIdx.y == 0) {
+    if (blockIdx.x == 0) chol_lead(A, ld, k, nblk, Lmat, Linv, fail, sA, sX, sLi, sLj);
+    return;
+  }
+  const int ti = blockIdx.y - 1, tj = blockIdx.x;
   if (tj > ti) return;
-#ifdef WC_PROF_CHOL
-  long long ct_[8];
-#endif
-  WC_CT(0);
-  if (*fail) return;
-  WC_CT(1);
+  const int failed = *fail;  // tested after the first barrier: one round trip together with the tile's loads, not before them
   const int tid = threadIdx.x;
   const int nrow = nblk * kNB;
   const int first = (k + 1) * kNB;
   const int row0 = first + ti * 64, col0 = first + tj * 64;
   const size_t pc = (size_t)k * kNB;  // first column of the panel
+  const int w = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+  // the tile's old values, requested with everything else the tile reads: unconditional loads from clamped addresses (a
+  // guarded load is a branch per element), all of them before the first store (a store to the same array orders every
+  // later load behind it: 16 dependent round trips, 17 us of a 42 us step, measured)
+  double old[4][4];
+#pragma unroll
+  for (int tq = 0; tq < 4; ++tq)
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) {
+      const int r = row0 + 16 * w + lk + 4 * r4, c = col0 + 16 * tq + li;
+      const bool in = r < nrow && c <= r;
+      old[tq][r4] = A[in ? (size_t)r * ld + c : (size_t)first * ld + first];
+    }
   // L_kk^-1 was left behind by the previous launch (tile (0,0) factors and inverts the next diagonal block in registers)
   for (int e = tid; e < kNB * kNB; e += 256) sX[e / kNB][e % kNB] = Linv[(size_t)k * kNB * kNB + e];
   // L rows of this tile's row range: Li = A[row0.., panel] * Linv^T
@@ -971,12 +1049,11 @@ __global__ void __launch_bounds__(256) k_chol_step(double *A, int ld, int k, int
     sA[r][c] = in ? v : 0.0;
   }
   __syncthreads();
-  WC_CT(2);
+  if (failed) return;
   // The two small GEMMs of a tile run on the fp64 matrix cores: v_mfma_f64_16x16x4 takes A[i = l & 15][k = l >> 4] and
   // B[k = l >> 4][j = l & 15] as ONE double per lane, i.e. one LDS read per lane feeds 16 x 16 x 4 products; the scalar
   // loops (9 LDS reads per 8 products, 8 per 16) were LDS-bandwidth bound at 3.4 us each.  fp64 MFMA runs at the fp64 vector
   // rate - the gain is operand reuse.  Wavefront w owns rows 16 w .. 16 w + 15 of the tile.
-  const int w = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
   {  // Li = A[rows, panel] * Linv^T  (64 x 32, K = 32)
     f64x4 t0 = {0.0, 0.0, 0.0, 0.0}, t1 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -1022,20 +1099,7 @@ __global__ void __launch_bounds__(256) k_chol_step(double *A, int ld, int k, int
   } else {
     for (int e = tid; e < 64 * kNB; e += 256) sLj[e / kNB][e % kNB] = sLi[e / kNB][e % kNB];
   }
-  // the tile's old values: requested before the update GEMM so that the round trip hides behind it.  Unconditional
-  // loads from clamped addresses (a guarded load is a branch per element), all of them before the first store (a store to
-  // the same array orders every later load behind it: 16 dependent round trips, 17 us of a 42 us step, measured)
-  double old[4][4];
-#pragma unroll
-  for (int tq = 0; tq < 4; ++tq)
-#pragma unroll
-    for (int r4 = 0; r4 < 4; ++r4) {
-      const int r = row0 + 16 * w + lk + 4 * r4, c = col0 + 16 * tq + li;
-      const bool in = r < nrow && c <= r;
-      old[tq][r4] = A[in ? (size_t)r * ld + c : (size_t)first * ld + first];
-    }
   __syncthreads();
-  WC_CT(3);
   // trailing update of this tile: A_ij -= Li Lj^T (64 x 64, K = 32)
   f64x4 acc[4];
 #pragma unroll
@@ -1046,38 +1110,15 @@ __global__ void __launch_bounds__(256) k_chol_step(double *A, int ld, int k, int
 #pragma unroll
     for (int tq = 0; tq < 4; ++tq) acc[tq] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, sLj[16 * tq + li][4 * ks + lk], acc[tq], 0, 0, 0);
   }
-  WC_CT(4);
-  const bool lead = (ti == 0 && tj == 0);
+  const bool corner = (ti == 0 && tj == 0);  // the next diagonal block belongs to the lead workgroup (which reads its old values)
 #pragma unroll
   for (int tq = 0; tq < 4; ++tq)
 #pragma unroll
     for (int r4 = 0; r4 < 4; ++r4) {
       const int rl = 16 * w + lk + 4 * r4, cl = 16 * tq + li;
       const int r = row0 + rl, c = col0 + cl;
-      if (r < nrow && c <= r) {
-        const double v = old[tq][r4] - acc[tq][r4];
-        A[(size_t)r * ld + c] = v;
-        if (lead && rl < kNB && cl < kNB) sA[rl][cl] = v;  // next diagonal block (lower part)
-      }
+      if (r < nrow && c <= r && !(corner && rl < kNB)) A[(size_t)r * ld + c] = old[tq][r4] - acc[tq][r4];
     }
-  if (!lead) return;
-  WC_CT(5);
-  // look-ahead: factor + invert the next diagonal block right away (one wavefront, register resident)
-  __syncthreads();
-  const bool ok = factor_inv32_blk(sA, sLi);  // rows 0..31 of sA hold the block; the inverse lands in sLi
-  __syncthreads();
-  WC_CT(6);
-#ifdef WC_PROF_CHOL
-  if (tid == 0 && k == 20)
-    printf("chol step 20, lead tile, shader clocks: fail-check %lld loads %lld trsm %lld mac %lld rmw %lld factor %lld\n", ct_[1] - ct_[0], ct_[2] - ct_[1],
-           ct_[3] - ct_[2], ct_[4] - ct_[3], ct_[5] - ct_[4], ct_[6] - ct_[5]);
-#endif
-  if (tid == 0 && !ok) atomicOr(fail, 1);
-  for (int e = tid; e < kNB * kNB; e += 256) {
-    const int r = e / kNB, c = e % kNB;
-    Lmat[(size_t)(first + r) * ld + first + c] = sA[r][c];
-    Linv[(size_t)(k + 1) * kNB * kNB + e] = sLi[r][c];
-  }
 }
 
 // workgroup barrier that only waits for this wavefront's LDS traffic: __syncthreads() also drains the outstanding global
@@ -1633,7 +1674,7 @@ extern "C" int wc_window_solve(wc_ctx *ctx, double *h_x_inout, wc_solve_summary 
       k_chol_first<<<1, 256, 0, st>>>(A, ld, Lmat, (double *)W->Linv.p, fail);
       for (int k = 0; k + 1 < nblk; ++k) {
         const int tiles = ((nblk - k - 1) * kNB + 63) / 64;
-        k_chol_step<<<dim3(tiles, tiles), 256, 0, st>>>(A, ld, k, nblk, Lmat, (double *)W->Linv.p, fail);
+        k_chol_step<<<dim3(tiles, tiles + 1), 256, 0, st>>>(A, ld, k, nblk, Lmat, (double *)W->Linv.p, fail);
       }
       {  // back substitution, chunk by chunk from the last block row
         const double *zsrc = Lmat + (size_t)n * ld;
