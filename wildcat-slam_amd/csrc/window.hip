@@ -847,77 +847,140 @@ __device__ __forceinline__ double rsqrt_nr(double a) {
   return fma(h, fma(-a * inv, inv, 1.0), inv);  // inv + inv/2 (1 - a inv^2)
 }
 
+constexpr int kFacEnt = 4;  // ceil((kNB - 4) * kNB / 256) update entries per thread
+struct Piv4 {  // Cholesky factor of a 4x4 pivot block and its inverse (both lower triangular)
+  double l00, l10, l11, l20, l21, l22, l30, l31, l32, l33;
+  double i00, i10, i11, i20, i21, i22, i30, i31, i32, i33;
+};
+
+// Writes of block step pj that nobody reads while the next step's updates run (so they need no barrier of their own):
+// the L rows of the 4-column panel (row r of A times Lp^-T), the pivot rows of L, zeros above the diagonal (lanes 0..31,
+// one row each) and rows pj..pj+3 of X = Lp^-1 times the same rows of W (lanes 32..63, one column each).  Both are the
+// same lower-triangular 4x4 product on four values that sit 1 resp. kNB+1 doubles apart; load, arithmetic and store are
+// separate calls so that the loads go out with the step's other loads and the arithmetic fills the pivot chain's bubbles.
+struct Fin4 {
+  double *base;
+  int stride;
+  double v0, v1, v2, v3;
+};
+__device__ __forceinline__ Fin4 factor_finish_load(double (*sB)[kNB + 1], double (*sXi)[kNB + 1], int pj, int tid) {
+  Fin4 f;
+  const int l = tid & 63;
+  f.base = l < kNB ? &sB[l][pj] : &sXi[pj][l - kNB];
+  f.stride = l < kNB ? 1 : kNB + 1;
+  f.v0 = f.base[0], f.v1 = f.base[f.stride], f.v2 = f.base[2 * f.stride], f.v3 = f.base[3 * f.stride];
+  return f;
+}
+__device__ __forceinline__ void factor_finish_store(const Fin4 f, int pj, const Piv4 p, int tid) {
+  const int l = tid & 63, a = l - pj;  // lanes < 32: row l of the panel; a = its position relative to the pivot rows
+  double o0 = f.v0 * p.i00;
+  double o1 = fma(f.v0, p.i10, f.v1 * p.i11);
+  double o2 = fma(f.v0, p.i20, fma(f.v1, p.i21, f.v2 * p.i22));
+  double o3 = fma(f.v0, p.i30, fma(f.v1, p.i31, fma(f.v2, p.i32, f.v3 * p.i33)));
+  if (l < kNB && a < 4) {
+    if (a < 0) {
+      o0 = o1 = o2 = o3 = 0.0;  // above the diagonal
+    } else {
+      o0 = a == 0 ? p.l00 : (a == 1 ? p.l10 : (a == 2 ? p.l20 : p.l30));
+      o1 = a == 0 ? 0.0 : (a == 1 ? p.l11 : (a == 2 ? p.l21 : p.l31));
+      o2 = a <= 1 ? 0.0 : (a == 2 ? p.l22 : p.l32);
+      o3 = a <= 2 ? 0.0 : p.l33;
+    }
+  }
+  if (tid < 64) f.base[0] = o0, f.base[f.stride] = o1, f.base[2 * f.stride] = o2, f.base[3 * f.stride] = o3;
+}
+
+// ONE barrier per block step: the rank-4 updates read the UNSCALED panel and solve their two 4-vectors against the pivot
+// block themselves (the pivot chain runs redundantly in every thread's registers), A[r][c] -= (a_r Lp^-T)(a_c Lp^-T)^T and
+// W[r][c] -= (a_r Lp^-T)(Lp^-1 Wp[:,c]), so they do not wait for a panel solve by other threads; the panel / pivot / X
+// rows of a step are written during the next step (nobody reads them before the end).  The version with the panel
+// solve between two barriers and a load - compute - store loop over the update entries measured 2.7 k clk per block
+// step, this one 1.5 k.
 __device__ __forceinline__ bool factor_inv32_blk(double (*sB)[kNB + 1], double (*sXi)[kNB + 1]) {
   const int tid = threadIdx.x;
   // sXi starts as the identity: rows below the current block step hold W = E - L X (right-looking substitution), rows
-  // at or above it the finished rows of X = L^-1
+  // above it the finished rows of X = L^-1
   for (int e = tid; e < kNB * kNB; e += 256) sXi[e / kNB][e % kNB] = (e / kNB == e % kNB) ? 1.0 : 0.0;
   bool ok = true;
+  Piv4 prev;
   __syncthreads();
   for (int j0 = 0; j0 < kNB; j0 += 4) {
-    // ---- 4x4 pivot block: factor + inverse, every thread on its own ----
+    // the pivot block first: LDS returns in order, and the chain below waits for nothing else (behind the ~40 operand
+    // loads of the updates it started 800 clk into the step)
     const double p00 = sB[j0][j0], p10 = sB[j0 + 1][j0], p11 = sB[j0 + 1][j0 + 1], p20 = sB[j0 + 2][j0], p21 = sB[j0 + 2][j0 + 1],
                  p22 = sB[j0 + 2][j0 + 2], p30 = sB[j0 + 3][j0], p31 = sB[j0 + 3][j0 + 1], p32 = sB[j0 + 3][j0 + 2],
                  p33 = sB[j0 + 3][j0 + 3];
+    // operands of this step's rank-4 updates (rows below the pivot block; at most kFacEnt entries per thread), requested
+    // before the pivot chain: a loop of load - compute - store per entry runs its entries one after the other (the
+    // compiler cannot move an LDS load above the previous entry's store): 2.2 k clk for 3.5 entries, measured.
+    // (Thread = 2x2 block of entries, 20 reads and 4 substitutions for 4 entries instead of 36 and 8, was slower: the
+    // column-pair stride costs more in bank conflicts than the reads it saves.)
+    double ar[kFacEnt][4], oc[kFacEnt][4], uv[kFacEnt];
+    double *ud[kFacEnt];
+    bool ua[kFacEnt];
+#pragma unroll
+    for (int u = 0; u < kFacEnt; ++u) {
+      const int e = tid + 256 * u;
+      const bool in = e < (kNB - j0 - 4) * kNB;
+      const int r = in ? j0 + 4 + e / kNB : kNB - 1, c = e % kNB;
+      const bool trail = c >= j0 + 4;
+      ua[u] = in && !(trail && c > r);
+      // the other factor: row c of the panel (trailing block) or column c of the pivot rows of W
+      const double *o = trail ? &sB[c][j0] : &sXi[j0][c];
+      const int os = trail ? 1 : kNB + 1;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) ar[u][t] = sB[r][j0 + t], oc[u][t] = o[t * os];
+      ud[u] = trail ? &sB[r][c] : &sXi[r][c];
+      uv[u] = *ud[u];
+    }
+    const Fin4 fin = factor_finish_load(sB, sXi, j0 > 0 ? j0 - 4 : 0, tid);
+    // ---- 4x4 pivot block: factor + inverse, every thread on its own ----
     // (explicit fma: this chain of dependent fp64 operations is the critical path of the whole factorisation, and the
     // solve is compared with the oracle at 1e-6, not bit for bit)
-    const double i00 = rsqrt_nr(p00);
-    const double l00 = p00 * i00, l10 = p10 * i00, l20 = p20 * i00, l30 = p30 * i00;
-    const double d1 = fma(-l10, l10, p11);
-    const double i11 = rsqrt_nr(d1);
-    const double l11 = d1 * i11, l21 = fma(-l20, l10, p21) * i11, l31 = fma(-l30, l10, p31) * i11;
-    const double d2 = fma(-l21, l21, fma(-l20, l20, p22));
-    const double i22 = rsqrt_nr(d2);
-    const double l22 = d2 * i22, l32 = fma(-l31, l21, fma(-l30, l20, p32)) * i22;
-    const double d3 = fma(-l32, l32, fma(-l31, l31, fma(-l30, l30, p33)));
-    const double i33 = rsqrt_nr(d3);
-    const double l33 = d3 * i33;
-    if (!(p00 > 0.0 && d1 > 0.0 && d2 > 0.0 && d3 > 0.0)) ok = false;
-    const double i10 = -(l10 * i00) * i11;
-    const double i21 = -(l21 * i11) * i22;
-    const double i20 = -(l20 * i00 + l21 * i10) * i22;
-    const double i32 = -(l32 * i22) * i33;
-    const double i31 = -(l31 * i11 + l32 * i21) * i33;
-    const double i30 = -(l30 * i00 + l31 * i10 + l32 * i20) * i33;
-    // (no barrier here: the pivot block is only overwritten after the next barrier, see below)
-    if (tid < kNB) {
-      // ---- the 4-column panel: row r of L = row r of A times Lp^-T ----
-      const int r = tid;
-      if (r >= j0 + 4) {
-        const double v0 = sB[r][j0], v1 = sB[r][j0 + 1], v2 = sB[r][j0 + 2], v3 = sB[r][j0 + 3];
-        sB[r][j0] = v0 * i00;
-        sB[r][j0 + 1] = v0 * i10 + v1 * i11;
-        sB[r][j0 + 2] = v0 * i20 + v1 * i21 + v2 * i22;
-        sB[r][j0 + 3] = v0 * i30 + v1 * i31 + v2 * i32 + v3 * i33;
-      } else if (r < j0) {
-        sB[r][j0] = sB[r][j0 + 1] = sB[r][j0 + 2] = sB[r][j0 + 3] = 0.0;  // above the diagonal
-      }
-    } else if (tid < 2 * kNB) {
-      // ---- rows j0..j0+3 of X = Lp^-1 times the same rows of W, one column per thread (columns right of the block: zero) ----
-      const int c = tid - kNB;
-      const double w0 = sXi[j0][c], w1 = sXi[j0 + 1][c], w2 = sXi[j0 + 2][c], w3 = sXi[j0 + 3][c];
-      sXi[j0][c] = i00 * w0;
-      sXi[j0 + 1][c] = i10 * w0 + i11 * w1;
-      sXi[j0 + 2][c] = i20 * w0 + i21 * w1 + i22 * w2;
-      sXi[j0 + 3][c] = i30 * w0 + i31 * w1 + i32 * w2 + i33 * w3;
-    }
-    __syncthreads();
-    if (tid >= j0 && tid < j0 + 4) {  // the pivot rows become Lp (every thread has its own copy of Lp by now)
-      const int r = tid, a = r - j0;
-      sB[r][j0] = a == 0 ? l00 : (a == 1 ? l10 : (a == 2 ? l20 : l30));
-      sB[r][j0 + 1] = a == 0 ? 0.0 : (a == 1 ? l11 : (a == 2 ? l21 : l31));
-      sB[r][j0 + 2] = a <= 1 ? 0.0 : (a == 2 ? l22 : l32);
-      sB[r][j0 + 3] = a <= 2 ? 0.0 : l33;
-    }
+    Piv4 q;
+    // pivots in pairs: 1 / l11 = sqrt(p00) rsqrt(p00 p11 - p10^2), so the two reciprocal square roots of a 2x2 block run
+    // side by side (the determinant carries the same cancellation as p11 - l10^2); same for the 2x2 Schur complement
+    q.i00 = rsqrt_nr(p00);
+    const double det01 = fma(p00, p11, -(p10 * p10));
+    const double rd01 = rsqrt_nr(det01);
+    q.l00 = p00 * q.i00, q.l10 = p10 * q.i00, q.l20 = p20 * q.i00, q.l30 = p30 * q.i00;
+    q.i11 = q.l00 * rd01;
+    q.l11 = (det01 * rd01) * q.i00;
+    q.l21 = fma(-q.l20, q.l10, p21) * q.i11, q.l31 = fma(-q.l30, q.l10, p31) * q.i11;
+    const double s22 = fma(-q.l21, q.l21, fma(-q.l20, q.l20, p22));
+    const double s32 = fma(-q.l31, q.l21, fma(-q.l30, q.l20, p32));
+    const double s33 = fma(-q.l31, q.l31, fma(-q.l30, q.l30, p33));
+    q.i22 = rsqrt_nr(s22);
+    const double det23 = fma(s22, s33, -(s32 * s32));
+    const double rd23 = rsqrt_nr(det23);
+    q.l22 = s22 * q.i22, q.l32 = s32 * q.i22;
+    q.i33 = q.l22 * rd23;
+    q.l33 = (det23 * rd23) * q.i22;
+    if (!(p00 > 0.0 && det01 > 0.0 && s22 > 0.0 && det23 > 0.0)) ok = false;
+    q.i10 = -(q.l10 * q.i00) * q.i11;
+    q.i21 = -(q.l21 * q.i11) * q.i22;
+    q.i20 = -fma(q.l20, q.i00, q.l21 * q.i10) * q.i22;
+    q.i32 = -(q.l32 * q.i22) * q.i33;
+    q.i31 = -fma(q.l31, q.i11, q.l32 * q.i21) * q.i33;
+    q.i30 = -fma(q.l30, q.i00, fma(q.l31, q.i10, q.l32 * q.i20)) * q.i33;
     // ---- rank-4 updates: the trailing lower triangle of the block, and W below the block step (columns 0..j0+3) ----
-    for (int e = tid; e < (kNB - j0 - 4) * kNB; e += 256) {  // rows below the pivot block only
-      const int r = j0 + 4 + e / kNB, c = e % kNB;
-      const double a0 = sB[r][j0], a1 = sB[r][j0 + 1], a2 = sB[r][j0 + 2], a3 = sB[r][j0 + 3];
-      if (c >= j0 + 4 && c <= r) sB[r][c] -= a0 * sB[c][j0] + a1 * sB[c][j0 + 1] + a2 * sB[c][j0 + 2] + a3 * sB[c][j0 + 3];
-      if (c < j0 + 4) sXi[r][c] -= a0 * sXi[j0][c] + a1 * sXi[j0 + 1][c] + a2 * sXi[j0 + 2][c] + a3 * sXi[j0 + 3][c];
-    }
+    // both factors of an entry go through the same forward substitution with Lp (l_r = a_r Lp^-T, and l_c resp.
+    // x_c = Lp^-1 Wp[:,c]); written so that only one multiplication per factor waits for the last pivot (i33)
+#pragma unroll
+    for (int u = 0; u < kFacEnt; ++u)
+      if (ua[u]) {
+        const double r0 = ar[u][0] * q.i00, s0 = oc[u][0] * q.i00;
+        const double r1 = fma(-r0, q.l10, ar[u][1]) * q.i11, s1 = fma(-s0, q.l10, oc[u][1]) * q.i11;
+        const double r2 = fma(-r1, q.l21, fma(-r0, q.l20, ar[u][2])) * q.i22, s2 = fma(-s1, q.l21, fma(-s0, q.l20, oc[u][2])) * q.i22;
+        const double r3 = fma(-r2, q.l32, fma(-r1, q.l31, fma(-r0, q.l30, ar[u][3]))) * q.i33;
+        const double s3 = fma(-s2, q.l32, fma(-s1, q.l31, fma(-s0, q.l30, oc[u][3]))) * q.i33;
+        *ud[u] = fma(-r3, s3, fma(-r2, s2, fma(-r1, s1, fma(-r0, s0, uv[u]))));
+      }
+    if (j0 > 0) factor_finish_store(fin, j0 - 4, prev, tid);
+    prev = q;
     __syncthreads();
   }
+  factor_finish_store(factor_finish_load(sB, sXi, kNB - 4, tid), kNB - 4, prev, tid);
   return ok;
 }
 
