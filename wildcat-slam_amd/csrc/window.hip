@@ -847,7 +847,6 @@ __device__ __forceinline__ double rsqrt_nr(double a) {
   return fma(h, fma(-a * inv, inv, 1.0), inv);  // inv + inv/2 (1 - a inv^2)
 }
 
-constexpr int kFacEnt = 4;  // ceil((kNB - 4) * kNB / 256) update entries per thread
 struct Piv4 {  // Cholesky factor of a 4x4 pivot block and its inverse (both lower triangular)
   double l00, l10, l11, l20, l21, l22, l30, l31, l32, l33;
   double i00, i10, i11, i20, i21, i22, i30, i31, i32, i33;
@@ -887,17 +886,32 @@ __device__ __forceinline__ void factor_finish_store(const Fin4 f, int pj, const 
       o3 = a <= 2 ? 0.0 : p.l33;
     }
   }
-  if (tid < 64) f.base[0] = o0, f.base[f.stride] = o1, f.base[2 * f.stride] = o2, f.base[3 * f.stride] = o3;
+  f.base[0] = o0, f.base[f.stride] = o1, f.base[2 * f.stride] = o2, f.base[3 * f.stride] = o3;
 }
 
-// ONE barrier per block step: the rank-4 updates read the UNSCALED panel and solve their two 4-vectors against the pivot
-// block themselves (the pivot chain runs redundantly in every thread's registers), A[r][c] -= (a_r Lp^-T)(a_c Lp^-T)^T and
-// W[r][c] -= (a_r Lp^-T)(Lp^-1 Wp[:,c]), so they do not wait for a panel solve by other threads; the panel / pivot / X
-// rows of a step are written during the next step (nobody reads them before the end).  The version with the panel
-// solve between two barriers and a load - compute - store loop over the update entries measured 2.7 k clk per block
-// step, this one 1.5 k.
+// element lk of the forward substitution of (v0..v3) against the pivot block: (Lp^-1 v)[lk]
+__device__ __forceinline__ double piv_solve_elem(const Piv4 &q, double v0, double v1, double v2, double v3, int lk) {
+  const double f0 = v0 * q.i00;
+  const double f1 = fma(-f0, q.l10, v1) * q.i11;
+  const double f2 = fma(-f1, q.l21, fma(-f0, q.l20, v2)) * q.i22;
+  const double f3 = fma(-f2, q.l32, fma(-f1, q.l31, fma(-f0, q.l30, v3))) * q.i33;
+  return lk == 0 ? f0 : (lk == 1 ? f1 : (lk == 2 ? f2 : f3));
+}
+
+// ONE barrier per block step, and the rank-4 updates on the fp64 matrix cores.  A block step's updates are
+//   A[r][c] -= (a_r Lp^-T)(a_c Lp^-T)^T  (trailing block)   and   W[r][c] -= (a_r Lp^-T)(Lp^-1 Wp[:,c])  (inverse),
+// over rows r below the pivot block: one 32 x 32 x 4 product = four 16x16x4 MFMA tiles, one per wavefront (tile (0,1) lies
+// above the diagonal: idle).  A lane supplies ONE element of each operand, so it solves its two 4-vectors against the
+// pivot block itself (the pivot chain runs redundantly in every thread's registers; nobody waits for a panel solve by
+// other threads); the panel / pivot / X rows of a step are written during the next step (nobody reads them before the
+// end).  What bounds a block step is instruction issue, not the dependent chain: with one thread per update entry (24
+// fp64 operations each, 3.5 entries per thread) a step took 1.6 k clk whatever the length of the pivot chain; with the
+// panel solve between two barriers and a load - compute - store loop over the entries, 2.7 k.
 __device__ __forceinline__ bool factor_inv32_blk(double (*sB)[kNB + 1], double (*sXi)[kNB + 1]) {
   const int tid = threadIdx.x;
+  const int w = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+  const int rt = w >> 1, ct = w & 1;
+  const int ra = 16 * rt + li, cb = 16 * ct + li;  // this lane's row of the A operand / column of the B operand
   // sXi starts as the identity: rows below the current block step hold W = E - L X (right-looking substitution), rows
   // above it the finished rows of X = L^-1
   for (int e = tid; e < kNB * kNB; e += 256) sXi[e / kNB][e % kNB] = (e / kNB == e % kNB) ? 1.0 : 0.0;
@@ -905,38 +919,28 @@ __device__ __forceinline__ bool factor_inv32_blk(double (*sB)[kNB + 1], double (
   Piv4 prev;
   __syncthreads();
   for (int j0 = 0; j0 < kNB; j0 += 4) {
-    // the pivot block first: LDS returns in order, and the chain below waits for nothing else (behind the ~40 operand
-    // loads of the updates it started 800 clk into the step)
+    // the pivot block first: the chain below waits for nothing else
     const double p00 = sB[j0][j0], p10 = sB[j0 + 1][j0], p11 = sB[j0 + 1][j0 + 1], p20 = sB[j0 + 2][j0], p21 = sB[j0 + 2][j0 + 1],
                  p22 = sB[j0 + 2][j0 + 2], p30 = sB[j0 + 3][j0], p31 = sB[j0 + 3][j0 + 1], p32 = sB[j0 + 3][j0 + 2],
                  p33 = sB[j0 + 3][j0 + 3];
-    // operands of this step's rank-4 updates (rows below the pivot block; at most kFacEnt entries per thread), requested
-    // before the pivot chain: a loop of load - compute - store per entry runs its entries one after the other (the
-    // compiler cannot move an LDS load above the previous entry's store): 2.2 k clk for 3.5 entries, measured.
-    // (Thread = 2x2 block of entries, 20 reads and 4 substitutions for 4 entries instead of 36 and 8, was slower: the
-    // column-pair stride costs more in bank conflicts than the reads it saves.)
-    double ar[kFacEnt][4], oc[kFacEnt][4], uv[kFacEnt];
-    double *ud[kFacEnt];
-    bool ua[kFacEnt];
+    // operands of this wavefront's update tile, requested before the pivot chain
+    const bool tile = (w != 1) && (16 * rt + 15 >= j0 + 4);  // wave-uniform
+    const bool bt = cb >= j0 + 4;                             // this lane's column: trailing block (else a column of W)
+    double va[4] = {0.0, 0.0, 0.0, 0.0}, vb[4] = {0.0, 0.0, 0.0, 0.0};
+    f64x4 cc = {0.0, 0.0, 0.0, 0.0};
+    double *cbase = bt ? &sB[0][cb] : &sXi[0][cb];
+    if (tile) {
+      const double *o = bt ? &sB[cb][j0] : &sXi[j0][cb];  // row cb of the panel / column cb of W's pivot rows
+      const int os = bt ? 1 : kNB + 1;
 #pragma unroll
-    for (int u = 0; u < kFacEnt; ++u) {
-      const int e = tid + 256 * u;
-      const bool in = e < (kNB - j0 - 4) * kNB;
-      const int r = in ? j0 + 4 + e / kNB : kNB - 1, c = e % kNB;
-      const bool trail = c >= j0 + 4;
-      ua[u] = in && !(trail && c > r);
-      // the other factor: row c of the panel (trailing block) or column c of the pivot rows of W
-      const double *o = trail ? &sB[c][j0] : &sXi[j0][c];
-      const int os = trail ? 1 : kNB + 1;
+      for (int t = 0; t < 4; ++t) va[t] = sB[ra][j0 + t], vb[t] = o[t * os];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) ar[u][t] = sB[r][j0 + t], oc[u][t] = o[t * os];
-      ud[u] = trail ? &sB[r][c] : &sXi[r][c];
-      uv[u] = *ud[u];
+      for (int r4 = 0; r4 < 4; ++r4) cc[r4] = cbase[(16 * rt + lk + 4 * r4) * (kNB + 1)];
     }
-    const Fin4 fin = factor_finish_load(sB, sXi, j0 > 0 ? j0 - 4 : 0, tid);
+    Fin4 fin;
+    if (w == 1) fin = factor_finish_load(sB, sXi, j0 > 0 ? j0 - 4 : 0, tid);  // wavefront 1 has no tile: it finishes the previous step
     // ---- 4x4 pivot block: factor + inverse, every thread on its own ----
-    // (explicit fma: this chain of dependent fp64 operations is the critical path of the whole factorisation, and the
-    // solve is compared with the oracle at 1e-6, not bit for bit)
+    // (explicit fma: the solve is compared with the oracle at 1e-6, not bit for bit)
     Piv4 q;
     // pivots in pairs: 1 / l11 = sqrt(p00) rsqrt(p00 p11 - p10^2), so the two reciprocal square roots of a 2x2 block run
     // side by side (the determinant carries the same cancellation as p11 - l10^2); same for the 2x2 Schur complement
@@ -957,30 +961,30 @@ __device__ __forceinline__ bool factor_inv32_blk(double (*sB)[kNB + 1], double (
     q.i33 = q.l22 * rd23;
     q.l33 = (det23 * rd23) * q.i22;
     if (!(p00 > 0.0 && det01 > 0.0 && s22 > 0.0 && det23 > 0.0)) ok = false;
-    q.i10 = -(q.l10 * q.i00) * q.i11;
-    q.i21 = -(q.l21 * q.i11) * q.i22;
-    q.i20 = -fma(q.l20, q.i00, q.l21 * q.i10) * q.i22;
-    q.i32 = -(q.l32 * q.i22) * q.i33;
-    q.i31 = -fma(q.l31, q.i11, q.l32 * q.i21) * q.i33;
-    q.i30 = -fma(q.l30, q.i00, fma(q.l31, q.i10, q.l32 * q.i20)) * q.i33;
-    // ---- rank-4 updates: the trailing lower triangle of the block, and W below the block step (columns 0..j0+3) ----
-    // both factors of an entry go through the same forward substitution with Lp (l_r = a_r Lp^-T, and l_c resp.
-    // x_c = Lp^-1 Wp[:,c]); written so that only one multiplication per factor waits for the last pivot (i33)
+    if (w == 1) {  // the off-diagonal part of Lp^-1 is only needed to finish the step
+      q.i10 = -(q.l10 * q.i00) * q.i11;
+      q.i21 = -(q.l21 * q.i11) * q.i22;
+      q.i20 = -fma(q.l20, q.i00, q.l21 * q.i10) * q.i22;
+      q.i32 = -(q.l32 * q.i22) * q.i33;
+      q.i31 = -fma(q.l31, q.i11, q.l32 * q.i21) * q.i33;
+      q.i30 = -fma(q.l30, q.i00, fma(q.l31, q.i10, q.l32 * q.i20)) * q.i33;
+    }
+    // ---- rank-4 update of this wavefront's tile ----
+    if (tile) {
+      const double fa = piv_solve_elem(q, va[0], va[1], va[2], va[3], lk);
+      const double fb = piv_solve_elem(q, vb[0], vb[1], vb[2], vb[3], lk);
+      const f64x4 d = __builtin_amdgcn_mfma_f64_16x16x4f64(ra >= j0 + 4 ? -fa : 0.0, fb, cc, 0, 0, 0);
 #pragma unroll
-    for (int u = 0; u < kFacEnt; ++u)
-      if (ua[u]) {
-        const double r0 = ar[u][0] * q.i00, s0 = oc[u][0] * q.i00;
-        const double r1 = fma(-r0, q.l10, ar[u][1]) * q.i11, s1 = fma(-s0, q.l10, oc[u][1]) * q.i11;
-        const double r2 = fma(-r1, q.l21, fma(-r0, q.l20, ar[u][2])) * q.i22, s2 = fma(-s1, q.l21, fma(-s0, q.l20, oc[u][2])) * q.i22;
-        const double r3 = fma(-r2, q.l32, fma(-r1, q.l31, fma(-r0, q.l30, ar[u][3]))) * q.i33;
-        const double s3 = fma(-s2, q.l32, fma(-s1, q.l31, fma(-s0, q.l30, oc[u][3]))) * q.i33;
-        *ud[u] = fma(-r3, s3, fma(-r2, s2, fma(-r1, s1, fma(-r0, s0, uv[u]))));
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const int row = 16 * rt + lk + 4 * r4;
+        if (row >= j0 + 4 && (!bt || cb <= row)) cbase[row * (kNB + 1)] = d[r4];
       }
-    if (j0 > 0) factor_finish_store(fin, j0 - 4, prev, tid);
+    }
+    if (w == 1 && j0 > 0) factor_finish_store(fin, j0 - 4, prev, tid);
     prev = q;
     __syncthreads();
   }
-  factor_finish_store(factor_finish_load(sB, sXi, kNB - 4, tid), kNB - 4, prev, tid);
+  if (w == 1) factor_finish_store(factor_finish_load(sB, sXi, kNB - 4, tid), kNB - 4, prev, tid);
   return ok;
 }
 
