@@ -1210,19 +1210,27 @@ __global__ void __launch_bounds__(1024) k_chol_back_chunk(const double *A, int l
   const int base = lo_blk * kNB, span = (hi_blk - lo_blk) * kNB;
   if (tid < span) sz[tid] = (base + tid < n) ? zsrc[base + tid] : 0.0;
   lds_barrier();
+  // L and Linv of a step do not depend on y: they are requested one step ahead (registers li / lv hold step kb while
+  // the loads of step kb - 1 are in flight behind the barriers, which only wait for LDS)
+  auto fetch = [&](int kb, double &li_out, double (&lv_out)[8]) {
+    const int loc = (kb - lo_blk) * kNB;
+    const int rows = min(kNB, n - kb * kNB);
+    li_out = Linv[(size_t)kb * kNB * kNB + tid];
+    const bool upd = tid < 4 * loc;
+    const int j = upd ? tid % loc : 0, qr = upd ? tid / loc : 0;
+    const double *col = A + (size_t)(kb * kNB + qr * 8) * ld + base + j;
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) lv_out[rr] = (upd && qr * 8 + rr < rows) ? col[(size_t)rr * ld] : 0.0;
+  };
+  double li, lv[8];
+  fetch(hi_blk - 1, li, lv);
   for (int kb = hi_blk - 1; kb >= lo_blk; --kb) {
     const int loc = (kb - lo_blk) * kNB;  // local index of block kb's first row = number of chunk columns left of it
-    const int rows = min(kNB, n - kb * kNB);
-    const double li = Linv[(size_t)kb * kNB * kNB + tid];
     // thread = (column j < loc, quarter of the block's rows): 8 independent loads, the quarters are added in fixed order
     const bool upd = tid < 4 * loc;
     const int j = upd ? tid % loc : 0, qr = upd ? tid / loc : 0;
-    double lv[8];
-    {
-      const double *col = A + (size_t)(kb * kNB + qr * 8) * ld + base + j;
-#pragma unroll
-      for (int rr = 0; rr < 8; ++rr) lv[rr] = (upd && qr * 8 + rr < rows) ? col[(size_t)rr * ld] : 0.0;
-    }
+    double li_n = 0.0, lv_n[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    if (kb > lo_blk) fetch(kb - 1, li_n, lv_n);
     sP[m][c] = (m >= c) ? li * sz[loc + m] : 0.0;  // Linv[m][c] z[m]
     lds_barrier();
     if (tid < kNB) {
@@ -1243,6 +1251,9 @@ __global__ void __launch_bounds__(1024) k_chol_back_chunk(const double *A, int l
     lds_barrier();
     if (tid < loc) sz[tid] -= (sQ[0][tid] + sQ[1][tid]) + (sQ[2][tid] + sQ[3][tid]);
     lds_barrier();
+    li = li_n;
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr) lv[rr] = lv_n[rr];
   }
   if (tid < span && base + tid < n) y[base + tid] = sz[tid];
 }
