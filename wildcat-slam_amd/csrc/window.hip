@@ -889,13 +889,15 @@ __device__ __forceinline__ void factor_finish_store(const Fin4 f, int pj, const 
   f.base[0] = o0, f.base[f.stride] = o1, f.base[2 * f.stride] = o2, f.base[3 * f.stride] = o3;
 }
 
-// element lk of the forward substitution of (v0..v3) against the pivot block: (Lp^-1 v)[lk]
-__device__ __forceinline__ double piv_solve_elem(const Piv4 &q, double v0, double v1, double v2, double v3, int lk) {
+// element lk of the forward substitution of (v0..v3) against the pivot block: (Lp^-1 v)[lk], picked with the lane's 0/1
+// weights m[k] = (lk == k).  Straight-line on purpose: with a select by lk the compiler builds a branch tree per call
+// (lanes with lk = 0 "save" three elements), which cannot be interleaved with the pivot chain or with the second call.
+__device__ __forceinline__ double piv_solve_elem(const Piv4 &q, double v0, double v1, double v2, double v3, const double (&m)[4]) {
   const double f0 = v0 * q.i00;
   const double f1 = fma(-f0, q.l10, v1) * q.i11;
   const double f2 = fma(-f1, q.l21, fma(-f0, q.l20, v2)) * q.i22;
   const double f3 = fma(-f2, q.l32, fma(-f1, q.l31, fma(-f0, q.l30, v3))) * q.i33;
-  return lk == 0 ? f0 : (lk == 1 ? f1 : (lk == 2 ? f2 : f3));
+  return fma(m[3], f3, fma(m[2], f2, fma(m[1], f1, m[0] * f0)));
 }
 
 // ONE barrier per block step, and the rank-4 updates on the fp64 matrix cores.  A block step's updates are
@@ -912,12 +914,22 @@ __device__ __forceinline__ bool factor_inv32_blk(double (*sB)[kNB + 1], double (
   const int w = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
   const int rt = w >> 1, ct = w & 1;
   const int ra = 16 * rt + li, cb = 16 * ct + li;  // this lane's row of the A operand / column of the B operand
+  const double mk[4] = {lk == 0 ? 1.0 : 0.0, lk == 1 ? 1.0 : 0.0, lk == 2 ? 1.0 : 0.0, lk == 3 ? 1.0 : 0.0};
   // sXi starts as the identity: rows below the current block step hold W = E - L X (right-looking substitution), rows
   // above it the finished rows of X = L^-1
   for (int e = tid; e < kNB * kNB; e += 256) sXi[e / kNB][e % kNB] = (e / kNB == e % kNB) ? 1.0 : 0.0;
   bool ok = true;
   Piv4 prev;
   __syncthreads();
+  // The update tile of a wavefront stays in registers for the whole factorisation (MFMA C / D layout: register r4 of a
+  // lane = element (16 rt + lk + 4 r4, cb)): LDS only carries what OTHER wavefronts read - the next step's panel columns
+  // and W's next pivot rows.  A column holds the trailing block until its block step, then W (whose untouched part below
+  // the diagonal is zero).
+  f64x4 cc = {0.0, 0.0, 0.0, 0.0};
+  if (w != 1) {
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) cc[r4] = sB[16 * rt + lk + 4 * r4][cb];
+  }
   for (int j0 = 0; j0 < kNB; j0 += 4) {
     // the pivot block first: the chain below waits for nothing else
     const double p00 = sB[j0][j0], p10 = sB[j0 + 1][j0], p11 = sB[j0 + 1][j0 + 1], p20 = sB[j0 + 2][j0], p21 = sB[j0 + 2][j0 + 1],
@@ -926,16 +938,13 @@ __device__ __forceinline__ bool factor_inv32_blk(double (*sB)[kNB + 1], double (
     // operands of this wavefront's update tile, requested before the pivot chain
     const bool tile = (w != 1) && (16 * rt + 15 >= j0 + 4);  // wave-uniform
     const bool bt = cb >= j0 + 4;                             // this lane's column: trailing block (else a column of W)
+    if ((cb >> 2) == (j0 >> 2)) cc = f64x4{0.0, 0.0, 0.0, 0.0};  // the pivot columns turn into columns of W
     double va[4] = {0.0, 0.0, 0.0, 0.0}, vb[4] = {0.0, 0.0, 0.0, 0.0};
-    f64x4 cc = {0.0, 0.0, 0.0, 0.0};
-    double *cbase = bt ? &sB[0][cb] : &sXi[0][cb];
     if (tile) {
       const double *o = bt ? &sB[cb][j0] : &sXi[j0][cb];  // row cb of the panel / column cb of W's pivot rows
       const int os = bt ? 1 : kNB + 1;
 #pragma unroll
       for (int t = 0; t < 4; ++t) va[t] = sB[ra][j0 + t], vb[t] = o[t * os];
-#pragma unroll
-      for (int r4 = 0; r4 < 4; ++r4) cc[r4] = cbase[(16 * rt + lk + 4 * r4) * (kNB + 1)];
     }
     Fin4 fin;
     if (w == 1) fin = factor_finish_load(sB, sXi, j0 > 0 ? j0 - 4 : 0, tid);  // wavefront 1 has no tile: it finishes the previous step
@@ -970,14 +979,21 @@ __device__ __forceinline__ bool factor_inv32_blk(double (*sB)[kNB + 1], double (
       q.i30 = -fma(q.l30, q.i00, fma(q.l31, q.i10, q.l32 * q.i20)) * q.i33;
     }
     // ---- rank-4 update of this wavefront's tile ----
+    const double fa = piv_solve_elem(q, va[0], va[1], va[2], va[3], mk);
+    const double fb = piv_solve_elem(q, vb[0], vb[1], vb[2], vb[3], mk);
     if (tile) {
-      const double fa = piv_solve_elem(q, va[0], va[1], va[2], va[3], lk);
-      const double fb = piv_solve_elem(q, vb[0], vb[1], vb[2], vb[3], lk);
-      const f64x4 d = __builtin_amdgcn_mfma_f64_16x16x4f64(ra >= j0 + 4 ? -fa : 0.0, fb, cc, 0, 0, 0);
+      cc = __builtin_amdgcn_mfma_f64_16x16x4f64(ra >= j0 + 4 ? -fa : 0.0, fb, cc, 0, 0, 0);
+      if (bt) {
+        if (cb < j0 + 8) {  // the next step's panel (and pivot block): lower part, rows from the next pivot block on
 #pragma unroll
-      for (int r4 = 0; r4 < 4; ++r4) {
-        const int row = 16 * rt + lk + 4 * r4;
-        if (row >= j0 + 4 && (!bt || cb <= row)) cbase[row * (kNB + 1)] = d[r4];
+          for (int r4 = 0; r4 < 4; ++r4) {
+            const int row = 16 * rt + lk + 4 * r4;
+            if (row >= j0 + 4 && cb <= row) sB[row][cb] = cc[r4];
+          }
+        }
+      } else {  // W's next pivot rows j0+4 .. j0+7: row j0 + 4 + lk is register (j0 + 4 - 16 rt) / 4 of this lane
+        const int rn = j0 + 4 - 16 * rt;
+        if (rn >= 0 && rn < 16) sXi[j0 + 4 + lk][cb] = rn == 0 ? cc[0] : (rn == 4 ? cc[1] : (rn == 8 ? cc[2] : cc[3]));
       }
     }
     if (w == 1 && j0 > 0) factor_finish_store(fin, j0 - 4, prev, tid);
