@@ -1349,8 +1349,8 @@ int sort_u32(wc_ctx *ctx, wc_window_state *W, uint32_t *kin, uint32_t *kout, uin
 template <typename T>
 int upload(wc_ctx *ctx, wc_buf &b, const std::vector<T> &v) {
   WC_TRY(wc_ensure(ctx, b, std::max<size_t>(v.size() * sizeof(T), 16)));
+  // no synchronisation here: every vector passed in lives until the one hipStreamSynchronize at the end of wc_window_build
   if (!v.empty()) WC_HIP(ctx, hipMemcpyAsync(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
-  WC_HIP(ctx, hipStreamSynchronize(ctx->stream));  // v may be a temporary
   return WC_OK;
 }
 
@@ -1359,19 +1359,21 @@ struct Seg {
 };
 
 // sorted keys -> segments (device head detection, host ordering)
-int find_segments(wc_ctx *ctx, wc_window_state *W, const uint32_t *d_keys, uint32_t n, std::vector<Seg> &segs) {
+int find_segments(wc_ctx *ctx, wc_window_state *W, const uint32_t *d_keys, uint32_t n, uint32_t max_heads, uint32_t st[4],
+                  std::vector<Seg> &segs) {
   segs.clear();
   if (n == 0) return WC_OK;
   WC_TRY(wc_ensure(ctx, W->heads, (size_t)n * 8));
-  WC_TRY(wc_ensure(ctx, W->status, 64 * 4));
-  WC_HIP(ctx, hipMemsetAsync(W->status.p, 0, 64 * 4, ctx->stream));
   k_seg_heads<<<(n + 255) / 256, 256, 0, ctx->stream>>>(d_keys, n, (uint32_t *)W->heads.p, (uint32_t *)W->status.p);
-  uint32_t st[4];
+  // ONE round trip: the status words (also k_pair_keys' flags) and as many head slots as there can be distinct keys
+  const uint32_t cap = std::min(n, max_heads);
+  std::vector<std::pair<uint32_t, uint32_t>> heads(cap);
   WC_HIP(ctx, hipMemcpyAsync(st, W->status.p, 16, hipMemcpyDeviceToHost, ctx->stream));
+  WC_HIP(ctx, hipMemcpyAsync(heads.data(), W->heads.p, (size_t)cap * 8, hipMemcpyDeviceToHost, ctx->stream));
   WC_HIP(ctx, hipStreamSynchronize(ctx->stream));
   const uint32_t nh = st[2];
-  std::vector<std::pair<uint32_t, uint32_t>> heads(nh);
-  WC_HIP(ctx, hipMemcpy(heads.data(), W->heads.p, (size_t)nh * 8, hipMemcpyDeviceToHost));
+  if (nh > cap) return wc_fail(ctx, WC_ERR_RANGE, "more key segments (%u) than distinct keys (%u)", nh, cap);
+  heads.resize(nh);
   std::sort(heads.begin(), heads.end());
   for (uint32_t i = 0; i < nh; ++i) {
     const uint32_t end = (i + 1 < nh) ? heads[i + 1].first : n;
@@ -1415,11 +1417,7 @@ int build_family(wc_ctx *ctx, wc_window_state *W, bool unary, const wc_surfel *s
   const unsigned grid = (n + 255) / 256;
   k_pair_keys<<<grid, 256, 0, ctx->stream>>>(s1, s2, pairs, n, (const double *)W->times_d.p, W->ns, unary ? 1 : 0,
                                             (uint32_t *)W->keys_tmp[0].p, (uint32_t *)W->vals_tmp[0].p, (uint32_t *)W->status.p);
-  uint32_t st[4];
-  WC_HIP(ctx, hipMemcpyAsync(st, W->status.p, 16, hipMemcpyDeviceToHost, ctx->stream));
-  WC_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  if (st[1] & 2u) return wc_fail(ctx, WC_ERR_ORDER, "correspondence is not (older, newer)");
-  if (st[1] & 1u) return wc_fail(ctx, WC_ERR_RANGE, "surfel timestamp outside the sample-state range");
+  // (k_pair_keys' flags are read back with the segment heads: a flagged record gets key 0, so everything downstream is safe)
   unsigned bits = 1;
   const uint64_t maxkey = unary ? (uint64_t)W->ns : (uint64_t)W->ns * W->ns;
   while ((1ull << bits) < maxkey + 1) ++bits;
@@ -1429,7 +1427,10 @@ int build_family(wc_ctx *ctx, wc_window_state *W, bool unary, const wc_surfel *s
                                                 (const uint32_t *)W->keys_tmp[1].p, n, (const double *)W->times_d.p, W->ns,
                                                 unary ? 1 : 0, W->wp.sigma0_sq, (double *)rec.p, (uint32_t *)key.p, (uint32_t *)orig.p);
   WC_HIP(ctx, hipGetLastError());
-  WC_TRY(find_segments(ctx, W, (const uint32_t *)key.p, n, segs));
+  uint32_t st[4] = {0, 0, 0, 0};
+  WC_TRY(find_segments(ctx, W, (const uint32_t *)key.p, n, (uint32_t)maxkey + 1, st, segs));
+  if (st[1] & 2u) return wc_fail(ctx, WC_ERR_ORDER, "correspondence is not (older, newer)");
+  if (st[1] & 1u) return wc_fail(ctx, WC_ERR_RANGE, "surfel timestamp outside the sample-state range");
   return WC_OK;
 }
 
@@ -1460,6 +1461,16 @@ extern "C" int wc_window_build(wc_ctx *ctx, const wc_surfel *d_sld_surf, const w
   wp.quirks = P.reference_quirks;
   wp.ns = ns;
   wp.fix_first = fix_first_pos ? 1 : 0;
+  // host arrays the asynchronous uploads below read; the guard (destroyed first) waits for the stream on every way out
+  std::vector<ImuRec> irecs;
+  std::vector<Piece> pieces;
+  std::vector<Src> src;
+  std::vector<GSrc> gsrc;
+  std::vector<uint32_t> src_begin, gsrc_begin, heavy;
+  struct SyncGuard {
+    hipStream_t s;
+    ~SyncGuard() { (void)hipStreamSynchronize(s); }
+  } guard{ctx->stream};
   WC_TRY(upload(ctx, W->times_d, W->times));
 
   std::vector<Seg> segs_b, segs_u;
@@ -1471,7 +1482,6 @@ extern "C" int wc_window_build(wc_ctx *ctx, const wc_surfel *d_sld_surf, const w
                       W->uorig, segs_u));
 
   // IMU factors (BuildImuResiduals, lidar_odometry.cc:319-363), selected on the host: a few thousand records
-  std::vector<ImuRec> irecs;
   std::vector<Seg> segs_i;
   if (h_imu && n_imu >= 3) {
     for (uint64_t i = 0; i + 2 < n_imu; ++i) {
@@ -1494,7 +1504,6 @@ extern "C" int wc_window_build(wc_ctx *ctx, const wc_surfel *d_sld_surf, const w
   WC_TRY(upload(ctx, W->irec, irecs));
 
   // pieces + the CSR source lists of the gather
-  std::vector<Piece> pieces;
   uint32_t off = 0;
   auto cut = [&](const std::vector<Seg> &segs, uint32_t T, bool split) {
     for (const Seg &s : segs) {
@@ -1516,54 +1525,62 @@ extern "C" int wc_window_build(wc_ctx *ctx, const wc_surfel *d_sld_surf, const w
   const uint32_t npairs = (uint32_t)(ns * (ns + 1) / 2);
   W->npairs = npairs;
   auto pair_id = [&](int I, int J) { return (uint32_t)(I * ns - I * (I - 1) / 2 + (J - I)); };
-  std::vector<std::vector<Src>> per_pair(npairs);
-  std::vector<std::vector<GSrc>> per_blk(ns);
-  for (size_t pi = 0; pi < pieces.size(); ++pi) {
+  // CSR source lists in two passes over the pieces (count, fill): sources of a pair / block in piece order
+  auto blocks_of = [&](size_t pi, int blk[4], uint8_t &w, uint8_t &T) -> int {
     const Piece &pc = pieces[pi];
-    int blk[4], nblk;
-    uint8_t w, T;
     if (pi < W->npiece_b) {
       const int sp1l = pc.key & 0xFFFF, sp2l = pc.key >> 16;
       w = 6, T = 25;
+      blk[0] = sp1l, blk[1] = sp1l + 1;
       if (sp2l > sp1l + 1) {
-        nblk = 4, blk[0] = sp1l, blk[1] = sp1l + 1, blk[2] = sp2l, blk[3] = sp2l + 1;
-      } else if (sp2l == sp1l + 1) {
-        nblk = 3, blk[0] = sp1l, blk[1] = sp1l + 1, blk[2] = sp2l + 1;
-      } else {
-        nblk = 2, blk[0] = sp1l, blk[1] = sp1l + 1;
+        blk[2] = sp2l, blk[3] = sp2l + 1;
+        return 4;
       }
-    } else if (pi < W->npiece_b + W->npiece_u) {
-      w = 6, T = 13, nblk = 2, blk[0] = (int)pc.key, blk[1] = (int)pc.key + 1;
-    } else {
-      w = 12, T = 37;
-      const bool last = ((int)pc.key + 1 == ns - 1);
-      nblk = last ? 2 : 3;
-      blk[0] = (int)pc.key, blk[1] = (int)pc.key + 1, blk[2] = (int)pc.key + 2;
+      if (sp2l == sp1l + 1) {
+        blk[2] = sp2l + 1;
+        return 3;
+      }
+      return 2;
     }
+    if (pi < W->npiece_b + W->npiece_u) {
+      w = 6, T = 13, blk[0] = (int)pc.key, blk[1] = (int)pc.key + 1;
+      return 2;
+    }
+    w = 12, T = 37;
+    blk[0] = (int)pc.key, blk[1] = (int)pc.key + 1, blk[2] = (int)pc.key + 2;
+    return ((int)pc.key + 1 == ns - 1) ? 2 : 3;
+  };
+  src_begin.assign(npairs + 1, 0), gsrc_begin.assign(ns + 1, 0);
+  for (size_t pi = 0; pi < pieces.size(); ++pi) {
+    int blk[4];
+    uint8_t w, T;
+    const int nblk = blocks_of(pi, blk, w, T);
     for (int p = 0; p < nblk; ++p) {
-      per_blk[blk[p]].push_back({pc.part_off, (uint8_t)p, w, T, 0});
-      for (int q = p; q < nblk; ++q) per_pair[pair_id(blk[p], blk[q])].push_back({pc.part_off, (uint8_t)p, (uint8_t)q, w, T});
+      gsrc_begin[blk[p] + 1]++;
+      for (int q = p; q < nblk; ++q) src_begin[pair_id(blk[p], blk[q]) + 1]++;
     }
   }
-  std::vector<Src> src;
-  std::vector<uint32_t> src_begin(npairs + 1, 0);
-  for (uint32_t i = 0; i < npairs; ++i) {
-    src_begin[i] = (uint32_t)src.size();
-    src.insert(src.end(), per_pair[i].begin(), per_pair[i].end());
+  for (uint32_t i = 0; i < npairs; ++i) src_begin[i + 1] += src_begin[i];
+  for (int i = 0; i < ns; ++i) gsrc_begin[i + 1] += gsrc_begin[i];
+  src.resize(src_begin[npairs]);
+  gsrc.resize(gsrc_begin[ns]);
+  {
+    std::vector<uint32_t> cur(src_begin.begin(), src_begin.end() - 1), gcur(gsrc_begin.begin(), gsrc_begin.end() - 1);
+    for (size_t pi = 0; pi < pieces.size(); ++pi) {
+      int blk[4];
+      uint8_t w, T;
+      const int nblk = blocks_of(pi, blk, w, T);
+      const uint32_t po = pieces[pi].part_off;
+      for (int p = 0; p < nblk; ++p) {
+        gsrc[gcur[blk[p]]++] = {po, (uint8_t)p, w, T, 0};
+        for (int q = p; q < nblk; ++q) src[cur[pair_id(blk[p], blk[q])]++] = {po, (uint8_t)p, (uint8_t)q, w, T};
+      }
+    }
   }
-  src_begin[npairs] = (uint32_t)src.size();
-  std::vector<uint32_t> heavy;
   for (uint32_t i = 0; i < npairs; ++i)
     if (src_begin[i + 1] - src_begin[i] > kHeavySrc) heavy.push_back(i);
   W->nheavy = (uint32_t)heavy.size();
   WC_TRY(upload(ctx, W->heavy, heavy));
-  std::vector<GSrc> gsrc;
-  std::vector<uint32_t> gsrc_begin(ns + 1, 0);
-  for (int i = 0; i < ns; ++i) {
-    gsrc_begin[i] = (uint32_t)gsrc.size();
-    gsrc.insert(gsrc.end(), per_blk[i].begin(), per_blk[i].end());
-  }
-  gsrc_begin[ns] = (uint32_t)gsrc.size();
   WC_TRY(upload(ctx, W->pieces, pieces));
   WC_TRY(upload(ctx, W->src, src));
   WC_TRY(upload(ctx, W->src_begin, src_begin));
@@ -1584,6 +1601,7 @@ extern "C" int wc_window_build(wc_ctx *ctx, const wc_surfel *d_sld_surf, const w
   WC_TRY(wc_ensure(ctx, W->mail, 64 * 8));
   const size_t ncb = (W->nb + 255) / 256 + (W->nu + 255) / 256 + (W->ni + 255) / 256 + 8;
   WC_TRY(wc_ensure(ctx, W->cost_part, ncb * 8));
+  WC_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the uploads above read host vectors of this scope
   W->built = true;
   return WC_OK;
 }
