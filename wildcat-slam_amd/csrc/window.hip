@@ -435,13 +435,26 @@ __global__ void __launch_bounds__(kPiece) k_lin_surfel(WinParams wp, const Piece
   lt_[0] = clock64();
 #endif
   double c = 0.0;
+#ifdef WC_PROF_LIN
+  long long la_[4] = {0, 0, 0, 0};
+  asm volatile("" ::"s"(pc.count), "s"(pc.begin));
+  la_[0] = clock64();  // descriptor has arrived
+#endif
   if (tid < (int)pc.count) {
     double v[W], r;
     const uint32_t k = pc.begin + tid;
+    constexpr int NF = UNARY ? 11 : 15;
+    double rv[NF];
+#pragma unroll
+    for (int f = 0; f < NF; ++f) rv[f] = rec[(size_t)f * nrec + k];
+#ifdef WC_PROF_LIN
+    asm volatile("" ::"v"(rv[0]), "v"(rv[NF - 1]), "v"(rv[5]));
+    la_[1] = clock64();  // records have arrived
+#endif
     if (UNARY)
-      eval_unary(wp, rec, nrec, k, pc.key, x, r, c, v);  // one key per piece: the sample blocks are wave-uniform
+      eval_unary(wp, rv, 1, 0, pc.key, x, r, c, v);  // one key per piece: the sample blocks are wave-uniform
     else
-      eval_binary(wp, rec, nrec, k, pc.key, x, r, c, v);
+      eval_binary(wp, rv, 1, 0, pc.key, x, r, c, v);
 #pragma unroll
     for (int i = 0; i < W; ++i) sV[tid * T + i] = v[i];
     sV[tid * T + W] = r;
@@ -497,12 +510,12 @@ __global__ void __launch_bounds__(kPiece) k_lin_surfel(WinParams wp, const Piece
   __syncthreads();
   constexpr int NOUT = T * (T + 1) / 2;
   for (int e = tid; e < NOUT; e += kPiece) {
-    int i = 0, rem = e;
-    while (rem >= T - i) {
-      rem -= T - i;
-      ++i;
-    }
-    const int j = i + rem;
+    // row of the packed upper triangle: e = i T - i (i - 1) / 2 + (j - i); closed form + one correction step each way
+    int i = (int)(((float)(2 * T + 1) - sqrtf((float)((2 * T + 1) * (2 * T + 1) - 8 * e))) * 0.5f);
+    i = min(max(i, 0), T - 1);
+    if (i * T - i * (i - 1) / 2 > e) --i;
+    if ((i + 1) * T - (i + 1) * i / 2 <= e) ++i;
+    const int j = i + (e - (i * T - i * (i - 1) / 2));
     double out = 0.0;
     if (i == W) {
       out = (sC[0] + sC[1]) + (sC[2] + sC[3]);
@@ -517,8 +530,9 @@ __global__ void __launch_bounds__(kPiece) k_lin_surfel(WinParams wp, const Piece
 #ifdef WC_PROF_LIN
   lt_[4] = clock64();
   if (tid == 0 && (blockIdx.x % 997) == 500)
-    printf("lin W=%d blk %u count %u: A %lld sync %lld B %lld tail %lld total %lld\n", W, blockIdx.x, pc.count, lt_[1] - lt_[0],
-           lt_[2] - lt_[1], lt_[3] - lt_[2], lt_[4] - lt_[3], lt_[4] - lt_[0]);
+    printf("lin W=%d blk %u count %u: A %lld (descriptor %lld records %lld evaluate %lld) sync %lld B %lld tail %lld total %lld\n", W, blockIdx.x,
+           pc.count, lt_[1] - lt_[0], la_[0] - lt_[0], la_[1] - la_[0], lt_[1] - la_[1], lt_[2] - lt_[1], lt_[3] - lt_[2], lt_[4] - lt_[3],
+           lt_[4] - lt_[0]);
 #endif
 }
 
