@@ -147,6 +147,31 @@ def main():
     except Exception as e:  # the headline must survive a failure of this extra measurement
         pipelined = {"error": repr(e)}
 
+    # --- the same sweep in the 20 B / point layout SURVEY 8(d) counts (packed float32 xyz + float64 time instead of the
+    # reference's 48-byte record): what the input layout costs.  Reported next to the headline, never as `value`.
+    soa = None
+    try:
+        xyz = np.stack([pts["x"], pts["y"], pts["z"]], axis=1).astype(np.float32)
+        d_xyz = torch.from_numpy(xyz.reshape(-1)).to(dev)
+        d_t = torch.from_numpy(np.ascontiguousarray(pts["time"], np.float64)).to(dev)
+        desc_soa = R.Points(d_xyz.data_ptr(), d_t.data_ptr(), 12, 8, n_pts)
+        enq2, fin2 = ctx.prepare_extract(desc_soa, out_p, ids_p, cap, t_lo, t_hi)
+        for _ in range(max(3, args.warmup)):
+            enq2()
+            n2 = fin2()
+        assert os.environ.get("WC_DEBUG_SKIP") or n2 == exp_surfels, (n2, exp_surfels)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            enq2()
+            fin2()
+        ctx.sync()
+        el3 = time.perf_counter() - t0
+        soa = {"layout": "float32 xyz (stride 12) + float64 time (stride 8): 20 B / point", "value": round(n_pts / (el3 / args.steps) / 1e6, 2),
+               "unit": "Mpts/s (this rank)", "ms_per_step": round(el3 / args.steps * 1e3, 5)}
+    except Exception as e:
+        soa = {"error": repr(e)}
+
     # --- per-stage device time (HIP events on the ctx stream), same steps, for the roofline object ---------------
     ctx.extract_profile(True)
     acc = {}
@@ -185,6 +210,7 @@ def main():
                    % (n_pts, exp_surfels), "points_per_gpu": n_pts, "surfels_per_gpu": exp_surfels, "parallelism": "sweep-per-gpu x%d" % world},
         "roofline": roofline,
         "pipelined": pipelined,
+        "soa_input": soa,
         "stages_ms": {k_: round(v, 5) for k_, v in stages.items()},
     }
 

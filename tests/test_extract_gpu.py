@@ -184,3 +184,24 @@ def test_non_default_parameters(gpu, oracle, override):
                 helpers.check_surfels(s_gpu, id_gpu, s_ref, id_ref, tol=1e-6, t_tol=1e-5)
     finally:
         gpu.set_params(oracle.default_params())
+
+
+@pytest.mark.parametrize("xyz_stride", [12, 16])
+def test_soa_point_layouts_match_the_aos_record(gpu, oracle, xyz_stride):
+    """wc_points takes any (xyz pointer + stride, time pointer + stride): packed 12-byte xyz / padded 16-byte xyz with a
+    separate time array must give bit-for-bit what the 48-byte hilti_ros::Point record gives (common.h:12-28)"""
+    for pts in (synth.g2_lattice(300, m=32)[0], synth.g1_room(60_000)):
+        n = len(pts)
+        s_ref, id_ref = gpu.extract_surfels(pts)
+        xyz = np.zeros((n, xyz_stride // 4), np.float32)
+        xyz[:, 0], xyz[:, 1], xyz[:, 2] = pts["x"], pts["y"], pts["z"]
+        t = np.ascontiguousarray(pts["time"], np.float64)
+        d_xyz, d_t = gpu.to_device(xyz), gpu.to_device(t)
+        cap = max(1024, (3 * n) // 20 + 1)
+        d_out, d_ids = gpu.alloc(cap * 144), gpu.alloc(cap * 16)
+        desc = R.Points(d_xyz.ptr, d_t.ptr, xyz_stride, 8, n)
+        gpu.extract_enqueue(desc, d_out, d_ids, cap, float(t[0]), float(t[-1]))
+        m = gpu.extract_finish()
+        assert m == len(s_ref) > 0
+        s, ids = d_out.download(R.SURFEL, m), d_ids.download(R.SURFEL_ID, m)
+        assert s.tobytes() == s_ref.tobytes() and ids.tobytes() == id_ref.tobytes()
