@@ -10,6 +10,7 @@
 // in order) is a recurrence choice(q) = f(choice(c) : c < q); it is solved by fixed-point iteration on the device.
 // Memory bound gather/scan work; no MFMA.
 #include <hip/hip_runtime.h>
+#include <cstdio>
 
 #include <cmath>
 #include <cstring>
@@ -152,6 +153,10 @@ __device__ __forceinline__ uint32_t lower_bound_u32(const uint32_t *a, uint32_t 
   return lo;
 }
 
+#ifdef WC_PROF_KNN
+__device__ unsigned long long g_knn_prof[4];  // candidates scanned, rows visited, shells, queries
+#endif
+
 template <int K>
 struct TopK {
   double d[K];
@@ -177,6 +182,8 @@ struct TopK {
   }
 };
 
+constexpr int kRowChunk = 4;  // rows of a shell whose candidate ranges are looked up together
+
 // exact k-NN + gates.  gated[j][q] (plane j of nq entries: the resolve rounds read plane 0 coalesced and rarely more) =
 // j-th neighbour of q passing the first three gates (kNone-terminated).
 template <int K>
@@ -186,6 +193,7 @@ __global__ void __launch_bounds__(128, 4) k_knn_gate(const wc_surfel *q_surf, co
                                                  const uint32_t *__restrict__ qorder) {
   // qorder: the queries in the order of their grid cell (same-set matching: the sorted target permutation).  Neighbouring
   // threads then scan the same cell ranges: their feature loads hit the same cache lines and their trip counts agree.
+  __shared__ uint2 s_rng[2 * kRowChunk][128];  // per thread: the candidate ranges of a chunk of rows (only its own column)
   const uint32_t qi = blockIdx.x * blockDim.x + threadIdx.x;
   if (qi >= nq) return;
   const uint32_t q = qorder ? qorder[qi] : qi;
@@ -207,42 +215,98 @@ __global__ void __launch_bounds__(128, 4) k_knn_gate(const wc_surfel *q_surf, co
   const double in_cell = fmin(fmin(fmin(gx - cx, cx + 1 - gx), fmin(gy - cy, cy + 1 - gy)), fmin(gz - cz, cz + 1 - gz)) * M.h;
   const int rmax = max(max(max(cx, M.dim[0] - 1 - cx), max(cy, M.dim[1] - 1 - cy)), max(cz, M.dim[2] - 1 - cz));
 
+#ifdef WC_PROF_KNN
+  unsigned long long pc_ = 0, pr_ = 0, ps_ = 0;
+#endif
   for (int r = 0; r <= rmax; ++r) {
+#ifdef WC_PROF_KNN
+    ++ps_;
+#endif
     // shell r of the cube of cells around the query: rows (dy, dz); full x-span on the faces |dy| = r or |dz| = r,
-    // only the two end cells elsewhere.  ONE scan site (the kernel stays small enough to keep the top-k in registers).
+    // only the two end cells elsewhere
     for (int dz = -r; dz <= r; ++dz)
-      for (int dy = -r; dy <= r; ++dy) {
-        const int y = cy + dy, z = cz + dz;
-        if (y < 0 || y >= M.dim[1] || z < 0 || z >= M.dim[2]) continue;
-        const bool face = max(abs(dy), abs(dz)) == r;
-        const int nparts = (face || r == 0) ? 1 : 2;
-        for (int part = 0; part < nparts; ++part) {
-          int x0 = face ? cx - r : (part == 0 ? cx - r : cx + r);
-          int x1 = face ? cx + r : x0;
-          x0 = max(x0, 0);
-          x1 = min(x1, M.dim[0] - 1);
-          if (x0 > x1) continue;
-          uint32_t b, e;
+      for (int dy0 = -r; dy0 <= r; dy0 += kRowChunk) {
+        // ---- the ranges of kRowChunk rows (two parts each off the faces), looked up TOGETHER: against a sparse target set
+        // a query visits ~200 rows of ~4 candidates, and a dependent table lookup per row is a round trip to L2 per row
+        uint32_t bb[2 * kRowChunk], ee[2 * kRowChunk];
+        // Exact pruning against the current k-th distance: a target in a row is at least (dyd, dzd) cells away in y and
+        // z, a target in cell x at least |x - cx| - 1 cells in x.  Rows and x-cells beyond the k-th distance are not
+        // looked up (1e-9 relative slack and one spare cell: the bound is rounded differently from the distances it is
+        // compared with; the k-th distance only shrinks while the chunk is scanned, so the test stays conservative).
+        const double wq = top.worst() / (M.h * M.h);
+        const int z = cz + dz;
+        const double dzd = dz > 0 ? (double)(cz + dz) - gz : (dz < 0 ? gz - (double)(cz + dz + 1) : 0.0);
+#pragma unroll
+        for (int u = 0; u < kRowChunk; ++u) {
+          const int dy = dy0 + u, y = cy + dy;
+          bb[2 * u] = ee[2 * u] = bb[2 * u + 1] = ee[2 * u + 1] = 0u;
+          if (dy > r || y < 0 || y >= M.dim[1] || z < 0 || z >= M.dim[2]) continue;
+          const bool face = max(abs(dy), abs(dz)) == r;
+          const int nparts = (face || r == 0) ? 1 : 2;
+          const double dyd = dy > 0 ? (double)(cy + dy) - gy : (dy < 0 ? gy - (double)(cy + dy + 1) : 0.0);
+          const double rem = wq - (dyd * dyd + dzd * dzd);
+          if (rem < -1e-9 * wq) continue;
+          const int xs = rem < 1e12 ? (int)sqrt(fmax(rem, 0.0)) + 2 : (1 << 20);
+          if (!face && r > xs) continue;
           const size_t row = (size_t)M.dim[0] * ((size_t)y + (size_t)M.dim[1] * (size_t)z);
-          {
+#pragma unroll
+          for (int part = 0; part < 2; ++part) {
+            if (part >= nparts) continue;
+            int x0 = face ? max(cx - r, cx - xs) : (part == 0 ? cx - r : cx + r);
+            int x1 = face ? min(cx + r, cx + xs) : x0;
+            x0 = max(x0, 0);
+            x1 = min(x1, M.dim[0] - 1);
+            if (x0 > x1) continue;
             if (M.cell_start) {  // the x-run of cells is one contiguous range of sorted targets
-              b = M.cell_start[row + x0];
-              e = M.cell_start[row + x1 + 1];
+              bb[2 * u + part] = M.cell_start[row + x0];
+              ee[2 * u + part] = M.cell_start[row + x1 + 1];
             } else {  // binary-search fallback
               const uint32_t base = ((uint32_t)y << 10) | ((uint32_t)z << 20);
-              b = lower_bound_u32(skeys, nt, base | (uint32_t)x0);
-              e = lower_bound_u32(skeys, nt, (base | (uint32_t)x1) + 1u);
+              bb[2 * u + part] = lower_bound_u32(skeys, nt, base | (uint32_t)x0);
+              ee[2 * u + part] = lower_bound_u32(skeys, nt, (base | (uint32_t)x1) + 1u);
             }
-            for (uint32_t i = b; i < e; ++i) {
-              const double *p = sfeat + (size_t)i * 6;
-              double s = 0.0;
+          }
+        }
 #pragma unroll
-              for (int d = 0; d < 6; ++d) {  // flann::L2_Simple: plain running sum of squared differences
-                const double df = f[d] - p[d];
-                s += df * df;
-              }
-              top.push(s, sorig[i]);
+        for (int sl = 0; sl < 2 * kRowChunk; ++sl) s_rng[sl][threadIdx.x] = make_uint2(bb[sl], ee[sl]);
+        // ---- ONE scan site for all ranges (the kernel stays small enough to keep the top-k in registers)
+        for (int sl = 0; sl < 2 * kRowChunk; ++sl) {
+          const uint2 be = s_rng[sl][threadIdx.x];
+          const uint32_t b = be.x, e = be.y;
+#ifdef WC_PROF_KNN
+          pc_ += e - b, pr_ += (e > b);
+#endif
+          // Candidates in groups of four: the centre parts of a group are requested together (one candidate per trip of a
+          // load - test - insert loop costs a full round trip to L2 each), then tested in order.  The running sum only
+          // grows: a candidate whose centre part already exceeds the current k-th distance cannot enter the list (ties
+          // are decided on the full sum, hence the strict test) - its normal part and its index are not loaded.
+          auto visit = [&](uint32_t i, double s) {
+            if (s > top.worst()) return;
+            const double *p = sfeat + (size_t)i * 6;
+#pragma unroll
+            for (int d = 3; d < 6; ++d) {  // flann::L2_Simple: plain running sum of squared differences
+              const double df = f[d] - p[d];
+              s += df * df;
             }
+            if (s > top.worst()) return;
+            top.push(s, sorig[i]);
+          };
+          uint32_t i = b;
+          for (; i + 4 <= e; i += 4) {
+            const double *p = sfeat + (size_t)i * 6;
+            double s4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const double d0 = f[0] - p[6 * u], d1 = f[1] - p[6 * u + 1], d2 = f[2] - p[6 * u + 2];
+              s4[u] = (0.0 + d0 * d0 + d1 * d1) + d2 * d2;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) visit(i + u, s4[u]);
+          }
+          for (; i < e; ++i) {
+            const double *p = sfeat + (size_t)i * 6;
+            const double d0 = f[0] - p[0], d1 = f[1] - p[1], d2 = f[2] - p[2];
+            visit(i, (0.0 + d0 * d0 + d1 * d1) + d2 * d2);
           }
         }
       }
@@ -250,6 +314,9 @@ __global__ void __launch_bounds__(128, 4) k_knn_gate(const wc_surfel *q_surf, co
     const double bound = r * M.h + in_cell;
     if (top.cnt == K && top.worst() < bound * bound) break;
   }
+#ifdef WC_PROF_KNN
+  atomicAdd(&g_knn_prof[0], pc_), atomicAdd(&g_knn_prof[1], pr_), atomicAdd(&g_knn_prof[2], ps_), atomicAdd(&g_knn_prof[3], 1ull);
+#endif
   // Q10: FLANN leaves the tail of the result untouched (zero-initialised) when fewer than k targets exist
   uint32_t out = 0;
 #pragma unroll
@@ -450,6 +517,15 @@ extern "C" int wc_match(wc_ctx *ctx, const wc_surfel *d_q_surf, const wc_pose *d
   WC_HIP(ctx, hipGetLastError());
   WC_HIP(ctx, hipMemcpyAsync(ctx->h_status, status, 8, hipMemcpyDeviceToHost, st));
   WC_HIP(ctx, hipStreamSynchronize(st));
+#ifdef WC_PROF_KNN
+  {
+    unsigned long long h[4], z[4] = {0, 0, 0, 0};
+    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_knn_prof), sizeof(h));
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_knn_prof), z, sizeof(z));
+    fprintf(stderr, "knn: %llu queries, per query %.1f candidates, %.1f rows, %.2f shells; cell h = %.4f, dims %d x %d x %d\n", h[3], (double)h[0] / h[3],
+            (double)h[1] / h[3], (double)h[2] / h[3], M.h, M.dim[0], M.dim[1], M.dim[2]);
+  }
+#endif
   *h_n_pairs = ctx->h_status[0];
   if (ctx->h_status[1] & 2u) return wc_fail(ctx, WC_ERR_ORDER, "fixed-window surfel newer than its sliding-window match");
   if (ctx->h_status[0] > cap) return wc_fail(ctx, WC_ERR_CAPACITY, "pair capacity %llu < %u", (unsigned long long)cap, ctx->h_status[0]);
