@@ -116,3 +116,61 @@ def test_update_surfel_poses(gpu, oracle):
     with pytest.raises(lib.WildcatError) as e:
         gpu.update_surfel_poses(gpu.to_device(imu[:5]), 5, d_s, d_p, d_b, n)
     assert e.value.code == 2
+
+
+def _random_surfels(rng, n, extent, t0=0.0):
+    s = np.zeros(n, R.SURFEL)
+    s["center"] = rng.uniform(-extent / 2, extent / 2, size=(n, 3))
+    nrm = rng.normal(size=(n, 3))
+    s["normal"] = nrm / np.linalg.norm(nrm, axis=1, keepdims=True)
+    s["t"] = t0 + np.sort(rng.uniform(0, 5, size=n))
+    p = np.zeros(n, R.POSE)
+    p["quat"][:, 0] = 1.0
+    return s, p
+
+
+def _feat(s):
+    return np.concatenate([s["center"] / 1.0, s["normal"] / (5.0 * np.pi / 180.0)], 1)
+
+
+def test_sparse_wide_extent_uses_binary_search_fallback(gpu, oracle):
+    """3 000 surfels in a 600 m cube: 600^3 one-unit cells do not fit the dense cell table (<= 2^24 cells), the kernel
+    falls back to binary searches on the sorted cell keys, and a query needs many shells; k-NN table and pairs exact"""
+    rng = np.random.default_rng(77)
+    s, p = _random_surfels(rng, 3000, 600.0)
+    pairs, idx, d2 = gpu.match(s, p, s, p, True, want_knn=True)
+    ridx, rd2 = oracle.knn6(_feat(s), _feat(s), 10)
+    assert np.array_equal(idx.astype(np.int64), ridx.astype(np.int64)) and np.array_equal(d2, rd2)
+    assert np.array_equal(pairs, oracle.match(s, p, s, p, True))
+
+
+def test_queries_outside_the_target_box_and_pruned_shells(gpu, oracle):
+    """targets in a 20 m cube, queries in a 60 m cube around it (most of them outside the grid: unclamped query cells,
+    row / cell pruning against the k-th distance with the query far from every cell)"""
+    rng = np.random.default_rng(78)
+    t, tp = _random_surfels(rng, 2500, 20.0)
+    q, qp = _random_surfels(rng, 800, 60.0, t0=10.0)
+    pairs, idx, d2 = gpu.match(q, qp, t, tp, False, want_knn=True)
+    ridx, rd2 = oracle.knn6(_feat(t), _feat(q), 10)
+    assert np.array_equal(idx.astype(np.int64), ridx.astype(np.int64)) and np.array_equal(d2, rd2)
+    assert np.array_equal(pairs, oracle.match(q, qp, t, tp, False))
+
+
+@pytest.mark.parametrize("k", [1, 3, 16])
+def test_other_neighbour_counts(gpu, oracle, k):
+    """knn_k is a parameter (the reference hard-codes 10, knn_surfel_matcher.h:17): every instantiation of the top-k kernel"""
+    params = oracle.default_params()
+    params.knn_k = k
+    gpu.set_params(params)
+    try:
+        w = synth.surfel_window(3, 200, seed=21, fixed_patches=100)
+        _, idx, d2 = gpu.match(w["surf"], w["pose"], w["surf"], w["pose"], True, want_knn=True)
+        ref = oracle.match(w["surf"], w["pose"], w["surf"], w["pose"], True, params)
+        got = gpu.match(w["surf"], w["pose"], w["surf"], w["pose"], True)
+        assert np.array_equal(got, ref)
+        ref = oracle.match(w["surf"], w["pose"], w["fix_surf"], w["fix_pose"], False, params)
+        got = gpu.match(w["surf"], w["pose"], w["fix_surf"], w["fix_pose"], False)
+        assert np.array_equal(got, ref)
+        assert idx.shape == (len(w["surf"]), k) and (np.diff(d2, axis=1) >= 0).all()
+    finally:
+        gpu.set_params(oracle.default_params())
