@@ -124,7 +124,9 @@ int wc_match(wc_ctx *ctx, const wc_surfel *d_q_surf, const wc_pose *d_q_pose, ui
  *   BuildImuResiduals         (cc:319-363) — h_imu: the window's IMU states (host; a few thousand records),
  * with SampleState timestamps h_sample_times[ns] (ascending), gravity of the last sample state and the
  * SubsetParameterization gauge flag (cc:556-560).  Surfels must already carry poses (wc_update_surfel_poses).
- * The packed per-correspondence records are built once here; the calls below reuse them. */
+ * The packed per-correspondence records are built once here; the calls below reuse them.
+ * 2 <= ns <= 340 (dense normal equations of 12 ns unknowns; the reference's default 6.5 s window has 82 sample states),
+ * otherwise WC_ERR_ARG. */
 int wc_window_build(wc_ctx *ctx, const wc_surfel *d_sld_surf, const wc_pose *d_sld_pose, const wc_pair *d_pairs_sld,
                     uint64_t n_pairs_sld, const wc_surfel *d_fix_surf, const wc_pose *d_fix_pose, const wc_pair *d_pairs_fix,
                     uint64_t n_pairs_fix, const wc_imu_state *h_imu, uint64_t n_imu, const double *h_sample_times, uint64_t ns,

@@ -86,7 +86,7 @@ struct wc_window_state {
   uint32_t nheavy = 0;  // lin = [H (n*n) | g (np) | cost, spare]: ONE contiguous buffer, the unit of the multi-GPU all-reduce
   int (*allreduce)(void *, double *, uint64_t) = nullptr;
   void *allreduce_user = nullptr;
-  wc_buf x, xc, H_unused, g_unused, scale, diag, A, y, mail, cost_part, keys_tmp[2], vals_tmp[2], heads, status;
+  wc_buf x, xc, scale, diag, A, y, mail, cost_part, keys_tmp[2], vals_tmp[2], heads, status;
   bool built = false;
 };
 
@@ -1454,7 +1454,7 @@ extern "C" int wc_window_build(wc_ctx *ctx, const wc_surfel *d_sld_surf, const w
                                uint64_t n_pairs_sld, const wc_surfel *d_fix_surf, const wc_pose *d_fix_pose,
                                const wc_pair *d_pairs_fix, uint64_t n_pairs_fix, const wc_imu_state *h_imu, uint64_t n_imu,
                                const double *h_sample_times, uint64_t ns_, const double *h_grav, int fix_first_pos) {
-  if (!ctx || !h_sample_times || ns_ < 2 || ns_ > 340 || !h_grav) return WC_ERR_ARG;  // 12*ns <= 4096 (k_chol_back LDS)
+  if (!ctx || !h_sample_times || ns_ < 2 || ns_ > 340 || !h_grav) return WC_ERR_ARG;  // 12 ns <= 4096 unknowns: dense H (134 MB), the largest window the solve has been exercised on; the reference's default window has 82 sample states
   if (n_pairs_sld >= (1ull << 31) || n_pairs_fix >= (1ull << 31)) return WC_ERR_ARG;
   WC_HIP(ctx, hipSetDevice(ctx->device));
   if (!ctx->win) ctx->win = new wc_window_state;
