@@ -275,31 +275,37 @@ __device__ void eval_imu(const WinParams &wp, const ImuRec &f, const double *x, 
   res[0] = r0.x, res[1] = r0.y, res[2] = r0.z, res[3] = r1.x, res[4] = r1.y, res[5] = r1.z;
   res[6] = r2.x, res[7] = r2.y, res[8] = r2.z, res[9] = r3.x, res[10] = r3.y, res[11] = r3.z;
   if (!rows) return;
-  for (int r = 0; r < 12; ++r)
-    for (int c = 0; c < 36; ++c) rows[r * stride + c] = 0.0;
-  // tau Jacobians (cost_functor.h:301-321) scattered with (1 - f), f onto the bracketing blocks (:402-444)
-  auto add33 = [&](const StateCorr &c, int r0_, int c0_, const M3 &m, double s) {
+  // tau Jacobians (cost_functor.h:301-321) scattered with (1 - f), f onto the bracketing blocks (:402-444).  The caller has
+  // zeroed the rows; every 3x3 group is summed in registers over the states that contribute to it (in the reference's
+  // order: state 1, 2, 3) and stored once per block - a read-modify-write per contribution on LDS rows serialises ~230
+  // dependent round trips per factor.
+  double w1[3], w2[3], w3[3];
+  for (int b = 0; b < 3; ++b) {
+    w1[b] = c1.bl == b ? 1 - c1.f : (c1.bl + 1 == b ? c1.f : 0.0);
+    w2[b] = c2.bl == b ? 1 - c2.f : (c2.bl + 1 == b ? c2.f : 0.0);
+    w3[b] = c3.bl == b ? 1 - c3.f : (c3.bl + 1 == b ? c3.f : 0.0);
+  }
+  auto group = [&](int r0_, int c0_, const M3 &ma, double sa, const M3 *mb, double sb, const M3 *mc, double sc_) {
     for (int i = 0; i < 3; ++i)
       for (int j = 0; j < 3; ++j) {
-        const double val = s * m.m[i][j];
-        rows[(r0_ + i) * stride + c.bl * 12 + c0_ + j] += val * (1 - c.f);
-        rows[(r0_ + i) * stride + (c.bl + 1) * 12 + c0_ + j] += val * c.f;
+        const double va = sa * ma.m[i][j], vb = mb ? sb * mb->m[i][j] : 0.0, vc = mc ? sc_ * mc->m[i][j] : 0.0;
+        for (int b = 0; b < 3; ++b) {
+          double acc = va * w1[b];
+          if (mb) acc += vb * w2[b];
+          if (mc) acc += vc * w3[b];
+          rows[(r0_ + i) * stride + b * 12 + c0_ + j] = acc;
+        }
       }
   };
   const M3 I = m3_identity();
-  add33(c1, 0, 0, Ffun(qconj(R1), E2R2, c1.r), wp.w_gyr * (1 / dt));
-  add33(c1, 0, 6, I, -wp.w_gyr);
-  add33(c1, 3, 0, (qmat(so3_exp(c1.r)) * hat(qrot(R1, ld3(f.i1.acc) - c1.ba))) * so3_Jr(c1.r), -wp.w_acc);
-  add33(c1, 3, 3, I, -wp.w_acc * (1 / dt / dt));
-  add33(c1, 3, 9, qmat(E1R1), -wp.w_acc);
-  add33(c1, 6, 6, I, wp.w_bg);
-  add33(c1, 9, 9, I, wp.w_ba);
-  add33(c2, 0, 0, Ffun(qconj(E1R1), R2, c2.r), -wp.w_gyr * (1 / dt));
-  if (wp.quirks) add33(c2, 0, 6, I, -wp.w_gyr);  // Q3 (cost_functor.h:314)
-  add33(c2, 3, 3, I, wp.w_acc * (2 / dt / dt));
-  add33(c2, 6, 6, I, -wp.w_bg);
-  add33(c2, 9, 9, I, -wp.w_ba);
-  add33(c3, 3, 3, I, -wp.w_acc * (1 / dt / dt));
+  const M3 F1 = Ffun(qconj(R1), E2R2, c1.r), F2 = Ffun(qconj(E1R1), R2, c2.r);
+  group(0, 0, F1, wp.w_gyr * (1 / dt), &F2, -wp.w_gyr * (1 / dt), nullptr, 0.0);
+  group(0, 6, I, -wp.w_gyr, wp.quirks ? &I : nullptr, -wp.w_gyr, nullptr, 0.0);  // Q3 (cost_functor.h:314)
+  group(3, 0, (qmat(so3_exp(c1.r)) * hat(qrot(R1, ld3(f.i1.acc) - c1.ba))) * so3_Jr(c1.r), -wp.w_acc, nullptr, 0.0, nullptr, 0.0);
+  group(3, 3, I, -wp.w_acc * (1 / dt / dt), &I, wp.w_acc * (2 / dt / dt), &I, -wp.w_acc * (1 / dt / dt));
+  group(3, 9, qmat(E1R1), -wp.w_acc, nullptr, 0.0, nullptr, 0.0);
+  group(6, 6, I, wp.w_bg, &I, -wp.w_bg, nullptr, 0.0);
+  group(9, 9, I, wp.w_ba, &I, -wp.w_ba, nullptr, 0.0);
 }
 
 __device__ __forceinline__ uint32_t tri_index(uint32_t i, uint32_t j, uint32_t T) {  // i <= j, row-major upper
@@ -545,6 +551,8 @@ __global__ void __launch_bounds__(256) k_lin_imu(WinParams wp, const Piece *piec
   __shared__ double sC[kImuMax];
   const Piece pc = pieces[blockIdx.x];
   const int tid = threadIdx.x;
+  for (int e = tid; e < (int)pc.count * 12 * T; e += 256) sV[e] = 0.0;  // eval_imu stores the non-zero 3x3 groups only
+  __syncthreads();
   if (tid < (int)pc.count) {
     double res[12];
     eval_imu(wp, recs[pc.begin + tid], x, times, res, &sV[tid * 12 * T], T);
