@@ -188,10 +188,30 @@ def main():
     achieved = algo_bytes / (dom_ms * 1e-3) / 1e9
     kernel_names = {"init": "k_init", "point_sort": "k_pt_runs + k_pt_bucket", "roots_stream": "k_roots<unsigned int, 1, true>",
                     "roots_emit": "k_roots_emit<unsigned int, true>", "slot_order": "k_slot_emit"}
+    # measured ceiling of this device: a 1 GiB device-to-device copy, bytes read + written per second
+    copy_gbs = None
+    try:
+        src = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
+        dst = torch.empty_like(src)
+        for _ in range(3):
+            dst.copy_(src)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            dst.copy_(src)
+        e1.record()
+        torch.cuda.synchronize()
+        copy_gbs = 2.0 * (1 << 30) * 10 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        del src, dst
+    except Exception:
+        copy_gbs = None
+    args._copy_gbs = copy_gbs
     roofline = {"bound": "hbm", "kernel": kernel_names[dom], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(kernel_names[dom]), "algorithmic_bytes_per_launch": algo_bytes,
                 "avg_kernel_ms": round(dom_ms, 5),
-                "whole_pipeline_frac": round(algo_bytes / (sum(stages.values()) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
+                "whole_pipeline_frac": round(algo_bytes / (sum(stages.values()) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                "measured_copy_GBs": round(copy_gbs, 1) if copy_gbs else None,
+                "frac_of_measured_copy": round(achieved / copy_gbs, 5) if copy_gbs else None}
 
     result = {
         "metric": "surfel-extract Mpts/s",
@@ -331,7 +351,8 @@ def bench_window(ctx, args, world, rank, dev, torch, dist, cpu=False):
         "cost": [summ.initial_cost, summ.final_cost], "termination": summ.termination,
         "linearize_ms": round(lin_ms, 4), "assembly_corr_per_s": round(world * (nb + nu) / (lin_ms * 1e-3), 1),
         "assembly_roofline": {"bound": "hbm", "achieved": round(algo / (lin_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                              "frac": round(algo / (lin_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "algorithmic_bytes_per_linearisation": algo},
+                              "frac": round(algo / (lin_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "algorithmic_bytes_per_linearisation": algo,
+                              "frac_of_measured_copy": round(algo / (lin_ms * 1e-3) / 1e9 / args._copy_gbs, 5) if getattr(args, "_copy_gbs", None) else None},
         "build_ms": round(t_build * 1e3, 3), "match_s": round(t_match, 4), "match_surfels_per_s": round(2 * n_s / t_match, 1), "generate_s": round(t_gen, 2),
     }
     if cpu:
