@@ -33,6 +33,7 @@
 namespace {
 
 constexpr int kMom = 11;    // n, St, Sx, Sy, Sz, Sxx, Sxy, Sxz, Syy, Syz, Szz
+constexpr int kProdStride = 66;  // row stride (doubles) of k_roots' moment-major staging table: even (16-byte rows), not a multiple of 16
 constexpr unsigned kRootsGrid = 256 * 16;  // wavefronts of the layer-0/1 pass (one root each from the dense work list; all resident)
 constexpr unsigned kEmitGrid = 256 * 8;   // wavefronts of the node-test + emission pass (three roots at a time each)
 constexpr unsigned kRoots2Grid = 256 * 4;  // wavefronts of the (rare) layer-2 pass
@@ -359,7 +360,12 @@ __global__ void __launch_bounds__(64) k_roots(RootsArgs A, const K *__restrict__
   __shared__ double s_last[ntab];
   __shared__ int s_cnt[ntab];
   __shared__ uint32_t s_ord[ntab];
-  __shared__ double s_prod[64 * kMom];  // the 11 moment terms {1, t, x, y, z, xx, xy, xz, yy, yz, zz} of every staged point
+  // the 11 moment terms {1, t, x, y, z, xx, xy, xz, yy, yz, zz} of every staged point, MOMENT-major (row m = term m of the 64
+  // points, kProdStride doubles apart): the lane of term m reads two consecutive points with one 16-byte LDS read (an LDS
+  // read costs ~3.3 clk per wavefront whatever its width, profiles/micro/lds.hip).  Measured: half the read instructions
+  // do not shorten the sequential pass (87 clk per point with 15 wavefronts per CU streaming) - it is bound by issuing
+  // two dependent fp64 additions per point and wavefront, which only two roots per wavefront would halve.
+  __shared__ __attribute__((aligned(16))) double s_prod[kMom * kProdStride];
   __shared__ uint32_t s_code[64];
 
   const int lane = threadIdx.x;
@@ -483,9 +489,10 @@ __global__ void __launch_bounds__(64) k_roots(RootsArgs A, const K *__restrict__
         const int o2 = 4 * (px > c1x) + 2 * (py > c1y) + (pz > c1z);
         // the moment terms are formed here, lane-parallel: the sequential pass below is bound by LDS reads (15 wavefronts
         // per CU stream at once), and one 8-byte read per (point, moment) is half of what two factors would cost
-        double *pr = s_prod + lane * kMom;
-        pr[0] = 1.0, pr[1] = pt, pr[2] = px, pr[3] = py, pr[4] = pz;
-        pr[5] = px * px, pr[6] = px * py, pr[7] = px * pz, pr[8] = py * py, pr[9] = py * pz, pr[10] = pz * pz;
+        double *pr = s_prod + lane;
+        pr[0] = 1.0, pr[kProdStride] = pt, pr[2 * kProdStride] = px, pr[3 * kProdStride] = py, pr[4 * kProdStride] = pz;
+        pr[5 * kProdStride] = px * px, pr[6 * kProdStride] = px * py, pr[7 * kProdStride] = px * pz, pr[8 * kProdStride] = py * py,
+                         pr[9 * kProdStride] = py * pz, pr[10 * kProdStride] = pz * pz;
         s_code[lane] = (uint32_t)(o1 * 8 + o2);
         my_o1 = o1;
       }
@@ -527,24 +534,34 @@ __global__ void __launch_bounds__(64) k_roots(RootsArgs A, const K *__restrict__
         if (je > j) {  // event-free segment: every active lane keeps accumulating into its cached node
           if (act) {
             double ao = a_open, at = a_total;
-#pragma unroll 4
-            for (int q = j; q < je; ++q) {
-              const double v = s_prod[q * kMom + m];
-              ao += v;
-              at += v;
+            const double *sp = s_prod + m * kProdStride;
+            int q = j;
+            if (q & 1) {  // (16-byte reads start at even points)
+              const double v = sp[q++];
+              ao += v, at += v;
+            }
+#pragma unroll 2
+            for (; q + 2 <= je; q += 2) {
+              const double2 v = *(const double2 *)(sp + q);
+              ao += v.x, at += v.x;
+              ao += v.y, at += v.y;
+            }
+            if (q < je) {
+              const double v = sp[q];
+              ao += v, at += v;
             }
             a_open = ao;
             a_total = at;
             n_open += je - j;
-            last = s_prod[(je - 1) * kMom + 1];
+            last = s_prod[kProdStride + (je - 1)];
           }
           j = je;
           if (j >= nvalid) break;
         }
         // ---- event point: full logic ----
         const uint32_t code = s_code[j];
-        const double t = s_prod[j * kMom + 1];
-        const double v_ev = s_prod[j * kMom + m];
+        const double t = s_prod[kProdStride + j];
+        const double v_ev = s_prod[m * kProdStride + j];
         ++j;
         if (phase == 2 && !((split1 >> (code >> 3)) & 1ull)) continue;  // parent layer-1 node is not split
         const int nu = (phase == 2) ? (int)code : (Lq == 0 ? 0 : 1 + (int)(code >> 3));
