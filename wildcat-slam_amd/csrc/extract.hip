@@ -378,11 +378,17 @@ __global__ void __launch_bounds__(64) k_roots(RootsArgs A, const K *__restrict__
   // bucket are simply missing - and the host reruns the general path; a check would put one more dependent load in
   // front of every wavefront)
 
-  // lane roles while streaming: lane = (level, moment)
-  const int Lq = lane / kMom;      // 0,1 used in phase 1; phase 2 uses lanes 0..10 only
-  const int m = lane - Lq * kMom;
-  const int nlev = (phase == 1) ? (P.max_layer >= 1 ? 2 : 1) : 1;
-  const bool act = lane < nlev * kMom;
+  // lane roles while streaming: lane = (copy, level, moment).  Copy 0 accumulates the OPEN cluster of its node, copy 1 the
+  // node TOTAL: the two sums see the same terms but restart at different times, and as two additions per lane and point
+  // they were what the sequential pass issued (it is bound by exactly that); side by side they are one addition.
+  // Everything else (current node, open count, last time stamp) is mirrored by both copies.
+  const int nlev = (phase == 1) ? (P.max_layer >= 1 ? 2 : 1) : 1;  // levels: 0,1 in phase 1; phase 2 streams one level
+  const int lgrp = nlev * kMom;
+  const bool is_tot = lane >= lgrp && lane < 2 * lgrp;
+  const int lane2 = is_tot ? lane - lgrp : lane;
+  const int Lq = lane2 / kMom;
+  const int m = lane2 - Lq * kMom;
+  const bool act = lane < 2 * lgrp;
 
   double x0, y0, z0;
   load_xyz(A.pts, 0, x0, y0, z0);
@@ -460,7 +466,7 @@ __global__ void __launch_bounds__(64) k_roots(RootsArgs A, const K *__restrict__
 
     // register-cached accumulators of the node this lane is currently feeding
     int cur = -1, n_open = 0;
-    double a_open = 0.0, a_total = 0.0, last = 0.0;
+    double a_acc = 0.0, last = 0.0;  // this lane's sum: the open cluster (copy 0) or the node total (copy 1)
 
     // ---- software-pipelined chunk loop: the next 64 points are in flight while the current ones stream ----
     uint32_t pp = lane;  // position inside the root
@@ -533,25 +539,22 @@ __global__ void __launch_bounds__(64) k_roots(RootsArgs A, const K *__restrict__
         const int je = rem ? j + (__ffsll((long long)rem) - 1) : nvalid;  // next event (or end of chunk)
         if (je > j) {  // event-free segment: every active lane keeps accumulating into its cached node
           if (act) {
-            double ao = a_open, at = a_total;
+            double ao = a_acc;
             const double *sp = s_prod + m * kProdStride;
             int q = j;
-            if (q & 1) {  // (16-byte reads start at even points)
-              const double v = sp[q++];
-              ao += v, at += v;
+            if (q & 1) ao += sp[q++];  // (16-byte reads start at even points)
+            for (; q + 8 <= je; q += 8) {  // (all four reads first, then the eight dependent additions)
+              const double2 v0 = *(const double2 *)(sp + q), v1 = *(const double2 *)(sp + q + 2), v2 = *(const double2 *)(sp + q + 4),
+                            v3 = *(const double2 *)(sp + q + 6);
+              ao += v0.x, ao += v0.y, ao += v1.x, ao += v1.y, ao += v2.x, ao += v2.y, ao += v3.x, ao += v3.y;
             }
-#pragma unroll 2
             for (; q + 2 <= je; q += 2) {
               const double2 v = *(const double2 *)(sp + q);
-              ao += v.x, at += v.x;
-              ao += v.y, at += v.y;
+              ao += v.x;
+              ao += v.y;
             }
-            if (q < je) {
-              const double v = sp[q];
-              ao += v, at += v;
-            }
-            a_open = ao;
-            a_total = at;
+            if (q < je) ao += sp[q];
+            a_acc = ao;
             n_open += je - j;
             last = s_prod[kProdStride + (je - 1)];
           }
@@ -566,16 +569,15 @@ __global__ void __launch_bounds__(64) k_roots(RootsArgs A, const K *__restrict__
         if (phase == 2 && !((split1 >> (code >> 3)) & 1ull)) continue;  // parent layer-1 node is not split
         const int nu = (phase == 2) ? (int)code : (Lq == 0 ? 0 : 1 + (int)(code >> 3));
         if (act && nu != cur) {  // switch node: write the cached accumulators back, fetch the new node's
+          double *tab = is_tot ? s_total : s_open;
           if (cur >= 0) {
-            s_open[cur * kMom + m] = a_open;
-            s_total[cur * kMom + m] = a_total;
-            if (m == 0) {
+            tab[cur * kMom + m] = a_acc;
+            if (m == 0 && !is_tot) {
               s_last[cur] = last;
               s_cnt[cur] = n_open;
             }
           }
-          a_open = s_open[nu * kMom + m];
-          a_total = s_total[nu * kMom + m];
+          a_acc = tab[nu * kMom + m];
           last = s_last[nu];
           n_open = s_cnt[nu];
           cur = nu;
@@ -591,8 +593,8 @@ __global__ void __launch_bounds__(64) k_roots(RootsArgs A, const K *__restrict__
             if (cnt_l >= P.cluster_min) {  // clusters with fewer points are dropped (cc:33)
               const uint64_t slot = slot_base + ncand;
               if (slot < A.total_slots) {
-                if (mine) {
-                  A.cand[slot * kMom + m] = a_open;
+                if (mine && !is_tot) {
+                  A.cand[slot * kMom + m] = a_acc;
                   if (m == 0) A.cand_meta[slot] = (uint32_t)nu | ((uint32_t)(phase - 1) << 7) | (s_ord[nu] << 8);
                 }
               } else if (lane == 0) {
@@ -601,16 +603,14 @@ __global__ void __launch_bounds__(64) k_roots(RootsArgs A, const K *__restrict__
               ++ncand;
             }
             if (mine) {
-              a_open = 0.0;
+              if (!is_tot) a_acc = 0.0;
               n_open = 0;
-              if (m == 0) s_ord[nu] += 1;
+              if (m == 0 && !is_tot) s_ord[nu] += 1;
             }
           }
         }
         if (act) {
-          const double v = v_ev;
-          a_open += v;
-          a_total += v;
+          a_acc += v_ev;
           n_open += 1;
           last = t;
         }
@@ -621,9 +621,8 @@ __global__ void __launch_bounds__(64) k_roots(RootsArgs A, const K *__restrict__
     }
     // write the cached node back
     if (act && cur >= 0) {
-      s_open[cur * kMom + m] = a_open;
-      s_total[cur * kMom + m] = a_total;
-      if (m == 0) {
+      (is_tot ? s_total : s_open)[cur * kMom + m] = a_acc;
+      if (m == 0 && !is_tot) {
         s_last[cur] = last;
         s_cnt[cur] = n_open;
       }
