@@ -746,19 +746,27 @@ __global__ void __launch_bounds__(144 * kGG) k_gather(GatherArgs a) {
 }
 
 // ---- cost-only evaluation (candidate step; problem.Evaluate) ----------------------------------------------------------
-template <bool UNARY>
-__global__ void __launch_bounds__(256) k_eval_surfel(WinParams wp, const double *rec, const uint32_t *keys, const uint32_t *orig,
-                                                    uint32_t n, const double *x, double *residuals, double *block_cost) {
+// binary factors (workgroups 0 .. gb-1) and unary factors (the rest) in ONE launch: two launches of these short kernels
+// cost a kernel boundary and the tail of the first
+struct EvalArgs {
+  const double *rec;
+  const uint32_t *keys, *orig;
+  uint32_t n;
+  double *residuals;
+};
+__global__ void __launch_bounds__(256) k_eval_surfel(WinParams wp, EvalArgs B, EvalArgs U, uint32_t gb, const double *x, double *block_cost) {
   __shared__ double s[256];
-  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool unary = blockIdx.x >= gb;
+  const EvalArgs &E = unary ? U : B;
+  const uint32_t k = (blockIdx.x - (unary ? gb : 0u)) * blockDim.x + threadIdx.x;
   double c = 0.0;
-  if (k < n) {
+  if (k < E.n) {
     double r;
-    if (UNARY)
-      eval_unary(wp, rec, n, k, keys[k], x, r, c, nullptr);
+    if (unary)
+      eval_unary(wp, E.rec, E.n, k, E.keys[k], x, r, c, nullptr);
     else
-      eval_binary(wp, rec, n, k, keys[k], x, r, c, nullptr);
-    if (residuals) residuals[orig[k]] = r;
+      eval_binary(wp, E.rec, E.n, k, E.keys[k], x, r, c, nullptr);
+    if (E.residuals) E.residuals[E.orig[k]] = r;
   }
   s[threadIdx.x] = c;
   __syncthreads();
@@ -1694,12 +1702,12 @@ int enqueue_evaluate(wc_ctx *ctx, wc_window_state *W, const double *d_x, double 
   hipStream_t st = ctx->stream;
   double *cp = (double *)W->cost_part.p;
   const uint32_t gb = (W->nb + 255) / 256, gu = (W->nu + 255) / 256, gi = (W->ni + 255) / 256;
-  if (gb)
-    k_eval_surfel<false><<<gb, 256, 0, st>>>(W->wp, (const double *)W->brec.p, (const uint32_t *)W->bkey.p, (const uint32_t *)W->borig.p,
-                                            W->nb, d_x, d_res, cp);
-  if (gu)
-    k_eval_surfel<true><<<gu, 256, 0, st>>>(W->wp, (const double *)W->urec.p, (const uint32_t *)W->ukey.p, (const uint32_t *)W->uorig.p,
-                                           W->nu, d_x, d_res ? d_res + W->nb : nullptr, cp + gb);
+  if (gb + gu) {
+    const EvalArgs B{(const double *)W->brec.p, (const uint32_t *)W->bkey.p, (const uint32_t *)W->borig.p, W->nb, d_res};
+    const EvalArgs U{(const double *)W->urec.p, (const uint32_t *)W->ukey.p, (const uint32_t *)W->uorig.p, W->nu,
+                     d_res ? d_res + W->nb : nullptr};
+    k_eval_surfel<<<gb + gu, 256, 0, st>>>(W->wp, B, U, gb, d_x, cp);
+  }
   if (gi)
     k_eval_imu<<<gi, 256, 0, st>>>(W->wp, (const ImuRec *)W->irec.p, W->ni, d_x, (const double *)W->times_d.p,
                                   d_res ? d_res + W->nb + W->nu : nullptr, cp + gb + gu);
