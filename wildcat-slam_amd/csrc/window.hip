@@ -82,7 +82,7 @@ struct wc_window_state {
   std::vector<double> times;
   // device buffers
   wc_buf times_d, brec, bkey, borig, urec, ukey, uorig, irec, pieces, partial, src, src_begin, gsrc, gsrc_begin;
-  wc_buf lin, Linv, heavy, Lmat;
+  wc_buf lin, Linv, heavy, Lmat, reduce;
   uint32_t nheavy = 0;  // lin = [H (n*n) | g (np) | cost, spare]: ONE contiguous buffer, the unit of the multi-GPU all-reduce
   int (*allreduce)(void *, double *, uint64_t) = nullptr;
   void *allreduce_user = nullptr;
@@ -605,6 +605,7 @@ struct GatherArgs {
   double *H, *g, *cost;
   uint32_t nheavy, npairs, npieces, nb_pieces, nu_pieces;
   int ns, fix_first;
+  int packed;  // H = block pairs in pair order, 144 doubles each (the multi-GPU reduction buffer); else the dense n x n matrix
 };
 
 template <int STRIDE>
@@ -675,8 +676,12 @@ __global__ void __launch_bounds__(144 * kGG) k_gather(GatherArgs a) {
     const int n = 12 * ns;
     const int gi = I * 12 + u, gj = J * 12 + v;
     if (a.fix_first && ((gi >= 3 && gi < 6) || (gj >= 3 && gj < 6))) acc = 0.0;  // SubsetParameterization(12,{3,4,5})
-    a.H[(size_t)gi * n + gj] = acc;
-    a.H[(size_t)gj * n + gi] = acc;
+    if (a.packed) {
+      a.H[(size_t)pid * 144 + e] = acc;
+    } else {
+      a.H[(size_t)gi * n + gj] = acc;
+      a.H[(size_t)gj * n + gi] = acc;
+    }
     return;
   }
   blk -= a.nheavy + nlight;
@@ -743,6 +748,27 @@ __global__ void __launch_bounds__(144 * kGG) k_gather(GatherArgs a) {
       a.cost[0] = t;
     }
   }
+}
+
+// multi-GPU: the reduced block pairs (pair order, 144 doubles each) -> both triangles of the dense matrix; g and the cost
+// follow the pairs in the reduction buffer and are copied behind H
+__global__ void __launch_bounds__(144) k_expand_pairs(const double *packed, uint32_t npairs, int ns, int np, double *H, double *g) {
+  const uint32_t pid = blockIdx.x;
+  const int e = threadIdx.x;
+  if (pid == npairs) {  // tail: g (np doubles) + cost, spare
+    for (int i = e; i < np + 2; i += 144) g[i] = packed[(size_t)npairs * 144 + i];
+    return;
+  }
+  const float f = 2.f * ns + 1.f;
+  int I = (int)((f - sqrtf(fmaxf(f * f - 8.f * (float)pid, 0.f))) * 0.5f);
+  I = max(0, min(I, ns - 1));
+  while (I > 0 && (uint32_t)(I * ns - I * (I - 1) / 2) > pid) --I;
+  while ((uint32_t)((I + 1) * ns - (I + 1) * I / 2) <= pid) ++I;
+  const int J = I + (int)(pid - (uint32_t)(I * ns - I * (I - 1) / 2));
+  const int n = 12 * ns, gi = I * 12 + e / 12, gj = J * 12 + e % 12;
+  const double v = packed[(size_t)pid * 144 + e];
+  H[(size_t)gi * n + gj] = v;
+  H[(size_t)gj * n + gi] = v;
 }
 
 // ---- cost-only evaluation (candidate step; problem.Evaluate) ----------------------------------------------------------
@@ -1418,7 +1444,7 @@ void wc_window_free(wc_ctx *ctx) {
   wc_window_state *W = ctx->win;
   if (!W) return;
   wc_buf *all[] = {&W->times_d, &W->brec, &W->bkey, &W->borig, &W->urec, &W->ukey, &W->uorig, &W->irec, &W->pieces, &W->partial,
-                   &W->src, &W->src_begin, &W->gsrc, &W->gsrc_begin, &W->x, &W->xc, &W->lin, &W->Linv, &W->heavy, &W->Lmat, &W->scale, &W->diag, &W->A, &W->y,
+                   &W->src, &W->src_begin, &W->gsrc, &W->gsrc_begin, &W->x, &W->xc, &W->lin, &W->Linv, &W->heavy, &W->Lmat, &W->reduce, &W->scale, &W->diag, &W->A, &W->y,
                    &W->mail, &W->cost_part, &W->keys_tmp[0], &W->keys_tmp[1], &W->vals_tmp[0], &W->vals_tmp[1], &W->heads, &W->status};
   for (wc_buf *b : all)
     if (b->p) (void)hipFree(b->p);
@@ -1641,7 +1667,6 @@ namespace {
 inline double *lin_H(wc_window_state *W) { return (double *)W->lin.p; }
 inline double *lin_g(wc_window_state *W) { return (double *)W->lin.p + (size_t)W->n * W->n; }
 inline double *lin_cost(wc_window_state *W) { return lin_g(W) + W->np; }
-inline size_t lin_count(wc_window_state *W) { return (size_t)W->n * W->n + W->np + 2; }
 
 __global__ void __launch_bounds__(1024) k_post_reduce(const double *g, const double *cost, int n, double *mail, int slot) {
   __shared__ double s[1024];
@@ -1686,12 +1711,27 @@ int enqueue_linearize(wc_ctx *ctx, wc_window_state *W, const double *d_x, int ma
   ga.src = (const Src *)W->src.p, ga.src_begin = (const uint32_t *)W->src_begin.p;
   ga.gsrc = (const GSrc *)W->gsrc.p, ga.gsrc_begin = (const uint32_t *)W->gsrc_begin.p;
   ga.pieces = pcs, ga.heavy = (const uint32_t *)W->heavy.p, ga.partial = partial;
-  ga.H = lin_H(W), ga.g = lin_g(W), ga.cost = lin_cost(W);
+  // multi-GPU: the ranks reduce the upper block triangle only (pair order, 144 doubles per block pair, then g and the cost):
+  // half the bytes of the dense matrix on the wire; one more kernel spreads the sum into both triangles
+  const bool packed = W->allreduce != nullptr;
+  double *red = nullptr;
+  const size_t red_count = (size_t)W->npairs * 144 + W->np + 2;
+  if (packed) {
+    WC_TRY(wc_ensure(ctx, W->reduce, red_count * 8));
+    red = (double *)W->reduce.p;
+  }
+  ga.H = packed ? red : lin_H(W);
+  ga.g = packed ? red + (size_t)W->npairs * 144 : lin_g(W);
+  ga.cost = ga.g + W->np;
+  ga.packed = packed ? 1 : 0;
   ga.nheavy = W->nheavy, ga.npairs = W->npairs, ga.npieces = W->npiece_b + W->npiece_u + W->npiece_i;
   ga.nb_pieces = W->npiece_b, ga.nu_pieces = W->npiece_u, ga.ns = W->ns, ga.fix_first = W->wp.fix_first;
   k_gather<<<W->nheavy + (W->npairs + kGG - 1) / kGG + W->ns + 1, 144 * kGG, 0, st>>>(ga);
   WC_HIP(ctx, hipGetLastError());
-  WC_TRY(do_allreduce(ctx, W, lin_H(W), lin_count(W)));  // the ONE collective of a linearisation
+  if (packed) {
+    WC_TRY(do_allreduce(ctx, W, red, red_count));  // the ONE collective of a linearisation
+    k_expand_pairs<<<W->npairs + 1, 144, 0, st>>>(red, W->npairs, W->ns, W->np, lin_H(W), lin_g(W));
+  }
   k_post_reduce<<<1, 1024, 0, st>>>(lin_g(W), lin_cost(W), W->n, (double *)W->mail.p, mail_slot);
   WC_HIP(ctx, hipGetLastError());
   return WC_OK;
