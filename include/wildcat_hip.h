@@ -143,7 +143,8 @@ int wc_window_linearize(wc_ctx *ctx, const double *h_x, double *d_H, double *d_g
  * h_x_inout: corrections in / optimised corrections out; h_first_step (may be NULL) receives the first LM increment. */
 int wc_window_solve(wc_ctx *ctx, double *h_x_inout, wc_solve_summary *summary, double *h_first_step);
 /* multi-GPU: install a "sum this device buffer over all ranks" callback (RCCL all-reduce); called once per
- * linearisation on the packed {H, g, cost} buffer and once per candidate-cost evaluation. */
+ * linearisation on the packed {upper block triangle of H (144 doubles per pair of sample blocks), g, cost} buffer and
+ * once per candidate-cost evaluation (one double). */
 int wc_window_set_allreduce(wc_ctx *ctx, int (*fn)(void *user, double *d_buf, uint64_t count), void *user);
 
 #ifdef __cplusplus
