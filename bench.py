@@ -304,7 +304,7 @@ def bench_window(ctx, args, world, rank, dev, torch, dist, cpu=False):
     n_b = ctx.match_device(d_surf, d_pose, n_s, d_surf, d_pose, n_s, True, d_pairs, n_s)
     n_u = ctx.match_device(d_surf, d_pose, n_s, d_fs, d_fp, len(w["fix_surf"]), False, d_pf, n_s)
     t_match = time.perf_counter() - t0
-    # shard the correspondences (contiguous slices), IMU factors on rank 0 only
+    # shard the correspondences (contiguous slices) and the IMU factors
     lo_b, cnt_b = wdist.shard_range(n_b, rank, world)
     lo_u, cnt_u = wdist.shard_range(n_u, rank, world)
 
@@ -314,7 +314,8 @@ def bench_window(ctx, args, world, rank, dev, torch, dist, cpu=False):
 
     if world > 1 or os.environ.get("WC_BENCH_FORCE_DIST") == "1":
         ctx.window_set_allreduce(wdist.make_allreduce(torch, dist, dev))
-    build_args = (d_surf, d_pose, _Off(d_pairs.ptr + 8 * lo_b), cnt_b, w["imu"] if rank == 0 else None, w["sample_times"], w["grav"],
+    imu_r = wdist.shard_imu(w["imu"], rank, world)  # IMU factors: a contiguous share of the state triples per rank
+    build_args = (d_surf, d_pose, _Off(d_pairs.ptr + 8 * lo_b), cnt_b, imu_r if len(imu_r) >= 3 else None, w["sample_times"], w["grav"],
                   False, d_fs, d_fp, _Off(d_pf.ptr + 8 * lo_u), cnt_u)
     ctx.window_build(*build_args)  # (first call allocates)
     ctx.sync()

@@ -1,6 +1,6 @@
-"""N > 1 path of the window solve on CPU: two gloo ranks shard the correspondences, linearise their shard with the
-oracle, all-reduce the packed {H, g, cost} buffer (the same layout and shard helper bench.py uses with RCCL) and must
-end up with the normal equations of the unsharded problem."""
+"""N > 1 path of the window solve on CPU: two gloo ranks shard the correspondences and the IMU factors, linearise their
+shard with the oracle, all-reduce the packed {upper block pairs of H, g, cost} buffer (the layout of the device path and
+the shard helpers bench.py uses with RCCL) and must end up with the normal equations of the unsharded problem."""
 import os
 import sys
 
@@ -32,8 +32,9 @@ def _worker(rank, world, port, out_dir):
     W = O.Window(w["sample_times"], w["grav"], True)
     W.add_binary(w["surf"], w["pose"], pairs[lo_b : lo_b + n_b])
     W.add_unary(w["fix_surf"], w["fix_pose"], w["surf"], w["pose"], pf[lo_u : lo_u + n_u])
-    if rank == 0:  # IMU factors are counted once
-        W.add_imu(w["imu"])
+    imu_r = wd.shard_imu(w["imu"], rank, world)  # every IMU factor (triple of consecutive states) on exactly one rank
+    if len(imu_r) >= 3:
+        W.add_imu(imu_r)
     x = 1e-3 * np.random.default_rng(5).normal(size=12 * W.ns)
     H, g, cost = W.linearize(x)
     buf = torch.from_numpy(wd.pack(H, g, cost))
