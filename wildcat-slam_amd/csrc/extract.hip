@@ -4,12 +4,13 @@
 // ExtractSurfelInfo :304-314, ClusterSurfels :12-65).  Decision rules: SURVEY.md Appendix A.
 //
 // Pipeline of one sweep (all on one stream, no host synchronisation until wc_extract_surfels_finish):
-//   0. k_init        every per-call fill in one launch (status words, bucket / bin counters, mailbox address)
+//   0. k_init        every per-call fill in one launch (status words, bucket / bin counters, mailbox address); on the fast
+//                    path it is issued by the PREVIOUS finish(), so that it runs while the host turns around
 //   1. k_pt_runs     the only pass over the AoS input: root-voxel key relative to the voxel of point 0
 //                    (floor(p / (double)0.8f), true fp64 division; 10 bits per axis, 21 in the wide fallback), RUNS of
 //                    consecutive points with one key, one composite per run into the bin of its bucket (4096 buckets)
 //   2. k_pt_bucket   per bucket: sorted runs (voxel, start) + point offsets + the compacted work list of live roots
-//   3. k_roots<1>    one wavefront per root voxel, lanes = (level, moment): the root's points are streamed IN TIME ORDER
+//   3. k_roots<1>    one wavefront per root voxel, lanes = (copy, level, moment): the root's points are streamed IN TIME ORDER
 //                    through per-node accumulators, so every sum is formed in exactly the order the reference forms it
 //                    (bit-identical moments => bit-identical gate decisions); open-cluster sums become candidate
 //                    slots when the gap rule fires (ClusterSurfels, cc:22-29)

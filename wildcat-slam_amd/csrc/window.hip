@@ -16,13 +16,16 @@
 //     once per solve; per LM iteration a record is read exactly once per pass.)
 //   * records with one key form a segment; segments are cut into pieces of <= 256 records; one workgroup per piece
 //     evaluates r and the 1 x 24 (1 x 12) Jacobian row of every record into LDS and reduces the piece's Gram matrix
-//     [J r]^T [J r] with lanes mapped to OUTPUT entries (no atomics, fixed summation order => bitwise reproducible,
-//     which keeps replicated LM state in lock-step across ranks after the all-reduce).
+//     [J r]^T [J r] in 4x4 register blocks over slices of the records, slices added in fixed order (no atomics, fixed
+//     summation order => bitwise reproducible, which keeps replicated LM state in lock-step across ranks after the
+//     all-reduce).
 //   * a gather kernel sums the piece partials into the dense normal equations H (12 ns x 12 ns) and g through a CSR
 //     source list built on the host once per solve.
 //   * LM: Jacobi scaling, damping, blocked Cholesky (own kernels, fp64), back substitution, step and candidate-cost
 //     evaluation all stay on the device; only a 6-double mailbox crosses PCIe per iteration.
-// The assembly is HBM/LDS bound (136 B in, ~0.9 kflop per record); no MFMA (rank-1 fp64 6-wide blocks).
+// The assembly streams 136 B and issues ~0.9 kflop of fp64 per record: no MFMA there (rank-1 fp64 updates of 6-wide blocks;
+// a 25-wide Gram matrix wastes most of a 32 x 32 tile).  The dense Cholesky of the damped system does its panel solves,
+// trailing updates and the rank-4 updates of the diagonal factor with v_mfma_f64_16x16x4.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
