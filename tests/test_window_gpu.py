@@ -96,7 +96,10 @@ def test_evaluate_and_linearize_match_oracle(gpu, oracle, quirks):
 
 
 @pytest.mark.parametrize("cfg", [dict(), dict(quirks=0), dict(fix_first=False), dict(with_imu=False, fix_first=True), dict(fixed=0),
-                                 dict(one_plane=True), dict(one_plane=True, with_imu=False)])
+                                 dict(one_plane=True), dict(one_plane=True, with_imu=False),
+                                 # 64 sample states = 768 unknowns = 25 Cholesky panels: several chunks of the back substitution,
+                                 # 64 x 64 tiles off the diagonal, the lead workgroup next to real tiles
+                                 dict(n_scans=10, patches=80, fixed=40)])
 def test_lm_solve_matches_oracle(gpu, oracle, cfg):
     w, W, keep = _setup(gpu, oracle, **cfg)
     x0 = np.zeros(12 * W.ns)
