@@ -243,3 +243,16 @@ def test_c3_window_size_independent_properties(gpu):
     _, g_end, c_end = gpu.window_linearize(x)
     assert abs(c_end - s.final_cost) <= 1e-9 * c_end
     assert np.abs(g_end).max() < 1e-2 * np.abs(g).max()
+
+
+def test_c4_geometry_full_state_count_matches_oracle(gpu, oracle):
+    """the C4 window geometry (20 sweeps, 127 sample states = 1 524 unknowns = 48 Cholesky panels, IMU factors) with 1/20 of
+    the surfels, so that the CPU oracle finishes in seconds: same iterations, same steps, increments within 1e-6"""
+    w, W, keep = _setup(gpu, oracle, n_scans=20, patches=2500, fixed=2500, fix_first=False, extra_mode2=False, seed=7)
+    assert W.ns >= 120
+    x0 = np.zeros(12 * W.ns)
+    x_ref, s_ref, first_ref = W.solve(x0)
+    x, s, first = gpu.window_solve(x0)
+    assert s.termination == s_ref.termination and s.iterations == s_ref.iterations and s.successful_steps == s_ref.successful_steps
+    assert abs(s.final_cost - s_ref.final_cost) <= 1e-8 * s_ref.final_cost
+    assert _rel(first, first_ref) <= 1e-6 and _rel(x, x_ref) <= 1e-6
