@@ -31,6 +31,7 @@
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -594,7 +595,7 @@ __global__ void __launch_bounds__(256) k_lin_imu(WinParams wp, const Piece *piec
 //   light  - the other pairs (at most a few sources): one pair per group;
 //   g      - one sample block per workgroup, 16 groups of 12 lanes stride over the block's source list;
 //   cost   - the last workgroup adds the cost slots of all partials.
-// Every source costs two dependent loads (descriptor, value): four sources are in flight per thread, added in list order
+// Every source costs two dependent loads (descriptor, value): four (heavy pairs: eight) sources are in flight per thread, added in list order
 // (bitwise reproducible, no atomics).
 constexpr int kGG = 7;
 struct GatherArgs {
@@ -611,14 +612,14 @@ struct GatherArgs {
   int packed;  // H = block pairs in pair order, 144 doubles each (the multi-GPU reduction buffer); else the dense n x n matrix
 };
 
-template <int STRIDE>
+template <int STRIDE, int ILP>
 __device__ __forceinline__ double gather_pair_sum(const Src *src, const double *partial, uint32_t s0, uint32_t eend, int u, int v) {
   double acc = 0.0;
-  for (uint32_t s = s0; s < eend; s += 4 * STRIDE) {
-    double val[4];
-    bool ok[4];
+  for (uint32_t s = s0; s < eend; s += ILP * STRIDE) {
+    double val[ILP];
+    bool ok[ILP];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < ILP; ++q) {
       const uint32_t sq = s + q * STRIDE;
       const bool live = sq < eend;
       const Src sr = src[live ? sq : s];
@@ -631,7 +632,7 @@ __device__ __forceinline__ double gather_pair_sum(const Src *src, const double *
       val[q] = partial[sr.part_off + (ok[q] ? tri_index(r, c, sr.T) : 0u)];
     }
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
+    for (int q = 0; q < ILP; ++q)
       if (ok[q]) acc += val[q];
   }
   return acc;
@@ -652,9 +653,9 @@ __global__ void __launch_bounds__(144 * kGG) k_gather(GatherArgs a) {
     if (pid < a.npairs) {
       const uint32_t b = a.src_begin[pid], eend = a.src_begin[pid + 1];
       if (heavy) {
-        acc = gather_pair_sum<kGG>(a.src, a.partial, b + grp, eend, u, v);
+        acc = gather_pair_sum<kGG, 8>(a.src, a.partial, b + grp, eend, u, v);  // (up to 350 sources: 50 per group)
       } else if (eend - b <= kHeavySrc) {
-        acc = gather_pair_sum<1>(a.src, a.partial, b, eend, u, v);
+        acc = gather_pair_sum<1, 4>(a.src, a.partial, b, eend, u, v);
         write = true;
       }
     }
@@ -667,24 +668,33 @@ __global__ void __launch_bounds__(144 * kGG) k_gather(GatherArgs a) {
         write = true;
       }
     }
-    if (!write) return;
     // invert pid = I*ns - I(I-1)/2 + (J-I)
     const int ns = a.ns;
-    const float f = 2.f * ns + 1.f;
-    int I = (int)((f - sqrtf(fmaxf(f * f - 8.f * (float)pid, 0.f))) * 0.5f);
-    I = max(0, min(I, ns - 1));
-    while (I > 0 && (uint32_t)(I * ns - I * (I - 1) / 2) > pid) --I;
-    while ((uint32_t)((I + 1) * ns - (I + 1) * I / 2) <= pid) ++I;
-    const int J = I + (int)(pid - (uint32_t)(I * ns - I * (I - 1) / 2));
+    int I = 0, J = 0;
+    if (write) {
+      const float f = 2.f * ns + 1.f;
+      I = (int)((f - sqrtf(fmaxf(f * f - 8.f * (float)pid, 0.f))) * 0.5f);
+      I = max(0, min(I, ns - 1));
+      while (I > 0 && (uint32_t)(I * ns - I * (I - 1) / 2) > pid) --I;
+      while ((uint32_t)((I + 1) * ns - (I + 1) * I / 2) <= pid) ++I;
+      J = I + (int)(pid - (uint32_t)(I * ns - I * (I - 1) / 2));
+    }
     const int n = 12 * ns;
     const int gi = I * 12 + u, gj = J * 12 + v;
     if (a.fix_first && ((gi >= 3 && gi < 6) || (gj >= 3 && gj < 6))) acc = 0.0;  // SubsetParameterization(12,{3,4,5})
     if (a.packed) {
-      a.H[(size_t)pid * 144 + e] = acc;
-    } else {
-      a.H[(size_t)gi * n + gj] = acc;
-      a.H[(size_t)gj * n + gi] = acc;
+      if (write) a.H[(size_t)pid * 144 + e] = acc;
+      return;
     }
+    // block (I, J) row by row, and its transpose as block (J, I) ALSO row by row: the transposed entries come through
+    // LDS (written straight from the registers the mirror block is 144 scattered 8-byte stores per pair, 9 MB of them)
+    const int slot = heavy ? 0 : grp;
+    __syncthreads();  // (heavy: every group has read the partial sums)
+    if (write) sred[slot * 144 + e] = acc;
+    __syncthreads();
+    if (!write) return;
+    a.H[(size_t)gi * n + gj] = acc;
+    a.H[(size_t)(J * 12 + u) * n + I * 12 + v] = sred[slot * 144 + v * 12 + u];
     return;
   }
   blk -= a.nheavy + nlight;
@@ -1639,6 +1649,12 @@ extern "C" int wc_window_build(wc_ctx *ctx, const wc_surfel *d_sld_surf, const w
   for (uint32_t i = 0; i < npairs; ++i)
     if (src_begin[i + 1] - src_begin[i] > kHeavySrc) heavy.push_back(i);
   W->nheavy = (uint32_t)heavy.size();
+  if (getenv("WC_DEBUG_GATHER")) {
+    uint32_t mx = 0;
+    for (uint32_t i = 0; i < npairs; ++i) mx = std::max(mx, src_begin[i + 1] - src_begin[i]);
+    fprintf(stderr, "gather: %u pairs, %u heavy, %zu sources (max %u per pair), %zu g-sources, %zu pieces\n", npairs, W->nheavy, src.size(), mx,
+            gsrc.size(), pieces.size());
+  }
   WC_TRY(upload(ctx, W->heavy, heavy));
   WC_TRY(upload(ctx, W->pieces, pieces));
   WC_TRY(upload(ctx, W->src, src));
