@@ -1588,10 +1588,15 @@ extern "C" int wc_window_build(wc_ctx *ctx, const wc_surfel *d_sld_surf, const w
       }
     }
   };
+  // (longest pieces first inside a family: workgroups are dispatched in piece order, and a full piece started last would
+  // run alone at the end of the launch)
+  auto by_size = [](const Piece &a, const Piece &b) { return a.count > b.count; };
   cut(segs_b, 25, true);
   W->npiece_b = (uint32_t)pieces.size();
+  std::stable_sort(pieces.begin(), pieces.end(), by_size);
   cut(segs_u, 13, true);
   W->npiece_u = (uint32_t)pieces.size() - W->npiece_b;
+  std::stable_sort(pieces.begin() + W->npiece_b, pieces.end(), by_size);
   cut(segs_i, 37, false);
   W->npiece_i = (uint32_t)pieces.size() - W->npiece_b - W->npiece_u;
   W->npart_doubles = off;
