@@ -547,7 +547,7 @@ __global__ void __launch_bounds__(kPiece) k_lin_surfel(WinParams wp, const Piece
 }
 
 // IMU factors of one sample interval: <= kImuMax factors x 12 residual rows, 36-wide Jacobian
-constexpr int kImuMax = 16;
+constexpr int kImuMax = 8;  // (16: 30 us at C4, 8: 24 us - one round of 252 workgroups, 4: 37 us - two rounds)
 __global__ void __launch_bounds__(256) k_lin_imu(WinParams wp, const Piece *pieces, const ImuRec *recs, const double *x,
                                                 const double *times, double *partial) {
   constexpr int T = 37;
