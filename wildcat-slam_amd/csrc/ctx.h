@@ -31,7 +31,7 @@ struct wc_ctx {
       b_status, b_misc[8];
   // pinned host mailbox
   uint32_t *h_status = nullptr;  // [0] n_emitted, [1] flags, ...
-  double *h_mail = nullptr;      // small double mailbox (costs etc.)
+  double *h_mail = nullptr;      // pinned: 64 doubles of mailbox (costs etc.) + 4096 doubles of staging (the window's unknowns)
   // pending extraction (enqueue/finish split)
   struct {
     bool active = false;

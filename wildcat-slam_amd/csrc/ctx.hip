@@ -70,7 +70,7 @@ extern "C" int wc_ctx_create(const wc_params *params, int device, wc_ctx **out) 
   if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess ||
       hipHostMalloc((void **)&ctx->h_status, 64 * sizeof(uint32_t)) != hipSuccess ||
-      hipHostMalloc((void **)&ctx->h_mail, 64 * sizeof(double)) != hipSuccess) {
+      hipHostMalloc((void **)&ctx->h_mail, (64 + 4096) * sizeof(double)) != hipSuccess) {
     delete ctx;
     return WC_ERR_HIP;
   }

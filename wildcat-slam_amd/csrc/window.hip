@@ -1862,6 +1862,24 @@ extern "C" int wc_window_solve(wc_ctx *ctx, double *h_x_inout, wc_solve_summary 
   x_norm = std::sqrt(x_norm);
   int iter = 0, consecutive_invalid = 0;
   bool first_recorded = false;
+  // ONE host round trip per iteration: the linearisation at an accepted point is enqueued without waiting for it; its
+  // cost, max |g| and the accepted x are read back with the NEXT iteration's mailbox (the next step only needs the trust
+  // region radius, which is known).  If that read-back shows a gradient below tolerance, the iteration that was enqueued
+  // on top of it is discarded - the reference stops before it.
+  bool lin_pending = false;
+  auto resolve_pending = [&]() {
+    cost = ctx->h_mail[0];
+    gmax = ctx->h_mail[1];
+    std::memcpy(cur.data(), ctx->h_mail + 64, (size_t)n * 8);
+    x_norm = 0.0;
+    for (int i = 0; i < n; ++i) x_norm += cur[i] * cur[i];
+    x_norm = std::sqrt(x_norm);
+    if (cost < min_cost) {
+      min_cost = cost;
+      best = cur;
+    }
+    lin_pending = false;
+  };
   summary->termination = 1;
   if (gmax <= 1e-10) {
     summary->termination = 0;
@@ -1871,7 +1889,7 @@ extern "C" int wc_window_solve(wc_ctx *ctx, double *h_x_inout, wc_solve_summary 
         summary->termination = 1;
         break;
       }
-      if (gmax <= 1e-10 || radius <= 1e-32) {
+      if ((!lin_pending && gmax <= 1e-10) || radius <= 1e-32) {
         summary->termination = 0;
         break;
       }
@@ -1902,6 +1920,14 @@ extern "C" int wc_window_solve(wc_ctx *ctx, double *h_x_inout, wc_solve_summary 
       WC_HIP(ctx, hipGetLastError());
       WC_HIP(ctx, hipMemcpyAsync(ctx->h_mail, mail, 40 * 8, hipMemcpyDeviceToHost, st));
       WC_HIP(ctx, hipStreamSynchronize(st));
+      if (lin_pending) {
+        resolve_pending();
+        if (gmax <= 1e-10) {  // GradientToleranceReached at the point this iteration started from
+          --iter;
+          summary->termination = 0;
+          break;
+        }
+      }
       summary->n_cost_evaluations++;
       int hfail;
       std::memcpy(&hfail, &ctx->h_mail[32], 4);
@@ -1938,29 +1964,25 @@ extern "C" int wc_window_solve(wc_ctx *ctx, double *h_x_inout, wc_solve_summary 
         std::swap(W->x, W->xc);
         x = (double *)W->x.p, xc = (double *)W->xc.p;
         WC_TRY(enqueue_linearize(ctx, W, x, 0));
-        // |x| of the accepted point: k_step computed |x_old|; recompute from the candidate on the host side
-        WC_HIP(ctx, hipMemcpyAsync(cur.data(), x, (size_t)n * 8, hipMemcpyDeviceToHost, st));
-        WC_TRY(read_mail(ctx, W, 2));
+        // the accepted point goes to the pinned staging area behind the mailbox (|x| and the best point are host state)
+        WC_HIP(ctx, hipMemcpyAsync(ctx->h_mail + 64, x, (size_t)n * 8, hipMemcpyDeviceToHost, st));
+        lin_pending = true;
         summary->n_linearizations++;
-        cost = ctx->h_mail[0];
-        gmax = ctx->h_mail[1];
-        x_norm = 0.0;
-        for (int i = 0; i < n; ++i) x_norm += cur[i] * cur[i];
-        x_norm = std::sqrt(x_norm);
         radius = radius / std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * rho - 1.0, 3));
         radius = std::min(1e16, radius);
         decrease = 2.0;
         summary->successful_steps++;
-        if (cost < min_cost) {
-          min_cost = cost;
-          best = cur;
-        }
       } else {  // HandleUnsuccessfulStep
         radius = radius / decrease;
         decrease *= 2;
         summary->unsuccessful_steps++;
       }
     }
+  }
+  if (lin_pending) {  // the last accepted point's linearisation is still in flight
+    WC_HIP(ctx, hipMemcpyAsync(ctx->h_mail, mail, 2 * 8, hipMemcpyDeviceToHost, st));
+    WC_HIP(ctx, hipStreamSynchronize(st));
+    resolve_pending();
   }
   summary->iterations = iter;
   summary->final_cost = min_cost;
