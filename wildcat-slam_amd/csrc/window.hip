@@ -844,7 +844,9 @@ __global__ void __launch_bounds__(256) k_eval_imu(WinParams wp, const ImuRec *re
   if (threadIdx.x == 0) block_cost[blockIdx.x] = s[0];
 }
 
-__global__ void __launch_bounds__(1024) k_sum_blocks(const double *v, uint32_t n, double *mail, int slot) {
+// (host_mail != null: the whole 40-double mailbox is stored to pinned host memory right here - the copy node that would
+// follow is a 4 us blit kernel on the critical path of every LM iteration)
+__global__ void __launch_bounds__(1024) k_sum_blocks(const double *v, uint32_t n, double *mail, int slot, double *host_mail) {
   __shared__ double s[1024];
   const int tid = threadIdx.x;
   double acc = 0.0;
@@ -856,6 +858,10 @@ __global__ void __launch_bounds__(1024) k_sum_blocks(const double *v, uint32_t n
     __syncthreads();
   }
   if (tid == 0) mail[slot] = s[0];
+  if (host_mail) {
+    __syncthreads();
+    if (tid < 40) host_mail[tid] = (tid == slot) ? s[0] : mail[tid];
+  }
 }
 
 // ---- LM linear algebra on the device -------------------------------------------------------------------------------
@@ -866,9 +872,10 @@ __global__ void __launch_bounds__(256) k_scale_init(const double *H, int n, doub
 
 // A (lower, row-major, ld) = S H S + diag(clamp(diag(S H S), 1e-6, 1e32) / radius); row n = (S g)^T; padding = identity
 __global__ void __launch_bounds__(256) k_damp(const double *H, const double *g, const double *scale, int n, int np, int ld,
-                                             double radius, double *A, double *diag) {
+                                             double radius, double *A, double *diag, int *fail) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   const int i = blockIdx.y;
+  if (i == 0 && j == 0) *fail = 0;  // the factorisation's failure flag (a memset node of its own is a 3 us blit kernel)
   if (j >= np || j > i) return;
   double v;
   if (i < n) {
@@ -1381,13 +1388,14 @@ __global__ void __launch_bounds__(1024) k_chol_back_gemv(const double *A, int ld
 // candidate point and the scalars the trust-region logic needs:
 //   xc = x - y * scale ; mail[2] = model_cost_change = (y.gs + sum D y^2) / 2 ; mail[3] = |step| ; mail[4] = |x|
 __global__ void __launch_bounds__(1024) k_step(const double *x, const double *y, const double *scale, const double *g,
-                                              const double *diag, int n, double *xc, double *mail) {
+                                              const double *diag, int n, double *xc, double *mail, double *host_xc) {
   __shared__ double s0[1024], s1[1024], s2[1024];
   const int tid = threadIdx.x;
   double mc = 0.0, sn = 0.0, xn = 0.0;
   for (int i = tid; i < n; i += 1024) {
     const double d = -y[i] * scale[i];
     xc[i] = x[i] + d;
+    host_xc[i] = x[i] + d;  // pinned host staging: an accepted candidate is host state (|x|, best point) without a copy node
     mc += y[i] * (g[i] * scale[i]) + diag[i] * y[i] * y[i];
     sn += d * d;
     xn += x[i] * x[i];
@@ -1767,7 +1775,7 @@ int enqueue_linearize(wc_ctx *ctx, wc_window_state *W, const double *d_x, int ma
 }
 
 // cost (and optionally residuals in the reference's block order: binary, unary, imu x 12) at x -> mail[slot]
-int enqueue_evaluate(wc_ctx *ctx, wc_window_state *W, const double *d_x, double *d_res, int mail_slot) {
+int enqueue_evaluate(wc_ctx *ctx, wc_window_state *W, const double *d_x, double *d_res, int mail_slot, double *host_mail = nullptr) {
   hipStream_t st = ctx->stream;
   double *cp = (double *)W->cost_part.p;
   const uint32_t gb = (W->nb + 255) / 256, gu = (W->nu + 255) / 256, gi = (W->ni + 255) / 256;
@@ -1780,7 +1788,7 @@ int enqueue_evaluate(wc_ctx *ctx, wc_window_state *W, const double *d_x, double 
   if (gi)
     k_eval_imu<<<gi, 256, 0, st>>>(W->wp, (const ImuRec *)W->irec.p, W->ni, d_x, (const double *)W->times_d.p,
                                   d_res ? d_res + W->nb + W->nu : nullptr, cp + gb + gu);
-  k_sum_blocks<<<1, 1024, 0, st>>>(cp, gb + gu + gi, (double *)W->mail.p, mail_slot);
+  k_sum_blocks<<<1, 1024, 0, st>>>(cp, gb + gu + gi, (double *)W->mail.p, mail_slot, W->allreduce ? nullptr : host_mail);
   WC_HIP(ctx, hipGetLastError());
   WC_TRY(do_allreduce(ctx, W, (double *)W->mail.p + mail_slot, 1));
   return WC_OK;
@@ -1848,7 +1856,7 @@ extern "C" int wc_window_solve(wc_ctx *ctx, double *h_x_inout, wc_solve_summary 
   double *Lmat = (double *)W->Lmat.p;
   double *mail = (double *)W->mail.p;
   int *fail = (int *)((double *)W->mail.p + 32);
-  std::vector<double> best(h_x_inout, h_x_inout + n), cur(best), cand(n);
+  std::vector<double> best(h_x_inout, h_x_inout + n), cur(best);
 
   WC_HIP(ctx, hipMemcpyAsync(x, cur.data(), (size_t)n * 8, hipMemcpyHostToDevice, st));
   WC_TRY(enqueue_linearize(ctx, W, x, 0));
@@ -1867,13 +1875,16 @@ extern "C" int wc_window_solve(wc_ctx *ctx, double *h_x_inout, wc_solve_summary 
   // region radius, which is known).  If that read-back shows a gradient below tolerance, the iteration that was enqueued
   // on top of it is discarded - the reference stops before it.
   bool lin_pending = false;
+  double *h_mail_dev = nullptr, *h_stage_dev = nullptr;  // device addresses of the pinned mailbox and of its staging area
+  {
+    void *dp = nullptr;
+    if (hipHostGetDevicePointer(&dp, ctx->h_mail, 0) != hipSuccess || !dp) return wc_fail(ctx, WC_ERR_HIP, "pinned mailbox is not device-mapped");
+    h_mail_dev = (double *)dp;
+    h_stage_dev = h_mail_dev + 64;
+  }
   auto resolve_pending = [&]() {
     cost = ctx->h_mail[0];
     gmax = ctx->h_mail[1];
-    std::memcpy(cur.data(), ctx->h_mail + 64, (size_t)n * 8);
-    x_norm = 0.0;
-    for (int i = 0; i < n; ++i) x_norm += cur[i] * cur[i];
-    x_norm = std::sqrt(x_norm);
     if (cost < min_cost) {
       min_cost = cost;
       best = cur;
@@ -1895,10 +1906,9 @@ extern "C" int wc_window_solve(wc_ctx *ctx, double *h_x_inout, wc_solve_summary 
       }
       ++iter;
       // LevenbergMarquardtStrategy::ComputeStep on the device
-      WC_HIP(ctx, hipMemsetAsync(fail, 0, 4, st));
       {
         dim3 grid((np + 255) / 256, np);
-        k_damp<<<grid, 256, 0, st>>>(H, g, scale, n, np, ld, radius, A, diag);
+        k_damp<<<grid, 256, 0, st>>>(H, g, scale, n, np, ld, radius, A, diag, fail);
       }
       k_chol_first<<<1, 256, 0, st>>>(A, ld, Lmat, (double *)W->Linv.p, fail);
       for (int k = 0; k + 1 < nblk; ++k) {
@@ -1915,10 +1925,11 @@ extern "C" int wc_window_solve(wc_ctx *ctx, double *h_x_inout, wc_solve_summary 
           hi = lo;
         }
       }
-      k_step<<<1, 1024, 0, st>>>(x, y, scale, g, diag, n, xc, mail);
-      WC_TRY(enqueue_evaluate(ctx, W, xc, nullptr, 5));
+      k_step<<<1, 1024, 0, st>>>(x, y, scale, g, diag, n, xc, mail, h_stage_dev);
+      WC_TRY(enqueue_evaluate(ctx, W, xc, nullptr, 5, h_mail_dev));
       WC_HIP(ctx, hipGetLastError());
-      WC_HIP(ctx, hipMemcpyAsync(ctx->h_mail, mail, 40 * 8, hipMemcpyDeviceToHost, st));
+      // (one GPU: k_sum_blocks has stored the mailbox to pinned host memory itself; with an all-reduce behind it, copy)
+      if (W->allreduce || !h_mail_dev) WC_HIP(ctx, hipMemcpyAsync(ctx->h_mail, mail, 40 * 8, hipMemcpyDeviceToHost, st));
       WC_HIP(ctx, hipStreamSynchronize(st));
       if (lin_pending) {
         resolve_pending();
@@ -1945,10 +1956,8 @@ extern "C" int wc_window_solve(wc_ctx *ctx, double *h_x_inout, wc_solve_summary 
       if (!first_recorded) {
         first_recorded = true;
         summary->first_step[0] = step_norm;
-        if (h_first_step) {
-          WC_HIP(ctx, hipMemcpy(cand.data(), xc, (size_t)n * 8, hipMemcpyDeviceToHost));
-          for (int i = 0; i < n; ++i) h_first_step[i] = cand[i] - cur[i];
-        }
+        if (h_first_step)
+          for (int i = 0; i < n; ++i) h_first_step[i] = ctx->h_mail[64 + i] - cur[i];  // (the candidate k_step staged)
       }
       if (step_norm <= 1e-8 * (x_norm + 1e-8)) {  // ParameterToleranceReached
         summary->termination = 0;
@@ -1964,8 +1973,11 @@ extern "C" int wc_window_solve(wc_ctx *ctx, double *h_x_inout, wc_solve_summary 
         std::swap(W->x, W->xc);
         x = (double *)W->x.p, xc = (double *)W->xc.p;
         WC_TRY(enqueue_linearize(ctx, W, x, 0));
-        // the accepted point goes to the pinned staging area behind the mailbox (|x| and the best point are host state)
-        WC_HIP(ctx, hipMemcpyAsync(ctx->h_mail + 64, x, (size_t)n * 8, hipMemcpyDeviceToHost, st));
+        // the accepted point = the candidate k_step staged in pinned memory (|x| and the best point are host state)
+        std::memcpy(cur.data(), ctx->h_mail + 64, (size_t)n * 8);
+        x_norm = 0.0;
+        for (int i = 0; i < n; ++i) x_norm += cur[i] * cur[i];
+        x_norm = std::sqrt(x_norm);
         lin_pending = true;
         summary->n_linearizations++;
         radius = radius / std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * rho - 1.0, 3));
