@@ -1212,6 +1212,15 @@ __global__ void __launch_bounds__(256) k_chol_step(double *A, int ld, int k, int
     const double v = A[(size_t)(in ? row0 + r : first) * ld + pc + c];
     sA[r][c] = in ? v : 0.0;
   }
+  if (ti != tj) {  // panel rows of the tile's columns, in the same round trip
+#pragma unroll
+    for (int e0 = 0; e0 < 64 * kNB; e0 += 256) {
+      const int e = e0 + tid, r = e / kNB, c = e % kNB;
+      const bool in = col0 + r < nrow;
+      const double v = A[(size_t)(in ? col0 + r : first) * ld + pc + c];
+      sLj[r][c] = in ? v : 0.0;
+    }
+  }
   __syncthreads();
   if (failed) return;
   // The two small GEMMs of a tile run on the fp64 matrix cores: v_mfma_f64_16x16x4 takes A[i = l & 15][k = l >> 4] and
@@ -1239,19 +1248,12 @@ __global__ void __launch_bounds__(256) k_chol_step(double *A, int ld, int k, int
     }
   }
   __syncthreads();
-  if (ti != tj) {
-#pragma unroll
-    for (int e0 = 0; e0 < 64 * kNB; e0 += 256) {
-      const int e = e0 + tid, r = e / kNB, c = e % kNB;
-      const bool in = col0 + r < nrow;
-      const double v = A[(size_t)(in ? col0 + r : first) * ld + pc + c];
-      sA[r][c] = in ? v : 0.0;
-    }
-    __syncthreads();
+  if (ti != tj) {  // the tile's columns: their panel rows were staged in sLj with the first loads; solved in place (a
+                   // wavefront reads and writes only its own 16 rows, and writes after its last read)
     f64x4 t0 = {0.0, 0.0, 0.0, 0.0}, t1 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int ks = 0; ks < kNB / 4; ++ks) {
-      const double a = sA[16 * w + li][4 * ks + lk];
+      const double a = sLj[16 * w + li][4 * ks + lk];
       t0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, sX[li][4 * ks + lk], t0, 0, 0, 0);
       t1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, sX[16 + li][4 * ks + lk], t1, 0, 0, 0);
     }
