@@ -1600,13 +1600,20 @@ extern "C" int wc_window_build(wc_ctx *ctx, const wc_surfel *d_sld_surf, const w
   };
   // (longest pieces first inside a family: workgroups are dispatched in piece order, and a full piece started last would
   // run alone at the end of the launch)
-  auto by_size = [](const Piece &a, const Piece &b) { return a.count > b.count; };
+  auto by_size = [&](size_t first) {  // stable counting sort of pieces[first..) by count, descending (counts are 1..kPiece)
+    std::vector<uint32_t> pos(kPiece + 2, 0);
+    for (size_t i = first; i < pieces.size(); ++i) pos[kPiece - pieces[i].count + 1]++;
+    for (int c = 0; c <= kPiece; ++c) pos[c + 1] += pos[c];
+    std::vector<Piece> out(pieces.size() - first);
+    for (size_t i = first; i < pieces.size(); ++i) out[pos[kPiece - pieces[i].count]++] = pieces[i];
+    std::copy(out.begin(), out.end(), pieces.begin() + first);
+  };
   cut(segs_b, 25, true);
   W->npiece_b = (uint32_t)pieces.size();
-  std::stable_sort(pieces.begin(), pieces.end(), by_size);
+  by_size(0);
   cut(segs_u, 13, true);
   W->npiece_u = (uint32_t)pieces.size() - W->npiece_b;
-  std::stable_sort(pieces.begin() + W->npiece_b, pieces.end(), by_size);
+  by_size(W->npiece_b);
   cut(segs_i, 37, false);
   W->npiece_i = (uint32_t)pieces.size() - W->npiece_b - W->npiece_u;
   W->npart_doubles = off;
