@@ -15,6 +15,8 @@ def _run(gpu, oracle, pts, **kw):
     s_gpu, id_gpu = gpu.extract_surfels(pts, **kw)
     assert len(s_gpu) == len(s_ref) == st.surfels
     info = helpers.check_surfels(s_gpu, id_gpu, s_ref, id_ref, tol=1e-6, t_tol=1e-5)
+    # the ORDER is the oracle's as well: time stamp, then (ties) root voxel index and node id - SURVEY Q7
+    assert id_gpu.tobytes() == id_ref.tobytes()
     return info, st
 
 

@@ -51,3 +51,4 @@ def test_random_clouds_match_oracle(gpu, oracle, seed):
         assert len(s_gpu) == len(s_ref) == st.surfels, (seed, len(s_gpu), len(s_ref))
         if len(s_ref):
             helpers.check_surfels(s_gpu, id_gpu, s_ref, id_ref, tol=1e-6, t_tol=1e-5)
+            assert id_gpu.tobytes() == id_ref.tobytes()  # same order, ties included

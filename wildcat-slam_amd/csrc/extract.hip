@@ -1320,6 +1320,39 @@ __global__ void __launch_bounds__(256) k_gather(const uint32_t *__restrict__ sor
   }
 }
 
+// Surfels with EQUAL time stamps: the reference's std::sort on the stamp (surfel_extraction.cc:334) over an unordered hash
+// map leaves their order unspecified; here it is the canonical one of SURVEY Q7 - root voxel index, then node id - on
+// every path, so that the output is byte for byte the oracle's.
+__device__ __forceinline__ bool surfel_id_less(const wc_surfel_id &a, const wc_surfel_id &b) {
+  if (a.kx != b.kx) return a.kx < b.kx;
+  if (a.ky != b.ky) return a.ky < b.ky;
+  if (a.kz != b.kz) return a.kz < b.kz;
+  return a.node < b.node;
+}
+
+// radix-sort path: the sort is stable in the slot index; one thread per group of equal keys puts the group (two or three
+// slots, rarely) into canonical order
+__global__ void __launch_bounds__(256) k_fix_ties(const uint64_t *__restrict__ keys, uint32_t *idx, uint64_t n,
+                                                 const wc_surfel_id *__restrict__ slot_ids) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t key = keys[i];
+  if (key == ~0ull) return;  // no surfel in the slot
+  if ((i > 0 && keys[i - 1] == key) || i + 1 >= n || keys[i + 1] != key) return;
+  uint64_t e = i + 1;
+  while (e < n && keys[e] == key) ++e;
+  for (uint64_t a = i + 1; a < e; ++a) {  // insertion sort
+    const uint32_t v = idx[a];
+    const wc_surfel_id vid = slot_ids[v];
+    uint64_t b = a;
+    while (b > i && surfel_id_less(vid, slot_ids[idx[b - 1]])) {
+      idx[b] = idx[b - 1];
+      --b;
+    }
+    idx[b] = v;
+  }
+}
+
 // Fast slot order + gather in one launch.  The emission dropped every surfel into one of 4096 time buckets (a count and a
 // fixed-capacity bin per bucket), so what is left is: the exclusive prefix of the counts (every workgroup sums the counts
 // in front of its four buckets: 16 KB out of L2, cheaper than a separate scan launch), the order inside a bucket (rank by
@@ -1362,7 +1395,13 @@ __global__ void __launch_bounds__(256) k_slot_emit(const uint32_t *__restrict__ 
   for (uint32_t i = lane; i < c; i += 64) {
     const uint64_t mine = s_item[w][i];
     uint32_t rank = 0;
-    for (uint32_t j = 0; j < c; ++j) rank += (s_item[w][j] < mine) ? 1u : 0u;  // composites are unique (slot index)
+    for (uint32_t j = 0; j < c; ++j) {  // composites are unique (slot index)
+      const uint64_t other = s_item[w][j];
+      bool less = other < mine;
+      if ((other >> 32) == (mine >> 32) && other != mine)  // equal time stamps: canonical order, not slot order
+        less = surfel_id_less(slot_ids[(uint32_t)other], slot_ids[(uint32_t)mine]);
+      rank += less ? 1u : 0u;
+    }
     s_sorted[w][rank] = (uint32_t)mine;
   }
   __builtin_amdgcn_wave_barrier();
@@ -1728,6 +1767,8 @@ int pipeline_tail(wc_ctx *ctx, bool layer2) {
     WC_TRY(sort_pairs<uint64_t>(ctx, (uint64_t *)ctx->b_slot_keys[0].p, (uint64_t *)ctx->b_slot_keys[1].p,
                                 (uint32_t *)ctx->b_slot_idx[0].p, (uint32_t *)ctx->b_slot_idx[1].p, total_slots,
                                 ctx->ex.slot_end_bit));
+    k_fix_ties<<<(unsigned)((total_slots + 255) / 256), 256, 0, st>>>((const uint64_t *)ctx->b_slot_keys[1].p, (uint32_t *)ctx->b_slot_idx[1].p,
+                                                                     total_slots, (const wc_surfel_id *)ctx->b_slot_ids.p);
     const uint64_t gth = std::min<uint64_t>(total_slots, cap) * 10;
     if (gth)
       k_gather<<<(unsigned)((gth + 255) / 256), 256, 0, st>>>((const uint32_t *)ctx->b_slot_idx[1].p, (const wc_surfel *)ctx->b_slots.p,
