@@ -1,0 +1,27 @@
+"""Ad-hoc stress of the matcher against the CPU oracle's kd-tree on windows larger than the unit tests use (run on the GPU
+box: python profiles/stress_match.py).  k-NN tables and pair lists must be identical."""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "wildcat-slam_amd", "python"))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import pyoracle  # noqa: E402
+from wildcat_slam_amd import lib, synth  # noqa: E402
+
+ctx = lib.Context(0)
+for scans, patches, fixed, seed in ((20, 2500, 2500, 7), (10, 8000, 20000, 8), (5, 20000, 3000, 9)):
+    w = synth.surfel_window(scans, patches, seed=seed, fixed_patches=fixed)
+    t0 = time.perf_counter()
+    ref_s = pyoracle.match(w["surf"], w["pose"], w["surf"], w["pose"], True)
+    ref_f = pyoracle.match(w["surf"], w["pose"], w["fix_surf"], w["fix_pose"], False)
+    t_cpu = time.perf_counter() - t0
+    got_s, idx, d2 = ctx.match(w["surf"], w["pose"], w["surf"], w["pose"], True, want_knn=True)
+    got_f = ctx.match(w["surf"], w["pose"], w["fix_surf"], w["fix_pose"], False)
+    assert np.array_equal(got_s, ref_s) and np.array_equal(got_f, ref_f), (scans, patches, fixed)
+    assert (np.diff(d2, axis=1) >= 0).all() and (idx[:, 0] == np.arange(len(idx))).all()
+    print(f"{scans:3d} sweeps x {patches:6d} patches, {fixed:6d} fixed: {len(ref_s):7d} + {len(ref_f):7d} pairs identical (oracle {t_cpu:.1f} s)")
+print("all windows agree with the oracle")
