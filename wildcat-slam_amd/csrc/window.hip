@@ -1389,11 +1389,14 @@ __global__ void __launch_bounds__(1024) k_chol_back_gemv(const double *A, int ld
 
 // candidate point and the scalars the trust-region logic needs:
 //   xc = x - y * scale ; mail[2] = model_cost_change = (y.gs + sum D y^2) / 2 ; mail[3] = |step| ; mail[4] = |x|
+//   mail[0] = cost, mail[1] = max |g| of the linearisation this step starts from (what k_post_reduce writes after a
+//   stand-alone linearisation; inside the LM loop that launch is saved)
 __global__ void __launch_bounds__(1024) k_step(const double *x, const double *y, const double *scale, const double *g,
-                                              const double *diag, int n, double *xc, double *mail, double *host_xc) {
-  __shared__ double s0[1024], s1[1024], s2[1024];
+                                              const double *diag, int n, double *xc, double *mail, double *host_xc,
+                                              const double *lin_cost) {
+  __shared__ double s0[1024], s1[1024], s2[1024], s3[1024];
   const int tid = threadIdx.x;
-  double mc = 0.0, sn = 0.0, xn = 0.0;
+  double mc = 0.0, sn = 0.0, xn = 0.0, gm = 0.0;
   for (int i = tid; i < n; i += 1024) {
     const double d = -y[i] * scale[i];
     xc[i] = x[i] + d;
@@ -1401,14 +1404,16 @@ __global__ void __launch_bounds__(1024) k_step(const double *x, const double *y,
     mc += y[i] * (g[i] * scale[i]) + diag[i] * y[i] * y[i];
     sn += d * d;
     xn += x[i] * x[i];
+    gm = fmax(gm, fabs(g[i]));
   }
-  s0[tid] = mc, s1[tid] = sn, s2[tid] = xn;
+  s0[tid] = mc, s1[tid] = sn, s2[tid] = xn, s3[tid] = gm;
   __syncthreads();
   for (int st = 512; st > 0; st >>= 1) {
     if (tid < st) {
       s0[tid] += s0[tid + st];
       s1[tid] += s1[tid + st];
       s2[tid] += s2[tid + st];
+      s3[tid] = fmax(s3[tid], s3[tid + st]);
     }
     __syncthreads();
   }
@@ -1416,6 +1421,8 @@ __global__ void __launch_bounds__(1024) k_step(const double *x, const double *y,
     mail[2] = 0.5 * s0[0];
     mail[3] = sqrt(s1[0]);
     mail[4] = sqrt(s2[0]);
+    mail[0] = lin_cost[0];
+    mail[1] = s3[0];
   }
 }
 
@@ -1740,7 +1747,7 @@ int do_allreduce(wc_ctx *ctx, wc_window_state *W, double *d_buf, size_t count) {
 }
 
 // all kernels of one linearisation at x (device): partials -> H, g ; cost -> mail[slot], max|g| -> mail[slot+1]
-int enqueue_linearize(wc_ctx *ctx, wc_window_state *W, const double *d_x, int mail_slot) {
+int enqueue_linearize(wc_ctx *ctx, wc_window_state *W, const double *d_x, int mail_slot, bool post = true) {
   hipStream_t st = ctx->stream;
   const Piece *pcs = (const Piece *)W->pieces.p;
   double *partial = (double *)W->partial.p;
@@ -1778,7 +1785,8 @@ int enqueue_linearize(wc_ctx *ctx, wc_window_state *W, const double *d_x, int ma
     WC_TRY(do_allreduce(ctx, W, red, red_count));  // the ONE collective of a linearisation
     k_expand_pairs<<<W->npairs + 1, 144, 0, st>>>(red, W->npairs, W->ns, W->np, lin_H(W), lin_g(W));
   }
-  k_post_reduce<<<1, 1024, 0, st>>>(lin_g(W), lin_cost(W), W->n, (double *)W->mail.p, mail_slot);
+  // (inside the LM loop the next k_step forms cost / max |g| of this linearisation itself: post = false)
+  if (post) k_post_reduce<<<1, 1024, 0, st>>>(lin_g(W), lin_cost(W), W->n, (double *)W->mail.p, mail_slot);
   WC_HIP(ctx, hipGetLastError());
   return WC_OK;
 }
@@ -1934,7 +1942,7 @@ extern "C" int wc_window_solve(wc_ctx *ctx, double *h_x_inout, wc_solve_summary 
           hi = lo;
         }
       }
-      k_step<<<1, 1024, 0, st>>>(x, y, scale, g, diag, n, xc, mail, h_stage_dev);
+      k_step<<<1, 1024, 0, st>>>(x, y, scale, g, diag, n, xc, mail, h_stage_dev, lin_cost(W));
       WC_TRY(enqueue_evaluate(ctx, W, xc, nullptr, 5, h_mail_dev));
       WC_HIP(ctx, hipGetLastError());
       // (one GPU: k_sum_blocks has stored the mailbox to pinned host memory itself; with an all-reduce behind it, copy)
@@ -1981,7 +1989,7 @@ extern "C" int wc_window_solve(wc_ctx *ctx, double *h_x_inout, wc_solve_summary 
       if (rho > 1e-3) {  // HandleSuccessfulStep
         std::swap(W->x, W->xc);
         x = (double *)W->x.p, xc = (double *)W->xc.p;
-        WC_TRY(enqueue_linearize(ctx, W, x, 0));
+        WC_TRY(enqueue_linearize(ctx, W, x, 0, /*post=*/false));
         // the accepted point = the candidate k_step staged in pinned memory (|x| and the best point are host state)
         std::memcpy(cur.data(), ctx->h_mail + 64, (size_t)n * 8);
         x_norm = 0.0;
@@ -2000,7 +2008,8 @@ extern "C" int wc_window_solve(wc_ctx *ctx, double *h_x_inout, wc_solve_summary 
       }
     }
   }
-  if (lin_pending) {  // the last accepted point's linearisation is still in flight
+  if (lin_pending) {  // the last accepted point's linearisation is still in flight (and no k_step follows it)
+    k_post_reduce<<<1, 1024, 0, st>>>(lin_g(W), lin_cost(W), W->n, mail, 0);
     WC_HIP(ctx, hipMemcpyAsync(ctx->h_mail, mail, 2 * 8, hipMemcpyDeviceToHost, st));
     WC_HIP(ctx, hipStreamSynchronize(st));
     resolve_pending();
