@@ -44,6 +44,7 @@ struct wc_ctx {
     bool general;
     bool order_general = false;  // this call orders the surfels with the radix sort (a time bin overflowed)
     int general_calls = 0;       // upcoming calls that start on the radix-sort path right away
+    bool bucket_attr_set = false;  // hipFuncSetAttribute(k_pt_bucket) done on this ctx's device
     uint32_t lds_cap = 256;      // runs per bucket k_pt_bucket sorts in LDS (256 / 512 / 1024, grows with the data)
     bool unordered = false;      // the previous sweep had (almost) no run structure: stream with k_roots_banks
     uint32_t last_splits = 256;  // roots the previous call queued for the layer-2 pass (sizes / gates that launch)
@@ -62,6 +63,22 @@ struct wc_ctx {
   // optional per-stage HIP events of the extraction pipeline (wc_extract_profile)
   bool ex_prof = false;
   hipEvent_t ex_ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+};
+
+// Every extern "C" entry point runs on the ctx's device whatever the calling thread's current device is (a ctx created
+// for device 1 and driven from a thread whose current device is 0 would otherwise allocate scratch on GPU 0 and launch
+// kernels on a stream of GPU 1); the thread's previous device is restored on return.
+struct wc_dev_guard {
+  int prev = -1;
+  bool switched = false;
+  explicit wc_dev_guard(const wc_ctx *ctx) {
+    if (ctx && hipGetDevice(&prev) == hipSuccess && prev != ctx->device) switched = hipSetDevice(ctx->device) == hipSuccess;
+  }
+  ~wc_dev_guard() {
+    if (switched) (void)hipSetDevice(prev);
+  }
+  wc_dev_guard(const wc_dev_guard &) = delete;
+  wc_dev_guard &operator=(const wc_dev_guard &) = delete;
 };
 
 inline int wc_fail(wc_ctx *ctx, int code, const char *fmt, ...) {

@@ -67,6 +67,14 @@ extern "C" int wc_ctx_create(const wc_params *params, int device, wc_ctx **out) 
     delete ctx;
     return rc;
   }
+  int prev_dev = -1;
+  (void)hipGetDevice(&prev_dev);
+  struct Restore {
+    int d;
+    ~Restore() {
+      if (d >= 0) (void)hipSetDevice(d);
+    }
+  } restore{prev_dev};
   if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess ||
       hipHostMalloc((void **)&ctx->h_status, 64 * sizeof(uint32_t)) != hipSuccess ||
@@ -82,6 +90,7 @@ extern "C" int wc_ctx_create(const wc_params *params, int device, wc_ctx **out) 
 void wc_window_free(wc_ctx *ctx);  // window.hip
 
 extern "C" void wc_ctx_destroy(wc_ctx *ctx) {
+  wc_dev_guard dg_(ctx);
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
@@ -107,70 +116,81 @@ extern "C" void wc_ctx_destroy(wc_ctx *ctx) {
 extern "C" const char *wc_last_error(const wc_ctx *ctx) { return ctx ? ctx->err.c_str() : "no context"; }
 
 extern "C" int wc_ctx_set_stream(wc_ctx *ctx, void *hip_stream) {
-  if (!ctx) return WC_ERR_ARG;
+  wc_dev_guard dg_(ctx);
+  if (!ctx) return wc_fail(ctx, WC_ERR_ARG, "%s: null or out-of-range argument", __func__);
   WC_HIP(ctx, hipStreamSynchronize(ctx->stream));
   ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
   return WC_OK;
 }
 
 extern "C" int wc_ctx_set_params(wc_ctx *ctx, const wc_params *params) {
-  if (!ctx || !params) return WC_ERR_ARG;
+  wc_dev_guard dg_(ctx);
+  if (!ctx || !params) return wc_fail(ctx, WC_ERR_ARG, "%s: null or out-of-range argument", __func__);
   WC_TRY(check_params(ctx, params));
   ctx->P = *params;
   return WC_OK;
 }
 
 extern "C" int wc_dev_alloc(wc_ctx *ctx, size_t bytes, void **d_ptr) {
-  if (!ctx || !d_ptr) return WC_ERR_ARG;
+  wc_dev_guard dg_(ctx);
+  if (!ctx || !d_ptr) return wc_fail(ctx, WC_ERR_ARG, "%s: null or out-of-range argument", __func__);
   WC_HIP(ctx, hipSetDevice(ctx->device));
   WC_HIP(ctx, hipMalloc(d_ptr, bytes ? bytes : 1));
   return WC_OK;
 }
 extern "C" int wc_dev_free(wc_ctx *ctx, void *d_ptr) {
-  if (!ctx) return WC_ERR_ARG;
+  wc_dev_guard dg_(ctx);
+  if (!ctx) return wc_fail(ctx, WC_ERR_ARG, "%s: null or out-of-range argument", __func__);
   WC_HIP(ctx, hipStreamSynchronize(ctx->stream));
   WC_HIP(ctx, hipFree(d_ptr));
   return WC_OK;
 }
 extern "C" int wc_h2d(wc_ctx *ctx, void *d_dst, const void *h_src, size_t bytes) {
-  if (!ctx) return WC_ERR_ARG;
+  wc_dev_guard dg_(ctx);
+  if (!ctx) return wc_fail(ctx, WC_ERR_ARG, "%s: null or out-of-range argument", __func__);
   if (!bytes) return WC_OK;
   WC_HIP(ctx, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
   WC_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return WC_OK;
 }
 extern "C" int wc_d2h(wc_ctx *ctx, void *h_dst, const void *d_src, size_t bytes) {
-  if (!ctx) return WC_ERR_ARG;
+  wc_dev_guard dg_(ctx);
+  if (!ctx) return wc_fail(ctx, WC_ERR_ARG, "%s: null or out-of-range argument", __func__);
   if (!bytes) return WC_OK;
   WC_HIP(ctx, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
   WC_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return WC_OK;
 }
 extern "C" int wc_d2d(wc_ctx *ctx, void *d_dst, const void *d_src, size_t bytes) {
-  if (!ctx) return WC_ERR_ARG;
+  wc_dev_guard dg_(ctx);
+  if (!ctx) return wc_fail(ctx, WC_ERR_ARG, "%s: null or out-of-range argument", __func__);
   if (!bytes) return WC_OK;
   WC_HIP(ctx, hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
   WC_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return WC_OK;
 }
 extern "C" int wc_memset(wc_ctx *ctx, void *d_dst, int value, size_t bytes) {
-  if (!ctx) return WC_ERR_ARG;
+  wc_dev_guard dg_(ctx);
+  if (!ctx) return wc_fail(ctx, WC_ERR_ARG, "%s: null or out-of-range argument", __func__);
   if (!bytes) return WC_OK;
   WC_HIP(ctx, hipMemsetAsync(d_dst, value, bytes, ctx->stream));
   return WC_OK;
 }
 extern "C" int wc_sync(wc_ctx *ctx) {
-  if (!ctx) return WC_ERR_ARG;
+  wc_dev_guard dg_(ctx);
+  if (!ctx) return wc_fail(ctx, WC_ERR_ARG, "%s: null or out-of-range argument", __func__);
   WC_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return WC_OK;
 }
 extern "C" int wc_timer_start(wc_ctx *ctx) {
-  if (!ctx) return WC_ERR_ARG;
+  wc_dev_guard dg_(ctx);
+  if (!ctx) return wc_fail(ctx, WC_ERR_ARG, "%s: null or out-of-range argument", __func__);
   WC_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
   return WC_OK;
 }
 extern "C" int wc_timer_stop_ms(wc_ctx *ctx, float *h_ms) {
-  if (!ctx || !h_ms) return WC_ERR_ARG;
+  wc_dev_guard dg_(ctx);
+  if (!ctx || !h_ms) return wc_fail(ctx, WC_ERR_ARG, "%s: null or out-of-range argument", __func__);
   WC_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
   WC_HIP(ctx, hipEventSynchronize(ctx->ev1));
   WC_HIP(ctx, hipEventElapsedTime(h_ms, ctx->ev0, ctx->ev1));

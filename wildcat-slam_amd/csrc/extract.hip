@@ -53,6 +53,7 @@ struct ExParams {
   double gap;
   int cluster_min;
   uint64_t t_lo_bits;  // ordered bits of the time hint lower bound
+  uint64_t t_span_bits;  // ordered bits of the upper bound - t_lo_bits
   int dbg;             // WC_DEBUG_SKIP bits (profiling experiments only)
 };
 
@@ -258,6 +259,7 @@ __device__ __forceinline__ void emit_surfel(const RootsArgs &A, const Pca &rr, u
     key = 0;
   } else {
     key = ob - P.t_lo_bits;
+    if (key > P.t_span_bits) raise_flag(A.status, kFlagTimeRange);  // above the hint: the time order would be wrong
   }
   if (A.slot_counts) {  // fast slot order: drop the surfel into its time bucket right here (k_slot_emit sorts each bucket)
     if (key >> 32) raise_flag(A.status, kFlagTimeRange);
@@ -1708,10 +1710,9 @@ int point_sort_runs(wc_ctx *ctx, const wc_points &pts, double vs, HeadRec *head_
   uint32_t *counts = (uint32_t *)ctx->b_ex_ctrl.p + kCtrlCounts;  // run counts | point counts | root_cnt | root_first
   const unsigned tiles = (unsigned)((n + kTile - 1) / kTile);
   const size_t lds = (size_t)4 * lds_cap * 20;
-  static bool attr_set = false;
-  if (!attr_set) {
+  if (!ctx->ex.bucket_attr_set) {  // per ctx (= per device), not per process
     WC_HIP(ctx, hipFuncSetAttribute((const void *)k_pt_bucket, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(4 * kPtBinMax * 20)));
-    attr_set = true;
+    ctx->ex.bucket_attr_set = true;
   }
   k_pt_runs<<<tiles, kRunThreads, 0, st>>>(pts, vs, n, counts, (uint64_t *)ctx->b_misc[1].p, cap, status);
   k_pt_bucket<<<kBuckets / 4, 256, lds, st>>>((uint64_t *)ctx->b_misc[1].p, cap, lds_cap, counts, (uint32_t *)ctx->b_misc[3].p, head_slots,
@@ -1800,6 +1801,7 @@ int run_pipeline(wc_ctx *ctx, const wc_points &pts, double t_lo, double t_hi, wc
   E.t_lo_bits = ordered_bits_host(t_lo);
   E.dbg = getenv("WC_DEBUG_SKIP") ? atoi(getenv("WC_DEBUG_SKIP")) : 0;
   const uint64_t span = ordered_bits_host(t_hi) - E.t_lo_bits;
+  E.t_span_bits = span;
   unsigned tbits = 1;
   while (tbits < 64 && (span >> tbits)) ++tbits;
   const unsigned slot_end_bit = tbits >= 63 ? 64 : tbits + 1;  // one extra bit so that ~0 (invalid) sorts last
@@ -1925,7 +1927,8 @@ int run_pipeline(wc_ctx *ctx, const wc_points &pts, double t_lo, double t_hi, wc
 }  // namespace
 
 extern "C" int wc_voxel_keys(wc_ctx *ctx, const wc_points *pts, int32_t *d_keys_xyz) {
-  if (!ctx || !pts || !d_keys_xyz) return WC_ERR_ARG;
+  wc_dev_guard dg_(ctx);
+  if (!ctx || !pts || !d_keys_xyz) return wc_fail(ctx, WC_ERR_ARG, "%s: null or out-of-range argument", __func__);
   if (pts->n == 0) return WC_OK;
   k_voxel_keys<<<(unsigned)((pts->n + 255) / 256), 256, 0, ctx->stream>>>(*pts, (double)ctx->P.voxel_size, d_keys_xyz);
   WC_HIP(ctx, hipGetLastError());
@@ -1935,7 +1938,8 @@ extern "C" int wc_voxel_keys(wc_ctx *ctx, const wc_points *pts, int32_t *d_keys_
 
 extern "C" int wc_extract_surfels_enqueue(wc_ctx *ctx, const wc_points *pts, double t_lo, double t_hi, wc_surfel *d_out,
                                           wc_surfel_id *d_ids, uint64_t cap) {
-  if (!ctx || !pts) return WC_ERR_ARG;
+  wc_dev_guard dg_(ctx);
+  if (!ctx || !pts) return wc_fail(ctx, WC_ERR_ARG, "%s: null or out-of-range argument", __func__);
   if (pts->n >= (1ull << 32)) return wc_fail(ctx, WC_ERR_ARG, "at most 2^32-1 points per call");
   ctx->ex.active = true;
   ctx->ex.pts = *pts;
@@ -1953,6 +1957,15 @@ extern "C" int wc_extract_surfels_enqueue(wc_ctx *ctx, const wc_points *pts, dou
     t_lo = ctx->h_mail[0];
     t_hi = ctx->h_mail[1];
   }
+  {
+    // A surfel's timestamp is sum(t) / n formed in fp64 (surfel_extraction.cc:36-51): with epoch-sized stamps the running sum
+    // rounds at ~1e-5 s, so the mean of a cluster can fall a little outside [first, last] point time.  The hint is widened
+    // by 4096 ulp of the larger bound (1 ms at 1.6e9 s) on both sides; a surfel outside the widened range is an error.
+    const double mag = std::max(std::fabs(t_lo), std::fabs(t_hi));
+    const double m = 4096.0 * (std::nextafter(mag, INFINITY) - mag);
+    t_lo -= m;
+    t_hi += m;
+  }
   ctx->ex.t_lo = t_lo;
   ctx->ex.t_hi = t_hi;
   // after a bin overflow of the run-binned point sort (very many points in few voxels, or points in no spatial order)
@@ -1964,7 +1977,8 @@ extern "C" int wc_extract_surfels_enqueue(wc_ctx *ctx, const wc_points *pts, dou
 }
 
 extern "C" int wc_extract_surfels_finish(wc_ctx *ctx, uint64_t *h_n_out) {
-  if (!ctx || !ctx->ex.active) return WC_ERR_ARG;
+  wc_dev_guard dg_(ctx);
+  if (!ctx || !ctx->ex.active) return wc_fail(ctx, WC_ERR_ARG, "%s: null or out-of-range argument", __func__);
   ctx->ex.active = false;
   if (h_n_out) *h_n_out = 0;
   if (ctx->ex.pts.n == 0) return WC_OK;
@@ -2021,7 +2035,7 @@ extern "C" int wc_extract_surfels_finish(wc_ctx *ctx, uint64_t *h_n_out) {
   if (clear_ctrl(ctx) == WC_OK) ctx->ex.precleared = true;
   if (flags & kFlagKeyRange) return wc_fail(ctx, WC_ERR_ARG, "point cloud extent exceeds 2^20 root voxels");
   if (flags & kFlagSlotOverflow) return wc_fail(ctx, WC_ERR_HIP, "internal: candidate slot overflow");
-  if (flags & kFlagTimeRange) return wc_fail(ctx, WC_ERR_ARG, "surfel timestamp below the t_lo hint");
+  if (flags & kFlagTimeRange) return wc_fail(ctx, WC_ERR_ARG, "surfel timestamp outside the [t_lo, t_hi] hint");
   if (n_out > ctx->ex.cap) return wc_fail(ctx, WC_ERR_CAPACITY, "output capacity %llu < %u surfels",
                                           (unsigned long long)ctx->ex.cap, n_out);
   return WC_OK;
@@ -2029,12 +2043,14 @@ extern "C" int wc_extract_surfels_finish(wc_ctx *ctx, uint64_t *h_n_out) {
 
 extern "C" int wc_extract_surfels(wc_ctx *ctx, const wc_points *pts, double t_lo, double t_hi, wc_surfel *d_out,
                                   wc_surfel_id *d_ids, uint64_t cap, uint64_t *h_n_out) {
+  wc_dev_guard dg_(ctx);
   WC_TRY(wc_extract_surfels_enqueue(ctx, pts, t_lo, t_hi, d_out, d_ids, cap));
   return wc_extract_surfels_finish(ctx, h_n_out);
 }
 
 extern "C" int wc_extract_profile(wc_ctx *ctx, int enable) {
-  if (!ctx) return WC_ERR_ARG;
+  wc_dev_guard dg_(ctx);
+  if (!ctx) return wc_fail(ctx, WC_ERR_ARG, "%s: null or out-of-range argument", __func__);
   if (enable && !ctx->ex_ev[0])
     for (int i = 0; i < 8; ++i) WC_HIP(ctx, hipEventCreate(&ctx->ex_ev[i]));
   ctx->ex_prof = enable != 0;
@@ -2042,14 +2058,16 @@ extern "C" int wc_extract_profile(wc_ctx *ctx, int enable) {
 }
 
 extern "C" int wc_extract_stage_ms(wc_ctx *ctx, float *h_ms5) {
-  if (!ctx || !h_ms5 || !ctx->ex_ev[0]) return WC_ERR_ARG;
+  wc_dev_guard dg_(ctx);
+  if (!ctx || !h_ms5 || !ctx->ex_ev[0]) return wc_fail(ctx, WC_ERR_ARG, "%s: null or out-of-range argument", __func__);
   WC_HIP(ctx, hipEventSynchronize(ctx->ex_ev[5]));
   for (int i = 0; i < 5; ++i) WC_HIP(ctx, hipEventElapsedTime(&h_ms5[i], ctx->ex_ev[i], ctx->ex_ev[i + 1]));
   return WC_OK;
 }
 
-extern "C" int wc_debug_status(wc_ctx *ctx, uint32_t *h_out64) {  // profiling aid: status words [0..16) + section timers
-  if (!ctx || !h_out64 || !ctx->b_ex_ctrl.p) return WC_ERR_ARG;
+extern "C" int wc_debug_status(wc_ctx *ctx, uint32_t *h_out64) {
+  wc_dev_guard dg_(ctx);  // profiling aid: status words [0..16) + section timers
+  if (!ctx || !h_out64 || !ctx->b_ex_ctrl.p) return wc_fail(ctx, WC_ERR_ARG, "%s: null or out-of-range argument", __func__);
   // (the device copy has been cleared for the next call already: words 0..15 come from the host mailbox of the last call)
   for (int i = 0; i < 64; ++i) h_out64[i] = i < 16 ? ctx->h_status[i] : 0u;
 #ifdef WC_PROF_ROOTS

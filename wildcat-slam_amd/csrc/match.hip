@@ -382,10 +382,11 @@ __global__ void __launch_bounds__(256) k_emit_pairs(const uint32_t *choice, cons
 extern "C" int wc_match(wc_ctx *ctx, const wc_surfel *d_q_surf, const wc_pose *d_q_pose, uint64_t nq_, const wc_surfel *d_t_surf,
                         const wc_pose *d_t_pose, uint64_t nt_, int same_set, wc_pair *d_pairs, uint64_t cap, uint64_t *h_n_pairs,
                         uint32_t *d_knn_idx, double *d_knn_d2) {
-  if (!ctx || !h_n_pairs) return WC_ERR_ARG;
+  wc_dev_guard dg_(ctx);
+  if (!ctx || !h_n_pairs) return wc_fail(ctx, WC_ERR_ARG, "%s: null or out-of-range argument", __func__);
   *h_n_pairs = 0;
   if (nt_ == 0 || nq_ == 0) return WC_OK;  // knn_surfel_matcher.cc:18-20
-  if (nq_ >= (1ull << 31) || nt_ >= (1ull << 31)) return WC_ERR_ARG;
+  if (nq_ >= (1ull << 31) || nt_ >= (1ull << 31)) return wc_fail(ctx, WC_ERR_ARG, "%s: null or out-of-range argument", __func__);
   const uint32_t nq = (uint32_t)nq_, nt = (uint32_t)nt_;
   const wc_params &P = ctx->P;
   hipStream_t st = ctx->stream;
@@ -495,15 +496,22 @@ extern "C" int wc_match(wc_ctx *ctx, const wc_surfel *d_q_surf, const wc_pose *d
   uint32_t *flags = (uint32_t *)b_choice.p + 2 * (size_t)nq, *offsets = (uint32_t *)b_choice.p + 3 * (size_t)nq;
   WC_HIP(ctx, hipMemsetAsync(choice[0], 0xFF, (size_t)nq * 4, st));
   int cur = 0;
-  for (int it = 0; it < 1000000; ++it) {
-    WC_HIP(ctx, hipMemsetAsync(changed, 0, 4, st));
-    k_resolve<<<(nq + 255) / 256, 256, 0, st>>>((const uint32_t *)b_gated.p, nq, P.knn_k, same_set, choice[cur], choice[cur ^ 1], changed);
+  // rounds are issued four at a time between host checks (a round past the fixed point changes nothing, so the extra ones
+  // are harmless); round r of a batch reports into changed[r] and only the last word is read back
+  bool converged = false;
+  for (int batch = 0; batch < 250000 && !converged; ++batch) {
+    const int rounds = same_set ? 4 : 1;
+    WC_HIP(ctx, hipMemsetAsync(changed, 0, 16, st));
+    for (int r = 0; r < rounds; ++r) {
+      k_resolve<<<(nq + 255) / 256, 256, 0, st>>>((const uint32_t *)b_gated.p, nq, P.knn_k, same_set, choice[cur], choice[cur ^ 1], changed + r);
+      cur ^= 1;
+    }
     uint32_t hc = 0;
-    WC_HIP(ctx, hipMemcpyAsync(&hc, changed, 4, hipMemcpyDeviceToHost, st));
+    WC_HIP(ctx, hipMemcpyAsync(&hc, changed + rounds - 1, 4, hipMemcpyDeviceToHost, st));
     WC_HIP(ctx, hipStreamSynchronize(st));
-    cur ^= 1;
-    if (!hc || !same_set) break;
+    converged = !hc || !same_set;
   }
+  if (!converged) return wc_fail(ctx, WC_ERR_NUMERIC, "wc_match: the pair de-duplication did not reach its fixed point");
   // 5. compact in query order
   k_flags<<<(nq + 255) / 256, 256, 0, st>>>(choice[cur], nq, flags);
   {

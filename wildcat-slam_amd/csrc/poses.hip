@@ -57,7 +57,8 @@ __global__ void __launch_bounds__(256) k_update_poses(const wc_imu_state *__rest
 
 extern "C" int wc_update_surfel_poses(wc_ctx *ctx, const wc_imu_state *d_imu, uint64_t n_imu, wc_surfel *d_surf,
                                       wc_pose *d_pose, uint8_t *d_in_body, uint64_t n) {
-  if (!ctx || (n && (!d_imu || !d_surf || !d_pose || !d_in_body))) return WC_ERR_ARG;
+  wc_dev_guard dg_(ctx);
+  if (!ctx || (n && (!d_imu || !d_surf || !d_pose || !d_in_body))) return wc_fail(ctx, WC_ERR_ARG, "%s: null or out-of-range argument", __func__);
   if (n == 0) return WC_OK;
   WC_TRY(wc_ensure(ctx, ctx->b_status, 64 * 4));
   uint32_t *status = (uint32_t *)ctx->b_status.p;

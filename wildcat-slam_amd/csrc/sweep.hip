@@ -89,10 +89,11 @@ __global__ void __launch_bounds__(256) k_undistort(const Pt48 *in, uint64_t n, c
 extern "C" int wc_prefilter_points(wc_ctx *ctx, const void *d_pts_in, uint64_t n, const double ext_quat[4], const double ext_t[3],
                                    double min_range, double max_range, const double blind_min[3], const double blind_max[3],
                                    void *d_pts_out, uint64_t cap, uint64_t *h_n_out) {
-  if (!ctx || !h_n_out || (n && (!d_pts_in || !d_pts_out))) return WC_ERR_ARG;
+  wc_dev_guard dg_(ctx);
+  if (!ctx || !h_n_out || (n && (!d_pts_in || !d_pts_out))) return wc_fail(ctx, WC_ERR_ARG, "%s: null or out-of-range argument", __func__);
   *h_n_out = 0;
   if (n == 0) return WC_OK;
-  if (n >= (1ull << 32)) return WC_ERR_ARG;
+  if (n >= (1ull << 32)) return wc_fail(ctx, WC_ERR_ARG, "%s: null or out-of-range argument", __func__);
   hipStream_t st = ctx->stream;
   FilterParams F;
   for (int i = 0; i < 4; ++i) F.q[i] = ext_quat[i];
@@ -122,7 +123,8 @@ extern "C" int wc_prefilter_points(wc_ctx *ctx, const void *d_pts_in, uint64_t n
 }
 
 extern "C" int wc_undistort_sweep(wc_ctx *ctx, const void *d_pts_in, uint64_t n, const wc_imu_state *d_imu, uint64_t n_imu, void *d_pts_out) {
-  if (!ctx || (n && (!d_pts_in || !d_pts_out || !d_imu))) return WC_ERR_ARG;
+  wc_dev_guard dg_(ctx);
+  if (!ctx || (n && (!d_pts_in || !d_pts_out || !d_imu))) return wc_fail(ctx, WC_ERR_ARG, "%s: null or out-of-range argument", __func__);
   if (n == 0) return WC_OK;
   hipStream_t st = ctx->stream;
   WC_TRY(wc_ensure(ctx, ctx->b_status, 64 * 4));

@@ -1531,8 +1531,9 @@ extern "C" int wc_window_build(wc_ctx *ctx, const wc_surfel *d_sld_surf, const w
                                uint64_t n_pairs_sld, const wc_surfel *d_fix_surf, const wc_pose *d_fix_pose,
                                const wc_pair *d_pairs_fix, uint64_t n_pairs_fix, const wc_imu_state *h_imu, uint64_t n_imu,
                                const double *h_sample_times, uint64_t ns_, const double *h_grav, int fix_first_pos) {
-  if (!ctx || !h_sample_times || ns_ < 2 || ns_ > 340 || !h_grav) return WC_ERR_ARG;  // 12 ns <= 4096 unknowns: dense H (134 MB), the largest window the solve has been exercised on; the reference's default window has 82 sample states
-  if (n_pairs_sld >= (1ull << 31) || n_pairs_fix >= (1ull << 31)) return WC_ERR_ARG;
+  wc_dev_guard dg_(ctx);
+  if (!ctx || !h_sample_times || ns_ < 2 || ns_ > 340 || !h_grav) return wc_fail(ctx, WC_ERR_ARG, "%s: null or out-of-range argument", __func__);  // 12 ns <= 4096 unknowns: dense H (134 MB), the largest window the solve has been exercised on; the reference's default window has 82 sample states
+  if (n_pairs_sld >= (1ull << 31) || n_pairs_fix >= (1ull << 31)) return wc_fail(ctx, WC_ERR_ARG, "%s: null or out-of-range argument", __func__);
   WC_HIP(ctx, hipSetDevice(ctx->device));
   if (!ctx->win) ctx->win = new wc_window_state;
   wc_window_state *W = ctx->win;
@@ -1820,14 +1821,16 @@ int read_mail(wc_ctx *ctx, wc_window_state *W, int count) {
 }  // namespace
 
 extern "C" int wc_window_counts(wc_ctx *ctx, uint64_t counts[4]) {
-  if (!ctx || !ctx->win || !ctx->win->built) return WC_ERR_ARG;
+  wc_dev_guard dg_(ctx);
+  if (!ctx || !ctx->win || !ctx->win->built) return wc_fail(ctx, WC_ERR_ARG, "%s: null or out-of-range argument", __func__);
   counts[0] = ctx->win->nb, counts[1] = ctx->win->nu, counts[2] = ctx->win->ni;
   counts[3] = ctx->win->npiece_b + ctx->win->npiece_u + ctx->win->npiece_i;
   return WC_OK;
 }
 
 extern "C" int wc_window_evaluate(wc_ctx *ctx, const double *h_x, double *h_cost, double *d_residuals) {
-  if (!ctx || !ctx->win || !ctx->win->built || !h_x || !h_cost) return WC_ERR_ARG;
+  wc_dev_guard dg_(ctx);
+  if (!ctx || !ctx->win || !ctx->win->built || !h_x || !h_cost) return wc_fail(ctx, WC_ERR_ARG, "%s: null or out-of-range argument", __func__);
   wc_window_state *W = ctx->win;
   WC_HIP(ctx, hipMemcpyAsync(W->x.p, h_x, (size_t)W->n * 8, hipMemcpyHostToDevice, ctx->stream));
   WC_TRY(enqueue_evaluate(ctx, W, (const double *)W->x.p, d_residuals, 0));
@@ -1837,7 +1840,8 @@ extern "C" int wc_window_evaluate(wc_ctx *ctx, const double *h_x, double *h_cost
 }
 
 extern "C" int wc_window_linearize(wc_ctx *ctx, const double *h_x, double *d_H, double *d_g, double *h_cost) {
-  if (!ctx || !ctx->win || !ctx->win->built || !h_x) return WC_ERR_ARG;
+  wc_dev_guard dg_(ctx);
+  if (!ctx || !ctx->win || !ctx->win->built || !h_x) return wc_fail(ctx, WC_ERR_ARG, "%s: null or out-of-range argument", __func__);
   wc_window_state *W = ctx->win;
   WC_HIP(ctx, hipMemcpyAsync(W->x.p, h_x, (size_t)W->n * 8, hipMemcpyHostToDevice, ctx->stream));
   WC_TRY(enqueue_linearize(ctx, W, (const double *)W->x.p, 0));
@@ -1853,7 +1857,8 @@ extern "C" int wc_window_linearize(wc_ctx *ctx, const double *h_x, double *d_H, 
 // it is invoked once per linearisation on the packed buffer {H, g, cost} and once per candidate-cost evaluation on one
 // double.  Every rank then runs the identical, deterministic LM logic on identical numbers.
 extern "C" int wc_window_set_allreduce(wc_ctx *ctx, int (*fn)(void *user, double *d_buf, uint64_t count), void *user) {
-  if (!ctx) return WC_ERR_ARG;
+  wc_dev_guard dg_(ctx);
+  if (!ctx) return wc_fail(ctx, WC_ERR_ARG, "%s: null or out-of-range argument", __func__);
   if (!ctx->win) ctx->win = new wc_window_state;
   ctx->win->allreduce = fn;
   ctx->win->allreduce_user = user;
@@ -1863,7 +1868,8 @@ extern "C" int wc_window_set_allreduce(wc_ctx *ctx, int (*fn)(void *user, double
 // ceres::Solve with the reference's options (lidar_odometry.cc:551-561): Ceres-default trust-region LM restated
 // (upstream semantics, see oracle/window.cc for the per-rule citations).
 extern "C" int wc_window_solve(wc_ctx *ctx, double *h_x_inout, wc_solve_summary *summary, double *h_first_step) {
-  if (!ctx || !ctx->win || !ctx->win->built || !h_x_inout || !summary) return WC_ERR_ARG;
+  wc_dev_guard dg_(ctx);
+  if (!ctx || !ctx->win || !ctx->win->built || !h_x_inout || !summary) return wc_fail(ctx, WC_ERR_ARG, "%s: null or out-of-range argument", __func__);
   wc_window_state *W = ctx->win;
   hipStream_t st = ctx->stream;
   const int n = W->n, np = W->np, ld = W->ld, nblk = np / kNB;

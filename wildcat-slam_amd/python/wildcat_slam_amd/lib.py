@@ -6,6 +6,7 @@ point raises.  (`load()` alone works without a GPU so that the CPU test-suite ca
 import ctypes as C
 import os
 import re
+import weakref
 
 import numpy as np
 
@@ -62,6 +63,7 @@ class DeviceBuffer:
         p = C.c_void_p(0)
         ctx._ck(ctx.lib.wc_dev_alloc(ctx.h, C.c_size_t(max(self.nbytes, 1)), C.byref(p)))
         self.ptr = p.value
+        ctx._bufs.add(self)  # Context.close() frees what is still alive (wc_dev_free needs the live ctx)
 
     def upload(self, arr):
         arr = np.ascontiguousarray(arr)
@@ -75,9 +77,9 @@ class DeviceBuffer:
         return out
 
     def free(self):
-        if self.ptr:
+        if self.ptr and self.ctx.h:
             self.ctx.lib.wc_dev_free(self.ctx.h, C.c_void_p(self.ptr))
-            self.ptr = 0
+        self.ptr = 0
 
     def __del__(self):
         try:
@@ -92,6 +94,7 @@ class Context:
     def __init__(self, device=0, params=None):
         self.lib = load()
         self.params = params or default_params()
+        self._bufs = weakref.WeakSet()
         h = C.c_void_p(0)
         rc = self.lib.wc_ctx_create(C.byref(self.params), C.c_int(device), C.byref(h))
         if rc != WC_OK:
@@ -100,6 +103,8 @@ class Context:
 
     def close(self):
         if getattr(self, "h", None):
+            for b in list(self._bufs):  # buffers outliving the context would leak (wc_dev_free(NULL, p) is an error)
+                b.free()
             self.lib.wc_ctx_destroy(self.h)
             self.h = None
 
