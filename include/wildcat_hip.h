@@ -59,6 +59,16 @@ int wc_sync(wc_ctx *ctx);
 int wc_timer_start(wc_ctx *ctx);
 int wc_timer_stop_ms(wc_ctx *ctx, float *h_ms);
 
+/* known-answer hooks for the library's own math (csrc/dmath.h), so that the reference's KATs (src/common/utils_test.cc:5-21)
+ * run against the product code: on_device != 0 evaluates in a one-thread kernel on the ctx's GPU, on_device == 0 with the
+ * host instantiation of the same header (ctx may be NULL).
+ *   wc_selftest_so3 : out52 = Exp(v) quat (w,x,y,z) | Log(Exp(v)) | Jl | Jl_inv | Jr | Jr_inv | Hat   (3x3 row-major)
+ *   wc_selftest_eig3: a9 symmetric row-major -> out12 = ascending eigenvalues | eigenvectors in columns (row-major)
+ *   wc_selftest_quat: in12 = a(4) b(4) f p(3) -> out11 = slerp(a,f,b) | a*p (rotation) | a*b */
+int wc_selftest_so3(wc_ctx *ctx, const double v[3], int on_device, double out52[52]);
+int wc_selftest_eig3(wc_ctx *ctx, const double a9[9], int on_device, double out12[12]);
+int wc_selftest_quat(wc_ctx *ctx, const double in12[12], int on_device, double out11[11]);
+
 /* surfel extraction --------------------------------------------------------------------------------------------- */
 /* Replaces BuildSurfels(const std::vector<hilti_ros::Point>&, std::deque<Surfel::Ptr>&, GlobalMap&)
  * (src/odometry/surfel_extraction.h:145-147, .cc:316-337; call site lidar_odometry.cc:523-525).

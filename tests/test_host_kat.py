@@ -1,0 +1,173 @@
+"""The reference's own known-answer tests, run against the PRODUCT code (not the oracle):
+
+* csrc/dmath.h  — host instantiation inside libwildcat_hip.so (hipcc) and inside the facade library (g++) here; the device
+  instantiation in tests/test_kat_gpu.py                                      src/common/utils_test.cc:5-21
+* the facade's CubicBSpline (host/cubic_bspline.h)                            src/odometry/spline_interpolation_test.cc:79-96
+                                                                              + scripts/CubicBSpline3D.ipynb golden
+* the facade-side ImuResampler (host/imu_resampler.h)                         src/sensor/imu_resampler_test.cc:7-31
+"""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+from wildcat_slam_amd import lib
+from wildcat_slam_amd import records as R
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def is_approx(a, b, prec=1e-12):
+    """Eigen's isApprox: ||a - b||^2 <= prec^2 * min(||a||^2, ||b||^2)"""
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    return np.sum((a - b) ** 2) <= prec**2 * min(np.sum(a**2), np.sum(b**2))
+
+
+@pytest.fixture(scope="module")
+def host():
+    lib.load()
+    so = os.path.join(os.path.dirname(lib.so_path()), "..", "host", "libwildcat_odometry.so")
+    h = C.CDLL(os.path.abspath(so))
+    h.wc_host_resampler_create.restype = C.c_void_p
+    return h
+
+
+def unpack_so3(o):
+    return dict(exp=o[0:4], log_exp=o[4:7], jl=o[7:16].reshape(3, 3), jl_inv=o[16:25].reshape(3, 3), jr=o[25:34].reshape(3, 3),
+                jr_inv=o[34:43].reshape(3, 3), hat=o[43:52].reshape(3, 3))
+
+
+def so3_host_hipcc(v):
+    out = np.zeros(52)
+    rc = lib.load().wc_selftest_so3(C.c_void_p(0), R.ptr(np.ascontiguousarray(v, float)), C.c_int(0), R.ptr(out))
+    assert rc == 0
+    return unpack_so3(out)
+
+
+def so3_host_gxx(host, v):
+    out = np.zeros(52)
+    host.wc_host_so3(R.ptr(np.ascontiguousarray(v, float)), R.ptr(out))
+    return unpack_so3(out)
+
+
+def check_so3_kats(f):
+    """utils_test.cc:5-21 plus the identities the helpers are defined by"""
+    v = np.array([1.0, 2.0, 3.0])
+    r, rm = f(v), f(-v)
+    assert is_approx(r["jl_inv"], np.linalg.inv(r["jl"]))  # TEST(Utils, Jl_Jl_inv)
+    assert is_approx(r["jl"], rm["jr"])  # TEST(Utils, Jl_Jr)
+    assert is_approx(r["jr_inv"], np.linalg.inv(r["jr"]))
+    assert np.array_equal(r["hat"], np.array([[0, -3, 2], [3, 0, -1], [-2, 1, 0]], float))
+    rng = np.random.default_rng(5)
+    for _ in range(100):
+        w = rng.normal(size=3) * rng.choice([1e-12, 1e-3, 1.0, 3.0])
+        if np.linalg.norm(w) > 3.1:
+            continue
+        o = f(w)
+        assert abs(np.linalg.norm(o["exp"]) - 1) < 1e-14
+        assert np.allclose(o["log_exp"], w, rtol=1e-10, atol=1e-15)
+        # Jl is the left Jacobian of Exp: Exp(w + d) ~ Exp(Jl d) Exp(w)
+        if 1e-2 < np.linalg.norm(w):
+            d = 1e-6 * rng.normal(size=3)
+            th = np.linalg.norm(w)
+            a = w / th
+            jl = np.sin(th) / th * np.eye(3) + (1 - np.sin(th) / th) * np.outer(a, a) + (1 - np.cos(th)) / th * o["hat"] / th
+            assert np.abs(jl - o["jl"]).max() < 1e-13
+
+
+def test_dmath_so3_kats_hipcc_host_instantiation():
+    check_so3_kats(so3_host_hipcc)
+
+
+def test_dmath_so3_kats_gxx_host_instantiation(host):
+    check_so3_kats(lambda v: so3_host_gxx(host, v))
+
+
+def test_dmath_host_matches_oracle_math(oracle, host):
+    """same formulas, three compilers' worth of code: the oracle's math3.h is an independent restatement"""
+    rng = np.random.default_rng(9)
+    for _ in range(50):
+        v = rng.normal(size=3)
+        a, b = so3_host_hipcc(v), so3_host_gxx(host, v)
+        for k in a:
+            assert np.allclose(a[k], b[k], rtol=0, atol=4e-16 * max(1.0, np.abs(a[k]).max()))
+        assert np.allclose(a["jl"], oracle.so3_jl(v), atol=1e-15)
+        assert np.allclose(a["jl_inv"], oracle.so3_jl_inv(v), atol=1e-14)
+        assert np.allclose(a["exp"], oracle.so3_exp(v), atol=1e-16)
+
+
+def test_dmath_eig3_host_against_lapack():
+    rng = np.random.default_rng(1)
+    f = lib.load().wc_selftest_eig3
+    for _ in range(300):
+        a = rng.normal(size=(3, 3))
+        a = a @ a.T * 10 ** rng.uniform(-6, 2)
+        out = np.zeros(12)
+        assert f(C.c_void_p(0), R.ptr(np.ascontiguousarray(a)), C.c_int(0), R.ptr(out)) == 0
+        ev, v = out[:3], out[3:].reshape(3, 3)
+        ev2 = np.linalg.eigvalsh(a)
+        assert np.abs(ev - ev2).max() <= 4e-15 * ev2.max()
+        assert np.abs(a @ v - v * ev).max() <= 1e-14 * ev2.max()
+
+
+def bspline(host, ts, p, q):
+    ts, p, q = (np.ascontiguousarray(x, float) for x in (ts, p, q))
+    out, valid, ctrl = np.zeros((len(q), 3)), np.zeros(len(q), np.uint8), np.zeros((len(ts), 3))
+    host.wc_host_bspline_fit_eval(R.ptr(ts), R.ptr(p), C.c_uint64(len(ts)), R.ptr(q), C.c_uint64(len(q)), R.ptr(out), R.ptr(valid), R.ptr(ctrl))
+    return out, valid.astype(bool), ctrl
+
+
+def test_facade_bspline_knot_reproduction(host):
+    # src/odometry/spline_interpolation_test.cc:79-96, against the class UpdateImuPoses uses
+    ts = np.array([0.3, 0.4, 0.5, 0.6, 0.7, 0.8, 0.9, 1.0])
+    p = np.array([1, 1, 1, 2, 3, 2, 4, 5, 5, 6, 6, 3, 5, 4, 1, 6, 7, 1, 9, 9, 8, 12, 15, 11], float).reshape(8, 3)
+    out, valid, _ = bspline(host, ts, p, ts)
+    assert valid.all()
+    for i in range(8):
+        assert is_approx(out[i], p[i], 1e-6)
+    _, valid, _ = bspline(host, ts, p, np.array([0.29, 1.01]))
+    assert not valid.any()  # Interp returns nullptr outside the knot range (spline_interpolation.h:52-54)
+
+
+def test_facade_bspline_against_notebook_golden(host, oracle):
+    g = json.load(open(os.path.join(HERE, "golden", "bspline_notebook.json")))
+    p = np.array(g["p"], float)
+    f = np.array(g["index_f"])
+    ts = np.arange(8, dtype=float)  # index_f = t + 1 for these knots
+    out, valid, ctrl = bspline(host, ts, p, f - 1.0)
+    assert valid.all()
+    assert np.abs(out - np.array(g["curve"])).max() < 1e-9
+    assert np.abs(ctrl - np.array(g["Q"], float).reshape(ctrl.shape)).max() < 1e-9  # control points of the notebook's fit
+    # and the oracle's restatement agrees with the facade's class on random data
+    rng = np.random.default_rng(2)
+    ts = 0.08 * np.arange(40) + 1.6e9
+    p = rng.normal(size=(40, 3)) * 1e-2
+    q = rng.uniform(ts[0], ts[-1], 500)
+    a, va, _ = bspline(host, ts, p, q)
+    b, vb = oracle.bspline_fit_eval(ts, p, q)
+    assert np.array_equal(va, vb.astype(bool)) and np.abs(a - b).max() < 1e-12
+
+
+def test_imu_resampler_kat(host):
+    # src/sensor/imu_resampler_test.cc:7-31
+    h = C.c_void_p(host.wc_host_resampler_create(C.c_int(10)))
+    acc1, gyr1 = np.array([1.0, 2, 3]), np.array([435.0, 342, 434])
+    acc2, gyr2 = np.array([11.0, 234, 453]), np.array([234.0, 46, 32])
+    host.wc_host_resampler_add(h, C.c_double(0), R.ptr(acc1), R.ptr(gyr1))
+    out = np.zeros(7)
+    assert host.wc_host_resampler_advance(h, R.ptr(out)) == 0  # one sample only: nothing due yet
+    host.wc_host_resampler_add(h, C.c_double(1), R.ptr(acc2), R.ptr(gyr2))
+    assert host.wc_host_resampler_advance(h, R.ptr(out)) == 1 and out[0] == 0
+    assert host.wc_host_resampler_advance(h, R.ptr(out)) == 1 and out[0] == 0.1
+    assert host.wc_host_resampler_advance(h, R.ptr(out)) == 1 and out[0] == 0.2
+    assert is_approx(out[4:7], 0.8 * gyr1 + 0.2 * gyr2) and is_approx(out[1:4], 0.8 * acc1 + 0.2 * acc2)
+    # the grid runs on until it leaves [older, newer]; then nothing is due until a newer raw sample arrives
+    n = 3
+    while host.wc_host_resampler_advance(h, R.ptr(out)) == 1:
+        n += 1
+    assert n in (10, 11) and out[0] <= 1.0 + 1e-12
+    host.wc_host_resampler_add(h, C.c_double(2), R.ptr(acc1), R.ptr(gyr1))
+    assert host.wc_host_resampler_advance(h, R.ptr(out)) == 1 and 1.0 <= out[0] <= 1.1 + 1e-12
+    host.wc_host_resampler_destroy(h)

@@ -1,0 +1,61 @@
+"""The reference's SO(3) known-answer tests (src/common/utils_test.cc:5-21) against the DEVICE instantiation of
+csrc/dmath.h — the code the kernels run — through the C-ABI self-test entry points."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from test_host_kat import check_so3_kats, unpack_so3
+from wildcat_slam_amd import records as R
+
+pytestmark = pytest.mark.gpu
+
+
+def so3_device(gpu, v):
+    out = np.zeros(52)
+    gpu._ck(gpu.lib.wc_selftest_so3(gpu.h, R.ptr(np.ascontiguousarray(v, float)), C.c_int(1), R.ptr(out)))
+    return unpack_so3(out)
+
+
+def test_dmath_so3_kats_on_the_device(gpu):
+    check_so3_kats(lambda v: so3_device(gpu, v))
+
+
+def test_device_and_host_instantiations_agree(gpu, oracle):
+    rng = np.random.default_rng(11)
+    for _ in range(30):
+        v = rng.normal(size=3) * rng.choice([1e-11, 1e-2, 1.0])
+        d = so3_device(gpu, v)
+        out = np.zeros(52)
+        assert gpu.lib.wc_selftest_so3(C.c_void_p(0), R.ptr(np.ascontiguousarray(v)), C.c_int(0), R.ptr(out)) == 0
+        h = unpack_so3(out)
+        for k in d:  # device libm (ocml) vs glibc: a few ulp
+            assert np.allclose(d[k], h[k], rtol=0, atol=8e-16 * max(1.0, np.abs(h[k]).max())), k
+        assert np.allclose(d["jl"], oracle.so3_jl(v), atol=1e-14)
+
+
+def test_eig3_and_quaternions_on_the_device(gpu):
+    rng = np.random.default_rng(4)
+    for _ in range(100):
+        a = rng.normal(size=(3, 3))
+        a = a @ a.T * 10 ** rng.uniform(-6, 2)
+        out = np.zeros(12)
+        gpu._ck(gpu.lib.wc_selftest_eig3(gpu.h, R.ptr(np.ascontiguousarray(a)), C.c_int(1), R.ptr(out)))
+        ev, v = out[:3], out[3:].reshape(3, 3)
+        ev2 = np.linalg.eigvalsh(a)
+        assert np.abs(ev - ev2).max() <= 4e-15 * ev2.max()
+        assert np.abs(a @ v - v * ev).max() <= 1e-14 * ev2.max()
+    for _ in range(50):
+        qa, qb = rng.normal(size=4), rng.normal(size=4)
+        qa, qb = qa / np.linalg.norm(qa), qb / np.linalg.norm(qb)
+        f, p = rng.uniform(), rng.normal(size=3)
+        inp = np.concatenate([qa, qb, [f], p])
+        od, oh = np.zeros(11), np.zeros(11)
+        gpu._ck(gpu.lib.wc_selftest_quat(gpu.h, R.ptr(inp), C.c_int(1), R.ptr(od)))
+        assert gpu.lib.wc_selftest_quat(C.c_void_p(0), R.ptr(inp), C.c_int(0), R.ptr(oh)) == 0
+        assert np.allclose(od, oh, atol=1e-15)
+        # slerp end points and unit rotation
+        w, x, y, z = qa
+        Rm = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)], [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                       [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+        assert np.allclose(od[4:7], Rm @ p, atol=1e-14)

@@ -2,6 +2,8 @@
 // object wildcat_slam_node.cc would drive through its C++ interface.
 #include <cstring>
 
+#include "cubic_bspline.h"
+#include "imu_resampler.h"
 #include "lidar_odometry.h"
 
 extern "C" {
@@ -50,5 +52,58 @@ void wc_odom_stats(void *h, double *stats) {
   stats[5] = o->last_solve().initial_cost;
   stats[6] = o->last_solve().final_cost;
   stats[7] = o->last_solve().termination;
+}
+
+// ---- known-answer hooks for the host-side product code (the g++ instantiation of csrc/dmath.h, the facade's spline, the
+// resampler): the reference's own unit tests are run against these in tests/test_host_kat.py -------------------------------
+
+// utils_test.cc:5-21 inputs -> out52 = Exp(v) | Log(Exp(v)) | Jl | Jl_inv | Jr | Jr_inv | Hat (layout of wc_selftest_so3)
+void wc_host_so3(const double v3[3], double out52[52]) {
+  using namespace wc;
+  const V3 v = mk3(v3[0], v3[1], v3[2]);
+  const Q4 q = so3_exp(v);
+  const V3 l = so3_log(q);
+  double *o = out52;
+  o[0] = q.w, o[1] = q.x, o[2] = q.y, o[3] = q.z, o[4] = l.x, o[5] = l.y, o[6] = l.z;
+  const M3 ms[5] = {so3_Jl(v), so3_Jl_inv(v), so3_Jr(v), so3_Jr_inv(v), hat(v)};
+  for (int m = 0; m < 5; ++m)
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j) o[7 + 9 * m + 3 * i + j] = ms[m].m[i][j];
+}
+
+// CubicBSplineInterpolator(timestamps, points).Interp(t) (spline_interpolation.h:42-113) through the facade's class.
+// ctrl3 (may be NULL) receives the np control points.
+void wc_host_bspline_fit_eval(const double *ts, const double *pts3, uint64_t np, const double *query, uint64_t nq, double *out3,
+                              uint8_t *valid, double *ctrl3) {
+  using namespace wc;
+  std::vector<double> t(ts, ts + np);
+  std::vector<V3> p(np);
+  for (uint64_t i = 0; i < np; ++i) p[i] = mk3(pts3[3 * i], pts3[3 * i + 1], pts3[3 * i + 2]);
+  const CubicBSpline sp(t, p);
+  for (uint64_t i = 0; i < nq; ++i) {
+    V3 o = mk3(0, 0, 0);
+    valid[i] = sp.Interp(query[i], o) ? 1 : 0;
+    out3[3 * i] = o.x, out3[3 * i + 1] = o.y, out3[3 * i + 2] = o.z;
+  }
+  if (ctrl3)
+    for (uint64_t i = 0; i < np; ++i)
+      ctrl3[3 * i] = sp.control_points()[i].x, ctrl3[3 * i + 1] = sp.control_points()[i].y, ctrl3[3 * i + 2] = sp.control_points()[i].z;
+}
+
+void *wc_host_resampler_create(int freq) { return new ImuResampler(freq); }
+void wc_host_resampler_destroy(void *h) { delete (ImuResampler *)h; }
+void wc_host_resampler_add(void *h, double t, const double acc[3], const double gyr[3]) {
+  ImuData d;
+  d.timestamp = t;
+  for (int i = 0; i < 3; ++i) d.linear_acceleration[i] = acc[i], d.angular_velocity[i] = gyr[i];
+  ((ImuResampler *)h)->AddImuData(d);
+}
+// out7 = t, acc, gyr; returns 1 when a resampled measurement was due (the shared_ptr was non-null)
+int wc_host_resampler_advance(void *h, double out7[7]) {
+  const std::shared_ptr<ImuData> r = ((ImuResampler *)h)->AdvanceGetResampledImuData();
+  if (!r) return 0;
+  out7[0] = r->timestamp;
+  for (int i = 0; i < 3; ++i) out7[1 + i] = r->linear_acceleration[i], out7[4 + i] = r->angular_velocity[i];
+  return 1;
 }
 }
