@@ -54,6 +54,8 @@ int wc_h2d(wc_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);
 int wc_d2h(wc_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);
 int wc_d2d(wc_ctx *ctx, void *d_dst, const void *d_src, size_t bytes);
 int wc_memset(wc_ctx *ctx, void *d_dst, int value, size_t bytes);
+/* one field of every record: n elements of elem_bytes, src_stride bytes apart on the device, packed on the host */
+int wc_d2h_strided(wc_ctx *ctx, void *h_dst, const void *d_src, size_t elem_bytes, size_t src_stride, size_t n);
 int wc_sync(wc_ctx *ctx);
 /* HIP-event timing on the ctx stream (used by bench.py: torch.cuda.Event only sees torch's stream) */
 int wc_timer_start(wc_ctx *ctx);
@@ -113,6 +115,12 @@ int wc_undistort_sweep(wc_ctx *ctx, const void *d_pts_in, uint64_t n, const wc_i
  * CHECK at lidar_odometry.cc:164. */
 int wc_update_surfel_poses(wc_ctx *ctx, const wc_imu_state *d_imu, uint64_t n_imu, wc_surfel *d_surf, wc_pose *d_pose,
                            uint8_t *d_in_body, uint64_t n);
+
+/* ShrinkToFit (src/odometry/lidar_odometry.cc:243-246) moves the oldest sliding-window surfels to the fixed window with
+ * push_front, oldest first: the fixed window is kept NEWEST-first.  dst[j] = src[n-1-j]; asynchronous on the
+ * ctx stream. */
+int wc_reverse_copy_surfels(wc_ctx *ctx, const wc_surfel *d_src_surf, const wc_pose *d_src_pose, uint64_t n,
+                            wc_surfel *d_dst_surf, wc_pose *d_dst_pose);
 
 /* correspondence -------------------------------------------------------------------------------------------------- */
 /* Replaces KnnSurfelMatcher::BuildIndex(const std::deque<Surfel::Ptr>&) + Match(std::deque<Surfel::Ptr>&,

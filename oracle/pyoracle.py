@@ -228,3 +228,54 @@ def bspline_fit_eval(timestamps, points, query_t):
 def update_imu_poses(sample_times, x, ba, bg, grav, imu):
     rc = lib().wco_update_imu_poses(R.ptr(_vec(sample_times)), R.ptr(_vec(x)), C.c_uint64(len(sample_times)), R.ptr(_vec(ba)), R.ptr(_vec(bg)), R.ptr(_vec(grav)), R.ptr(imu), C.c_uint64(len(imu)))
     return rc
+
+
+class Odometry:
+    """the orchestrated oracle (oracle/odometry.cc): AddImuData / AddLidarScan of lidar_odometry.cc:487-611 on the oracle stages"""
+
+    def __init__(self):
+        l = lib()
+        l.wco_odom_create.restype = C.c_void_p
+        l.wco_odom_num_samples.restype = C.c_uint64
+        l.wco_odom_window_times.restype = C.c_uint64
+        self._h = C.c_void_p(l.wco_odom_create())
+
+    def close(self):
+        if self._h:
+            lib().wco_odom_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def add_imu(self, t, acc, gyr):
+        a, g = (C.c_double * 3)(*acc), (C.c_double * 3)(*gyr)
+        lib().wco_odom_add_imu(self._h, C.c_double(t), a, g)
+
+    def add_scan(self, points):
+        assert points.dtype == R.POINT
+        points = np.ascontiguousarray(points)
+        lib().wco_odom_add_scan(self._h, R.ptr(points), C.c_uint64(len(points)))
+        err = lib().wco_odom_error(self._h)
+        assert err == 0, f"a reference CHECK would have fired (oracle/odometry.cc:{err})"
+
+    def sweeps(self):
+        return int(lib().wco_odom_sweeps(self._h))
+
+    def samples(self):
+        n = int(lib().wco_odom_num_samples(self._h))
+        out = np.zeros((n, 15))
+        for i in range(n):
+            lib().wco_odom_sample(self._h, C.c_uint64(i), R.ptr(out[i]))
+        return out
+
+    def stats(self):
+        s = np.zeros(10)
+        lib().wco_odom_stats(self._h, R.ptr(s))
+        return dict(zip(("sld_surfels", "fix_surfels", "binary", "unary", "lm_iters", "cost0", "cost1", "termination", "new_surfels", "imu_states"), s.tolist()))
+
+    def window_times(self, fixed):
+        n = int(lib().wco_odom_window_times(self._h, C.c_int(1 if fixed else 0), None, C.c_uint64(0)))
+        out = np.zeros(max(n, 1))
+        lib().wco_odom_window_times(self._h, C.c_int(1 if fixed else 0), R.ptr(out), C.c_uint64(n))
+        return out[:n]

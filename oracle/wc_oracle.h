@@ -100,6 +100,19 @@ int wco_bspline_fit_eval(const double *timestamps, const double *points3, uint64
 int wco_update_imu_poses(const double *sample_times, const double *x, uint64_t ns, const double ba[3],
                          const double bg[3], const double grav[3], wc_imu_state *imu, uint64_t n_imu);
 
+/* ---- the orchestrated odometry (lidar_odometry.cc:365-611): see oracle/odometry.cc ---- */
+typedef struct wco_odom wco_odom;
+wco_odom *wco_odom_create(void);
+void wco_odom_destroy(wco_odom *o);
+int wco_odom_error(const wco_odom *o); /* non-zero: a CHECK of the reference would have aborted */
+void wco_odom_add_imu(wco_odom *o, double t, const double acc[3], const double gyr[3]);  /* AddImuData cc:607-611 */
+void wco_odom_add_scan(wco_odom *o, const void *points48, uint64_t n);                  /* AddLidarScan cc:487-605 */
+int wco_odom_sweeps(const wco_odom *o);
+uint64_t wco_odom_num_samples(const wco_odom *o);
+int wco_odom_sample(const wco_odom *o, uint64_t i, double *out15);
+void wco_odom_stats(const wco_odom *o, double *stats10);
+uint64_t wco_odom_window_times(const wco_odom *o, int fixed, double *out, uint64_t cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -44,3 +44,49 @@ def test_facade_multi_sweep(gpu):
     assert abs(yaw_est - yaw_true) < 0.5 * 0.02 * t_rel
     assert err.max() < 0.25
     odo.close()
+
+
+def test_facade_matches_the_orchestrated_oracle_sweep_by_sweep(gpu, oracle):
+    """the host facade against oracle/odometry.cc (AddLidarScan of lidar_odometry.cc:487-605 restated on the oracle stages):
+    same raw stream into both; after EVERY completed sweep the sample states, window sizes and correspondence counts must
+    agree - sample-state poses to 1e-6.  The stream is long enough (8.2 s > the 6 s sliding window) for ShrinkToFit to move
+    surfels into the fixed window (newest-first order, Q11) and for unary factors to appear."""
+    from wildcat_slam_amd import lib
+
+    msgs, imu, _ = synth.raw_stream(8.2, pts_per_s=150_000, gyro_bias=(0.0, 0.0, 0.02), t_start=1000.0)
+    odo, ref = lib.Odometry(0), oracle.Odometry()
+    k, worst, compared = 0, 0.0, 0
+    for m in msgs:
+        if len(m) == 0:
+            continue
+        t_end = m["time"][-1]
+        while k < len(imu["t"]) and imu["t"][k] <= t_end + 0.02:
+            odo.add_imu(imu["t"][k], imu["acc"][k], imu["gyr"][k])
+            ref.add_imu(imu["t"][k], imu["acc"][k], imu["gyr"][k])
+            k += 1
+        before = ref.sweeps()
+        odo.add_scan(m)
+        ref.add_scan(m)
+        assert odo.sweeps() == ref.sweeps()
+        if ref.sweeps() == before:
+            continue
+        a, b = odo.samples(), ref.samples()
+        sa, sb = odo.stats(), ref.stats()
+        assert a.shape == b.shape and np.array_equal(a[:, 0], b[:, 0])  # same sample states, same timestamps
+        for key in ("sld_surfels", "fix_surfels", "binary", "unary", "lm_iters", "termination"):
+            assert sa[key] == sb[key], (ref.sweeps(), key, sa[key], sb[key])
+        d_pos = np.abs(a[:, 1:4] - b[:, 1:4]).max()
+        d_quat = np.abs(a[:, 4:8] - b[:, 4:8]).max()
+        d_bias = np.abs(a[:, 8:14] - b[:, 8:14]).max()
+        worst = max(worst, d_pos, d_quat, d_bias)
+        assert d_pos <= 1e-6 and d_quat <= 1e-6 and d_bias <= 1e-6, (ref.sweeps(), d_pos, d_quat, d_bias)
+        assert abs(sa["cost1"] - sb["cost1"]) <= 1e-6 * max(1.0, abs(sb["cost1"]))
+        ft = odo.fixed_times()
+        assert np.array_equal(ft, ref.window_times(True))  # same surfels in the same (newest-first) order
+        if len(ft) > 1:
+            assert np.all(np.diff(ft) <= 0)
+        compared += 1
+    print("sweeps compared", compared, "worst sample-state difference", worst, "fixed window", int(sb["fix_surfels"]), "unary", int(sb["unary"]))
+    assert compared >= 15 and sb["fix_surfels"] > 1000 and sb["unary"] > 1000
+    odo.close()
+    ref.close()

@@ -169,6 +169,16 @@ extern "C" int wc_d2d(wc_ctx *ctx, void *d_dst, const void *d_src, size_t bytes)
   WC_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return WC_OK;
 }
+// one field out of every record of an array (e.g. the timestamps of fresh surfels): n elements of elem_bytes, src_stride apart
+extern "C" int wc_d2h_strided(wc_ctx *ctx, void *h_dst, const void *d_src, size_t elem_bytes, size_t src_stride, size_t n) {
+  wc_dev_guard dg_(ctx);
+  if (!ctx || (n && (!h_dst || !d_src)) || elem_bytes == 0 || src_stride < elem_bytes)
+    return wc_fail(ctx, WC_ERR_ARG, "%s: null or out-of-range argument", __func__);
+  if (!n) return WC_OK;
+  WC_HIP(ctx, hipMemcpy2DAsync(h_dst, elem_bytes, d_src, src_stride, elem_bytes, n, hipMemcpyDeviceToHost, ctx->stream));
+  WC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return WC_OK;
+}
 extern "C" int wc_memset(wc_ctx *ctx, void *d_dst, int value, size_t bytes) {
   wc_dev_guard dg_(ctx);
   if (!ctx) return wc_fail(ctx, WC_ERR_ARG, "%s: null or out-of-range argument", __func__);

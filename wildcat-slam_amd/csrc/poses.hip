@@ -53,7 +53,26 @@ __global__ void __launch_bounds__(256) k_update_poses(const wc_imu_state *__rest
     surf[s] = sf;
   }
 }
+// dst[j] = src[n - 1 - j]: a batch of surfels leaving the sliding window oldest-first, each pushed to the FRONT of the fixed
+// window (ShrinkToFit, lidar_odometry.cc:243-246), ends up newest-first
+__global__ void __launch_bounds__(256) k_reverse_copy(const wc_surfel *ss, const wc_pose *sp, uint64_t n, wc_surfel *ds, wc_pose *dp) {
+  const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  ds[j] = ss[n - 1 - j];
+  dp[j] = sp[n - 1 - j];
+}
 }  // namespace
+
+extern "C" int wc_reverse_copy_surfels(wc_ctx *ctx, const wc_surfel *d_src_surf, const wc_pose *d_src_pose, uint64_t n,
+                                       wc_surfel *d_dst_surf, wc_pose *d_dst_pose) {
+  wc_dev_guard dg_(ctx);
+  if (!ctx || (n && (!d_src_surf || !d_src_pose || !d_dst_surf || !d_dst_pose)))
+    return wc_fail(ctx, WC_ERR_ARG, "%s: null or out-of-range argument", __func__);
+  if (n == 0) return WC_OK;
+  k_reverse_copy<<<(unsigned)((n + 255) / 256), 256, 0, ctx->stream>>>(d_src_surf, d_src_pose, n, d_dst_surf, d_dst_pose);
+  WC_HIP(ctx, hipGetLastError());
+  return WC_OK;
+}
 
 extern "C" int wc_update_surfel_poses(wc_ctx *ctx, const wc_imu_state *d_imu, uint64_t n_imu, wc_surfel *d_surf,
                                       wc_pose *d_pose, uint8_t *d_in_body, uint64_t n) {

@@ -74,6 +74,7 @@ LidarOdometry::LidarOdometry(int device) {
   wc_params P;
   wc_params_default(&P);
   P.max_iterations = config_.inner_iter_num_max;
+  P.reference_quirks = config_.reference_quirks ? 1 : 0;
   int rc = wc_ctx_create(&P, device, &ctx_);
   if (rc != WC_OK) {
     std::fprintf(stderr, "[wildcat] FATAL: no MI355X context (rc=%d); there is no CPU fallback\n", rc);
@@ -84,7 +85,7 @@ LidarOdometry::LidarOdometry(int device) {
 
 LidarOdometry::~LidarOdometry() {
   if (!ctx_) return;
-  void *bufs[] = {d_surf_, d_pose_, d_inbody_, d_pairs_sld_, d_pairs_fix_, d_imu_, d_sweep_, d_sweep_raw_};
+  void *bufs[] = {d_surf_, d_pose_, d_inbody_, d_pairs_sld_, d_pairs_fix_, d_imu_, d_sweep_, d_scan_raw_, d_pts_[0], d_pts_[1], d_fix_surf_, d_fix_pose_};
   for (void *b : bufs)
     if (b) wc_dev_free(ctx_, b);
   wc_ctx_destroy(ctx_);
@@ -106,19 +107,21 @@ bool LidarOdometry::sample_state(size_t i, SampleStateView *out) const {
   return true;
 }
 
+// room for n more sliding-window surfels behind n_surfels_; a reallocation drops the dead prefix [0, sld_begin_)
 void LidarOdometry::EnsureSurfelCapacity(size_t n) {
-  if (n <= cap_surfels_) return;
-  const size_t cap = std::max<size_t>(n + n / 2, 1 << 16);
+  if (n_surfels_ + n <= cap_surfels_) return;
+  const size_t live = n_surfels_ - sld_begin_;
+  const size_t cap = std::max<size_t>((live + n) + (live + n) / 2, 1 << 16);
   void *ns = nullptr, *np = nullptr, *nb = nullptr, *p1 = nullptr, *p2 = nullptr;
   WC_CALL(wc_dev_alloc(ctx_, cap * sizeof(wc_surfel), &ns));
   WC_CALL(wc_dev_alloc(ctx_, cap * sizeof(wc_pose), &np));
   WC_CALL(wc_dev_alloc(ctx_, cap, &nb));
   WC_CALL(wc_dev_alloc(ctx_, cap * sizeof(wc_pair), &p1));
   WC_CALL(wc_dev_alloc(ctx_, cap * sizeof(wc_pair), &p2));
-  if (n_surfels_) {
-    WC_CALL(wc_d2d(ctx_, ns, d_surf_, n_surfels_ * sizeof(wc_surfel)));
-    WC_CALL(wc_d2d(ctx_, np, d_pose_, n_surfels_ * sizeof(wc_pose)));
-    WC_CALL(wc_d2d(ctx_, nb, d_inbody_, n_surfels_));
+  if (live) {
+    WC_CALL(wc_d2d(ctx_, ns, d_surf_ + sld_begin_, live * sizeof(wc_surfel)));
+    WC_CALL(wc_d2d(ctx_, np, d_pose_ + sld_begin_, live * sizeof(wc_pose)));
+    WC_CALL(wc_d2d(ctx_, nb, d_inbody_ + sld_begin_, live));
   }
   void *old[] = {d_surf_, d_pose_, d_inbody_, d_pairs_sld_, d_pairs_fix_};
   for (void *b : old)
@@ -126,20 +129,88 @@ void LidarOdometry::EnsureSurfelCapacity(size_t n) {
   d_surf_ = (wc_surfel *)ns, d_pose_ = (wc_pose *)np, d_inbody_ = (uint8_t *)nb;
   d_pairs_sld_ = (wc_pair *)p1, d_pairs_fix_ = (wc_pair *)p2;
   cap_surfels_ = cap;
+  n_surfels_ = live;
+  sld_begin_ = 0;
+}
+
+// room for `extra` more surfels in FRONT of the fixed window (it is filled from the back of its array)
+void LidarOdometry::EnsureFixedCapacity(size_t extra) {
+  if (extra <= fix_start_) return;
+  const size_t live = fix_end_ - fix_start_;
+  const size_t cap = std::max<size_t>(2 * (live + extra), 1 << 16);
+  void *ns = nullptr, *np = nullptr;
+  WC_CALL(wc_dev_alloc(ctx_, cap * sizeof(wc_surfel), &ns));
+  WC_CALL(wc_dev_alloc(ctx_, cap * sizeof(wc_pose), &np));
+  if (live) {
+    WC_CALL(wc_d2d(ctx_, (wc_surfel *)ns + (cap - live), d_fix_surf_ + fix_start_, live * sizeof(wc_surfel)));
+    WC_CALL(wc_d2d(ctx_, (wc_pose *)np + (cap - live), d_fix_pose_ + fix_start_, live * sizeof(wc_pose)));
+  }
+  if (d_fix_surf_) WC_CALL(wc_dev_free(ctx_, d_fix_surf_));
+  if (d_fix_pose_) WC_CALL(wc_dev_free(ctx_, d_fix_pose_));
+  d_fix_surf_ = (wc_surfel *)ns, d_fix_pose_ = (wc_pose *)np;
+  fix_cap_ = cap, fix_end_ = cap, fix_start_ = cap - live;
+}
+
+// the per-point loop of AddLidarScan (:489-496) on the device: upload the raw message, wc_prefilter_points (extrinsic,
+// range / blind-box filter) appends the survivors to the device-resident points_buff_; only their timestamps come back
+void LidarOdometry::AppendScanOnDevice(const pcl::PointCloud<hilti_ros::Point> &msg) {
+  const size_t n = msg.size();
+  if (n == 0) return;
+  if (n > cap_scan_raw_) {
+    if (d_scan_raw_) WC_CALL(wc_dev_free(ctx_, d_scan_raw_));
+    cap_scan_raw_ = n + n / 2;
+    WC_CALL(wc_dev_alloc(ctx_, cap_scan_raw_ * sizeof(hilti_ros::Point), &d_scan_raw_));
+  }
+  WC_CALL(wc_h2d(ctx_, d_scan_raw_, msg.points.data(), n * sizeof(hilti_ros::Point)));
+  // make room behind pts_end_: consumed points in front are dropped by moving the live range to the other buffer
+  const size_t live = pts_end_ - pts_begin_;
+  if (pts_end_ + n > cap_pts_[pts_cur_]) {
+    const int other = pts_cur_ ^ 1;
+    if (live + n > cap_pts_[other]) {
+      if (d_pts_[other]) WC_CALL(wc_dev_free(ctx_, d_pts_[other]));
+      cap_pts_[other] = 2 * (live + n);
+      WC_CALL(wc_dev_alloc(ctx_, cap_pts_[other] * sizeof(hilti_ros::Point), &d_pts_[other]));
+    }
+    if (live)
+      WC_CALL(wc_d2d(ctx_, d_pts_[other], (const char *)d_pts_[pts_cur_] + pts_begin_ * sizeof(hilti_ros::Point), live * sizeof(hilti_ros::Point)));
+    pts_cur_ = other, pts_begin_ = 0, pts_end_ = live;
+  }
+  uint64_t kept = 0;
+  char *dst = (char *)d_pts_[pts_cur_] + pts_end_ * sizeof(hilti_ros::Point);
+  WC_CALL(wc_prefilter_points(ctx_, d_scan_raw_, n, ext_quat_, config_.ext_translation, config_.min_range, config_.max_range, config_.blind_min,
+                              config_.blind_max, dst, cap_pts_[pts_cur_] - pts_end_, &kept));
+  std::vector<double> kt(kept);
+  WC_CALL(wc_d2h_strided(ctx_, kt.data(), dst + WC_HILTI_POINT_TIME_OFFSET, 8, sizeof(hilti_ros::Point), kept));
+  // CHECK(points_buff_.empty() || pt.time >= points_buff_.back().time) (:491): every incoming point, filtered or not, against
+  // the last BUFFERED point at that moment
+  double prev = point_times_.empty() ? -INFINITY : point_times_.back();
+  size_t k = 0;
+  for (const hilti_ros::Point &pt : msg) {
+    WC_CHECK(pt.time >= prev);
+    if (k < kept && kt[k] == pt.time) prev = pt.time, ++k;
+  }
+  WC_CHECK(k == kept);
+  point_times_.insert(point_times_.end(), kt.begin(), kt.end());
+  pts_end_ += kept;
+}
+
+void LidarOdometry::DropBufferedPoints(size_t k) {
+  pts_begin_ += k;
+  point_times_.erase(point_times_.begin(), point_times_.begin() + (long)k);
 }
 
 // SyncHeadingMsgs (:457-485)
 bool LidarOdometry::SyncHeadingMsgs() {
   if (sync_done_) return true;
-  if (imu_buff_.empty() || points_buff_.empty()) return false;
-  if (imu_buff_.back().timestamp < points_buff_.front().time) return false;
-  while (imu_buff_.front().timestamp < points_buff_.front().time) {
+  if (imu_buff_.empty() || point_times_.empty()) return false;
+  if (imu_buff_.back().timestamp < point_times_.front()) return false;
+  while (imu_buff_.front().timestamp < point_times_.front()) {
     imu_buff_.pop_front();
     WC_CHECK(!imu_buff_.empty());
   }
-  while (points_buff_.front().time < imu_buff_.front().timestamp) {
-    points_buff_.pop_front();
-    WC_CHECK(!points_buff_.empty());
+  while (point_times_.front() < imu_buff_.front().timestamp) {
+    DropBufferedPoints(1);
+    WC_CHECK(!point_times_.empty());
   }
   sync_done_ = true;
   return true;
@@ -265,71 +336,71 @@ void LidarOdometry::UpdateSamplePoses() {  // :172-179
   }
 }
 
-// ShrinkToFit (:228-250).  Surfels live in one time-ordered device array, so moving the oldest sliding-window surfels
-// to the fixed window is an index bump; like the reference (Q11) the fixed window is never trimmed.
+// ShrinkToFit (:228-250).  The oldest sliding-window surfels move to the FRONT of the fixed window, oldest first
+// (push_front, :243-246), so the fixed window is newest-first: one reversed device copy per sweep.  Like the reference
+// (Q11: :247-249 compares back() with itself) the fixed window is never trimmed while reference_quirks is set; without the
+// quirk it is cut to fixed_window_duration from its old end.
 void LidarOdometry::ShrinkToFit() {
   if (samples_.empty() || samples_.back().timestamp - samples_.front().timestamp <= config_.sliding_window_duration) return;
   while (samples_.back().timestamp - samples_.front().timestamp > config_.sliding_window_duration) samples_.pop_front();
   while (imu_states_.front().t < samples_.front().timestamp) imu_states_.pop_front();
-  while (sld_begin_ < n_surfels_ && surfel_times_[sld_begin_] < imu_states_.front().t) ++sld_begin_;
+  size_t k = 0;
+  while (k < surfel_times_.size() && surfel_times_[k] < imu_states_.front().t) ++k;
+  if (k) {
+    EnsureFixedCapacity(k);
+    WC_CALL(wc_reverse_copy_surfels(ctx_, d_surf_ + sld_begin_, d_pose_ + sld_begin_, k, d_fix_surf_ + (fix_start_ - k), d_fix_pose_ + (fix_start_ - k)));
+    WC_CALL(wc_sync(ctx_));
+    fix_start_ -= k;
+    for (size_t i = 0; i < k; ++i) fix_times_.push_front(surfel_times_[i]);
+    surfel_times_.erase(surfel_times_.begin(), surfel_times_.begin() + (long)k);
+    sld_begin_ += k;
+  }
+  if (!config_.reference_quirks)
+    while (!fix_times_.empty() && fix_times_.front() - fix_times_.back() > config_.fixed_window_duration) {
+      fix_times_.pop_back();
+      --fix_end_;
+    }
 }
 
 void LidarOdometry::AddLidarScan(const pcl::PointCloud<hilti_ros::Point>::Ptr &msg) {
-  // lidar frame -> imu frame, range / blind-box filter (:489-496)
-  const Q4 eq = q4(ext_quat_);
-  const V3 et = v3(config_.ext_translation);
-  for (hilti_ros::Point pt : *msg) {
-    const V3 p = qrot(eq, mk3((double)pt.x, (double)pt.y, (double)pt.z)) + et;
-    pt.x = (float)p.x, pt.y = (float)p.y, pt.z = (float)p.z;
-    WC_CHECK(points_buff_.empty() || pt.time >= points_buff_.back().time);
-    const float nrm = std::sqrt(pt.x * pt.x + pt.y * pt.y + pt.z * pt.z);
-    const bool blind = (double)pt.x >= config_.blind_min[0] && (double)pt.x <= config_.blind_max[0] &&
-                       (double)pt.y >= config_.blind_min[1] && (double)pt.y <= config_.blind_max[1] &&
-                       (double)pt.z >= config_.blind_min[2] && (double)pt.z <= config_.blind_max[2];
-    if (nrm < config_.min_range || nrm > config_.max_range || blind) continue;
-    points_buff_.push_back(pt);
-  }
+  // lidar frame -> imu frame, range / blind-box filter (:489-496): on the device, the points stay there
+  AppendScanOnDevice(*msg);
   if (!SyncHeadingMsgs()) return;
 
   // 1. collect scan to sweep (:501-509)
-  double sweep_endtime = points_buff_.front().time + config_.sweep_duration;
-  if (points_buff_.back().time < sweep_endtime || imu_buff_.empty() || imu_buff_.back().timestamp < sweep_endtime) return;
+  double sweep_endtime = point_times_.front() + config_.sweep_duration;
+  if (point_times_.back() < sweep_endtime || imu_buff_.empty() || imu_buff_.back().timestamp < sweep_endtime) return;
 
   // 2. integrate IMU poses in windows (:512-513)
   PredictImuStatesAndSampleStates(sweep_endtime);
   sweep_endtime = samples_.back().timestamp;
-  std::vector<hilti_ros::Point> sweep;  // BuildSweep (:134-141)
-  while (!points_buff_.empty() && points_buff_.front().time < sweep_endtime) {
-    sweep.push_back(points_buff_.front());
-    points_buff_.pop_front();
-  }
-  WC_CHECK(!sweep.empty());
+  size_t n_sweep = 0;  // BuildSweep (:134-141): the leading points with time < sweep_endtime
+  while (n_sweep < point_times_.size() && point_times_[n_sweep] < sweep_endtime) ++n_sweep;
+  WC_CHECK(n_sweep > 0);
+  const double sweep_t0 = point_times_.front(), sweep_t1 = point_times_[n_sweep - 1];
 
-  // 3. undistort sweep by IMU poses (:519-520) — on the device (wc_undistort_sweep replaces UndistortSweep :143-158);
-  //    the undistorted sweep never comes back to the host, extraction reads it where it lies
-  if (sweep.size() > cap_sweep_) {
-    if (d_sweep_raw_) WC_CALL(wc_dev_free(ctx_, d_sweep_raw_));
+  // 3. undistort sweep by IMU poses (:519-520) — wc_undistort_sweep replaces UndistortSweep :143-158; neither the raw nor
+  //    the undistorted sweep ever comes back to the host, extraction reads it where it lies
+  if (n_sweep > cap_sweep_) {
     if (d_sweep_) WC_CALL(wc_dev_free(ctx_, d_sweep_));
-    cap_sweep_ = sweep.size() * 2;
-    WC_CALL(wc_dev_alloc(ctx_, cap_sweep_ * sizeof(hilti_ros::Point), &d_sweep_raw_));
+    cap_sweep_ = n_sweep * 2;
     WC_CALL(wc_dev_alloc(ctx_, cap_sweep_ * sizeof(hilti_ros::Point), &d_sweep_));
   }
-  WC_CALL(wc_h2d(ctx_, d_sweep_raw_, sweep.data(), sweep.size() * sizeof(hilti_ros::Point)));
   UploadImuStates();
-  WC_CALL(wc_undistort_sweep(ctx_, d_sweep_raw_, sweep.size(), d_imu_, imu_states_.size(), d_sweep_));
-  const std::vector<hilti_ros::Point> &und = sweep;  // (only sizes and timestamps are used below)
+  WC_CALL(wc_undistort_sweep(ctx_, (const char *)d_pts_[pts_cur_] + pts_begin_ * sizeof(hilti_ros::Point), n_sweep, d_imu_, imu_states_.size(), d_sweep_));
+  DropBufferedPoints(n_sweep);
 
   // 4. ---- hot path: extract surfels, attach poses (:523-527) ----
-  const size_t max_new = (3 * und.size()) / 20 + 1;
-  EnsureSurfelCapacity(n_surfels_ + max_new);
-  wc_points desc{d_sweep_, (const char *)d_sweep_ + WC_HILTI_POINT_TIME_OFFSET, WC_HILTI_POINT_BYTES, WC_HILTI_POINT_BYTES, und.size()};
+  const size_t max_new = (3 * n_sweep) / 20 + 1;
+  EnsureSurfelCapacity(max_new);
+  wc_points desc{d_sweep_, (const char *)d_sweep_ + WC_HILTI_POINT_TIME_OFFSET, WC_HILTI_POINT_BYTES, WC_HILTI_POINT_BYTES, n_sweep};
   uint64_t n_new = 0;
-  WC_CALL(wc_extract_surfels(ctx_, &desc, und.front().time, und.back().time, d_surf_ + n_surfels_, nullptr, max_new, &n_new));
+  WC_CALL(wc_extract_surfels(ctx_, &desc, sweep_t0, sweep_t1, d_surf_ + n_surfels_, nullptr, max_new, &n_new));
   if (n_new) {
     WC_CALL(wc_memset(ctx_, d_inbody_ + n_surfels_, 0, n_new));
-    std::vector<wc_surfel> fresh(n_new);
-    WC_CALL(wc_d2h(ctx_, fresh.data(), d_surf_ + n_surfels_, n_new * sizeof(wc_surfel)));
-    for (const wc_surfel &s : fresh) surfel_times_.push_back(s.t);
+    std::vector<double> fresh(n_new);  // only the timestamps travel (8 of 144 bytes per surfel)
+    WC_CALL(wc_d2h_strided(ctx_, fresh.data(), d_surf_ + n_surfels_, 8, sizeof(wc_surfel), n_new));
+    surfel_times_.insert(surfel_times_.end(), fresh.begin(), fresh.end());
     n_surfels_ += n_new;
   }
   UpdateSurfelPosesOnDevice();
@@ -340,8 +411,9 @@ void LidarOdometry::AddLidarScan(const pcl::PointCloud<hilti_ros::Point>::Ptr &m
     uint64_t n_b = 0, n_u = 0;
     WC_CALL(wc_match(ctx_, d_surf_ + sld_begin_, d_pose_ + sld_begin_, n_sld, d_surf_ + sld_begin_, d_pose_ + sld_begin_, n_sld, 1,
                      d_pairs_sld_, cap_surfels_, &n_b, nullptr, nullptr));
-    WC_CALL(wc_match(ctx_, d_surf_ + sld_begin_, d_pose_ + sld_begin_, n_sld, d_surf_, d_pose_, sld_begin_, 0, d_pairs_fix_,
-                     cap_surfels_, &n_u, nullptr, nullptr));
+    const size_t n_fix = fix_end_ - fix_start_;
+    WC_CALL(wc_match(ctx_, d_surf_ + sld_begin_, d_pose_ + sld_begin_, n_sld, d_fix_surf_ + fix_start_, d_fix_pose_ + fix_start_, n_fix, 0,
+                     d_pairs_fix_, cap_surfels_, &n_u, nullptr, nullptr));
     last_corr_[0] = n_b, last_corr_[1] = n_u;
     // 5. solve poses in windows (:541-562)
     std::vector<double> ts, x;
@@ -351,7 +423,7 @@ void LidarOdometry::AddLidarScan(const pcl::PointCloud<hilti_ros::Point>::Ptr &m
     }
     std::vector<wc_imu_state> flat(imu_states_.begin(), imu_states_.end());
     const bool fix_first = first_sample_known_ && samples_.front().timestamp == first_sample_time_;  // :556-560
-    WC_CALL(wc_window_build(ctx_, d_surf_ + sld_begin_, d_pose_ + sld_begin_, d_pairs_sld_, n_b, d_surf_, d_pose_, d_pairs_fix_, n_u,
+    WC_CALL(wc_window_build(ctx_, d_surf_ + sld_begin_, d_pose_ + sld_begin_, d_pairs_sld_, n_b, d_fix_surf_ + fix_start_, d_fix_pose_ + fix_start_, d_pairs_fix_, n_u,
                             flat.data(), flat.size(), ts.data(), ts.size(), samples_.back().grav, fix_first ? 1 : 0));
     WC_CALL(wc_window_solve(ctx_, x.data(), &last_summary_, nullptr));
     for (size_t i = 0; i < samples_.size(); ++i) std::memcpy(samples_[i].cor, &x[12 * i], 96);

@@ -46,7 +46,9 @@ class LidarOdometry {
   size_t num_sample_states() const { return samples_.size(); }
   bool sample_state(size_t i, SampleStateView *out) const;
   size_t sliding_window_surfels() const { return n_surfels_ - sld_begin_; }
-  size_t fixed_window_surfels() const { return sld_begin_; }
+  size_t fixed_window_surfels() const { return fix_end_ - fix_start_; }
+  // timestamps of the fixed window in its own order (newest first, like the reference's deque after push_front, Q11)
+  const std::deque<double> &fixed_window_times() const { return fix_times_; }
   const wc_solve_summary &last_solve() const { return last_summary_; }
   uint64_t last_correspondences(int which) const { return last_corr_[which]; }
   LioConfig &config() { return config_; }
@@ -67,27 +69,42 @@ class LidarOdometry {
   void UpdateSurfelPosesOnDevice();
   void ShrinkToFit();
   void EnsureSurfelCapacity(size_t n);
+  void EnsureFixedCapacity(size_t extra);
+  void AppendScanOnDevice(const pcl::PointCloud<hilti_ros::Point> &msg);
+  void DropBufferedPoints(size_t k);
   void Fatal(const char *what, int rc) const;
 
   LioConfig config_;
   wc_ctx *ctx_ = nullptr;
   std::deque<ImuData> imu_buff_;
-  std::deque<hilti_ros::Point> points_buff_;
+  // points_buff_ of the reference (lidar_odometry.h:56) lives in HBM: the pre-filtered points of the scans not yet
+  // consumed are d_pts_[pts_cur_][pts_begin_ .. pts_end_); the host keeps only their timestamps
+  std::deque<double> point_times_;
+  void *d_pts_[2] = {nullptr, nullptr};
+  void *d_scan_raw_ = nullptr;
+  size_t cap_pts_[2] = {0, 0}, cap_scan_raw_ = 0, pts_begin_ = 0, pts_end_ = 0;
+  int pts_cur_ = 0;
   std::deque<Sample> samples_;
   std::deque<wc_imu_state> imu_states_;
   double ext_quat_[4];
   bool init_sld_win_ = false, sync_done_ = false, first_sample_known_ = false;
   double first_sample_time_ = 0.0;
   int sweep_id_ = 0;
-  // all surfels ever kept, time ordered, in HBM: [0, sld_begin_) = fixed window, [sld_begin_, n_surfels_) = sliding
+  // sliding window in HBM, time ordered: d_surf_[sld_begin_ .. n_surfels_) ([0, sld_begin_) has moved to the fixed window and
+  // is dropped at the next reallocation).  Fixed window: d_fix_surf_[fix_start_ .. fix_end_), NEWEST first - the array is
+  // filled from the back because the reference push_front()s (lidar_odometry.cc:243-246, Q11)
   wc_surfel *d_surf_ = nullptr;
+  wc_surfel *d_fix_surf_ = nullptr;
+  wc_pose *d_fix_pose_ = nullptr;
+  size_t fix_cap_ = 0, fix_start_ = 0, fix_end_ = 0;
+  std::deque<double> fix_times_;
   wc_pose *d_pose_ = nullptr;
   uint8_t *d_inbody_ = nullptr;
   wc_pair *d_pairs_sld_ = nullptr, *d_pairs_fix_ = nullptr;
   wc_imu_state *d_imu_ = nullptr;
-  void *d_sweep_ = nullptr, *d_sweep_raw_ = nullptr;
+  void *d_sweep_ = nullptr;
   size_t cap_surfels_ = 0, n_surfels_ = 0, sld_begin_ = 0, cap_imu_ = 0, cap_sweep_ = 0;
-  std::vector<double> surfel_times_;  // host copy of the surfel timestamps (window bookkeeping only)
+  std::deque<double> surfel_times_;  // host copy of the sliding window's surfel timestamps (window bookkeeping only)
   wc_solve_summary last_summary_{};
   uint64_t last_corr_[2] = {0, 0};
 };

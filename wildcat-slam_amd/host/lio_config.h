@@ -26,4 +26,7 @@ struct LioConfig {
   double gravity_norm = 9.81;
   int outer_iter_num_max = 1;
   int inner_iter_num_max = 100;
+  // not in the reference: true = reproduce its quirks (Q1/Q3 Jacobians, Q11 fixed window never trimmed); false = the
+  // mathematically intended behaviour (accumulated Jacobians, fixed window trimmed to fixed_window_duration)
+  bool reference_quirks = true;
 };

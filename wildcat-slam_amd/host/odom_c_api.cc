@@ -54,6 +54,14 @@ void wc_odom_stats(void *h, double *stats) {
   stats[7] = o->last_solve().termination;
 }
 
+// timestamps of the fixed window in its stored order (newest first, Q11); returns the window size
+uint64_t wc_odom_fixed_times(void *h, double *out, uint64_t cap) {
+  const std::deque<double> &t = ((LidarOdometry *)h)->fixed_window_times();
+  for (uint64_t i = 0; i < t.size() && i < cap; ++i) out[i] = t[i];
+  return t.size();
+}
+void wc_odom_set_quirks(void *h, int on) { ((LidarOdometry *)h)->config().reference_quirks = on != 0; }
+
 // ---- known-answer hooks for the host-side product code (the g++ instantiation of csrc/dmath.h, the facade's spline, the
 // resampler): the reference's own unit tests are run against these in tests/test_host_kat.py -------------------------------
 

@@ -371,6 +371,13 @@ class Odometry:
             self.lib.wc_odom_sample(self.h, C.c_uint64(i), R.ptr(out[i]))
         return out
 
+    def fixed_times(self):
+        self.lib.wc_odom_fixed_times.restype = C.c_uint64
+        n = int(self.lib.wc_odom_fixed_times(self.h, None, C.c_uint64(0)))
+        out = np.zeros(max(n, 1))
+        self.lib.wc_odom_fixed_times(self.h, R.ptr(out), C.c_uint64(n))
+        return out[:n]
+
     def stats(self):
         s = np.zeros(8)
         self.lib.wc_odom_stats(self.h, R.ptr(s))
