@@ -79,6 +79,26 @@ typedef struct wc_pair {
   int32_t second;
 } wc_pair;
 
+/* Record of the ONE exchange step of the sharded extraction: the 20 used bytes of a point
+ * (float xyz + double time) padded to 24.  A received buffer is a valid wc_points input (xyz_stride = time_stride = 24). */
+typedef struct wc_route_point {
+  float x, y, z;
+  uint32_t src; /* spare (keeps t 8-aligned) */
+  double t;
+} wc_route_point;
+
+/* Communicator of a multi-GPU job: one process (and one wc_ctx) per GPU.  The library calls these for its few collectives;
+ * wc_comm_rccl_init() installs an in-library RCCL implementation, tests / other runtimes install callbacks.
+ * All buffers are DEVICE pointers on the ctx's GPU; a callback returns 0 on success and must have completed (or be
+ * stream-ordered on the ctx's stream) when it returns.  Byte counts are per rank, data consecutive in rank order. */
+typedef struct wc_comm {
+  void *user;
+  int32_t rank, world;
+  int (*allreduce_f64)(void *user, double *d_buf, uint64_t count); /* in-place sum over ranks */
+  int (*alltoallv)(void *user, const void *d_send, const uint64_t *send_bytes, void *d_recv, const uint64_t *recv_bytes);
+  int (*allgatherv)(void *user, const void *d_send, uint64_t send_bytes, void *d_recv, const uint64_t *recv_bytes);
+} wc_comm;
+
 /* Hard-coded reference parameters of the path.  wc_params_default() fills the
  * reference values; tests may override them to reach edge cases. */
 typedef struct wc_params {

@@ -97,6 +97,29 @@ int wc_debug_status(wc_ctx *ctx, uint32_t *h_out64);
 /* root-voxel index of every point: VoxelLoc (src/odometry/surfel_extraction.h:55-64); d_keys_xyz = 3 int32 per point */
 int wc_voxel_keys(wc_ctx *ctx, const wc_points *pts, int32_t *d_keys_xyz);
 
+/* one cloud over several GPUs (BASELINE config 5) --------------------------------------------------- */
+/* The reference has no counterpart (single thread): root voxels are independent after binning (surfel_extraction.cc:217-219,
+ * :330-332) but each needs all its points in time order (:22-29), so a cloud shards by root voxel - see csrc/route.hip. */
+int wc_ctx_set_comm(wc_ctx *ctx, const wc_comm *comm); /* NULL removes it */
+/* owner rank of a root voxel (VoxelLoc index, surfel_extraction.h:59-64): hash(kx,ky,kz) mod world; needs no GPU */
+int wc_route_owner(int32_t kx, int32_t ky, int32_t kz, int world);
+/* stable partition of this rank's points by owner: d_send (capacity pts->n records) receives `world` consecutive segments
+ * (owner 0, 1, ...), time order preserved inside each; h_counts[world] = their lengths */
+int wc_route_partition(wc_ctx *ctx, const wc_points *pts, int world, wc_route_point *d_send, uint64_t *h_counts);
+/* the whole sharded call on one rank: partition the local time-contiguous slice, ONE all-to-all of 24-byte records through
+ * the ctx's communicator, wc_extract_surfels on the points of the voxels this rank owns.  t_lo <= t_hi: the time range of
+ * the WHOLE cloud.  Output: this rank's surfels (disjoint from the other ranks' by voxel), time sorted.
+ * h_n_points_owned (may be NULL): points this rank received. */
+int wc_extract_surfels_sharded(wc_ctx *ctx, const wc_points *pts, double t_lo, double t_hi, wc_surfel *d_out, wc_surfel_id *d_ids,
+                               uint64_t cap, uint64_t *h_n_out, uint64_t *h_n_points_owned);
+/* k time-sorted surfel lists, concatenated in d_in (h_counts[k] lengths) -> one list in the extraction's canonical order
+ * (timestamp, ties by root voxel index and node id; without ids: timestamp, ties by list).  d_out must not alias d_in. */
+int wc_merge_surfels(wc_ctx *ctx, const wc_surfel *d_in, const wc_surfel_id *d_in_ids, const uint64_t *h_counts, int k,
+                     wc_surfel *d_out, wc_surfel_id *d_out_ids);
+/* all-gather of every rank's surfel list + merge: every rank ends with the unsharded call's output (replicated window) */
+int wc_gather_surfels(wc_ctx *ctx, const wc_surfel *d_local, const wc_surfel_id *d_local_ids, uint64_t n_local, wc_surfel *d_out,
+                      wc_surfel_id *d_out_ids, uint64_t cap, uint64_t *h_n_out);
+
 /* sweep preparation ("next" row f-1 of SURVEY.md §8: the per-point stages right in front of the hot path) ------------ */
 /* Replaces the per-point loop of LidarOdometry::AddLidarScan (src/odometry/lidar_odometry.cc:489-496): lidar->imu
  * extrinsic in double (quat = w,x,y,z), cast to float, drop points with |p| < min_range, |p| > max_range or inside the

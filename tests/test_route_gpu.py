@@ -1,0 +1,138 @@
+"""One cloud over several "ranks" (csrc/route.hip; BASELINE config 5) on ONE GPU: the partition
+kernel against its host restatement, the whole sharded call with two / three contexts in lock-step (dist.ThreadComm stands
+in for RCCL), and the C5-sized cloud (10 M points) at full size."""
+import threading
+
+import numpy as np
+import pytest
+
+from wildcat_slam_amd import dist as wdist
+from wildcat_slam_amd import lib
+from wildcat_slam_amd import records as R
+from wildcat_slam_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _mixed_cloud(n_roots=300, n_room=120_000, seed=5):
+    a, _ = synth.g2_lattice(n_roots, m=32, seed=seed)
+    b = synth.g1_room(n_room, seed=seed + 1, t_start=float(a["time"][-1]) + 1e-3)
+    return synth.concat_points(a, b)
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+def test_route_partition_is_stable_and_complete(gpu, oracle, world):
+    pts = _mixed_cloud()
+    d_pts = gpu.to_device(pts)
+    d_send, counts = gpu.route_partition(d_pts, len(pts), world)
+    got = d_send.download(R.ROUTE_POINT, len(pts))
+    segs = wdist.route_partition_host(pts, oracle.voxel_keys(pts), world)  # library hash + oracle voxel index
+    assert [int(c) for c in counts] == [len(s) for s in segs] and int(counts.sum()) == len(pts)
+    o = 0
+    for s in segs:
+        g = got[o : o + len(s)]
+        for f, h in (("x", "x"), ("y", "y"), ("z", "z"), ("t", "time")):
+            assert np.array_equal(g[f], s[h]), f
+        o += len(s)
+
+
+def _run_ranks(world, pts, want_gather=True):
+    ctxs = [lib.Context(0) for _ in range(world)]
+    shared = wdist.ThreadComm.shared(world)
+    t_lo, t_hi = float(pts["time"][0]), float(pts["time"][-1])
+    out, errors = [None] * world, []
+
+    def run(r):
+        try:
+            ctx = ctxs[r]
+            ctx.set_comm(wdist.ThreadComm(shared, r, ctx))
+            lo, cnt = wdist.shard_range(len(pts), r, world)
+            d_slice = ctx.to_device(pts[lo : lo + cnt])
+            d_s, d_i, m, owned = ctx.extract_surfels_sharded(d_slice, cnt, t_lo, t_hi)
+            local = (d_s.download(R.SURFEL, m), d_i.download(R.SURFEL_ID, m), owned)
+            merged = ctx.gather_surfels(d_s, d_i, m, cap=len(pts) // 4 + 1024) if want_gather else None
+            out[r] = (local, merged)
+        except Exception as e:  # pragma: no cover
+            errors.append(e)
+            shared["bar"].abort()
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=300)
+    assert not errors, errors
+    for c in ctxs:
+        c.close()
+    return out
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_extraction_equals_unsharded(gpu, world):
+    """every rank extracts the voxels it owns from the routed points; the lists are disjoint by voxel, each rank owns work, and
+    the gathered + merged list is the unsharded call's output byte for byte (surfels AND ids, in order)"""
+    pts = _mixed_cloud()
+    s_ref, i_ref = gpu.extract_surfels(pts)
+    assert len(s_ref) > 2000
+    out = _run_ranks(world, pts)
+    owned_pts = sum(o[0][2] for o in out)
+    assert owned_pts == len(pts)
+    keys = [set(map(tuple, np.stack([o[0][1]["kx"], o[0][1]["ky"], o[0][1]["kz"]], 1).tolist())) for o in out]
+    for a in range(world):
+        assert len(out[a][0][0]) > len(s_ref) // (4 * world)
+        assert np.all(np.diff(out[a][0][0]["t"]) >= 0)
+        own = lib.route_owner(np.array(sorted(keys[a])), world)
+        assert np.all(own == a)  # a rank only emits surfels of voxels it owns
+        for b in range(a + 1, world):
+            assert not (keys[a] & keys[b])
+    assert sum(len(o[0][0]) for o in out) == len(s_ref)
+    for r in range(world):
+        ms, mi = out[r][1]
+        assert mi.tobytes() == i_ref.tobytes() and ms.tobytes() == s_ref.tobytes()
+
+
+def test_merge_surfels_kway(gpu):
+    pts = _mixed_cloud(200, 60_000, seed=11)
+    s, i = gpu.extract_surfels(pts)
+    rng = np.random.default_rng(0)
+    lab = rng.integers(0, 5, len(s))
+    lists, ids = [s[lab == r] for r in range(5)], [i[lab == r] for r in range(5)]
+    lists.insert(2, s[:0]), ids.insert(2, i[:0])  # an empty list in the middle
+    ms, mi = gpu.merge_surfels(lists, ids)
+    assert ms.tobytes() == s.tobytes() and mi.tobytes() == i.tobytes()
+
+
+def test_c5_cloud_10m_points_full_size(gpu, oracle):
+    """BASELINE config 5's cloud (G2, R = 39 062 roots, 9 999 872 points) at FULL size on one GPU: size-independent properties
+    (8 surfels per root, time sorted, every root present) and, for every 32nd root, byte equality with the oracle run on just
+    those roots' points (a root voxel's surfels depend on its own points only)."""
+    n_roots = 39_062
+    pts, info = synth.g2_lattice(n_roots, m=32, seed=synth.SEED + 50)
+    assert len(pts) == 9_999_872
+    s, ids = gpu.extract_surfels(pts)
+    assert len(s) == 8 * n_roots
+    assert np.all(np.diff(s["t"]) >= 0)
+    assert np.all(s["resolution"] == np.float64(np.float32(0.2) * 2))  # all at layer 1 (0.4 m)
+    got_roots = np.unique(np.stack([ids["kx"], ids["ky"], ids["kz"]], 1), axis=0)
+    assert len(got_roots) == n_roots
+    # 1/32 sub-sample of the roots: their points are the blocks [r * 256, (r + 1) * 256) of the root-major cloud
+    pick = np.arange(0, n_roots, 32)
+    sel = (pick[:, None] * 256 + np.arange(256)[None, :]).reshape(-1)
+    s_ref, i_ref, _ = oracle.extract_surfels(pts[sel])
+    assert len(s_ref) == 8 * len(pick)
+    want = set(map(tuple, info["root_keys"][pick].tolist()))
+    mask = np.array([(a, b, c) in want for a, b, c in zip(ids["kx"].tolist(), ids["ky"].tolist(), ids["kz"].tolist())])
+    assert ids[mask].tobytes() == i_ref.tobytes() and s[mask].tobytes() == s_ref.tobytes()
+
+
+def test_c5_cloud_routed_two_ranks(gpu):
+    """the same kind of cloud at 2 M points through the routed two-rank path: merged result = unsharded result"""
+    pts, _ = synth.g2_lattice(7_812, m=32, seed=synth.SEED + 51)
+    s_ref, i_ref = gpu.extract_surfels(pts)
+    assert len(s_ref) == 8 * 7_812
+    out = _run_ranks(2, pts)
+    share = [o[0][2] / len(pts) for o in out]
+    assert abs(share[0] - 0.5) < 0.05  # balanced ownership
+    for r in range(2):
+        ms, mi = out[r][1]
+        assert mi.tobytes() == i_ref.tobytes() and ms.tobytes() == s_ref.tobytes()

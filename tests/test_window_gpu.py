@@ -245,6 +245,52 @@ def test_c3_window_size_independent_properties(gpu):
     assert np.abs(g_end).max() < 1e-2 * np.abs(g).max()
 
 
+def test_c4_window_full_size_properties(gpu):
+    """BASELINE config C4 at FULL size (20 sweeps x 50 000 patches = 1 M sliding-window surfels, 50 000 fixed-window surfels,
+    IMU factors, ~2 M factors, 127 sample states) - the window bench.py times.  The oracle would need minutes, so: properties
+    that hold at any size.  wc_window_counts equals the matcher's counts; the normal equations are symmetric, bitwise
+    reproducible and positive on the diagonal; the gauge is free (first sample state long gone, Q12) so no row is zeroed; the
+    residual vector has one entry per surfel factor and 12 per IMU factor and reproduces the cost; LM decreases the cost."""
+    w = synth.surfel_window(20, 50_000, seed=synth.SEED + 7, fixed_patches=50_000)
+    n_s, n_f = len(w["surf"]), len(w["fix_surf"])
+    assert n_s == 1_000_000
+    d_surf, d_pose = gpu.to_device(w["surf"]), gpu.to_device(w["pose"])
+    d_fs, d_fp = gpu.to_device(w["fix_surf"]), gpu.to_device(w["fix_pose"])
+    d_pairs, d_pf = gpu.alloc(8 * n_s), gpu.alloc(8 * n_s)
+    n_b = gpu.match_device(d_surf, d_pose, n_s, d_surf, d_pose, n_s, True, d_pairs, n_s)
+    n_u = gpu.match_device(d_surf, d_pose, n_s, d_fs, d_fp, n_f, False, d_pf, n_s)
+    assert n_b > 0.9 * n_s and n_u > 0.9 * n_s
+    pairs, pf = d_pairs.download(R.PAIR, n_b), d_pf.download(R.PAIR, n_u)
+    t = w["surf"]["t"]
+    assert np.all(t[pairs["first"]] < t[pairs["second"]])  # (older, newer)
+    assert len(np.unique(pairs.view(np.uint64))) == n_b    # no duplicate pair (the std::set of cc:21,35-39)
+    assert np.all(pf["first"] >= 0) and np.all(pf["first"] < n_f) and len(np.unique(pf["second"])) == n_u  # <= 1 per query
+    # re-observations of one patch are what gets paired
+    pi = w["patch_index"]
+    assert np.mean(pi[pairs["first"]] == pi[pairs["second"]]) > 0.99
+    gpu.window_build(d_surf, d_pose, d_pairs, n_b, w["imu"], w["sample_times"], w["grav"], False, d_fs, d_fp, d_pf, n_u)
+    nb_, nu_, ni_, pieces = gpu.window_counts()
+    assert (nb_, nu_) == (n_b, n_u) and ni_ >= len(w["imu"]) - 12 and pieces > 8000
+    ns = len(w["sample_times"])
+    assert ns >= 120
+    x0 = np.zeros(12 * ns)
+    H, g, c0 = gpu.window_linearize(x0)
+    H2, g2, c02 = gpu.window_linearize(x0)
+    assert np.array_equal(H, H2) and np.array_equal(g, g2) and c0 == c02  # fixed reduction order at 12 k pieces too
+    assert np.array_equal(H, H.T)
+    assert np.all(np.diag(H) > 0) and np.all(np.isfinite(H)) and np.all(np.isfinite(g))
+    # block sparsity: a surfel factor couples sample blocks at most a window apart, bias blocks only couple through IMU factors
+    cost, res = gpu.window_evaluate(x0, want_residuals=True)
+    assert len(res) == n_b + n_u + 12 * ni_ and abs(cost - c0) <= 1e-9 * c0
+    assert abs(0.5 * float(np.dot(res, res)) - cost) <= 1e-9 * cost  # loss-corrected residuals reproduce 1/2 sum rho
+    x, s, _ = gpu.window_solve(x0)
+    assert s.iterations >= 1 and s.successful_steps >= 1 and s.final_cost < s.initial_cost
+    assert abs(s.initial_cost - c0) <= 1e-9 * c0
+    _, g_end, c_end = gpu.window_linearize(x)
+    assert abs(c_end - s.final_cost) <= 1e-9 * c_end
+    assert np.abs(g_end).max() < 1e-2 * np.abs(g).max()
+
+
 def test_c4_geometry_full_state_count_matches_oracle(gpu, oracle):
     """the C4 window geometry (20 sweeps, 127 sample states = 1 524 unknowns = 48 Cholesky panels, IMU factors) with 1/20 of
     the surfels, so that the CPU oracle finishes in seconds: same iterations, same steps, increments within 1e-6"""

@@ -103,6 +103,8 @@ extern "C" void wc_ctx_destroy(wc_ctx *ctx) {
     if (b->p) (void)hipFree(b->p);
   for (wc_buf &b : ctx->b_misc)
     if (b.p) (void)hipFree(b.p);
+  for (wc_buf &b : ctx->b_route)
+    if (b.p) (void)hipFree(b.p);
   if (ctx->h_status) (void)hipHostFree(ctx->h_status);
   if (ctx->h_mail) (void)hipHostFree(ctx->h_mail);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);

@@ -78,3 +78,116 @@ def make_allreduce(torch, dist, device):
         torch.cuda.synchronize(device)
 
     return allreduce
+
+
+# ---- communicators for Context.set_comm (the wc_comm callbacks of include/wc_types.h) --------------------------------------
+class ThreadComm:
+    """`world` contexts inside ONE process (one per thread) exchange through host staging - the 1-GPU stand-in for RCCL used
+    by the GPU tests.  shared = ThreadComm.shared(world); rank r's context gets ThreadComm(shared, r, ctx)."""
+
+    @staticmethod
+    def shared(world):
+        import threading
+
+        return {"world": world, "bar": threading.Barrier(world), "slot": [None] * world, "calls": [0] * world}
+
+    def __init__(self, shared, rank, ctx):
+        self.s, self.rank, self.world, self.ctx = shared, rank, shared["world"], ctx
+
+    def _publish(self, obj):
+        self.s["slot"][self.rank] = obj
+        self.s["bar"].wait()
+        got = list(self.s["slot"])
+        self.s["bar"].wait()
+        self.s["calls"][self.rank] += 1
+        return got
+
+    def allreduce(self, ptr, count):
+        mine = self.ctx.download_raw(ptr, count * 8).view(np.float64).copy()
+        total = np.zeros_like(mine)
+        for part in self._publish(mine):  # fixed rank order: bitwise the same sum on every rank
+            total = total + part
+        self.ctx.upload_raw(ptr, total)
+
+    def alltoallv(self, send_ptr, send_bytes, recv_ptr, recv_bytes):
+        total = int(sum(send_bytes))
+        mine = self.ctx.download_raw(send_ptr, total) if total else np.zeros(0, np.uint8)
+        offs = np.concatenate([[0], np.cumsum(send_bytes)]).astype(np.int64)
+        parts = [mine[offs[r] : offs[r + 1]].copy() for r in range(self.world)]
+        got = self._publish(parts)
+        recv = [got[src][self.rank] for src in range(self.world)]
+        assert [len(p) for p in recv] == [int(b) for b in recv_bytes], "alltoallv: receive counts disagree"
+        buf = np.concatenate(recv) if recv else np.zeros(0, np.uint8)
+        if len(buf):
+            self.ctx.upload_raw(recv_ptr, buf)
+
+    def allgatherv(self, send_ptr, send_bytes, recv_ptr, recv_bytes):
+        mine = self.ctx.download_raw(send_ptr, int(send_bytes)) if send_bytes else np.zeros(0, np.uint8)
+        got = self._publish(mine.copy())
+        assert [len(p) for p in got] == [int(b) for b in recv_bytes], "allgatherv: receive counts disagree"
+        buf = np.concatenate(got)
+        if len(buf):
+            self.ctx.upload_raw(recv_ptr, buf)
+
+
+class ByteView:
+    """zero-copy torch view of `nbytes` raw device bytes"""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+
+
+class TorchComm:
+    """the same three collectives through torch.distributed on the device buffers themselves (backend "nccl" = RCCL over xGMI)"""
+
+    def __init__(self, torch, dist, device):
+        self.torch, self.dist, self.device = torch, dist, device
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+
+        self.on_gpu = str(device) != "cpu"  # "cpu": the pointers are host addresses (gloo, CPU tests)
+
+    def _bytes(self, ptr, n):
+        if n == 0:
+            return self.torch.empty(0, dtype=self.torch.uint8, device=self.device)
+        if not self.on_gpu:
+            import ctypes
+
+            return self.torch.from_numpy(np.ctypeslib.as_array((ctypes.c_uint8 * int(n)).from_address(int(ptr))))
+        return self.torch.as_tensor(ByteView(ptr, n), device=self.device)
+
+    def _done(self):
+        if self.on_gpu:
+            self.torch.cuda.synchronize(self.device)
+
+    def allreduce(self, ptr, count):
+        t = self._bytes(ptr, 8 * count).view(self.torch.float64)
+        self.dist.all_reduce(t)
+        self._done()
+
+    def alltoallv(self, send_ptr, send_bytes, recv_ptr, recv_bytes):
+        s, r = self._bytes(send_ptr, int(sum(send_bytes))), self._bytes(recv_ptr, int(sum(recv_bytes)))
+        self.dist.all_to_all_single(r, s, [int(b) for b in recv_bytes], [int(b) for b in send_bytes])
+        self._done()
+
+    def allgatherv(self, send_ptr, send_bytes, recv_ptr, recv_bytes):
+        # contributions differ in size: an all-to-all in which every rank sends its whole contribution to every rank
+        s = self._bytes(send_ptr, int(send_bytes)).repeat(self.world)
+        r = self._bytes(recv_ptr, int(sum(recv_bytes)))
+        self.dist.all_to_all_single(r, s, [int(b) for b in recv_bytes], [int(send_bytes)] * self.world)
+        self._done()
+
+
+def route_partition_host(points, keys_xyz, world):
+    """host restatement of wc_route_partition (CPU / gloo test): stable partition of a POINT array by the owner of each
+    point's root voxel -> list of `world` arrays, time order preserved inside each"""
+    from . import lib
+
+    owners = lib.route_owner(keys_xyz, world)
+    return [points[owners == r] for r in range(world)]
+
+
+def merge_surfels_host(lists, id_lists):
+    """host restatement of wc_merge_surfels: the canonical order (timestamp, kx, ky, kz, node) over the concatenation"""
+    s, i = np.concatenate(lists), np.concatenate(id_lists)
+    order = np.lexsort((i["node"], i["kz"], i["ky"], i["kx"], s["t"]))
+    return s[order], i[order]

@@ -55,6 +55,15 @@ def default_params():
     return p
 
 
+def route_owner(keys_xyz, world):
+    """owner rank of every root voxel index (n x 3 int32) - wc_route_owner, needs no GPU"""
+    keys_xyz = np.asarray(keys_xyz, np.int64).reshape(-1, 3)
+    uniq, inv = np.unique(keys_xyz, axis=0, return_inverse=True)
+    f = load().wc_route_owner
+    own = np.array([f(int(k[0]), int(k[1]), int(k[2]), int(world)) for k in uniq], np.int32)
+    return own[inv.reshape(-1)]
+
+
 class DeviceBuffer:
     """A block of HBM owned through the C-ABI (wc_dev_alloc / wc_dev_free)."""
 
@@ -221,6 +230,72 @@ class Context:
         self.extract_enqueue(desc, d_out, d_ids, cap, t_lo, t_hi)
         m = self.extract_finish()
         return d_out.download(R.SURFEL, m), d_ids.download(R.SURFEL_ID, m)
+
+    # ---- one cloud over several GPUs (csrc/route.hip) --------------------------------------------------------------------
+    def set_comm(self, comm):
+        """comm: object with .rank, .world and methods allreduce(ptr, count), alltoallv(send_ptr, send_bytes, recv_ptr, recv_bytes),
+        allgatherv(send_ptr, send_bytes, recv_ptr, recv_bytes) on raw device pointers (see dist.py); None removes it"""
+        if comm is None:
+            self._comm = None
+            self._ck(self.lib.wc_ctx_set_comm(self.h, C.c_void_p(0)))
+            return
+        world = comm.world
+
+        def guard(fn):
+            def wrapped(*a):
+                try:
+                    fn(*a)
+                    return 0
+                except Exception as e:  # pragma: no cover
+                    print("communicator callback failed:", repr(e))
+                    return 1
+
+            return wrapped
+
+        ar = R.COMM_ALLREDUCE(guard(lambda user, p, n: comm.allreduce(p, n)))
+        a2a = R.COMM_ALLTOALLV(guard(lambda user, s, sb, r, rb: comm.alltoallv(s, [sb[i] for i in range(world)], r, [rb[i] for i in range(world)])))
+        ag = R.COMM_ALLGATHERV(guard(lambda user, s, n, r, rb: comm.allgatherv(s, n, r, [rb[i] for i in range(world)])))
+        c = R.Comm(None, comm.rank, world, ar, a2a, ag)
+        self._comm = (c, ar, a2a, ag, comm)  # keep the trampolines alive
+        self._ck(self.lib.wc_ctx_set_comm(self.h, C.byref(c)))
+
+    def route_partition(self, d_points, n, world):
+        """-> (DeviceBuffer of wc_route_point[n], counts[world])"""
+        d_send = self.alloc(24 * max(n, 1))
+        counts = (C.c_uint64 * world)()
+        desc = self.points_desc(d_points, n)
+        self._ck(self.lib.wc_route_partition(self.h, C.byref(desc), C.c_int(world), C.c_void_p(d_send.ptr), counts))
+        return d_send, np.array(list(counts), np.uint64)
+
+    def route_desc(self, d_route_points, n):
+        return R.Points(d_route_points.ptr, d_route_points.ptr + 16, 24, 24, n)
+
+    def extract_surfels_sharded(self, d_points, n, t_lo, t_hi, cap=None):
+        """this rank's slice (device POINT array) -> (surfels, ids, points owned) of the voxels this rank owns"""
+        cap = cap or max(1024, (3 * n) // 20 + 1) * 4
+        d_out, d_ids = self.alloc(cap * 144), self.alloc(cap * 16)
+        desc = self.points_desc(d_points, n)
+        m, owned = C.c_uint64(0), C.c_uint64(0)
+        self._ck(self.lib.wc_extract_surfels_sharded(self.h, C.byref(desc), C.c_double(t_lo), C.c_double(t_hi), C.c_void_p(d_out.ptr),
+                                                     C.c_void_p(d_ids.ptr), C.c_uint64(cap), C.byref(m), C.byref(owned)))
+        return d_out, d_ids, int(m.value), int(owned.value)
+
+    def merge_surfels(self, lists, id_lists):
+        """host convenience: k sorted SURFEL arrays (+ ids) -> merged (surfels, ids)"""
+        counts = (C.c_uint64 * len(lists))(*[len(a) for a in lists])
+        n = sum(len(a) for a in lists)
+        d_in, d_ids = self.to_device(np.concatenate(lists)), self.to_device(np.concatenate(id_lists))
+        d_out, d_oid = self.alloc(144 * max(n, 1)), self.alloc(16 * max(n, 1))
+        self._ck(self.lib.wc_merge_surfels(self.h, C.c_void_p(d_in.ptr), C.c_void_p(d_ids.ptr), counts, C.c_int(len(lists)), C.c_void_p(d_out.ptr),
+                                           C.c_void_p(d_oid.ptr)))
+        return d_out.download(R.SURFEL, n), d_oid.download(R.SURFEL_ID, n)
+
+    def gather_surfels(self, d_local, d_local_ids, n_local, cap):
+        d_out, d_oid = self.alloc(144 * max(cap, 1)), self.alloc(16 * max(cap, 1))
+        m = C.c_uint64(0)
+        self._ck(self.lib.wc_gather_surfels(self.h, C.c_void_p(d_local.ptr), C.c_void_p(d_local_ids.ptr), C.c_uint64(n_local), C.c_void_p(d_out.ptr),
+                                            C.c_void_p(d_oid.ptr), C.c_uint64(cap), C.byref(m)))
+        return d_out.download(R.SURFEL, int(m.value)), d_oid.download(R.SURFEL_ID, int(m.value))
 
     # ---- sweep preparation (row f-1) -------------------------------------------------------------------------------------
     def prefilter_points(self, points, ext_quat, ext_t, min_range, max_range, blind_min, blind_max):

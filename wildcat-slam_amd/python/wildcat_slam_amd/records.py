@@ -24,6 +24,9 @@ POSE = np.dtype([("pos", "f8", 3), ("quat", "f8", 4)])
 IMU_STATE = np.dtype([("t", "f8"), ("pos", "f8", 3), ("quat", "f8", 4), ("acc", "f8", 3), ("gyr", "f8", 3)])
 PAIR = np.dtype([("first", "i4"), ("second", "i4")])
 
+ROUTE_POINT = np.dtype([("x", "f4"), ("y", "f4"), ("z", "f4"), ("src", "u4"), ("t", "f8")])  # wc_route_point
+assert ROUTE_POINT.itemsize == 24
+
 assert SURFEL.itemsize == 144 and POSE.itemsize == 56 and IMU_STATE.itemsize == 112 and PAIR.itemsize == 8
 assert SURFEL_ID.itemsize == 16 and POINT.itemsize == 48
 
@@ -66,6 +69,24 @@ class Params(C.Structure):
         ("imu_dt", C.c_double),
         ("max_iterations", C.c_int32),
         ("reference_quirks", C.c_int32),
+    ]
+
+
+COMM_ALLREDUCE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64)
+COMM_ALLTOALLV = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p, C.POINTER(C.c_uint64))
+COMM_ALLGATHERV = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.POINTER(C.c_uint64))
+
+
+class Comm(C.Structure):
+    """wc_comm."""
+
+    _fields_ = [
+        ("user", C.c_void_p),
+        ("rank", C.c_int32),
+        ("world", C.c_int32),
+        ("allreduce_f64", COMM_ALLREDUCE),
+        ("alltoallv", COMM_ALLTOALLV),
+        ("allgatherv", COMM_ALLGATHERV),
     ]
 
 
