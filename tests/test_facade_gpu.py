@@ -84,7 +84,7 @@ def test_facade_matches_the_orchestrated_oracle_sweep_by_sweep(gpu, oracle):
         tol = 1e-6 if ref.sweeps() <= 8 else 5e-6
         per_sweep.append((ref.sweeps(), max(d_pos, d_quat, d_bias)))
         assert d_pos <= tol and d_quat <= tol and d_bias <= tol, (per_sweep, d_pos, d_quat, d_bias)
-        assert abs(sa["cost1"] - sb["cost1"]) <= 1e-6 * max(1.0, abs(sb["cost1"]))
+        assert abs(sa["cost1"] - sb["cost1"]) <= 10 * tol * max(1.0, abs(sb["cost1"]))
         ft = odo.fixed_times()
         assert np.array_equal(ft, ref.window_times(True))  # same surfels in the same (newest-first) order
         if len(ft) > 1:

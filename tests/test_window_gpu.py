@@ -282,7 +282,10 @@ def test_c4_window_full_size_properties(gpu):
     # block sparsity: a surfel factor couples sample blocks at most a window apart, bias blocks only couple through IMU factors
     cost, res = gpu.window_evaluate(x0, want_residuals=True)
     assert len(res) == n_b + n_u + 12 * ni_ and abs(cost - c0) <= 1e-9 * c0
-    assert abs(0.5 * float(np.dot(res, res)) - cost) <= 1e-9 * cost  # loss-corrected residuals reproduce 1/2 sum rho
+    assert np.all(np.isfinite(res))
+    # IMU factors carry a TrivialLoss (lidar_odometry.cc:342,356): their residuals enter the cost as plain squares; surfel
+    # residuals are Cauchy-corrected (sqrt(rho') r), so 1/2 r_c^2 <= 1/2 rho(r^2) for each of them
+    assert 0.5 * float(np.dot(res, res)) <= cost * (1 + 1e-12)
     x, s, _ = gpu.window_solve(x0)
     assert s.iterations >= 1 and s.successful_steps >= 1 and s.final_cost < s.initial_cost
     assert abs(s.initial_cost - c0) <= 1e-9 * c0
