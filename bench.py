@@ -1,15 +1,26 @@
 #!/usr/bin/env python3
-"""bench.py — headline benchmark of the MI355X hot path (contract: see the task statement / DESIGN.md §Measurement).
+"""bench.py — headline benchmark of the MI355X hot path (contract: the task statement; DESIGN.md §5 Measurement).
 
-A "step" is one pass of the hot path over one batch of synthetic input that is already resident in HBM:
-one BuildSurfels-equivalent surfel extraction of BASELINE.json config C2 (G2 patch lattice, 3 906 root voxels x 8
-patches x 32 points = 999 936 points -> 31 248 surfels) per GPU.  With N > 1 every rank extracts its own sweep
-(sweeps are independent jobs in the reference, lidar_odometry.cc:523-525: a fresh GlobalMap per sweep), so the
-data path has no collective and scaling is "weak".
+A "step" is one pass of the hot path over one batch of synthetic input that is already resident in HBM: one
+BuildSurfels-equivalent surfel extraction of BASELINE.json config C2 (G2 patch lattice, 3 906 root voxels x 8 patches x
+32 points = 999 936 points -> 31 248 surfels) per GPU.  With N > 1 every rank extracts its own sweep (sweeps are
+independent jobs in the reference, lidar_odometry.cc:523-525: a fresh GlobalMap per sweep), so the headline has no
+data-path collective and scaling is "weak".
 
-Prints ONE JSON line (rank 0).  Extra keys: "roofline" (dominant kernel, HIP-event timed on the kernel's stream),
-"cpu_baseline" (the CPU oracle timed on the same box, rank 0, N = 1 only), "stages_ms", "window" (LM-iteration
-figures once the window kernels are built).
+Prints ONE JSON line (rank 0).  Objects next to the contract keys:
+  roofline        SURVEY §8(d): algorithmic bytes of the extraction STAGE / device time of ALL kernels of the stage (HIP events on
+                  the ctx stream); the dominant kernel's own figure is a sub-object; `traffic` names the committed PMC summary it is
+                  read from (it is not measured in this run)
+  cpu_baseline    the CPU oracle on the same sweeps, one pinned core, rank 0 / N = 1 only
+  firing_order    the same extraction on a 1 M-point sweep in the order a spinning multi-beam lidar produces (G1), so that the
+                  run-structured headline is never quoted alone
+  cloud_10m       BASELINE config 5's cloud (10 M points) on ONE GPU; with N > 1 `sharded_cloud` routes it over the ranks
+                  (one all-to-all over RCCL, csrc/route.hip) - strong scaling of one cloud
+  window          BASELINE config 4 (1 M-surfel window + IMU): matcher, one linearisation (assembly roofline), LM iterations/s
+                  with their own roofline object; correspondences sharded over the ranks with ONE all-reduce per linearisation
+  odometry_step   north_star's headline workload: one full odometry step (lidar_odometry.cc:523-566) on a 10 x C2 window -
+                  extraction of the newest 1 M-point sweep -> pose update -> 2 x match -> build -> solve -> pose update - with its
+                  stage split, roofline fraction and the CPU oracle beside it
 """
 import argparse
 import json
@@ -23,6 +34,109 @@ sys.path.insert(0, os.path.join(ROOT, "wildcat-slam_amd", "python"))
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
+STAGE_KERNELS = {"init": "k_init", "point_sort": "k_pt_runs + k_pt_bucket", "roots_stream": "k_roots<unsigned int, 1, true>",
+                 "roots_emit": "k_roots_emit<unsigned int, true>", "slot_order": "k_slot_emit"}
+
+
+class _Ptr:
+    def __init__(self, p):
+        self.ptr = p
+
+
+def cpu_info():
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"model": model, "logical_cores": os.cpu_count()}
+
+
+class pinned_core:
+    """the CPU-baseline legs run on ONE pinned core (the reference is single-threaded)"""
+
+    def __enter__(self):
+        self.prev = None
+        try:
+            self.prev = os.sched_getaffinity(0)
+            self.core = max(self.prev)  # away from core 0 (interrupts) when there is a choice
+            os.sched_setaffinity(0, {self.core})
+        except (AttributeError, OSError):
+            self.core = None
+        return self
+
+    def __exit__(self, *a):
+        if self.prev is not None:
+            try:
+                os.sched_setaffinity(0, self.prev)
+            except OSError:
+                pass
+
+
+def pmc_traffic(kernels):
+    """HBM bytes per launch (reads x2-corrected + writes) summed over `kernels`, from the newest committed PMC summary
+    (profiles/<tag>_pmc.json, written by profiles/summarize.py from separate rocprofv3 --pmc passes).  Not measured in this run:
+    the returned object names its source."""
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")))
+    if not files:
+        return None
+    try:
+        ks = json.load(open(files[-1]))["kernels"]
+    except Exception:
+        return None
+    tot, missing = 0, []
+    for name in kernels:
+        if name in ks:
+            tot += ks[name]["read_bytes_per_launch"] + ks[name]["write_bytes_per_launch"]
+        else:
+            missing.append(name)
+    return {"bytes_per_launch": tot, "source": "profiles/" + os.path.basename(files[-1]), "kernels_missing_from_summary": missing}
+
+
+def extraction_stage(ctx, step, n_pts, n_surfels, steps):
+    """per-stage device time (HIP events on the ctx stream around every kernel group of the stage) -> (stages_ms, roofline)"""
+    ctx.extract_profile(True)
+    acc = {}
+    k = max(10, min(steps, 100))
+    for _ in range(k):
+        step()
+        for name, ms in ctx.extract_stage_ms().items():
+            acc[name] = acc.get(name, 0.0) + ms
+    ctx.extract_profile(False)
+    stages = {name: v / k for name, v in acc.items()}
+    algo = 20 * n_pts + 144 * n_surfels  # SURVEY §8(d): 20 B read per point + 144 B written per surfel
+    stage_ms = sum(v for name, v in stages.items() if name != "init")  # k_init runs ahead of the sweep (previous finish())
+    dom = max((s for s in stages if s != "init"), key=stages.get)
+    ach = algo / (stage_ms * 1e-3) / 1e9
+    roof = {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
+            "definition": "SURVEY 8(d): (20 B x points + 144 B x surfels) / device time of ALL kernels of the stage (HIP events, ctx stream)",
+            "algorithmic_bytes_per_step": algo, "stage_device_ms": round(stage_ms, 5),
+            "traffic": pmc_traffic([n for s in stages if s != "init" for n in STAGE_KERNELS.get(s, s).split(" + ")]),
+            "dominant_kernel": {"kernel": STAGE_KERNELS.get(dom, dom), "avg_ms": round(stages[dom], 5),
+                                "frac_if_it_ran_alone": round(algo / (stages[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}}
+    return stages, roof
+
+
+def time_extract(ctx, desc, out_p, ids_p, cap, t_lo, t_hi, steps, warmup, expect=None):
+    enq, fin = ctx.prepare_extract(desc, out_p, ids_p, cap, t_lo, t_hi)
+    n_s = 0
+    for _ in range(max(1, warmup)):
+        enq()
+        n_s = fin()
+    if expect is not None and not os.environ.get("WC_DEBUG_SKIP"):
+        assert n_s == expect, (n_s, expect)
+    ctx.sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        enq()
+        n_s = fin()
+    ctx.sync()
+    return (time.perf_counter() - t0) / steps, n_s, (enq, fin)
 
 
 def main():
@@ -32,10 +146,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--roots", type=int, default=3906, help="root voxels per sweep (C2: 3906 -> 999 936 points)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--window-scans", type=int, default=20, help="sweeps in the LM window (C4: 20)")
     ap.add_argument("--window-patches", type=int, default=50000, help="surfels per sweep (C4: 50 000 -> 1 M surfels)")
     ap.add_argument("--no-window", action="store_true", help="skip the LM-window section")
+    ap.add_argument("--no-extras", action="store_true", help="skip firing_order / cloud_10m / odometry_step")
     ap.add_argument("--in-flight", type=int, default=3, help="sweeps in flight (contexts) of the extra pipelined measurement")
     args = ap.parse_args()
 
@@ -55,12 +170,28 @@ def main():
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local_rank)
+    use_dist = dist.is_initialized()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+
+    def max_over_ranks(x):
+        if not use_dist:
+            return x
+        tt = torch.tensor([x], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt.item())
+
+    def to_dev(arr):
+        return torch.from_numpy(np.ascontiguousarray(arr).view(np.uint8).reshape(-1)).to(dev)
 
     # --- synthetic sweep of this rank (G2, seed + rank), resident in HBM before the timed region ------------------
-    pts, info = synth.g2_lattice(args.roots, m=32, seed=synth.SEED + rank)
+    pts, _ = synth.g2_lattice(args.roots, m=32, seed=synth.SEED + rank)
     n_pts = len(pts)
     exp_surfels = 8 * args.roots
-    d_pts = torch.from_numpy(pts.view(np.uint8).reshape(-1)).to(dev)
+    d_pts = to_dev(pts)
     cap = (3 * n_pts) // 20 + 1
     d_out = torch.empty(cap * 144, dtype=torch.uint8, device=dev)
     d_ids = torch.empty(cap * 16, dtype=torch.uint8, device=dev)
@@ -70,11 +201,6 @@ def main():
     base = d_pts.data_ptr()
     desc = R.Points(base, base + 24, 48, 48, n_pts)
     t_lo, t_hi = float(pts["time"][0]), float(pts["time"][-1])
-
-    class _Ptr:
-        def __init__(self, p):
-            self.ptr = p
-
     out_p, ids_p = _Ptr(d_out.data_ptr()), _Ptr(d_ids.data_ptr())
 
     enq, fin = ctx.prepare_extract(desc, out_p, ids_p, cap, t_lo, t_hi)  # ctypes argument objects built once
@@ -87,29 +213,62 @@ def main():
         n_s = step()
     assert os.environ.get("WC_DEBUG_SKIP") or n_s == exp_surfels, (n_s, exp_surfels)
 
-    def barrier():
-        ctx.sync()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-
+    ctx.sync()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         n_s = step()
     ctx.sync()
     torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed = max_over_ranks(time.perf_counter() - t0)
     ms_per_step = elapsed / args.steps * 1e3
     value = world * n_pts / (elapsed / args.steps) / 1e6  # Mpts/s, whole job
 
-    # --- two sweeps in flight (two contexts = two streams, each with its own scratch): what the chain of short, latency
-    # bound kernels leaves idle is filled by the other sweep.  Reported next to the headline, never as `value`.
-    pipelined = None
+    stages, roofline = extraction_stage(ctx, step, n_pts, exp_surfels, args.steps)
+    # measured ceiling of this device (SURVEY 8(d)): a 1 GiB device-to-device copy, bytes read + written per second
+    copy_gbs = None
+    try:
+        src = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
+        dst = torch.empty_like(src)
+        for _ in range(3):
+            dst.copy_(src)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            dst.copy_(src)
+        e1.record()
+        torch.cuda.synchronize()
+        copy_gbs = 2.0 * (1 << 30) * 10 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        del src, dst
+    except Exception:
+        copy_gbs = None
+    args._copy_gbs = copy_gbs
+    roofline["measured_copy_GBs"] = round(copy_gbs, 1) if copy_gbs else None
+    roofline["frac_of_measured_copy"] = round(roofline["achieved"] / copy_gbs, 5) if copy_gbs else None
+    roofline["driver_clock_frac"] = round((20 * n_pts + 144 * exp_surfels) / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)  # incl. host turn-around
+
+    result = {
+        "metric": "surfel-extract Mpts/s",
+        "value": round(value, 2),
+        "unit": "Mpts/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 5),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": "C2: 1M-pt single scan (G2 patch lattice, %d pts -> %d surfels) per GPU, voxel-grid + 3-level octree + per-cell 3x3 PCA; "
+                               "input = the reference's 48-byte hilti_ros::Point records, consumed in place" % (n_pts, exp_surfels),
+                   "points_per_gpu": n_pts, "surfels_per_gpu": exp_surfels, "parallelism": "sweep-per-gpu x%d" % world},
+        "roofline": roofline,
+        "stages_ms": {k_: round(v, 5) for k_, v in stages.items()},
+        "host": cpu_info(),
+    }
+
+    # --- several sweeps in flight (contexts = streams, each with its own scratch).  Never `value`. --------------------------
     try:
         if args.in_flight < 2:
             raise RuntimeError("skipped (--in-flight < 2)")
@@ -135,125 +294,67 @@ def main():
         for c2, _, _, _ in ring:
             c2.sync()
         torch.cuda.synchronize()
-        el2 = time.perf_counter() - t0
-        if world > 1:
-            tt = torch.tensor([el2], dtype=torch.float64, device=dev)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            el2 = float(tt.item())
-        pipelined = {"sweeps_in_flight": F, "value": round(world * n_pts / (el2 / args.steps) / 1e6, 2), "unit": "Mpts/s",
-                     "ms_per_step": round(el2 / args.steps * 1e3, 5)}
+        el2 = max_over_ranks(time.perf_counter() - t0)
+        result["pipelined"] = {"sweeps_in_flight": F, "value": round(world * n_pts / (el2 / args.steps) / 1e6, 2), "unit": "Mpts/s",
+                               "ms_per_step": round(el2 / args.steps * 1e3, 5)}
         for c2, _, _, keep in ring[1:]:
             c2.close()
     except Exception as e:  # the headline must survive a failure of this extra measurement
-        pipelined = {"error": repr(e)}
+        result["pipelined"] = {"error": repr(e)}
 
-    # --- the same sweep in the 20 B / point layout SURVEY 8(d) counts (packed float32 xyz + float64 time instead of the
-    # reference's 48-byte record): what the input layout costs.  Reported next to the headline, never as `value`.
-    soa = None
+    # --- the same sweep in the 20 B / point layout SURVEY 8(d) counts.  Never `value`. ---------------------------------------
     try:
         xyz = np.stack([pts["x"], pts["y"], pts["z"]], axis=1).astype(np.float32)
         d_xyz = torch.from_numpy(xyz.reshape(-1)).to(dev)
         d_t = torch.from_numpy(np.ascontiguousarray(pts["time"], np.float64)).to(dev)
         desc_soa = R.Points(d_xyz.data_ptr(), d_t.data_ptr(), 12, 8, n_pts)
-        enq2, fin2 = ctx.prepare_extract(desc_soa, out_p, ids_p, cap, t_lo, t_hi)
-        for _ in range(max(3, args.warmup)):
+        sec, _, (enq2, fin2) = time_extract(ctx, desc_soa, out_p, ids_p, cap, t_lo, t_hi, args.steps, max(3, args.warmup), exp_surfels)
+
+        def step2():
             enq2()
-            n2 = fin2()
-        assert os.environ.get("WC_DEBUG_SKIP") or n2 == exp_surfels, (n2, exp_surfels)
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            enq2()
-            fin2()
-        ctx.sync()
-        el3 = time.perf_counter() - t0
-        soa = {"layout": "float32 xyz (stride 12) + float64 time (stride 8): 20 B / point", "value": round(n_pts / (el3 / args.steps) / 1e6, 2),
-               "unit": "Mpts/s (this rank)", "ms_per_step": round(el3 / args.steps * 1e3, 5)}
+            return fin2()
+
+        st2, roof2 = extraction_stage(ctx, step2, n_pts, exp_surfels, args.steps)
+        result["soa_input"] = {"layout": "float32 xyz (stride 12) + float64 time (stride 8): 20 B / point", "value": round(n_pts / sec / 1e6, 2),
+                               "unit": "Mpts/s (this rank)", "ms_per_step": round(sec * 1e3, 5), "stage_device_ms": roof2["stage_device_ms"],
+                               "roofline_frac": roof2["frac"]}
+        del d_xyz, d_t
     except Exception as e:
-        soa = {"error": repr(e)}
+        result["soa_input"] = {"error": repr(e)}
 
-    # --- per-stage device time (HIP events on the ctx stream), same steps, for the roofline object ---------------
-    ctx.extract_profile(True)
-    acc = {}
-    k = max(10, min(args.steps, 100))
-    for _ in range(k):
-        step()
-        for name, ms in ctx.extract_stage_ms().items():
-            acc[name] = acc.get(name, 0.0) + ms
-    ctx.extract_profile(False)
-    stages = {name: v / k for name, v in acc.items()}
-    dom = max(stages, key=stages.get)
-    algo_bytes = 20 * n_pts + 144 * exp_surfels  # 20 B read per point + 144 B written per surfel
-    dom_ms = stages[dom]
-    achieved = algo_bytes / (dom_ms * 1e-3) / 1e9
-    kernel_names = {"init": "k_init", "point_sort": "k_pt_runs + k_pt_bucket", "roots_stream": "k_roots<unsigned int, 1, true>",
-                    "roots_emit": "k_roots_emit<unsigned int, true>", "slot_order": "k_slot_emit"}
-    # measured ceiling of this device (SURVEY 8(d)): a 1 GiB device-to-device copy, bytes read + written per second
-    copy_gbs = None
-    try:
-        src = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
-        dst = torch.empty_like(src)
-        for _ in range(3):
-            dst.copy_(src)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(10):
-            dst.copy_(src)
-        e1.record()
-        torch.cuda.synchronize()
-        copy_gbs = 2.0 * (1 << 30) * 10 / (e0.elapsed_time(e1) * 1e-3) / 1e9
-        del src, dst
-    except Exception:
-        copy_gbs = None
-    args._copy_gbs = copy_gbs
-    roofline = {"bound": "hbm", "kernel": kernel_names[dom], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(kernel_names[dom]), "algorithmic_bytes_per_launch": algo_bytes,
-                "avg_kernel_ms": round(dom_ms, 5),
-                "whole_pipeline_frac": round(algo_bytes / (sum(stages.values()) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                "measured_copy_GBs": round(copy_gbs, 1) if copy_gbs else None,
-                "frac_of_measured_copy": round(achieved / copy_gbs, 5) if copy_gbs else None}
-
-    result = {
-        "metric": "surfel-extract Mpts/s",
-        "value": round(value, 2),
-        "unit": "Mpts/s",
-        "n_gpus": world,
-        "steps": args.steps,
-        "warmup": args.warmup,
-        "ms_per_step": round(ms_per_step, 5),
-        "higher_is_better": True,
-        "scaling": "weak",
-        "vs_baseline": None,
-        "dtype": "f64",
-        "data": "synthetic",
-        "config": {"workload": "C2: 1M-pt single scan (G2 patch lattice, %d pts -> %d surfels) per GPU, voxel-grid + 3-level octree + per-cell 3x3 PCA"
-                   % (n_pts, exp_surfels), "points_per_gpu": n_pts, "surfels_per_gpu": exp_surfels, "parallelism": "sweep-per-gpu x%d" % world},
-        "roofline": roofline,
-        "pipelined": pipelined,
-        "soa_input": soa,
-        "stages_ms": {k_: round(v, 5) for k_, v in stages.items()},
-    }
-
-    # --- CPU baseline: the single-thread oracle on the same workload, rank 0, N = 1 only --------------------------
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
+    if cpu:  # CPU baseline: the single-thread oracle on the same workload, one pinned core
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import pyoracle  # test infrastructure, used here ONLY as the timed CPU baseline
 
-        reps, t_cpu = 0, 0.0
-        while t_cpu < args.cpu_seconds:
-            t1 = time.perf_counter()
-            s_ref, _, _ = pyoracle.extract_surfels(pts, cap=cap)
-            t_cpu += time.perf_counter() - t1
-            reps += 1
+        with pinned_core() as pc:
+            reps, t_cpu = 0, 0.0
+            while t_cpu < args.cpu_seconds:
+                t1 = time.perf_counter()
+                s_ref, _, _ = pyoracle.extract_surfels(pts, cap=cap)
+                t_cpu += time.perf_counter() - t1
+                reps += 1
         assert len(s_ref) == exp_surfels
-        result["cpu_baseline"] = {"value": round(reps * n_pts / t_cpu / 1e6, 3), "unit": "Mpts/s", "cores": 1, "kind": "port",
+        result["cpu_baseline"] = {"value": round(reps * n_pts / t_cpu / 1e6, 3), "unit": "Mpts/s", "cores": 1, "kind": "port", "pinned_core": pc.core,
+                                  "cpu": result["host"]["model"],
                                   "sample": "%d full C2 sweeps (%d pts each), %.1f s of single-thread oracle (oracle/extract.cc)" % (reps, n_pts, t_cpu)}
 
+    if not args.no_extras:
+        for name, fn in (("firing_order", bench_firing_order), ("cloud_10m", bench_cloud_10m)):
+            try:
+                result[name] = fn(ctx, args, world, rank, dev, torch, dist, to_dev)
+            except Exception as e:
+                result[name] = {"error": repr(e)}
     if not args.no_window:
         try:
-            result["window"] = bench_window(ctx, args, world, rank, dev, torch, dist, cpu=(rank == 0 and world == 1 and not args.no_cpu_baseline))
+            result["window"] = bench_window(ctx, args, world, rank, dev, torch, dist, cpu=cpu)
         except Exception as e:  # the headline line must survive a failure of the extra section
             result["window"] = {"error": repr(e)}
+    if not args.no_extras:
+        try:
+            result["odometry_step"] = bench_odometry_step(ctx, args, world, rank, dev, torch, dist, cpu=cpu)
+        except Exception as e:
+            result["odometry_step"] = {"error": repr(e)}
 
     if rank == 0:
         print(json.dumps(result))
@@ -262,31 +363,88 @@ def main():
         dist.destroy_process_group()
 
 
-def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` (reads x2-corrected + writes) from the newest committed PMC summary
-    (profiles/<tag>_pmc.json, written by profiles/summarize.py from separate rocprofv3 --pmc passes); None if absent."""
-    import glob
+def bench_firing_order(ctx, args, world, rank, dev, torch, dist, to_dev):
+    """a 1 M-point sweep in FIRING ORDER (G1 room ray-cast, ring = i mod 32): what a spinning multi-beam lidar delivers.  One run
+    per point, heavy-tailed voxel occupancy, octree layer 2 in use."""
+    from wildcat_slam_amd import records as R, synth
 
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")))
-    if not files:
-        return None
-    try:
-        ks = json.load(open(files[-1]))["kernels"]
-    except Exception:
-        return None
-    tot = 0
-    for name in kernel.split(" + "):
-        if name not in ks:
-            return None
-        tot += ks[name]["read_bytes_per_launch"] + ks[name]["write_bytes_per_launch"]
-    return tot
+    pts = synth.g1_room(1_000_000, seed=synth.SEED + 3)
+    n = len(pts)
+    d = to_dev(pts)
+    cap = (3 * n) // 20 + 1
+    d_out, d_ids = torch.empty(cap * 144, dtype=torch.uint8, device=dev), torch.empty(cap * 16, dtype=torch.uint8, device=dev)
+    desc = R.Points(d.data_ptr(), d.data_ptr() + 24, 48, 48, n)
+    steps = max(10, args.steps // 4)
+    sec, n_s, (enq, fin) = time_extract(ctx, desc, _Ptr(d_out.data_ptr()), _Ptr(d_ids.data_ptr()), cap, float(pts["time"][0]), float(pts["time"][-1]), steps, 20)
+
+    def step():
+        enq()
+        return fin()
+
+    stages, roof = extraction_stage(ctx, step, n, n_s, steps)
+    return {"workload": "G1 room ray-cast in firing order: %d points -> %d surfels" % (n, n_s), "ms_per_step": round(sec * 1e3, 5),
+            "value": round(n / sec / 1e6, 2), "unit": "Mpts/s (this rank)", "stage_device_ms": roof["stage_device_ms"], "roofline_frac": roof["frac"],
+            "stages_ms": {k: round(v, 5) for k, v in stages.items()}}
+
+
+def bench_cloud_10m(ctx, args, world, rank, dev, torch, dist, to_dev):
+    """BASELINE config 5's cloud: G2, 39 062 roots = 9 999 872 points.  N = 1: the whole cloud on this GPU.  N > 1: every rank
+    holds a time-contiguous 1/N slice; wc_extract_surfels_sharded routes the points to the owner of their root voxel (ONE
+    all-to-all of 24-byte records over RCCL) and each rank extracts its voxels - strong scaling of one cloud."""
+    from wildcat_slam_amd import dist as wdist, records as R, synth
+
+    n_roots = 39_062
+    pts, _ = synth.g2_lattice(n_roots, m=32, seed=synth.SEED + 50)
+    n = len(pts)
+    t_lo, t_hi = float(pts["time"][0]), float(pts["time"][-1])
+    steps = max(5, args.steps // 10)
+    if world == 1:
+        d = to_dev(pts)
+        cap = (3 * n) // 20 + 1
+        d_out, d_ids = torch.empty(cap * 144, dtype=torch.uint8, device=dev), torch.empty(cap * 16, dtype=torch.uint8, device=dev)
+        desc = R.Points(d.data_ptr(), d.data_ptr() + 24, 48, 48, n)
+        sec, n_s, (enq, fin) = time_extract(ctx, desc, _Ptr(d_out.data_ptr()), _Ptr(d_ids.data_ptr()), cap, t_lo, t_hi, steps, 5, 8 * n_roots)
+
+        def step():
+            enq()
+            return fin()
+
+        stages, roof = extraction_stage(ctx, step, n, n_s, steps)
+        return {"workload": "C5 cloud on one GPU: %d points -> %d surfels" % (n, n_s), "ms_per_step": round(sec * 1e3, 5), "value": round(n / sec / 1e6, 2),
+                "unit": "Mpts/s", "stage_device_ms": roof["stage_device_ms"], "roofline_frac": roof["frac"], "dominant_kernel": roof["dominant_kernel"],
+                "stages_ms": {k: round(v, 5) for k, v in stages.items()}}
+    lo, cnt = wdist.shard_range(n, rank, world)
+    d_slice = ctx.to_device(pts[lo: lo + cnt])
+    ctx.set_comm(wdist.TorchComm(torch, dist, dev))
+    cap = (3 * n) // 20 // world * 2 + 4096
+    bufs = (ctx.alloc(cap * 144), ctx.alloc(cap * 16), cap)
+    out = None
+    for _ in range(2):
+        out = ctx.extract_surfels_sharded(d_slice, cnt, t_lo, t_hi, out=bufs)
+    torch.cuda.synchronize()
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = ctx.extract_surfels_sharded(d_slice, cnt, t_lo, t_hi, out=bufs)
+    ctx.sync()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    tt = torch.tensor([el, float(out[2]), float(out[3])], dtype=torch.float64, device=dev)
+    mx = tt.clone()
+    dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+    dist.all_reduce(tt, op=dist.ReduceOp.SUM)
+    ctx.set_comm(None)
+    sec = float(mx[0].item()) / steps
+    return {"workload": "C5 cloud sharded by root voxel over %d GPUs (route: one all-to-all of 24 B / point)" % world, "ms_per_step": round(sec * 1e3, 5),
+            "value": round(n / sec / 1e6, 2), "unit": "Mpts/s (whole cloud)", "surfels_total": int(tt[1].item()), "points_routed_total": int(tt[2].item()),
+            "max_points_on_a_rank": int(mx[2].item()), "scaling": "strong", "roofline_frac": round((20 * n + 144 * 8 * n_roots) / sec / 1e9 / (world * HBM_PEAK_GBS), 5)}
 
 
 def bench_window(ctx, args, world, rank, dev, torch, dist, cpu=False):
     """LM ("GN") iterations per second on a C4-like window: `scans` sweeps x `patches` surfels, binary + unary surfel
     factors + IMU factors, correspondences from the GPU matcher.  With N > 1 the correspondences are sharded over the
     ranks (unknowns replicated) and every linearisation ends in ONE RCCL all-reduce of the packed {H, g, cost}."""
-    from wildcat_slam_amd import dist as wdist, records as R, synth
+    from wildcat_slam_amd import dist as wdist, synth
 
     t_gen = time.perf_counter()
     w = synth.surfel_window(args.window_scans, args.window_patches, seed=synth.SEED + 7, fixed_patches=args.window_patches)
@@ -307,16 +465,11 @@ def bench_window(ctx, args, world, rank, dev, torch, dist, cpu=False):
     # shard the correspondences (contiguous slices) and the IMU factors
     lo_b, cnt_b = wdist.shard_range(n_b, rank, world)
     lo_u, cnt_u = wdist.shard_range(n_u, rank, world)
-
-    class _Off:
-        def __init__(self, ptr):
-            self.ptr = ptr
-
     if world > 1 or os.environ.get("WC_BENCH_FORCE_DIST") == "1":
         ctx.window_set_allreduce(wdist.make_allreduce(torch, dist, dev))
     imu_r = wdist.shard_imu(w["imu"], rank, world)  # IMU factors: a contiguous share of the state triples per rank
-    build_args = (d_surf, d_pose, _Off(d_pairs.ptr + 8 * lo_b), cnt_b, imu_r if len(imu_r) >= 3 else None, w["sample_times"], w["grav"],
-                  False, d_fs, d_fp, _Off(d_pf.ptr + 8 * lo_u), cnt_u)
+    build_args = (d_surf, d_pose, _Ptr(d_pairs.ptr + 8 * lo_b), cnt_b, imu_r if len(imu_r) >= 3 else None, w["sample_times"], w["grav"],
+                  False, d_fs, d_fp, _Ptr(d_pf.ptr + 8 * lo_u), cnt_u)
     ctx.window_build(*build_args)  # (first call allocates)
     ctx.sync()
     t0 = time.perf_counter()
@@ -345,6 +498,8 @@ def bench_window(ctx, args, world, rank, dev, torch, dist, cpu=False):
     ctx.sync()
     t_solve = time.perf_counter() - t0
     iters = max(1, summ.iterations)
+    it_ms = t_solve * 1e3 / iters
+    copy = getattr(args, "_copy_gbs", None)
     out = {
         "workload": "C4-like: %d sweeps x %d surfels = %d surfels, %d sample states (%d unknowns)" % (args.window_scans, args.window_patches, n_s, ns, 12 * ns),
         "factors_total": {"binary": n_b, "unary": n_u}, "factors_this_rank": {"binary": nb, "unary": nu, "imu": ni, "pieces": npieces},
@@ -353,7 +508,12 @@ def bench_window(ctx, args, world, rank, dev, torch, dist, cpu=False):
         "linearize_ms": round(lin_ms, 4), "assembly_corr_per_s": round(world * (nb + nu) / (lin_ms * 1e-3), 1),
         "assembly_roofline": {"bound": "hbm", "achieved": round(algo / (lin_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": round(algo / (lin_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "algorithmic_bytes_per_linearisation": algo,
-                              "frac_of_measured_copy": round(algo / (lin_ms * 1e-3) / 1e9 / args._copy_gbs, 5) if getattr(args, "_copy_gbs", None) else None},
+                              "frac_of_measured_copy": round(algo / (lin_ms * 1e-3) / 1e9 / copy, 5) if copy else None},
+        # one LM iteration = one linearisation + one candidate-cost pass over the same records (2 x the bytes) + the
+        # replicated damped solve; the time is the whole iteration (wall clock of the solve / iterations)
+        "lm_roofline": {"bound": "hbm", "achieved": round(2 * algo / (it_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(2 * algo / (it_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "algorithmic_bytes_per_iteration": 2 * algo,
+                        "ms_per_iteration": round(it_ms, 4)},
         "build_ms": round(t_build * 1e3, 3), "match_s": round(t_match, 4), "match_surfels_per_s": round(2 * n_s / t_match, 1), "generate_s": round(t_gen, 2),
     }
     if cpu:
@@ -366,23 +526,172 @@ def bench_window(ctx, args, world, rank, dev, torch, dist, cpu=False):
         ws = synth.surfel_window(args.window_scans, max(1, args.window_patches // frac), seed=synth.SEED + 7,
                                  fixed_patches=max(1, args.window_patches // frac))
         prm = pyoracle.default_params()
-        t1 = time.perf_counter()
-        pb = pyoracle.match(ws["surf"], ws["pose"], ws["surf"], ws["pose"], True, prm)
-        pu = pyoracle.match(ws["surf"], ws["pose"], ws["fix_surf"], ws["fix_pose"], False, prm)
-        t_cm = time.perf_counter() - t1
-        Wc = pyoracle.Window(ws["sample_times"], ws["grav"], False, prm)
-        Wc.add_binary(ws["surf"], ws["pose"], pb)
-        Wc.add_unary(ws["fix_surf"], ws["fix_pose"], ws["surf"], ws["pose"], pu)
-        Wc.add_imu(ws["imu"])
-        t1 = time.perf_counter()
-        _, sc, _ = Wc.solve(np.zeros(12 * len(ws["sample_times"])))
-        t_cs = time.perf_counter() - t1
+        with pinned_core() as pc:
+            t1 = time.perf_counter()
+            pb = pyoracle.match(ws["surf"], ws["pose"], ws["surf"], ws["pose"], True, prm)
+            pu = pyoracle.match(ws["surf"], ws["pose"], ws["fix_surf"], ws["fix_pose"], False, prm)
+            t_cm = time.perf_counter() - t1
+            Wc = pyoracle.Window(ws["sample_times"], ws["grav"], False, prm)
+            Wc.add_binary(ws["surf"], ws["pose"], pb)
+            Wc.add_unary(ws["fix_surf"], ws["fix_pose"], ws["surf"], ws["pose"], pu)
+            Wc.add_imu(ws["imu"])
+            t1 = time.perf_counter()
+            _, sc, _ = Wc.solve(np.zeros(12 * len(ws["sample_times"])))
+            t_cs = time.perf_counter() - t1
         out["cpu_baseline"] = {
-            "value": round(max(1, sc.iterations) / t_cs, 3), "unit": "LM iterations/s", "cores": 1, "kind": "port",
+            "value": round(max(1, sc.iterations) / t_cs, 3), "unit": "LM iterations/s", "cores": 1, "kind": "port", "pinned_core": pc.core, "cpu": cpu_info()["model"],
             "sample": "same window geometry with 1/%d of the surfels (%d surfels, %d + %d surfel factors, %d unknowns): %d LM iterations in %.1f s; "
                       "matcher %.0f surfels/s" % (frac, len(ws["surf"]), len(pb), len(pu), 12 * len(ws["sample_times"]), sc.iterations, t_cs,
                                                    2 * len(ws["surf"]) / t_cm)}
+    ctx.window_set_allreduce(None)
     return out
+
+
+def bench_odometry_step(ctx, args, world, rank, dev, torch, dist, cpu=False):
+    """north_star's headline workload, one FULL odometry step (LidarOdometry::AddLidarScan, lidar_odometry.cc:523-566) through the
+    C-ABI on a 10-sweep window of 1 M-point sweeps (10 x C2): 9 sweeps are already in the window (extracted, posed; the two oldest
+    form the fixed window), the step takes the newest sweep: BuildSurfels -> UpdateSurfelPoses -> 2 x KnnSurfelMatcher -> problem
+    construction -> solve -> UpdateSurfelPoses.  Single GPU (the N > 1 legs of its stages are `window` and `cloud_10m`)."""
+    from wildcat_slam_amd import records as R, synth
+
+    K, roots = 10, args.roots
+    w = synth.g2_scan_sequence(K, roots, m=32, seed=synth.SEED + 21)
+    imu = w["imu"]
+    d_imu = ctx.to_device(imu)
+    n_pts = len(w["scans"][-1])
+    cap_all = K * 8 * roots + 4096
+    d_surf, d_pose, d_inb = ctx.alloc(144 * cap_all), ctx.alloc(56 * cap_all), ctx.alloc(cap_all)
+    ctx._ck(ctx.lib.wc_memset(ctx.h, ctx_ptr(d_inb), 0, ctx_size(cap_all)))
+    counts, d_scans = [], []
+    for s in w["scans"]:
+        d_scans.append(ctx.to_device(s))
+    n_have = 0
+    for k in range(K - 1):  # the window before the step: sweeps 0 .. K-2
+        s = w["scans"][k]
+        desc = ctx.points_desc(d_scans[k], len(s))
+        ctx.extract_enqueue(desc, _Ptr(d_surf.ptr + 144 * n_have), None, cap_all - n_have, float(s["time"][0]), float(s["time"][-1]))
+        m = ctx.extract_finish()
+        counts.append(m)
+        n_have += m
+    ctx.update_surfel_poses(d_imu, len(imu), d_surf, d_pose, d_inb, n_have)
+    n_fix = counts[0] + counts[1]  # the two oldest sweeps: fixed window (constant world pose)
+    d_pb, d_pu = ctx.alloc(8 * cap_all), ctx.alloc(8 * cap_all)
+    newest = w["scans"][-1]
+    desc_new = ctx.points_desc(d_scans[-1], n_pts)
+    ns = len(w["sample_times"])
+    x0 = np.zeros(12 * ns)
+    # a copy of the window state so that every timed repetition starts from the same window
+    keep = (ctx.alloc(144 * n_have), ctx.alloc(56 * n_have))
+    ctx._ck(ctx.lib.wc_d2d(ctx.h, ctx_ptr(keep[0]), ctx_ptr(d_surf), ctx_size(144 * n_have)))
+    ctx._ck(ctx.lib.wc_d2d(ctx.h, ctx_ptr(keep[1]), ctx_ptr(d_pose), ctx_size(56 * n_have)))
+
+    def one_step(timed):
+        ctx._ck(ctx.lib.wc_d2d(ctx.h, ctx_ptr(d_surf), ctx_ptr(keep[0]), ctx_size(144 * n_have)))
+        ctx._ck(ctx.lib.wc_d2d(ctx.h, ctx_ptr(d_pose), ctx_ptr(keep[1]), ctx_size(56 * n_have)))
+        ctx._ck(ctx.lib.wc_memset(ctx.h, ctx_ptr(_Ptr(d_inb.ptr + n_have)), 0, ctx_size(cap_all - n_have)))
+        ctx.sync()
+        T = {}
+        t0 = time.perf_counter()
+        ctx.extract_enqueue(desc_new, _Ptr(d_surf.ptr + 144 * n_have), None, cap_all - n_have, float(newest["time"][0]), float(newest["time"][-1]))
+        m = ctx.extract_finish()
+        T["extract"] = time.perf_counter() - t0
+        n_all = n_have + m
+        n_sld = n_all - n_fix
+        sld_s, sld_p, sld_b = _Ptr(d_surf.ptr + 144 * n_fix), _Ptr(d_pose.ptr + 56 * n_fix), _Ptr(d_inb.ptr + n_fix)
+        t1 = time.perf_counter()
+        ctx.update_surfel_poses(d_imu, len(imu), sld_s, sld_p, sld_b, n_sld)
+        T["pose_update"] = time.perf_counter() - t1
+        t1 = time.perf_counter()
+        nb = ctx.match_device(sld_s, sld_p, n_sld, sld_s, sld_p, n_sld, True, d_pb, cap_all)
+        nu = ctx.match_device(sld_s, sld_p, n_sld, d_surf, d_pose, n_fix, False, d_pu, cap_all)
+        T["match"] = time.perf_counter() - t1
+        t1 = time.perf_counter()
+        ctx.window_build(sld_s, sld_p, d_pb, nb, imu, w["sample_times"], w["grav"], False, d_surf, d_pose, d_pu, nu)
+        T["build"] = time.perf_counter() - t1
+        t1 = time.perf_counter()
+        x, summ, _ = ctx.window_solve(x0)
+        T["solve"] = time.perf_counter() - t1
+        t1 = time.perf_counter()
+        ctx.update_surfel_poses(d_imu, len(imu), sld_s, sld_p, sld_b, n_sld)  # (the IMU poses would carry the B-spline correction)
+        ctx.sync()
+        T["pose_update2"] = time.perf_counter() - t1
+        T["total"] = time.perf_counter() - t0
+        return T, dict(new_surfels=m, sld=n_sld, fix=n_fix, binary=nb, unary=nu, iters=summ.iterations, cost=[summ.initial_cost, summ.final_cost],
+                       term=summ.termination, imu=max(0, len(imu) - 2))
+
+    one_step(False)
+    one_step(False)
+    reps = 5
+    acc, info = {}, None
+    for _ in range(reps):
+        T, info = one_step(True)
+        for k, v in T.items():
+            acc[k] = acc.get(k, 0.0) + v
+    T = {k: v / reps for k, v in acc.items()}
+    it = max(1, info["iters"])
+    # algorithmic bytes of the step (SURVEY 8(d)): extraction 20 B/pt + 144 B/surfel; pose update ~200 B/surfel R+W per call; matcher
+    # 48 B feature + 144 B surfel per query and target per call; assembly (136 / 96 / 128 B per factor) x 2 passes per LM iteration
+    b_ext = 20 * n_pts + 144 * info["new_surfels"]
+    b_pose = 2 * 200 * info["sld"]
+    b_match = 192 * (2 * info["sld"] + info["sld"] + info["fix"])
+    b_asm = 2 * it * (136 * info["binary"] + 96 * info["unary"] + 128 * info["imu"])
+    total_b = b_ext + b_pose + b_match + b_asm
+    out = {"workload": "10 x C2 window: %d-point newest sweep; sliding window %d surfels, fixed window %d; %d binary + %d unary + %d IMU factors; %d sample states"
+                       % (n_pts, info["sld"], info["fix"], info["binary"], info["unary"], info["imu"], ns),
+           "ms_per_step": round(T["total"] * 1e3, 4), "steps_per_s": round(1.0 / T["total"], 2), "points_per_s": round(n_pts / T["total"], 1),
+           "stage_ms": {k: round(v * 1e3, 4) for k, v in T.items() if k != "total"}, "lm_iterations": info["iters"], "cost": info["cost"],
+           "termination": info["term"],
+           "roofline": {"bound": "hbm", "achieved": round(total_b / T["total"] / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(total_b / T["total"] / 1e9 / HBM_PEAK_GBS, 5),
+                        "algorithmic_bytes": {"extract": b_ext, "pose_update": b_pose, "match": b_match, "assembly_all_iterations": b_asm}},
+           "timing": "wall clock around each C-ABI call (every call is synchronous on return), mean of %d repetitions from the same window state" % reps}
+    if cpu:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import pyoracle  # test infrastructure, used here ONLY as the timed CPU baseline
+
+        # bounded sample: the same step with 1/10 of the roots per sweep (same 10-sweep geometry, same sample states and IMU factors)
+        ws = synth.g2_scan_sequence(K, max(8, roots // 10), m=32, seed=synth.SEED + 21)
+        with pinned_core() as pc:
+            surf = []
+            for s in ws["scans"][:-1]:
+                surf.append(pyoracle.extract_surfels(s)[0])
+            n_fx = len(surf[0]) + len(surf[1])
+            S = np.concatenate(surf)
+            P = np.zeros(len(S), R.POSE)
+            B = np.zeros(len(S), np.uint8)
+            pyoracle.update_surfel_poses(ws["imu"], S, P, B)
+            t0 = time.perf_counter()
+            new = pyoracle.extract_surfels(ws["scans"][-1])[0]
+            S2 = np.concatenate([S, new])
+            P2 = np.concatenate([P, np.zeros(len(new), R.POSE)])
+            B2 = np.concatenate([B, np.zeros(len(new), np.uint8)])
+            pyoracle.update_surfel_poses(ws["imu"], S2[n_fx:], P2[n_fx:], B2[n_fx:])
+            sl_s, sl_p = np.ascontiguousarray(S2[n_fx:]), np.ascontiguousarray(P2[n_fx:])
+            pb = pyoracle.match(sl_s, sl_p, sl_s, sl_p, True)
+            pu = pyoracle.match(sl_s, sl_p, np.ascontiguousarray(S2[:n_fx]), np.ascontiguousarray(P2[:n_fx]), False)
+            Wc = pyoracle.Window(ws["sample_times"], ws["grav"], False)
+            Wc.add_binary(sl_s, sl_p, pb)
+            Wc.add_unary(np.ascontiguousarray(S2[:n_fx]), np.ascontiguousarray(P2[:n_fx]), sl_s, sl_p, pu)
+            Wc.add_imu(ws["imu"])
+            _, sc, _ = Wc.solve(np.zeros(12 * len(ws["sample_times"])))
+            pyoracle.update_surfel_poses(ws["imu"], sl_s, sl_p, np.ones(len(sl_s), np.uint8))
+            t_cpu = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": round(1.0 / t_cpu, 4), "unit": "steps/s", "cores": 1, "kind": "port", "pinned_core": pc.core, "cpu": cpu_info()["model"],
+                               "sample": "the same step at 1/10 scale (%d-point sweeps, %d sliding + %d fixed surfels, %d + %d surfel factors, %d LM iterations): %.2f s "
+                                         "of single-thread oracle" % (len(ws["scans"][-1]), len(sl_s), n_fx, len(pb), len(pu), sc.iterations, t_cpu)}
+    return out
+
+
+def ctx_ptr(buf):
+    import ctypes
+
+    return ctypes.c_void_p(buf.ptr)
+
+
+def ctx_size(n):
+    import ctypes
+
+    return ctypes.c_size_t(int(n))
 
 
 if __name__ == "__main__":

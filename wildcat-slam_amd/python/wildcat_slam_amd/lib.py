@@ -270,10 +270,14 @@ class Context:
     def route_desc(self, d_route_points, n):
         return R.Points(d_route_points.ptr, d_route_points.ptr + 16, 24, 24, n)
 
-    def extract_surfels_sharded(self, d_points, n, t_lo, t_hi, cap=None):
-        """this rank's slice (device POINT array) -> (surfels, ids, points owned) of the voxels this rank owns"""
-        cap = cap or max(1024, (3 * n) // 20 + 1) * 4
-        d_out, d_ids = self.alloc(cap * 144), self.alloc(cap * 16)
+    def extract_surfels_sharded(self, d_points, n, t_lo, t_hi, cap=None, out=None):
+        """this rank's slice (device POINT array) -> (surfels, ids, count, points owned) of the voxels this rank owns;
+        out = (d_out, d_ids, cap) reuses buffers"""
+        if out is not None:
+            d_out, d_ids, cap = out
+        else:
+            cap = cap or max(1024, (3 * n) // 20 + 1) * 4
+            d_out, d_ids = self.alloc(cap * 144), self.alloc(cap * 16)
         desc = self.points_desc(d_points, n)
         m, owned = C.c_uint64(0), C.c_uint64(0)
         self._ck(self.lib.wc_extract_surfels_sharded(self.h, C.byref(desc), C.c_double(t_lo), C.c_double(t_hi), C.c_void_p(d_out.ptr),

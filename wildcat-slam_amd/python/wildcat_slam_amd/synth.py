@@ -89,7 +89,8 @@ def concat_points(*parts):
 
 
 # --------------------------------------------------------------------------------------------------------------------
-def g2_lattice(n_roots, m=32, seed=SEED, span=60, patches_per_root=8, t_start=T0, duration=0.5, noise=0.005):
+def g2_lattice(n_roots, m=32, seed=SEED, span=60, patches_per_root=8, t_start=T0, duration=0.5, noise=0.005, sample_seed=None,
+               pose_fn=None):
     """G2 "patch lattice": `n_roots` distinct 0.8 m root voxels inside a cube of `span` voxels per side centred on
     the origin; each root carries `patches_per_root` planar patches (one per 0.4 m child octant, m points each).
     Returns (points[POINT], info) with info = dict(centres, normals, root_keys)."""
@@ -113,13 +114,18 @@ def g2_lattice(n_roots, m=32, seed=SEED, span=60, patches_per_root=8, t_start=T0
     u = np.cross(nrm, helper)
     u /= np.linalg.norm(u, axis=1, keepdims=True)
     v = np.cross(nrm, u)
+    if sample_seed is not None:  # same world patches, fresh samples on them (a re-observation by another sweep)
+        rng = np.random.Generator(np.random.PCG64(sample_seed))
     rad = 0.15 * np.sqrt(rng.random((npatch, m)))
     ang = 2 * np.pi * rng.random((npatch, m))
     h = noise * rng.normal(size=(npatch, m))
     xyz = centres[:, None, :] + (rad * np.cos(ang))[..., None] * u[:, None, :] + (rad * np.sin(ang))[..., None] * v[:, None, :] + h[..., None] * nrm[:, None, :]
-    xyz = xyz.reshape(-1, 3)
-    n = len(xyz)
+    n = npatch * m
     t = t_start + duration * (np.arange(n, dtype=np.float64) / n)
+    if pose_fn is not None:  # express every patch through the (erroneous) pose estimate of its time: x -> A x + b, per patch
+        A, b = pose_fn(t.reshape(npatch, m)[:, 0])
+        xyz = np.einsum("pij,pmj->pmi", A, xyz) + b[:, None, :]
+    xyz = xyz.reshape(-1, 3)
     return make_points(xyz, t), dict(centres=centres, normals=nrm, root_keys=keys, patches_per_root=P, m=m)
 
 
@@ -158,6 +164,42 @@ def g1_room(n_points, seed=SEED, t_start=T0, duration=0.5, noise=0.01, beams=32,
     xyz = o + (best + rng_noise)[:, None] * d
     t = t_start + t_rel
     return make_points(xyz[good], t[good])
+
+
+def g2_scan_sequence(n_scans, n_roots, m=32, seed=SEED, scan_dur=0.5, t_start=T0, sample_dt=0.08, pose_err=(0.01, 2e-4)):
+    """`n_scans` sweeps of n_roots * 8 * m points each that re-observe the SAME world patches (fresh samples per sweep), as a
+    sensor on the analytic trajectory would see them through a pose ESTIMATE that is off by a smooth error (the drift the
+    window solve removes): a point of sweep k is T_est(t) T_true(t)^-1 x_world.  Returns dict(scans=[POINT arrays],
+    imu, grav, sample_times): the input of a full odometry step (extraction -> poses -> matching -> solve) at point level."""
+    rng = np.random.Generator(np.random.PCG64(seed + 977))
+    ep, er = pose_err
+    ph = rng.random(6) * 2 * np.pi
+
+    def perturb(tr):
+        dp = ep * np.stack([np.sin(0.9 * tr + ph[0]), np.sin(1.3 * tr + ph[1]), np.sin(0.7 * tr + ph[2])], -1)
+        dr = er * np.stack([np.sin(1.1 * tr + ph[3]), np.sin(0.8 * tr + ph[4]), np.sin(1.7 * tr + ph[5])], -1)
+        return dp, dr
+
+    def pose_fn(t):
+        tr = t - T0
+        pos_t, R_t = traj_pos(tr), traj_rot(tr)
+        dp, dr = perturb(tr)
+        R_e = so3_exp_mat(dr) @ R_t
+        A = np.einsum("pij,pkj->pik", R_e, R_t)  # R_e R_t^T
+        return A, (pos_t + dp) - np.einsum("pij,pj->pi", A, pos_t)
+
+    dur = n_scans * scan_dur
+    ns = int(np.floor(dur / sample_dt + 1e-9)) + 2
+    sample_times = t_start + sample_dt * np.arange(ns)
+    lo = sample_times[0] + 1e-3
+    scans = []
+    for k in range(n_scans):
+        a = max(t_start + k * scan_dur, lo)
+        b = min(t_start + (k + 1) * scan_dur, sample_times[-1] - 1e-3)
+        pts, _ = g2_lattice(n_roots, m=m, seed=seed, t_start=a, duration=b - a, sample_seed=seed + 1000 + k, pose_fn=pose_fn)
+        scans.append(pts)
+    imu, grav = imu_states(t_start, sample_times[-1] + 0.01, t_origin=T0, perturb=perturb)
+    return dict(scans=scans, imu=imu, grav=grav, sample_times=sample_times)
 
 
 # --------------------------------------------------------------------------------------------------------------------
