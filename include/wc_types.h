@@ -124,6 +124,11 @@ typedef struct wc_params {
   double imu_dt;             /* 1 / imu_rate = 0.005                                  */
   int32_t max_iterations;    /* 100                                                   */
   int32_t reference_quirks;  /* 1: reproduce Q1 (Jacobian overwrite) and Q3           */
+  /* extraction arithmetic (not a reference parameter).  0 (default): order-independent integer moments - counts / ids exact,
+   * geometry ~1e-9, surfel time stamp = the correctly rounded mean, sweeps with a gate inside the reference's own rounding
+   * noise are repeated on the exact path.  1: every sum formed in the reference's order (bit-identical to the CPU path,
+   * including the output order among surfels whose stamps differ by less than the running sum's rounding). */
+  int32_t exact_sums;
 } wc_params;
 
 /* Solver summary (subset of ceres::Solver::Summary the reference logs, lidar_odometry.cc:562). */

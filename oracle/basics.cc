@@ -42,6 +42,7 @@ extern "C" void wco_params_default(wc_params *p) {
   p->imu_dt = 1 / rate;
   p->max_iterations = 100;  // lio_config.h:41
   p->reference_quirks = 1;
+  p->exact_sums = 0;  // (the oracle always sums in the reference's order; the field only steers the HIP library)
 }
 
 static void store(const M3 &m, double out9[9]) {

@@ -50,3 +50,32 @@ def check_surfels(s_gpu, id_gpu, s_ref, id_ref, tol=1e-6, t_tol=None):
     assert np.all(np.diff(s_gpu["t"]) >= 0)
     bit_exact = all(np.array_equal(g[f], s_ref[f], equal_nan=True) for f in ("t", "center", "cov", "normal", "sigma"))
     return dict(n=n, dn=dn, dc=dc, dcov=dcov, dsig=dsig, dt=dt, bit_exact=bit_exact)
+
+
+def check_fast_and_exact(gpu, oracle, pts, params=None, expect_fast=None, **kw):
+    """wc_extract_surfels in both arithmetic modes against the oracle:
+    exact  - every sum in the reference's order: surfels AND ids byte for byte the oracle's, in the oracle's order;
+    fast   - (default) integer moments: counts and ids identical as sets, geometry within 1e-6 (north_star), output sorted by
+             its own (correctly rounded) time stamps.  expect_fast: True = the sweep must have been completed by the fast path
+             itself (no silent fall-back to the exact path), None = either."""
+    s_ref, id_ref, st = oracle.extract_surfels(pts, params) if params is not None else oracle.extract_surfels(pts)
+    out = {}
+    for exact in (True, False):
+        gpu.set_exact_sums(exact)
+        try:
+            s_gpu, id_gpu = gpu.extract_surfels(pts, **kw)
+            path = gpu.extract_path_info()
+        finally:
+            gpu.set_exact_sums(False)
+        assert len(s_gpu) == len(s_ref) == st.surfels, (exact, len(s_gpu), len(s_ref))
+        if exact:
+            assert not path["fast"]
+            assert id_gpu.tobytes() == id_ref.tobytes()  # the ORDER is the oracle's too: stamp, then voxel index and node id (Q7)
+            info = check_surfels(s_gpu, id_gpu, s_ref, id_ref, tol=1e-6, t_tol=1e-5) if len(s_ref) else dict(n=0)
+        else:
+            if expect_fast:
+                assert path["fast"], path
+            info = check_surfels(s_gpu, id_gpu, s_ref, id_ref, tol=1e-6, t_tol=1e-4) if len(s_ref) else dict(n=0)
+            info["fast_path"] = path["fast"]
+        out["exact" if exact else "fast"] = info
+    return out, st

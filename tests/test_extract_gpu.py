@@ -10,14 +10,12 @@ from wildcat_slam_amd import synth
 pytestmark = pytest.mark.gpu
 
 
-def _run(gpu, oracle, pts, **kw):
-    s_ref, id_ref, st = oracle.extract_surfels(pts)
-    s_gpu, id_gpu = gpu.extract_surfels(pts, **kw)
-    assert len(s_gpu) == len(s_ref) == st.surfels
-    info = helpers.check_surfels(s_gpu, id_gpu, s_ref, id_ref, tol=1e-6, t_tol=1e-5)
-    # the ORDER is the oracle's as well: time stamp, then (ties) root voxel index and node id - SURVEY Q7
-    assert id_gpu.tobytes() == id_ref.tobytes()
-    return info, st
+def _run(gpu, oracle, pts, expect_fast=None, **kw):
+    """both arithmetic modes of the library against the oracle (helpers.check_fast_and_exact)"""
+    info, st = helpers.check_fast_and_exact(gpu, oracle, pts, expect_fast=expect_fast, **kw)
+    res = dict(info["exact"])
+    res["fast"] = info["fast"]
+    return res, st
 
 
 def test_voxel_keys_bit_exact(gpu, oracle):
@@ -29,7 +27,7 @@ def test_voxel_keys_bit_exact(gpu, oracle):
 
 def test_g2_lattice_small(gpu, oracle):
     pts, info = synth.g2_lattice(400, m=32)
-    res, st = _run(gpu, oracle, pts)
+    res, st = _run(gpu, oracle, pts, expect_fast=True)
     assert res["n"] == 8 * 400
     print(res)
 
@@ -37,14 +35,14 @@ def test_g2_lattice_small(gpu, oracle):
 def test_g2_sparse_overlap_q4(gpu, oracle):
     # one patch per root: the root is a plane AND is force-split, so root (0.8 m) and child (0.4 m) surfels overlap (Q4)
     pts, info = synth.g2_lattice(500, m=48, patches_per_root=1)
-    res, st = _run(gpu, oracle, pts)
+    res, st = _run(gpu, oracle, pts, expect_fast=True)
     assert st.nodes_plane[0] > 0 and st.nodes_plane[1] > 0
     print(res)
 
 
 def test_g1_room_multires(gpu, oracle):
     pts = synth.g1_room(300_000)
-    res, st = _run(gpu, oracle, pts)
+    res, st = _run(gpu, oracle, pts, expect_fast=True)
     assert res["n"] > 1000
     print(res, list(st.nodes_plane))
 
@@ -60,7 +58,7 @@ def test_small_timestamps_and_temporal_clusters(gpu, oracle):
     b, _ = synth.g2_lattice(200, m=32, t_start=0.3, duration=0.1)
     b["x"] += np.float32(0.001)
     pts = synth.concat_points(a, b)
-    res, st = _run(gpu, oracle, pts)
+    res, st = _run(gpu, oracle, pts, expect_fast=True)
     assert res["n"] == 2 * 8 * 200
     assert st.clusters_total == 2 * 8 * 200  # two temporal clusters per layer-1 plane node
 
@@ -97,11 +95,12 @@ def test_c2_full_size_properties(gpu, oracle):
     and a 1/16 sub-sample of roots agrees with the oracle."""
     pts, info = synth.g2_lattice(3906, m=32)
     s_gpu, id_gpu = gpu.extract_surfels(pts)
+    assert gpu.extract_path_info()["fast"]  # the headline workload runs on the fast path, no fall-back
     assert len(pts) == 999_936 and len(s_gpu) == 8 * 3906
     assert np.all(np.diff(s_gpu["t"]) >= 0)
     assert np.all(s_gpu["resolution"] == np.float64(np.float32(0.4)))
-    s_ref, id_ref, st = oracle.extract_surfels(pts)
-    helpers.check_surfels(s_gpu, id_gpu, s_ref, id_ref, tol=1e-6, t_tol=1e-5)
+    res, st = _run(gpu, oracle, pts, expect_fast=True)
+    print(res["fast"])
 
 
 def test_dense_voxels_overflow_fast_sort_and_fall_back(gpu, oracle):
@@ -177,15 +176,13 @@ def test_non_default_parameters(gpu, oracle, override):
         else:
             setattr(params, k, v)
     gpu.set_params(params)
+    gpu.params = params
     try:
         for pts in (synth.g2_lattice(120, m=40)[0], synth.g1_room(90_000, seed=13)):
-            s_ref, id_ref, st = oracle.extract_surfels(pts, params)
-            s_gpu, id_gpu = gpu.extract_surfels(pts)
-            assert len(s_gpu) == len(s_ref) == st.surfels
-            if len(s_ref):
-                helpers.check_surfels(s_gpu, id_gpu, s_ref, id_ref, tol=1e-6, t_tol=1e-5)
+            helpers.check_fast_and_exact(gpu, oracle, pts, params=params)
     finally:
-        gpu.set_params(oracle.default_params())
+        gpu.params = oracle.default_params()
+        gpu.set_params(gpu.params)
 
 
 @pytest.mark.parametrize("xyz_stride", [12, 16])

@@ -36,8 +36,10 @@ def test_route_partition_is_stable_and_complete(gpu, oracle, world):
         o += len(s)
 
 
-def _run_ranks(world, pts, want_gather=True):
+def _run_ranks(world, pts, want_gather=True, exact=False):
     ctxs = [lib.Context(0) for _ in range(world)]
+    for c in ctxs:
+        c.set_exact_sums(exact)
     shared = wdist.ThreadComm.shared(world)
     t_lo, t_hi = float(pts["time"][0]), float(pts["time"][-1])
     out, errors = [None] * world, []
@@ -49,7 +51,7 @@ def _run_ranks(world, pts, want_gather=True):
             lo, cnt = wdist.shard_range(len(pts), r, world)
             d_slice = ctx.to_device(pts[lo : lo + cnt])
             d_s, d_i, m, owned = ctx.extract_surfels_sharded(d_slice, cnt, t_lo, t_hi)
-            local = (d_s.download(R.SURFEL, m), d_i.download(R.SURFEL_ID, m), owned)
+            local = (d_s.download(R.SURFEL, m), d_i.download(R.SURFEL_ID, m), owned, ctx.extract_path_info()["fast"])
             merged = ctx.gather_surfels(d_s, d_i, m, cap=len(pts) // 4 + 1024) if want_gather else None
             out[r] = (local, merged)
         except Exception as e:  # pragma: no cover
@@ -67,14 +69,23 @@ def _run_ranks(world, pts, want_gather=True):
     return out
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_extraction_equals_unsharded(gpu, world):
+@pytest.mark.parametrize("world,exact", [(2, True), (3, True), (2, False), (3, False)])
+def test_sharded_extraction_equals_unsharded(gpu, world, exact):
     """every rank extracts the voxels it owns from the routed points; the lists are disjoint by voxel, each rank owns work, and
-    the gathered + merged list is the unsharded call's output byte for byte (surfels AND ids, in order)"""
+    the gathered + merged list is the unsharded call's output byte for byte (surfels AND ids, in order) - in the exact
+    arithmetic always, in the default (integer-moment) arithmetic whenever no rank had to hand its share to the exact path
+    (then the two arithmetics meet in one list: ids / counts still identical, geometry within 1e-6)"""
+    import helpers
+
     pts = _mixed_cloud()
-    s_ref, i_ref = gpu.extract_surfels(pts)
+    gpu.set_exact_sums(exact)
+    try:
+        s_ref, i_ref = gpu.extract_surfels(pts)
+        ref_fast = gpu.extract_path_info()["fast"]
+    finally:
+        gpu.set_exact_sums(False)
     assert len(s_ref) > 2000
-    out = _run_ranks(world, pts)
+    out = _run_ranks(world, pts, exact=exact)
     owned_pts = sum(o[0][2] for o in out)
     assert owned_pts == len(pts)
     keys = [set(map(tuple, np.stack([o[0][1]["kx"], o[0][1]["ky"], o[0][1]["kz"]], 1).tolist())) for o in out]
@@ -86,9 +97,14 @@ def test_sharded_extraction_equals_unsharded(gpu, world):
         for b in range(a + 1, world):
             assert not (keys[a] & keys[b])
     assert sum(len(o[0][0]) for o in out) == len(s_ref)
+    same_arithmetic = exact or (ref_fast and all(o[0][3] for o in out))
     for r in range(world):
         ms, mi = out[r][1]
-        assert mi.tobytes() == i_ref.tobytes() and ms.tobytes() == s_ref.tobytes()
+        if same_arithmetic:
+            assert mi.tobytes() == i_ref.tobytes() and ms.tobytes() == s_ref.tobytes()
+        else:
+            helpers.check_surfels(ms, mi, s_ref, i_ref, tol=1e-6, t_tol=1e-4)
+        assert ms.tobytes() == out[0][1][0].tobytes()  # every rank holds the same merged list
 
 
 def test_merge_surfels_kway(gpu):
@@ -110,6 +126,7 @@ def test_c5_cloud_10m_points_full_size(gpu, oracle):
     pts, info = synth.g2_lattice(n_roots, m=32, seed=synth.SEED + 50)
     assert len(pts) == 9_999_872
     s, ids = gpu.extract_surfels(pts)
+    assert gpu.extract_path_info()["fast"]  # the default (integer-moment) path handles the 10 M-point cloud itself
     assert len(s) == 8 * n_roots
     assert np.all(np.diff(s["t"]) >= 0)
     assert np.all(s["resolution"] == np.float64(np.float32(0.2) * 2))  # all at layer 1 (0.4 m)
@@ -121,16 +138,30 @@ def test_c5_cloud_10m_points_full_size(gpu, oracle):
     s_ref, i_ref, _ = oracle.extract_surfels(pts[sel])
     assert len(s_ref) == 8 * len(pick)
     want = set(map(tuple, info["root_keys"][pick].tolist()))
-    mask = np.array([(a, b, c) in want for a, b, c in zip(ids["kx"].tolist(), ids["ky"].tolist(), ids["kz"].tolist())])
-    assert ids[mask].tobytes() == i_ref.tobytes() and s[mask].tobytes() == s_ref.tobytes()
+    import helpers
+
+    def sub(ids_):
+        return np.array([(a, b, c) in want for a, b, c in zip(ids_["kx"].tolist(), ids_["ky"].tolist(), ids_["kz"].tolist())])
+
+    mask = sub(ids)
+    helpers.check_surfels(s[mask], ids[mask], s_ref, i_ref, tol=1e-6, t_tol=1e-4)  # fast path: ids / counts exact, geometry 1e-6
+    gpu.set_exact_sums(True)
+    try:
+        s, ids = gpu.extract_surfels(pts)
+    finally:
+        gpu.set_exact_sums(False)
+    mask = sub(ids)
+    assert len(s) == 8 * n_roots
+    assert ids[mask].tobytes() == i_ref.tobytes() and s[mask].tobytes() == s_ref.tobytes()  # exact path: the oracle's bytes
 
 
 def test_c5_cloud_routed_two_ranks(gpu):
     """the same kind of cloud at 2 M points through the routed two-rank path: merged result = unsharded result"""
     pts, _ = synth.g2_lattice(7_812, m=32, seed=synth.SEED + 51)
     s_ref, i_ref = gpu.extract_surfels(pts)
-    assert len(s_ref) == 8 * 7_812
+    assert len(s_ref) == 8 * 7_812 and gpu.extract_path_info()["fast"]
     out = _run_ranks(2, pts)
+    assert all(o[0][3] for o in out)  # both ranks on the default (integer-moment) path
     share = [o[0][2] / len(pts) for o in out]
     assert abs(share[0] - 0.5) < 0.05  # balanced ownership
     for r in range(2):

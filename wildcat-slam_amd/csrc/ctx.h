@@ -28,7 +28,7 @@ struct wc_ctx {
   // scratch buffers (device), grown on demand and kept for the lifetime of the ctx
   wc_buf b_ex_ctrl;  // the extraction's control block (status words, bucket / bin counters): never shared, cleared ahead of time
   wc_buf b_keys[2], b_vals[2], b_sorttmp, b_slots, b_slot_ids, b_slot_keys[2], b_slot_idx[2], b_cand, b_cand_meta,
-      b_status, b_misc[8], b_route[4];
+      b_status, b_misc[8], b_route[4], b_fx[4];
   // multi-GPU: the job's communicator (wc_ctx_set_comm / wc_comm_rccl_init)
   wc_comm comm{};
   bool have_comm = false;
@@ -53,6 +53,9 @@ struct wc_ctx {
     uint32_t last_splits = 256;  // roots the previous call queued for the layer-2 pass (sizes / gates that launch)
     // the tail of the pipeline (layer-2 pass, surfel order, status read-back) is re-run by finish() when the call skipped
     // the layer-2 launch and roots were queued for it after all
+    bool fx_active = false;      // this call runs on the fast (integer-moment) path
+    bool fx_dirty = false;       // the fast path's tables may hold garbage (an aborted sweep): memset before the next use
+    uint32_t fx_last_flags = 0, fx_fallbacks = 0;
     bool precleared = false;     // the control block has been cleared (on the stream) by the previous finish()
     bool layer2_done = true;
     int (*tail)(wc_ctx *, bool) = nullptr;

@@ -41,6 +41,7 @@ extern "C" void wc_params_default(wc_params *p) {
   p->imu_dt = 1 / rate;
   p->max_iterations = 100;
   p->reference_quirks = 1;
+  p->exact_sums = 0;
 }
 
 static int check_params(wc_ctx *ctx, const wc_params *p) {
@@ -104,6 +105,8 @@ extern "C" void wc_ctx_destroy(wc_ctx *ctx) {
   for (wc_buf &b : ctx->b_misc)
     if (b.p) (void)hipFree(b.p);
   for (wc_buf &b : ctx->b_route)
+    if (b.p) (void)hipFree(b.p);
+  for (wc_buf &b : ctx->b_fx)
     if (b.p) (void)hipFree(b.p);
   if (ctx->h_status) (void)hipHostFree(ctx->h_status);
   if (ctx->h_mail) (void)hipHostFree(ctx->h_mail);

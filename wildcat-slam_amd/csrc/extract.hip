@@ -1380,7 +1380,12 @@ __global__ void __launch_bounds__(256) k_slot_emit(const uint32_t *__restrict__ 
     uint32_t *hm = host_mailbox(status);
     if (hm) {
       hm[0] = base + c0 + c1 + c2 + c3;
-      hm[4] = status[4];  // roots queued for the layer-2 pass (every emitting kernel has finished)
+      uint32_t queued = status[4];  // roots queued for the layer-2 pass (every emitting kernel has finished)
+      for (int j = 16; j < 48; ++j) {  // fast path: root / layer-2 node sub-counters (extract_fast.inc), for k_fx_clean
+        hm[j] = status[j];
+        if (j >= 32) queued += status[j];
+      }
+      hm[4] = queued;
       hm[5] = status[5];  // runs of the sweep (run-binned sort only): tells the host whether the input has run structure
     }
   }
@@ -1400,8 +1405,11 @@ __global__ void __launch_bounds__(256) k_slot_emit(const uint32_t *__restrict__ 
     for (uint32_t j = 0; j < c; ++j) {  // composites are unique (slot index)
       const uint64_t other = s_item[w][j];
       bool less = other < mine;
-      if ((other >> 32) == (mine >> 32) && other != mine)  // equal time stamps: canonical order, not slot order
-        less = surfel_id_less(slot_ids[(uint32_t)other], slot_ids[(uint32_t)mine]);
+      if ((other >> 32) == (mine >> 32) && other != mine) {  // equal keys: the time stamps themselves (a key of the fast path
+        // is a 32-bit fraction of the sweep), then - equal stamps - the canonical order, not the slot order
+        const double to = slots[(uint32_t)other].t, tm = slots[(uint32_t)mine].t;
+        less = to < tm || (to == tm && surfel_id_less(slot_ids[(uint32_t)other], slot_ids[(uint32_t)mine]));
+      }
       rank += less ? 1u : 0u;
     }
     s_sorted[w][rank] = (uint32_t)mine;
@@ -1734,6 +1742,170 @@ int sort_pairs(wc_ctx *ctx, K *kin, K *kout, uint32_t *vin, uint32_t *vout, size
   return WC_OK;
 }
 
+#include "extract_fast.inc"
+
+// ---- host side of the fast path ------------------------------------------------------------------------------------------
+// grow-only buffer that is ZERO when it is (re)allocated: the fast path's tables are zero at rest
+int fx_ensure_zero(wc_ctx *ctx, wc_buf &b, size_t bytes) {
+  if (bytes <= b.cap) return WC_OK;
+  WC_TRY(wc_ensure(ctx, b, bytes));
+  WC_HIP(ctx, hipMemsetAsync(b.p, 0, b.cap, ctx->stream));
+  return WC_OK;
+}
+
+bool fx_applicable(const wc_ctx *ctx, uint64_t n, double t_lo, double t_hi) {
+  const wc_params &P = ctx->P;
+  if (P.exact_sums || getenv("WC_EXACT_SUMS")) return false;
+  if (n < 64 || !(P.voxel_size > 0.0f) || P.voxel_size >= 0.99f) return false;  // |p - centre| 2^32 must fit an int32
+  if (!(P.cluster_gap > 1e-6) || !(t_hi > t_lo)) return false;
+  if ((t_hi - t_lo) / (P.cluster_gap * 0.999) >= 1048000.0) return false;
+  return true;
+}
+
+int fx_tail(wc_ctx *ctx, bool layer2);
+
+int run_pipeline_fast(wc_ctx *ctx, const wc_points &pts, double t_lo, double t_hi, wc_surfel *d_out, wc_surfel_id *d_ids, uint64_t cap) {
+  const wc_params &P = ctx->P;
+  const uint64_t n = pts.n;
+  hipStream_t st = ctx->stream;
+  FxArgs A;
+  std::memset(&A, 0, sizeof(A));
+  ExParams &E = A.P;
+  E.vs = (double)P.voxel_size, E.vs_f = P.voxel_size, E.max_layer = P.max_layer, E.min_points = P.min_points;
+  E.thr = (double)P.planer_threshold, E.min_like = P.min_plane_likeness;
+  for (int i = 0; i < 3; ++i) E.view[i] = P.view_point[i];
+  E.gap = P.cluster_gap, E.cluster_min = P.cluster_min_points;
+  E.t_lo_bits = ordered_bits_host(t_lo);
+  E.t_span_bits = ordered_bits_host(t_hi) - E.t_lo_bits;
+  E.dbg = 0;
+  unsigned tbits = 1;
+  while (tbits < 64 && (E.t_span_bits >> tbits)) ++tbits;
+  A.pts = pts;
+  A.t_lo = t_lo;
+  int e = 0;
+  (void)std::frexp(t_hi - t_lo, &e);  // span < 2^e
+  A.tick = std::ldexp(1.0, 40 - e), A.inv_tick = std::ldexp(1.0, e - 40);
+  A.inv_w = 1.0 / (P.cluster_gap * 0.999);
+  A.inv_span = 1.0 / (t_hi - t_lo);
+  A.qs = 4294967296.0, A.inv_q = 1.0 / 4294967296.0, A.inv_qq = std::ldexp(1.0, -44);
+  // capacities: a root block per 32 points, a layer-2 node block per 64; the hash holds 4 x the root blocks
+  uint32_t mr = 1024;
+  while ((uint64_t)mr * 32 < n) mr *= 2;
+  A.mr_per = mr / kFxSub, A.mq_per = std::max(64u, mr / 2 / kFxSub);
+  const uint32_t tr = mr * 4;
+  A.tr_mask = tr - 1;
+  const uint64_t total_slots = (n * (uint64_t)(P.max_layer + 1)) / (uint64_t)P.cluster_min_points + 1;
+  uint32_t bin_cap = 64;
+  while (bin_cap < kSlotBinMax && (uint64_t)bin_cap * kBuckets < 2 * total_slots) bin_cap *= 2;
+  WC_TRY(fx_ensure_zero(ctx, ctx->b_fx[0], (size_t)tr * 4));
+  WC_TRY(fx_ensure_zero(ctx, ctx->b_fx[1], (size_t)tr * 4));
+  WC_TRY(fx_ensure_zero(ctx, ctx->b_fx[2], (size_t)mr * kFxBlockW * 8));
+  WC_TRY(fx_ensure_zero(ctx, ctx->b_fx[3], (size_t)A.mq_per * kFxSub * kFxBlockW * 8));
+  WC_TRY(wc_ensure(ctx, ctx->b_slots, total_slots * sizeof(wc_surfel)));
+  WC_TRY(wc_ensure(ctx, ctx->b_slot_ids, total_slots * sizeof(wc_surfel_id)));
+  WC_TRY(wc_ensure(ctx, ctx->b_slot_keys[1], (uint64_t)kBuckets * bin_cap * 8));
+  if (ctx->ex.fx_dirty) {  // a previous sweep ended abnormally: everything back to zero
+    for (int i = 0; i < 4; ++i) WC_HIP(ctx, hipMemsetAsync(ctx->b_fx[i].p, 0, ctx->b_fx[i].cap, st));
+    ctx->ex.fx_dirty = false;
+  }
+  const bool precleared = ctx->ex.precleared && ctx->b_ex_ctrl.p;
+  ctx->ex.precleared = false;
+  if (!precleared) WC_TRY(clear_ctrl(ctx));
+  for (int q = 0; q < 64; ++q) ctx->h_status[q] = 0;
+  A.rkey = (uint32_t *)ctx->b_fx[0].p, A.rval = (uint32_t *)ctx->b_fx[1].p;
+  A.blk = (unsigned long long *)ctx->b_fx[2].p, A.blk2 = (unsigned long long *)ctx->b_fx[3].p;
+  A.status = (uint32_t *)ctx->b_ex_ctrl.p + kCtrlStatus;
+  A.slots = (wc_surfel *)ctx->b_slots.p, A.slot_ids = (wc_surfel_id *)ctx->b_slot_ids.p;
+  A.slots_per = (uint32_t)std::min<uint64_t>(total_slots / kFxSub, 0x7FFFFFFFu);
+  A.slot_counts = (uint32_t *)ctx->b_ex_ctrl.p + kCtrlBins;
+  A.slot_shift = tbits > 12 ? tbits - 12 : 0u;
+  A.slot_bins = (uint64_t *)ctx->b_slot_keys[1].p;
+  A.slot_bin_cap = bin_cap;
+  auto mark = [&](int i) {
+    if (ctx->ex_prof) (void)hipEventRecord(ctx->ex_ev[i], st);
+  };
+  mark(0);
+  mark(1);
+  const unsigned tiles = (unsigned)((n + kFxTile - 1) / kFxTile);
+  const bool dbg = getenv("WC_FX_DEBUG") != nullptr;
+  auto dbg_sync = [&](const char *what) {
+    if (!dbg) return;
+    fprintf(stderr, "[fx] %s ...", what);
+    const hipError_t e = hipStreamSynchronize(st);
+    uint32_t w[64];
+    (void)hipMemcpy(w, A.status, sizeof(w), hipMemcpyDeviceToHost);
+    uint32_t r = 0, q = 0, sl = 0;
+    for (int j = 0; j < 16; ++j) r += w[16 + j], q += w[32 + j], sl += w[48 + j];
+    fprintf(stderr, " %s flags=%u roots=%u nodes2=%u slots=%u | tested=%u planes=%u multi=%u single=%u tails=%u wants=%u occupied=%u\n", hipGetErrorString(e), w[1], r, q, sl,
+            w[10], w[11], w[12], w[13], w[14], w[15], w[6]);
+    unsigned long long *d_dbg = nullptr, h_dbg[4] = {0, 0, 0, 0};
+    if (hipMalloc(&d_dbg, 32) == hipSuccess) {
+      (void)hipMemset(d_dbg, 0, 32);
+      k_fx_debug_sum<<<(r * 128u + 255u) / 256u + 1u, 256, 0, st>>>(A, d_dbg);
+      (void)hipStreamSynchronize(st);
+      (void)hipMemcpy(h_dbg, d_dbg, 32, hipMemcpyDeviceToHost);
+      (void)hipFree(d_dbg);
+      fprintf(stderr, "[fx]    tables: points=%llu cells=%llu checksum=%llx unmasked=%llu\n", h_dbg[0], h_dbg[1], h_dbg[2], h_dbg[3]);
+    }
+  };
+  if (dbg) fprintf(stderr, "[fx] n=%llu tiles=%u mr_per=%u mq_per=%u tr=%u slots_per=%u bin_cap=%u\n", (unsigned long long)n, tiles, A.mr_per, A.mq_per, tr, A.slots_per, bin_cap);
+  k_fx_acc<1><<<tiles, kFxThreads, 0, st>>>(A);
+  dbg_sync("k_fx_acc<1>");
+  mark(2);
+  const unsigned ngrid = std::min<unsigned>(256 * 16, std::max<unsigned>(64, (unsigned)(n / 128)));
+  k_fx_nodes<1><<<ngrid, 64, 0, st>>>(A);
+  dbg_sync("k_fx_nodes<1>");
+  mark(3);
+  static_assert(sizeof(FxArgs) <= sizeof(ctx->ex.roots_args), "ctx.h: roots_args too small");
+  std::memcpy(ctx->ex.roots_args, &A, sizeof(A));
+  ctx->ex.total_slots = total_slots;
+  ctx->ex.bin_cap = bin_cap;
+  ctx->ex.fast_slots = true;
+  ctx->ex.tail = &fx_tail;
+  ctx->ex.d_out = d_out, ctx->ex.d_ids = d_ids, ctx->ex.cap = cap;
+  return fx_tail(ctx, P.max_layer >= 2 && ctx->ex.last_splits > 0);
+}
+
+// layer-2 pair (optional), time order + gather
+int fx_tail(wc_ctx *ctx, bool layer2) {
+  hipStream_t st = ctx->stream;
+  FxArgs A;
+  std::memcpy(&A, ctx->ex.roots_args, sizeof(A));
+  auto mark = [&](int i) {
+    if (ctx->ex_prof) (void)hipEventRecord(ctx->ex_ev[i], st);
+  };
+  if (layer2) {
+    const unsigned tiles = (unsigned)((A.pts.n + kFxTile - 1) / kFxTile);
+    k_fx_acc<2><<<tiles, kFxThreads, 0, st>>>(A);
+    k_fx_nodes<2><<<std::min(256u * 8u, std::max(64u, ctx->ex.last_splits)), 64, 0, st>>>(A);
+  }
+  ctx->ex.layer2_done = layer2;
+  mark(4);
+  k_slot_emit<<<kBuckets / 4, 256, 0, st>>>((const uint32_t *)ctx->b_ex_ctrl.p + kCtrlBins, A.slot_bins, ctx->ex.bin_cap, (const wc_surfel *)ctx->b_slots.p,
+                                           (const wc_surfel_id *)ctx->b_slot_ids.p, A.status, ctx->ex.d_out, ctx->ex.d_ids, ctx->ex.cap);
+  mark(5);
+  if (getenv("WC_FX_DEBUG")) fprintf(stderr, "[fx] k_slot_emit (layer2=%d) ... %s\n", (int)layer2, hipGetErrorString(hipStreamSynchronize(st)));
+  WC_HIP(ctx, hipGetLastError());
+  return WC_OK;
+}
+
+// after a finished fast sweep: headers and hash entries back to zero (asynchronously, in front of the next clear_ctrl)
+int fx_clean(wc_ctx *ctx) {
+  FxArgs A;
+  std::memcpy(&A, ctx->ex.roots_args, sizeof(A));
+  FxCleanArgs C;
+  uint32_t tot = 0;
+  for (int j = 0; j < kFxSub; ++j) {
+    C.cnt_r[j] = std::min(ctx->h_status[kFxStRoots + j], A.mr_per);
+    C.cnt_q[j] = std::min(ctx->h_status[kFxStNodes2 + j], A.mq_per);
+    tot += C.cnt_r[j] + C.cnt_q[j];
+  }
+  if (tot) k_fx_clean<<<(tot + 255) / 256, 256, 0, ctx->stream>>>(A, C);
+  if (getenv("WC_FX_DEBUG")) fprintf(stderr, "[fx] k_fx_clean tot=%u ... %s\n", tot, hipGetErrorString(hipStreamSynchronize(ctx->stream)));
+  WC_HIP(ctx, hipGetLastError());
+  return WC_OK;
+}
+
 // layer-2 pass of the queued roots (optional), time order + gather of the surfels, status read-back
 template <typename K, bool RUNS>
 int pipeline_tail(wc_ctx *ctx, bool layer2) {
@@ -1973,6 +2145,12 @@ extern "C" int wc_extract_surfels_enqueue(wc_ctx *ctx, const wc_points *pts, dou
   ctx->ex.general = ctx->ex.general_calls > 0 || getenv("WC_NO_BUCKET_SORT") != nullptr;
   if (ctx->ex.general_calls > 0) --ctx->ex.general_calls;
   ctx->ex.order_general = false;
+  ctx->ex.fx_active = fx_applicable(ctx, pts->n, t_lo, t_hi);
+  if (ctx->ex.fx_active) {
+    const int rc = run_pipeline_fast(ctx, *pts, t_lo, t_hi, d_out, d_ids, cap);
+    if (rc != WC_OK) ctx->ex.fx_dirty = true;
+    return rc;
+  }
   return run_pipeline<uint32_t>(ctx, *pts, t_lo, t_hi, d_out, d_ids, cap, !ctx->ex.general, true);
 }
 
@@ -1984,11 +2162,42 @@ extern "C" int wc_extract_surfels_finish(wc_ctx *ctx, uint64_t *h_n_out) {
   if (ctx->ex.pts.n == 0) return WC_OK;
   auto wait = [&]() -> int {  // stream done; fold the mailbox flag words (raise_flag) into h_status[1]
     WC_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    for (int i = 0; i < 6; ++i)
+    for (int i = 0; i < 7; ++i)
       if (ctx->h_status[8 + i]) ctx->h_status[1] |= 1u << i;
     return WC_OK;
   };
   WC_TRY(wait());
+  if (ctx->ex.fx_active) {
+    // layer-2 nodes were queued but the pair of launches was skipped (the previous sweep had none): run it now
+    if (!ctx->ex.layer2_done && ctx->P.max_layer >= 2 && ctx->h_status[4] > 0 && !(ctx->h_status[1] & (kFlagFxFallback | kFlagKeyRange))) {
+      ctx->ex.last_splits = ctx->h_status[4];
+      WC_TRY(fx_tail(ctx, true));
+      WC_TRY(wait());
+    }
+    const uint32_t fl = ctx->h_status[1];
+    ctx->ex.fx_last_flags = fl;
+    ctx->ex.last_splits = ctx->h_status[4];
+    if (fl & (kFlagFxFallback | kFlagKeyRange | kFlagSlotBinOverflow | kFlagTimeRange)) {
+      // a decision too close to its threshold, a table at capacity, a node spanning > 16 time bins, ...: the tables are put
+      // back to zero and the sweep is repeated on the exact path (below)
+      ++ctx->ex.fx_fallbacks;
+      if (fx_clean(ctx) != WC_OK) ctx->ex.fx_dirty = true;
+      WC_HIP(ctx, hipMemsetAsync(ctx->b_fx[0].p, 0, ctx->b_fx[0].cap, ctx->stream));  // (roots beyond the block capacity have no header
+      WC_HIP(ctx, hipMemsetAsync(ctx->b_fx[1].p, 0, ctx->b_fx[1].cap, ctx->stream));  //  to be found by: clear the whole hash)
+      ctx->ex.fx_active = false;
+      ctx->ex.general = ctx->ex.general_calls > 0;
+      WC_TRY(run_pipeline<uint32_t>(ctx, ctx->ex.pts, ctx->ex.t_lo, ctx->ex.t_hi, ctx->ex.d_out, ctx->ex.d_ids, ctx->ex.cap, !ctx->ex.general, true));
+      WC_TRY(wait());
+    } else {
+      const uint32_t n_fast = ctx->h_status[0];
+      if (h_n_out) *h_n_out = n_fast;
+      if (fx_clean(ctx) != WC_OK) ctx->ex.fx_dirty = true;
+      if (clear_ctrl(ctx) == WC_OK) ctx->ex.precleared = true;
+      if (n_fast > ctx->ex.cap)
+        return wc_fail(ctx, WC_ERR_CAPACITY, "output capacity %llu < %u surfels", (unsigned long long)ctx->ex.cap, n_fast);
+      return WC_OK;
+    }
+  }
   // a bucket had more runs than the LDS capacity of k_pt_bucket (but fits its bin): repeat one capacity up (sticky)
   while ((ctx->h_status[1] & kFlagLdsOverflow) && !(ctx->h_status[1] & (kFlagBucketOverflow | kFlagKeyRange)) && !ctx->ex.general &&
          ctx->ex.lds_cap < kPtBinMax) {
@@ -2070,6 +2279,9 @@ extern "C" int wc_debug_status(wc_ctx *ctx, uint32_t *h_out64) {
   if (!ctx || !h_out64 || !ctx->b_ex_ctrl.p) return wc_fail(ctx, WC_ERR_ARG, "%s: null or out-of-range argument", __func__);
   // (the device copy has been cleared for the next call already: words 0..15 come from the host mailbox of the last call)
   for (int i = 0; i < 64; ++i) h_out64[i] = i < 16 ? ctx->h_status[i] : 0u;
+  h_out64[60] = ctx->ex.fx_fallbacks;  // sweeps the fast path handed to the exact path so far
+  h_out64[61] = ctx->ex.fx_active ? 1u : 0u;  // the last sweep was completed by the fast (integer-moment) path
+  h_out64[62] = ctx->ex.fx_last_flags;
 #ifdef WC_PROF_ROOTS
   // average the per-root section timers into words [16, 24), number of timed roots in word 24
   const size_t nslots = ctx->ex.pts.n / (size_t)(ctx->P.min_points + 1) + 1;

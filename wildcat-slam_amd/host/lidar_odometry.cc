@@ -75,6 +75,7 @@ LidarOdometry::LidarOdometry(int device) {
   wc_params_default(&P);
   P.max_iterations = config_.inner_iter_num_max;
   P.reference_quirks = config_.reference_quirks ? 1 : 0;
+  P.exact_sums = config_.reference_quirks ? 1 : 0;  // the reference's summation order too: sample states match the CPU path to 1e-6
   int rc = wc_ctx_create(&P, device, &ctx_);
   if (rc != WC_OK) {
     std::fprintf(stderr, "[wildcat] FATAL: no MI355X context (rc=%d); there is no CPU fallback\n", rc);

@@ -205,6 +205,17 @@ class Context:
 
         return enqueue, finish
 
+    def set_exact_sums(self, exact):
+        """extraction arithmetic: False (default) = order-independent integer moments, True = the reference's summation order"""
+        self.params.exact_sums = 1 if exact else 0
+        self.set_params(self.params)
+
+    def extract_path_info(self):
+        """-> dict(fast=the last sweep was completed by the fast path, fallbacks=sweeps handed to the exact path so far, flags)"""
+        w = (C.c_uint32 * 64)()
+        self._ck(self.lib.wc_debug_status(self.h, w))
+        return dict(fast=bool(w[61]), fallbacks=int(w[60]), flags=int(w[62]))
+
     def extract_profile(self, enable=True):
         self._ck(self.lib.wc_extract_profile(self.h, C.c_int(1 if enable else 0)))
 

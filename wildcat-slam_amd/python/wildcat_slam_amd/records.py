@@ -69,6 +69,7 @@ class Params(C.Structure):
         ("imu_dt", C.c_double),
         ("max_iterations", C.c_int32),
         ("reference_quirks", C.c_int32),
+        ("exact_sums", C.c_int32),
     ]
 
 
