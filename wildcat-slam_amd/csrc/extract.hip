@@ -1777,7 +1777,7 @@ int run_pipeline_fast(wc_ctx *ctx, const wc_points &pts, double t_lo, double t_h
   E.gap = P.cluster_gap, E.cluster_min = P.cluster_min_points;
   E.t_lo_bits = ordered_bits_host(t_lo);
   E.t_span_bits = ordered_bits_host(t_hi) - E.t_lo_bits;
-  E.dbg = 0;
+  E.dbg = getenv("WC_DEBUG_SKIP") ? atoi(getenv("WC_DEBUG_SKIP")) : 0;
   unsigned tbits = 1;
   while (tbits < 64 && (E.t_span_bits >> tbits)) ++tbits;
   A.pts = pts;
@@ -1787,13 +1787,18 @@ int run_pipeline_fast(wc_ctx *ctx, const wc_points &pts, double t_lo, double t_h
   A.tick = std::ldexp(1.0, 40 - e), A.inv_tick = std::ldexp(1.0, e - 40);
   A.inv_w = 1.0 / (P.cluster_gap * 0.999);
   A.inv_span = 1.0 / (t_hi - t_lo);
+  A.inv_vs = 1.0 / (double)P.voxel_size;
   A.qs = 4294967296.0, A.inv_q = 1.0 / 4294967296.0, A.inv_qq = std::ldexp(1.0, -44);
-  // capacities: a root block per 32 points, a layer-2 node block per 64; the hash holds 4 x the root blocks
+  // capacities: a root block (640 B) per 8 points, a layer-2 node block per 16; the hash holds 4 x the root blocks; one
+  // 128-byte record per LDS hash slot of every tile + a spill pool
   uint32_t mr = 1024;
-  while ((uint64_t)mr * 32 < n) mr *= 2;
+  while ((uint64_t)mr * 8 < n) mr *= 2;
   A.mr_per = mr / kFxSub, A.mq_per = std::max(64u, mr / 2 / kFxSub);
   const uint32_t tr = mr * 4;
   A.tr_mask = tr - 1;
+  const unsigned tiles = (unsigned)((n + kFxTile - 1) / kFxTile);
+  A.rec_tiles = tiles;
+  A.rec_cap = tiles * (uint32_t)kFxLds + (uint32_t)std::max<uint64_t>(4096, n / 16);
   const uint64_t total_slots = (n * (uint64_t)(P.max_layer + 1)) / (uint64_t)P.cluster_min_points + 1;
   uint32_t bin_cap = 64;
   while (bin_cap < kSlotBinMax && (uint64_t)bin_cap * kBuckets < 2 * total_slots) bin_cap *= 2;
@@ -1801,11 +1806,12 @@ int run_pipeline_fast(wc_ctx *ctx, const wc_points &pts, double t_lo, double t_h
   WC_TRY(fx_ensure_zero(ctx, ctx->b_fx[1], (size_t)tr * 4));
   WC_TRY(fx_ensure_zero(ctx, ctx->b_fx[2], (size_t)mr * kFxBlockW * 8));
   WC_TRY(fx_ensure_zero(ctx, ctx->b_fx[3], (size_t)A.mq_per * kFxSub * kFxBlockW * 8));
+  WC_TRY(wc_ensure(ctx, ctx->b_fx[4], (size_t)2 * A.rec_cap * kFxRecW * 8));  // records: reachable through list heads only, never cleared
   WC_TRY(wc_ensure(ctx, ctx->b_slots, total_slots * sizeof(wc_surfel)));
   WC_TRY(wc_ensure(ctx, ctx->b_slot_ids, total_slots * sizeof(wc_surfel_id)));
   WC_TRY(wc_ensure(ctx, ctx->b_slot_keys[1], (uint64_t)kBuckets * bin_cap * 8));
   if (ctx->ex.fx_dirty) {  // a previous sweep ended abnormally: everything back to zero
-    for (int i = 0; i < 4; ++i) WC_HIP(ctx, hipMemsetAsync(ctx->b_fx[i].p, 0, ctx->b_fx[i].cap, st));
+    for (int i = 0; i < 4; ++i) WC_HIP(ctx, hipMemsetAsync(ctx->b_fx[i].p, 0, ctx->b_fx[i].cap, st));  // (not the records)
     ctx->ex.fx_dirty = false;
   }
   const bool precleared = ctx->ex.precleared && ctx->b_ex_ctrl.p;
@@ -1814,11 +1820,11 @@ int run_pipeline_fast(wc_ctx *ctx, const wc_points &pts, double t_lo, double t_h
   for (int q = 0; q < 64; ++q) ctx->h_status[q] = 0;
   A.rkey = (uint32_t *)ctx->b_fx[0].p, A.rval = (uint32_t *)ctx->b_fx[1].p;
   A.blk = (unsigned long long *)ctx->b_fx[2].p, A.blk2 = (unsigned long long *)ctx->b_fx[3].p;
+  A.rec = (unsigned long long *)ctx->b_fx[4].p;
   A.status = (uint32_t *)ctx->b_ex_ctrl.p + kCtrlStatus;
   A.slots = (wc_surfel *)ctx->b_slots.p, A.slot_ids = (wc_surfel_id *)ctx->b_slot_ids.p;
   A.slots_per = (uint32_t)std::min<uint64_t>(total_slots / kFxSub, 0x7FFFFFFFu);
   A.slot_counts = (uint32_t *)ctx->b_ex_ctrl.p + kCtrlBins;
-  A.slot_shift = tbits > 12 ? tbits - 12 : 0u;
   A.slot_bins = (uint64_t *)ctx->b_slot_keys[1].p;
   A.slot_bin_cap = bin_cap;
   auto mark = [&](int i) {
@@ -1826,7 +1832,6 @@ int run_pipeline_fast(wc_ctx *ctx, const wc_points &pts, double t_lo, double t_h
   };
   mark(0);
   mark(1);
-  const unsigned tiles = (unsigned)((n + kFxTile - 1) / kFxTile);
   const bool dbg = getenv("WC_FX_DEBUG") != nullptr;
   auto dbg_sync = [&](const char *what) {
     if (!dbg) return;
@@ -1836,23 +1841,13 @@ int run_pipeline_fast(wc_ctx *ctx, const wc_points &pts, double t_lo, double t_h
     (void)hipMemcpy(w, A.status, sizeof(w), hipMemcpyDeviceToHost);
     uint32_t r = 0, q = 0, sl = 0;
     for (int j = 0; j < 16; ++j) r += w[16 + j], q += w[32 + j], sl += w[48 + j];
-    fprintf(stderr, " %s flags=%u roots=%u nodes2=%u slots=%u | tested=%u planes=%u multi=%u single=%u tails=%u wants=%u occupied=%u\n", hipGetErrorString(e), w[1], r, q, sl,
-            w[10], w[11], w[12], w[13], w[14], w[15], w[6]);
-    unsigned long long *d_dbg = nullptr, h_dbg[4] = {0, 0, 0, 0};
-    if (hipMalloc(&d_dbg, 32) == hipSuccess) {
-      (void)hipMemset(d_dbg, 0, 32);
-      k_fx_debug_sum<<<(r * 128u + 255u) / 256u + 1u, 256, 0, st>>>(A, d_dbg);
-      (void)hipStreamSynchronize(st);
-      (void)hipMemcpy(h_dbg, d_dbg, 32, hipMemcpyDeviceToHost);
-      (void)hipFree(d_dbg);
-      fprintf(stderr, "[fx]    tables: points=%llu cells=%llu checksum=%llx unmasked=%llu\n", h_dbg[0], h_dbg[1], h_dbg[2], h_dbg[3]);
-    }
+    fprintf(stderr, " %s flags=%u roots=%u nodes2=%u slots=%u spill=%u\n", hipGetErrorString(e), w[1], r, q, sl, w[7]);
   };
   if (dbg) fprintf(stderr, "[fx] n=%llu tiles=%u mr_per=%u mq_per=%u tr=%u slots_per=%u bin_cap=%u\n", (unsigned long long)n, tiles, A.mr_per, A.mq_per, tr, A.slots_per, bin_cap);
   k_fx_acc<1><<<tiles, kFxThreads, 0, st>>>(A);
   dbg_sync("k_fx_acc<1>");
   mark(2);
-  const unsigned ngrid = std::min<unsigned>(256 * 16, std::max<unsigned>(64, (unsigned)(n / 128)));
+  const unsigned ngrid = std::min<unsigned>(256 * 16, std::max<unsigned>(64, (unsigned)(n / 256)));
   k_fx_nodes<1><<<ngrid, 64, 0, st>>>(A);
   dbg_sync("k_fx_nodes<1>");
   mark(3);
