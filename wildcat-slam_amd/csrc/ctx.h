@@ -56,6 +56,8 @@ struct wc_ctx {
     bool fx_active = false;      // this call runs on the fast (integer-moment) path
     bool fx_dirty = false;       // the fast path's tables may hold garbage (an aborted sweep): memset before the next use
     uint32_t fx_last_flags = 0, fx_fallbacks = 0;
+    bool fx_ctrl_ready = false;  // the fast path's two control blocks are initialised
+    int fx_parity = 0;           // which of them the next fast sweep uses
     bool precleared = false;     // the control block has been cleared (on the stream) by the previous finish()
     bool layer2_done = true;
     int (*tail)(wc_ctx *, bool) = nullptr;

@@ -1362,8 +1362,13 @@ __global__ void __launch_bounds__(256) k_fix_ties(const uint64_t *__restrict__ k
 constexpr int kSlotBinMax = 512;
 __global__ void __launch_bounds__(256) k_slot_emit(const uint32_t *__restrict__ counts, const uint64_t *__restrict__ bins, uint32_t bin_cap,
                                                   const wc_surfel *__restrict__ slots, const wc_surfel_id *__restrict__ slot_ids,
-                                                  uint32_t *status, wc_surfel *out, wc_surfel_id *out_ids, uint64_t cap) {
+                                                  uint32_t *status, wc_surfel *out, wc_surfel_id *out_ids, uint64_t cap, uint32_t *next_ctrl,
+                                                  uint32_t next_words) {
   __shared__ uint64_t s_item[4][kSlotBinMax];
+  if (next_ctrl) {  // fast path: the control block of the NEXT sweep (the other of two) is cleared here, off the host's path
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < next_words) next_ctrl[i] = (i == 8u || i == 9u) ? status[i] : 0u;  // (words 8, 9: the mailbox address)
+  }
   __shared__ uint32_t s_sorted[4][kSlotBinMax];
   __shared__ uint32_t s_red[4];
   const int t = threadIdx.x, w = t >> 6, lane = t & 63;
@@ -1381,10 +1386,8 @@ __global__ void __launch_bounds__(256) k_slot_emit(const uint32_t *__restrict__ 
     if (hm) {
       hm[0] = base + c0 + c1 + c2 + c3;
       uint32_t queued = status[4];  // roots queued for the layer-2 pass (every emitting kernel has finished)
-      for (int j = 16; j < 48; ++j) {  // fast path: root / layer-2 node sub-counters (extract_fast.inc), for k_fx_clean
-        hm[j] = status[j];
-        if (j >= 32) queued += status[j];
-      }
+      const uint32_t *fxc = counts + kBuckets;  // fast path: layer-2 node sub-counters (extract_fast.inc)
+      for (int j = 0; j < 16; ++j) queued += fxc[(16 + j) * 32];
       hm[4] = queued;
       hm[5] = status[5];  // runs of the sweep (run-binned sort only): tells the host whether the input has run structure
     }
@@ -1683,7 +1686,7 @@ inline uint32_t pt_bin_cap(uint64_t n) {
 // The extraction's control block (its own buffer: the other entry points of the library never touch it, so it can be
 // cleared ahead of time): status words | run counts, point counts | root_cnt, root_first | time-bin counts.
 constexpr uint32_t kCtrlStatus = 0, kCtrlCounts = 64, kCtrlRoots = kCtrlCounts + 2 * kBuckets, kCtrlBins = kCtrlRoots + 2 * (kBuckets / 4),
-                   kCtrlWords = kCtrlBins + kBuckets;
+                   kCtrlFx = kCtrlBins + kBuckets, kCtrlWords = kCtrlFx + 4 * 16 * 32;  // + the fast path's counter banks (extract_fast.inc)
 
 // clears the control block and stores the mailbox address (status words [8, 9]); used in front of a call, or - the usual
 // case - by finish() for the NEXT call: run ahead of time it hides behind the host's turn-around between two sweeps
@@ -1699,7 +1702,7 @@ int clear_ctrl(wc_ctx *ctx) {
   I.p[1] = ctrl + 10, I.nw[1] = kCtrlRoots - 10, I.val[1] = 0u;  // rest of the status words, run / point counts
   I.p[2] = ctrl + 8, I.nw[2] = 1, I.val[2] = (uint32_t)a;
   I.p[3] = ctrl + 9, I.nw[3] = 1, I.val[3] = (uint32_t)(a >> 32);
-  I.p[4] = ctrl + kCtrlBins, I.nw[4] = kBuckets, I.val[4] = 0u;
+  I.p[4] = ctrl + kCtrlBins, I.nw[4] = kBuckets + 4 * 16 * 32, I.val[4] = 0u;  // time-bin counts + fast-path counters
   k_init<<<(kCtrlRoots + 255) / 256, 256, 0, ctx->stream>>>(I);
   WC_HIP(ctx, hipGetLastError());
   return WC_OK;
@@ -1794,37 +1797,52 @@ int run_pipeline_fast(wc_ctx *ctx, const wc_points &pts, double t_lo, double t_h
   uint32_t mr = 1024;
   while ((uint64_t)mr * 8 < n) mr *= 2;
   A.mr_per = mr / kFxSub, A.mq_per = std::max(64u, mr / 2 / kFxSub);
-  const uint32_t tr = mr * 4;
+  uint32_t tr = 2048;  // hash slots = root blocks: one per four points
+  while ((uint64_t)tr * 4 < n) tr *= 2;
   A.tr_mask = tr - 1;
   const unsigned tiles = (unsigned)((n + kFxTile - 1) / kFxTile);
   A.rec_tiles = tiles;
-  A.rec_cap = tiles * (uint32_t)kFxLds + (uint32_t)std::max<uint64_t>(4096, n / 16);
+  A.spill_per = (uint32_t)std::max<uint64_t>(1024, n / 32);
+  A.rec_cap = tiles * (uint32_t)kFxRecTile + 8u * A.spill_per;
   const uint64_t total_slots = (n * (uint64_t)(P.max_layer + 1)) / (uint64_t)P.cluster_min_points + 1;
   uint32_t bin_cap = 64;
   while (bin_cap < kSlotBinMax && (uint64_t)bin_cap * kBuckets < 2 * total_slots) bin_cap *= 2;
   WC_TRY(fx_ensure_zero(ctx, ctx->b_fx[0], (size_t)tr * 4));
-  WC_TRY(fx_ensure_zero(ctx, ctx->b_fx[1], (size_t)tr * 4));
-  WC_TRY(fx_ensure_zero(ctx, ctx->b_fx[2], (size_t)mr * kFxBlockW * 8));
+  WC_TRY(wc_ensure(ctx, ctx->b_fx[1], (size_t)mr * 4));  // dense root list: written before it is read
+  WC_TRY(fx_ensure_zero(ctx, ctx->b_fx[2], (size_t)tr * kFxBlockW * 8));
   WC_TRY(fx_ensure_zero(ctx, ctx->b_fx[3], (size_t)A.mq_per * kFxSub * kFxBlockW * 8));
   WC_TRY(wc_ensure(ctx, ctx->b_fx[4], (size_t)2 * A.rec_cap * kFxRecW * 8));  // records: reachable through list heads only, never cleared
   WC_TRY(wc_ensure(ctx, ctx->b_slots, total_slots * sizeof(wc_surfel)));
   WC_TRY(wc_ensure(ctx, ctx->b_slot_ids, total_slots * sizeof(wc_surfel_id)));
   WC_TRY(wc_ensure(ctx, ctx->b_slot_keys[1], (uint64_t)kBuckets * bin_cap * 8));
   if (ctx->ex.fx_dirty) {  // a previous sweep ended abnormally: everything back to zero
-    for (int i = 0; i < 4; ++i) WC_HIP(ctx, hipMemsetAsync(ctx->b_fx[i].p, 0, ctx->b_fx[i].cap, st));  // (not the records)
+    for (int i : {0, 2, 3}) WC_HIP(ctx, hipMemsetAsync(ctx->b_fx[i].p, 0, ctx->b_fx[i].cap, st));  // (not the root list, not the records)
     ctx->ex.fx_dirty = false;
   }
-  const bool precleared = ctx->ex.precleared && ctx->b_ex_ctrl.p;
-  ctx->ex.precleared = false;
-  if (!precleared) WC_TRY(clear_ctrl(ctx));
+  // two control blocks, used alternately: k_slot_emit of a sweep clears the block of the next one
+  WC_TRY(wc_ensure(ctx, ctx->b_fx[5], (size_t)2 * kCtrlWords * 4));
+  if (!ctx->ex.fx_ctrl_ready) {
+    WC_HIP(ctx, hipMemsetAsync(ctx->b_fx[5].p, 0, (size_t)2 * kCtrlWords * 4, st));
+    void *dp = nullptr;
+    if (hipHostGetDevicePointer(&dp, ctx->h_status, 0) != hipSuccess) dp = nullptr;
+    const unsigned long long a = (unsigned long long)dp;
+    const uint32_t addr[2] = {(uint32_t)a, (uint32_t)(a >> 32)};
+    for (int b = 0; b < 2; ++b)
+      WC_HIP(ctx, hipMemcpyAsync((uint32_t *)ctx->b_fx[5].p + (size_t)b * kCtrlWords + 8, addr, 8, hipMemcpyHostToDevice, st));
+    WC_HIP(ctx, hipStreamSynchronize(st));  // (addr is a stack variable)
+    ctx->ex.fx_ctrl_ready = true;
+    ctx->ex.fx_parity = 0;
+  }
+  uint32_t *ctrl = (uint32_t *)ctx->b_fx[5].p + (size_t)ctx->ex.fx_parity * kCtrlWords;
   for (int q = 0; q < 64; ++q) ctx->h_status[q] = 0;
-  A.rkey = (uint32_t *)ctx->b_fx[0].p, A.rval = (uint32_t *)ctx->b_fx[1].p;
+  A.rkey = (uint32_t *)ctx->b_fx[0].p, A.rlist = (uint32_t *)ctx->b_fx[1].p;
   A.blk = (unsigned long long *)ctx->b_fx[2].p, A.blk2 = (unsigned long long *)ctx->b_fx[3].p;
   A.rec = (unsigned long long *)ctx->b_fx[4].p;
-  A.status = (uint32_t *)ctx->b_ex_ctrl.p + kCtrlStatus;
+  A.status = ctrl + kCtrlStatus;
+  A.cnt = ctrl + kCtrlFx;
   A.slots = (wc_surfel *)ctx->b_slots.p, A.slot_ids = (wc_surfel_id *)ctx->b_slot_ids.p;
   A.slots_per = (uint32_t)std::min<uint64_t>(total_slots / kFxSub, 0x7FFFFFFFu);
-  A.slot_counts = (uint32_t *)ctx->b_ex_ctrl.p + kCtrlBins;
+  A.slot_counts = ctrl + kCtrlBins;
   A.slot_bins = (uint64_t *)ctx->b_slot_keys[1].p;
   A.slot_bin_cap = bin_cap;
   auto mark = [&](int i) {
@@ -1837,11 +1855,12 @@ int run_pipeline_fast(wc_ctx *ctx, const wc_points &pts, double t_lo, double t_h
     if (!dbg) return;
     fprintf(stderr, "[fx] %s ...", what);
     const hipError_t e = hipStreamSynchronize(st);
-    uint32_t w[64];
+    uint32_t w[64], c[4 * 16 * 32];
     (void)hipMemcpy(w, A.status, sizeof(w), hipMemcpyDeviceToHost);
-    uint32_t r = 0, q = 0, sl = 0;
-    for (int j = 0; j < 16; ++j) r += w[16 + j], q += w[32 + j], sl += w[48 + j];
-    fprintf(stderr, " %s flags=%u roots=%u nodes2=%u slots=%u spill=%u\n", hipGetErrorString(e), w[1], r, q, sl, w[7]);
+    (void)hipMemcpy(c, A.cnt, sizeof(c), hipMemcpyDeviceToHost);
+    uint32_t r = 0, q = 0, sl = 0, sp = 0;
+    for (int j = 0; j < 16; ++j) r += c[j * 32], q += c[(16 + j) * 32], sl += c[(32 + j) * 32], sp += c[(48 + j) * 32];
+    fprintf(stderr, " %s flags=%u roots=%u nodes2=%u slots=%u spill=%u\n", hipGetErrorString(e), w[1], r, q, sl, sp);
   };
   if (dbg) fprintf(stderr, "[fx] n=%llu tiles=%u mr_per=%u mq_per=%u tr=%u slots_per=%u bin_cap=%u\n", (unsigned long long)n, tiles, A.mr_per, A.mq_per, tr, A.slots_per, bin_cap);
   k_fx_acc<1><<<tiles, kFxThreads, 0, st>>>(A);
@@ -1876,27 +1895,13 @@ int fx_tail(wc_ctx *ctx, bool layer2) {
   }
   ctx->ex.layer2_done = layer2;
   mark(4);
-  k_slot_emit<<<kBuckets / 4, 256, 0, st>>>((const uint32_t *)ctx->b_ex_ctrl.p + kCtrlBins, A.slot_bins, ctx->ex.bin_cap, (const wc_surfel *)ctx->b_slots.p,
-                                           (const wc_surfel_id *)ctx->b_slot_ids.p, A.status, ctx->ex.d_out, ctx->ex.d_ids, ctx->ex.cap);
+  uint32_t *next_ctrl = (uint32_t *)ctx->b_fx[5].p + (size_t)(ctx->ex.fx_parity ^ 1) * kCtrlWords;
+  static_assert(kCtrlWords <= (kBuckets / 4) * 256, "k_slot_emit's grid covers the control block");
+  k_slot_emit<<<kBuckets / 4, 256, 0, st>>>(A.slot_counts, A.slot_bins, ctx->ex.bin_cap, (const wc_surfel *)ctx->b_slots.p,
+                                           (const wc_surfel_id *)ctx->b_slot_ids.p, A.status, ctx->ex.d_out, ctx->ex.d_ids, ctx->ex.cap, next_ctrl,
+                                           kCtrlWords);
   mark(5);
   if (getenv("WC_FX_DEBUG")) fprintf(stderr, "[fx] k_slot_emit (layer2=%d) ... %s\n", (int)layer2, hipGetErrorString(hipStreamSynchronize(st)));
-  WC_HIP(ctx, hipGetLastError());
-  return WC_OK;
-}
-
-// after a finished fast sweep: headers and hash entries back to zero (asynchronously, in front of the next clear_ctrl)
-int fx_clean(wc_ctx *ctx) {
-  FxArgs A;
-  std::memcpy(&A, ctx->ex.roots_args, sizeof(A));
-  FxCleanArgs C;
-  uint32_t tot = 0;
-  for (int j = 0; j < kFxSub; ++j) {
-    C.cnt_r[j] = std::min(ctx->h_status[kFxStRoots + j], A.mr_per);
-    C.cnt_q[j] = std::min(ctx->h_status[kFxStNodes2 + j], A.mq_per);
-    tot += C.cnt_r[j] + C.cnt_q[j];
-  }
-  if (tot) k_fx_clean<<<(tot + 255) / 256, 256, 0, ctx->stream>>>(A, C);
-  if (getenv("WC_FX_DEBUG")) fprintf(stderr, "[fx] k_fx_clean tot=%u ... %s\n", tot, hipGetErrorString(hipStreamSynchronize(ctx->stream)));
   WC_HIP(ctx, hipGetLastError());
   return WC_OK;
 }
@@ -1929,7 +1934,7 @@ int pipeline_tail(wc_ctx *ctx, bool layer2) {
   mark(4);
   if (ctx->ex.fast_slots) {
     k_slot_emit<<<kBuckets / 4, 256, 0, st>>>((const uint32_t *)ctx->b_ex_ctrl.p + kCtrlBins, A.slot_bins, ctx->ex.bin_cap, (const wc_surfel *)ctx->b_slots.p,
-                                             (const wc_surfel_id *)ctx->b_slot_ids.p, status, d_out, d_ids, cap);
+                                             (const wc_surfel_id *)ctx->b_slot_ids.p, status, d_out, d_ids, cap, nullptr, 0u);
   } else {
     k_iota<<<(unsigned)((total_slots + 255) / 256), 256, 0, st>>>((uint32_t *)ctx->b_slot_idx[0].p, total_slots);
     WC_TRY(sort_pairs<uint64_t>(ctx, (uint64_t *)ctx->b_slot_keys[0].p, (uint64_t *)ctx->b_slot_keys[1].p,
@@ -2176,9 +2181,8 @@ extern "C" int wc_extract_surfels_finish(wc_ctx *ctx, uint64_t *h_n_out) {
       // a decision too close to its threshold, a table at capacity, a node spanning > 16 time bins, ...: the tables are put
       // back to zero and the sweep is repeated on the exact path (below)
       ++ctx->ex.fx_fallbacks;
-      if (fx_clean(ctx) != WC_OK) ctx->ex.fx_dirty = true;
-      WC_HIP(ctx, hipMemsetAsync(ctx->b_fx[0].p, 0, ctx->b_fx[0].cap, ctx->stream));  // (roots beyond the block capacity have no header
-      WC_HIP(ctx, hipMemsetAsync(ctx->b_fx[1].p, 0, ctx->b_fx[1].cap, ctx->stream));  //  to be found by: clear the whole hash)
+      ctx->ex.fx_dirty = true;        // tables (a root at capacity, roots waiting for a layer-2 pass that never ran) ...
+      ctx->ex.fx_ctrl_ready = false;  // ... and control blocks are set up anew by the next fast sweep
       ctx->ex.fx_active = false;
       ctx->ex.general = ctx->ex.general_calls > 0;
       WC_TRY(run_pipeline<uint32_t>(ctx, ctx->ex.pts, ctx->ex.t_lo, ctx->ex.t_hi, ctx->ex.d_out, ctx->ex.d_ids, ctx->ex.cap, !ctx->ex.general, true));
@@ -2186,8 +2190,7 @@ extern "C" int wc_extract_surfels_finish(wc_ctx *ctx, uint64_t *h_n_out) {
     } else {
       const uint32_t n_fast = ctx->h_status[0];
       if (h_n_out) *h_n_out = n_fast;
-      if (fx_clean(ctx) != WC_OK) ctx->ex.fx_dirty = true;
-      if (clear_ctrl(ctx) == WC_OK) ctx->ex.precleared = true;
+      ctx->ex.fx_parity ^= 1;  // the other control block has been cleared by this sweep's k_slot_emit
       if (n_fast > ctx->ex.cap)
         return wc_fail(ctx, WC_ERR_CAPACITY, "output capacity %llu < %u surfels", (unsigned long long)ctx->ex.cap, n_fast);
       return WC_OK;
@@ -2271,7 +2274,7 @@ extern "C" int wc_extract_stage_ms(wc_ctx *ctx, float *h_ms5) {
 
 extern "C" int wc_debug_status(wc_ctx *ctx, uint32_t *h_out64) {
   wc_dev_guard dg_(ctx);  // profiling aid: status words [0..16) + section timers
-  if (!ctx || !h_out64 || !ctx->b_ex_ctrl.p) return wc_fail(ctx, WC_ERR_ARG, "%s: null or out-of-range argument", __func__);
+  if (!ctx || !h_out64) return wc_fail(ctx, WC_ERR_ARG, "%s: null or out-of-range argument", __func__);
   // (the device copy has been cleared for the next call already: words 0..15 come from the host mailbox of the last call)
   for (int i = 0; i < 64; ++i) h_out64[i] = i < 16 ? ctx->h_status[i] : 0u;
   h_out64[60] = ctx->ex.fx_fallbacks;  // sweeps the fast path handed to the exact path so far
