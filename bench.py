@@ -198,6 +198,20 @@ def main():
     torch.cuda.synchronize()
 
     ctx = lib.Context(local_rank)  # raises if libwildcat_hip.so / the GPU is missing: there is no fallback path
+    comm_kind = None
+    if use_dist:
+        # the library's own RCCL communicator (csrc/comm.hip): collectives on the ctx stream, no host synchronisation; rank 0's
+        # unique id travels through torch.distributed, which is plumbing here
+        try:
+            ids = [lib.rccl_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(ids, src=0)
+            ctx.comm_rccl_init(rank, world, ids[0])
+            comm_kind = "in-library RCCL (ncclAllReduce / grouped ncclSend+ncclRecv on the ctx stream)"
+        except Exception as e:
+            from wildcat_slam_amd import dist as wdist
+
+            ctx.set_comm(wdist.TorchComm(torch, dist, dev))
+            comm_kind = "torch.distributed callbacks (in-library RCCL unavailable: %r)" % (e,)
     base = d_pts.data_ptr()
     desc = R.Points(base, base + 24, 48, 48, n_pts)
     t_lo, t_hi = float(pts["time"][0]), float(pts["time"][-1])
@@ -266,6 +280,7 @@ def main():
         "roofline": roofline,
         "stages_ms": {k_: round(v, 5) for k_, v in stages.items()},
         "host": cpu_info(),
+        "communicator": comm_kind,
     }
 
     # --- several sweeps in flight (contexts = streams, each with its own scratch).  Never `value`. --------------------------
@@ -415,7 +430,6 @@ def bench_cloud_10m(ctx, args, world, rank, dev, torch, dist, to_dev):
                 "stages_ms": {k: round(v, 5) for k, v in stages.items()}}
     lo, cnt = wdist.shard_range(n, rank, world)
     d_slice = ctx.to_device(pts[lo: lo + cnt])
-    ctx.set_comm(wdist.TorchComm(torch, dist, dev))
     cap = (3 * n) // 20 // world * 2 + 4096
     bufs = (ctx.alloc(cap * 144), ctx.alloc(cap * 16), cap)
     out = None
@@ -433,7 +447,6 @@ def bench_cloud_10m(ctx, args, world, rank, dev, torch, dist, to_dev):
     mx = tt.clone()
     dist.all_reduce(mx, op=dist.ReduceOp.MAX)
     dist.all_reduce(tt, op=dist.ReduceOp.SUM)
-    ctx.set_comm(None)
     sec = float(mx[0].item()) / steps
     return {"workload": "C5 cloud sharded by root voxel over %d GPUs (route: one all-to-all of 24 B / point)" % world, "ms_per_step": round(sec * 1e3, 5),
             "value": round(n / sec / 1e6, 2), "unit": "Mpts/s (whole cloud)", "surfels_total": int(tt[1].item()), "points_routed_total": int(tt[2].item()),
@@ -452,7 +465,8 @@ def bench_window(ctx, args, world, rank, dev, torch, dist, cpu=False):
     d_surf, d_pose = ctx.to_device(w["surf"]), ctx.to_device(w["pose"])
     d_fs, d_fp = ctx.to_device(w["fix_surf"]), ctx.to_device(w["fix_pose"])
     t_gen = time.perf_counter() - t_gen
-    # correspondences (timed: part of the hot path, lidar_odometry.cc:532-538)
+    # correspondences (timed: part of the hot path, lidar_odometry.cc:532-538); N > 1: the queries are sharded over the ranks and
+    # the gated neighbour lists all-gathered (csrc/match.hip)
     d_pairs, d_pf = ctx.alloc(8 * n_s), ctx.alloc(8 * n_s)
     # (one untimed pass first: the library's scratch buffers are allocated on first use)
     ctx.match_device(d_surf, d_pose, n_s, d_surf, d_pose, n_s, True, d_pairs, n_s)
@@ -465,8 +479,7 @@ def bench_window(ctx, args, world, rank, dev, torch, dist, cpu=False):
     # shard the correspondences (contiguous slices) and the IMU factors
     lo_b, cnt_b = wdist.shard_range(n_b, rank, world)
     lo_u, cnt_u = wdist.shard_range(n_u, rank, world)
-    if world > 1 or os.environ.get("WC_BENCH_FORCE_DIST") == "1":
-        ctx.window_set_allreduce(wdist.make_allreduce(torch, dist, dev))
+    # (N > 1: every linearisation ends in ONE all-reduce through the ctx's communicator, installed in main())
     imu_r = wdist.shard_imu(w["imu"], rank, world)  # IMU factors: a contiguous share of the state triples per rank
     build_args = (d_surf, d_pose, _Ptr(d_pairs.ptr + 8 * lo_b), cnt_b, imu_r if len(imu_r) >= 3 else None, w["sample_times"], w["grav"],
                   False, d_fs, d_fp, _Ptr(d_pf.ptr + 8 * lo_u), cnt_u)
@@ -543,7 +556,6 @@ def bench_window(ctx, args, world, rank, dev, torch, dist, cpu=False):
             "sample": "same window geometry with 1/%d of the surfels (%d surfels, %d + %d surfel factors, %d unknowns): %d LM iterations in %.1f s; "
                       "matcher %.0f surfels/s" % (frac, len(ws["surf"]), len(pb), len(pu), 12 * len(ws["sample_times"]), sc.iterations, t_cs,
                                                    2 * len(ws["surf"]) / t_cm)}
-    ctx.window_set_allreduce(None)
     return out
 
 

@@ -97,6 +97,9 @@ typedef struct wc_comm {
   int (*allreduce_f64)(void *user, double *d_buf, uint64_t count); /* in-place sum over ranks */
   int (*alltoallv)(void *user, const void *d_send, const uint64_t *send_bytes, void *d_recv, const uint64_t *recv_bytes);
   int (*allgatherv)(void *user, const void *d_send, uint64_t send_bytes, void *d_recv, const uint64_t *recv_bytes);
+  int32_t stream_ordered; /* 1: the callbacks enqueue on the ctx's stream themselves (the in-library RCCL binding): the library
+                             does not synchronise around them.  0: the library drains its stream before every call and the
+                             callback must have completed when it returns */
 } wc_comm;
 
 /* Hard-coded reference parameters of the path.  wc_params_default() fills the

@@ -101,6 +101,11 @@ int wc_voxel_keys(wc_ctx *ctx, const wc_points *pts, int32_t *d_keys_xyz);
 /* The reference has no counterpart (single thread): root voxels are independent after binning (surfel_extraction.cc:217-219,
  * :330-332) but each needs all its points in time order (:22-29), so a cloud shards by root voxel - see csrc/route.hip. */
 int wc_ctx_set_comm(wc_ctx *ctx, const wc_comm *comm); /* NULL removes it */
+/* the in-library RCCL communicator (csrc/comm.hip; librccl.so is dlopen()ed): rank 0 creates the 128-byte unique id, the
+ * launcher hands it to every rank, each rank calls wc_comm_rccl_init on its ctx.  Collectives run on the ctx's stream. */
+int wc_comm_rccl_unique_id(char out128[128]);
+int wc_comm_rccl_init(wc_ctx *ctx, int rank, int world, const char id128[128]);
+int wc_comm_rccl_destroy(wc_ctx *ctx);
 /* owner rank of a root voxel (VoxelLoc index, surfel_extraction.h:59-64): hash(kx,ky,kz) mod world; needs no GPU */
 int wc_route_owner(int32_t kx, int32_t ky, int32_t kz, int world);
 /* stable partition of this rank's points by owner: d_send (capacity pts->n records) receives `world` consecutive segments

@@ -174,3 +174,45 @@ def test_other_neighbour_counts(gpu, oracle, k):
         assert idx.shape == (len(w["surf"]), k) and (np.diff(d2, axis=1) >= 0).all()
     finally:
         gpu.set_params(oracle.default_params())
+
+
+def test_query_sharded_match_equals_unsharded(gpu):
+    """SURVEY 8(e) row 2: the queries of KnnSurfelMatcher::Match are independent (knn_surfel_matcher.cc:22-48); with a
+    communicator installed every rank searches a contiguous share of the queries, ONE all-gather of the gated neighbour lists
+    gives every rank the whole table and the order-dependent pair de-duplication runs replicated.  Two ranks on one GPU
+    (dist.ThreadComm stands in for RCCL): both must return exactly the unsharded call's pairs, for both matchers."""
+    import threading
+
+    from wildcat_slam_amd import dist as wdist
+    from wildcat_slam_amd import lib
+
+    w = synth.surfel_window(4, 3000, seed=11, fixed_patches=1500)
+    ref_b = gpu.match(w["surf"], w["pose"], w["surf"], w["pose"], True)
+    ref_u = gpu.match(w["surf"], w["pose"], w["fix_surf"], w["fix_pose"], False)
+    assert len(ref_b) > 5000 and len(ref_u) > 1000
+    world = 2
+    ctxs = [lib.Context(0) for _ in range(world)]
+    shared = wdist.ThreadComm.shared(world)
+    out, errors = [None] * world, []
+
+    def run(r):
+        try:
+            ctxs[r].set_comm(wdist.ThreadComm(shared, r, ctxs[r]))
+            b = ctxs[r].match(w["surf"], w["pose"], w["surf"], w["pose"], True)
+            u = ctxs[r].match(w["surf"], w["pose"], w["fix_surf"], w["fix_pose"], False)
+            out[r] = (b, u)
+        except Exception as e:  # pragma: no cover
+            errors.append(e)
+            shared["bar"].abort()
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=120)
+    assert not errors, errors
+    assert shared["calls"][0] == shared["calls"][1] == 2  # one all-gather per matcher call
+    for r in range(world):
+        assert out[r][0].tobytes() == ref_b.tobytes() and out[r][1].tobytes() == ref_u.tobytes()
+    for c in ctxs:
+        c.close()

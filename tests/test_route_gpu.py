@@ -167,3 +167,24 @@ def test_c5_cloud_routed_two_ranks(gpu):
     for r in range(2):
         ms, mi = out[r][1]
         assert mi.tobytes() == i_ref.tobytes() and ms.tobytes() == s_ref.tobytes()
+
+
+def test_in_library_rccl_communicator_world_of_one(gpu):
+    """csrc/comm.hip on the one GPU of this box: librccl.so is dlopen()ed, ncclCommInitRank with one rank, and the sharded
+    extraction + gather run their collectives (grouped ncclSend / ncclRecv to self on the ctx stream) through it - the result is
+    the plain call's, byte for byte.  (Two ranks need two GPUs: the driver's multi-GPU bench covers that leg.)"""
+    ctx = lib.Context(0)
+    try:
+        uid = lib.rccl_unique_id()
+        assert len(uid) == 128
+        ctx.comm_rccl_init(0, 1, uid)
+        pts = _mixed_cloud(150, 60_000, seed=21)
+        s_ref, i_ref = gpu.extract_surfels(pts)
+        d_pts = ctx.to_device(pts)
+        d_s, d_i, m, owned = ctx.extract_surfels_sharded(d_pts, len(pts), float(pts["time"][0]), float(pts["time"][-1]))
+        assert owned == len(pts) and m == len(s_ref)
+        ms, mi = ctx.gather_surfels(d_s, d_i, m, cap=m + 16)
+        assert mi.tobytes() == i_ref.tobytes() and ms.tobytes() == s_ref.tobytes()
+        ctx.comm_rccl_destroy()
+    finally:
+        ctx.close()

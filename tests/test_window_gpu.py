@@ -210,6 +210,53 @@ def test_two_rank_sharded_solve_on_one_gpu(gpu, oracle):
     del keep_all
 
 
+def test_sharded_solve_through_the_ctx_communicator(gpu, oracle):
+    """the same lock-step solve, the all-reduce going through the ctx's wc_comm (the slot the in-library RCCL binding of
+    csrc/comm.hip fills with ncclAllReduce on the ctx stream) instead of the legacy callback"""
+    import threading
+
+    from wildcat_slam_amd import dist as wdist
+    from wildcat_slam_amd import lib
+
+    w = synth.surfel_window(3, 300, seed=29, fixed_patches=150)
+    params = oracle.default_params()
+    pairs = oracle.match(w["surf"], w["pose"], w["surf"], w["pose"], True, params)
+    ns = len(w["sample_times"])
+    x0 = np.zeros(12 * ns)
+    keep = [gpu.to_device(w["surf"]), gpu.to_device(w["pose"]), gpu.to_device(pairs)]
+    gpu.window_build(keep[0], keep[1], keep[2], len(pairs), w["imu"], w["sample_times"], w["grav"], True)
+    x_ref, s_ref, _ = gpu.window_solve(x0)
+    world = 2
+    ctxs = [lib.Context(0) for _ in range(world)]
+    shared = wdist.ThreadComm.shared(world)
+    res, errors = [None] * world, []
+
+    def run(r):
+        try:
+            c = ctxs[r]
+            c.set_comm(wdist.ThreadComm(shared, r, c))
+            lo, cnt = wdist.shard_range(len(pairs), r, world)
+            k = [c.to_device(w["surf"]), c.to_device(w["pose"]), c.to_device(pairs[lo:lo + cnt])]
+            c.window_build(k[0], k[1], k[2], cnt, w["imu"] if r == 0 else None, w["sample_times"], w["grav"], True)
+            res[r] = c.window_solve(x0) + (k,)
+        except Exception as e:  # pragma: no cover
+            errors.append(e)
+            shared["bar"].abort()
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=120)
+    assert not errors, errors
+    assert shared["calls"][0] == shared["calls"][1] > 0
+    assert np.array_equal(res[0][0], res[1][0]), "ranks diverged"
+    assert res[0][1].iterations == res[1][1].iterations == s_ref.iterations
+    assert _rel(res[0][0], x_ref) < 1e-6
+    for c in ctxs:
+        c.close()
+
+
 def test_c3_window_size_independent_properties(gpu):
     """BASELINE config C3 (5-scan window, 200 k surfels) at full size, where the oracle would take minutes: properties that
     hold at any size.  Correspondences from the GPU matcher; the normal equations are symmetric with a positive diagonal,

@@ -1,0 +1,157 @@
+// comm.hip — the in-library RCCL communicator (one process and one wc_ctx per GPU, RCCL over xGMI).
+//
+// librccl.so is opened at run time (dlopen): the library has no link-time dependency on it and a single-GPU user never loads
+// it.  wc_comm_rccl_init() installs a wc_comm whose three collectives are ENQUEUED ON THE CTX'S STREAM - no host
+// synchronisation, no Python, no callback into the caller's runtime:
+//   allreduce_f64   ncclAllReduce(ncclDouble, ncclSum) in place: the packed {upper block triangle of H, g, cost} buffer of a
+//                   linearisation and the candidate-cost scalar (csrc/window.hip)
+//   alltoallv       grouped ncclSend / ncclRecv of bytes: the ONE exchange step of the sharded extraction (csrc/route.hip)
+//   allgatherv      grouped ncclSend / ncclRecv: surfel lists (route.hip) and the gated neighbour lists of the query-sharded
+//                   matcher (csrc/match.hip)
+// The unique id is created by rank 0 (wc_comm_rccl_unique_id) and handed to the other ranks by whatever launched them
+// (torch.distributed / MPI / a file): 128 opaque bytes.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <cstring>
+
+#include "ctx.h"
+
+namespace {
+
+struct RcclApi {
+  void *so = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+RcclApi *rccl_api(std::string *err) {
+  static RcclApi api;
+  static bool tried = false, ok = false;
+  if (!tried) {
+    tried = true;
+    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+      api.so = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (api.so) break;
+    }
+    if (api.so) {
+      ok = true;
+#define WC_SYM(field, sym)                                   \
+  api.field = (decltype(api.field))dlsym(api.so, sym);       \
+  if (!api.field) ok = false;
+      WC_SYM(GetUniqueId, "ncclGetUniqueId")
+      WC_SYM(CommInitRank, "ncclCommInitRank")
+      WC_SYM(CommDestroy, "ncclCommDestroy")
+      WC_SYM(AllReduce, "ncclAllReduce")
+      WC_SYM(Send, "ncclSend")
+      WC_SYM(Recv, "ncclRecv")
+      WC_SYM(GroupStart, "ncclGroupStart")
+      WC_SYM(GroupEnd, "ncclGroupEnd")
+      WC_SYM(GetErrorString, "ncclGetErrorString")
+#undef WC_SYM
+    }
+  }
+  if (!ok) {
+    if (err) *err = api.so ? "librccl.so lacks an expected symbol" : (std::string("dlopen(librccl.so) failed: ") + (dlerror() ? dlerror() : "?"));
+    return nullptr;
+  }
+  return &api;
+}
+
+struct RcclComm {
+  RcclApi *api;
+  ncclComm_t comm;
+  wc_ctx *ctx;
+  int rank, world;
+};
+
+int rc_allreduce(void *user, double *d_buf, uint64_t count) {
+  RcclComm *c = (RcclComm *)user;
+  return c->api->AllReduce(d_buf, d_buf, (size_t)count, ncclDouble, ncclSum, c->comm, c->ctx->stream) == ncclSuccess ? 0 : 1;
+}
+
+int rc_alltoallv(void *user, const void *d_send, const uint64_t *send_bytes, void *d_recv, const uint64_t *recv_bytes) {
+  RcclComm *c = (RcclComm *)user;
+  const char *s = (const char *)d_send;
+  char *r = (char *)d_recv;
+  bool ok = c->api->GroupStart() == ncclSuccess;
+  for (int p = 0; p < c->world && ok; ++p) {
+    if (send_bytes[p]) ok = ok && c->api->Send(s, (size_t)send_bytes[p], ncclUint8, p, c->comm, c->ctx->stream) == ncclSuccess;
+    if (recv_bytes[p]) ok = ok && c->api->Recv(r, (size_t)recv_bytes[p], ncclUint8, p, c->comm, c->ctx->stream) == ncclSuccess;
+    s += send_bytes[p];
+    r += recv_bytes[p];
+  }
+  ok = (c->api->GroupEnd() == ncclSuccess) && ok;
+  return ok ? 0 : 1;
+}
+
+int rc_allgatherv(void *user, const void *d_send, uint64_t send_bytes, void *d_recv, const uint64_t *recv_bytes) {
+  RcclComm *c = (RcclComm *)user;
+  char *r = (char *)d_recv;
+  bool ok = c->api->GroupStart() == ncclSuccess;
+  for (int p = 0; p < c->world && ok; ++p) {
+    if (send_bytes) ok = ok && c->api->Send(d_send, (size_t)send_bytes, ncclUint8, p, c->comm, c->ctx->stream) == ncclSuccess;
+    if (recv_bytes[p]) ok = ok && c->api->Recv(r, (size_t)recv_bytes[p], ncclUint8, p, c->comm, c->ctx->stream) == ncclSuccess;
+    r += recv_bytes[p];
+  }
+  ok = (c->api->GroupEnd() == ncclSuccess) && ok;
+  return ok ? 0 : 1;
+}
+
+}  // namespace
+
+extern "C" int wc_comm_rccl_unique_id(char out128[128]) {
+  if (!out128) return WC_ERR_ARG;
+  RcclApi *api = rccl_api(nullptr);
+  if (!api) return WC_ERR_HIP;
+  ncclUniqueId id;
+  if (api->GetUniqueId(&id) != ncclSuccess) return WC_ERR_HIP;
+  static_assert(sizeof(id) == 128, "ncclUniqueId is 128 bytes");
+  std::memcpy(out128, &id, 128);
+  return WC_OK;
+}
+
+extern "C" int wc_comm_rccl_init(wc_ctx *ctx, int rank, int world, const char id128[128]) {
+  wc_dev_guard dg_(ctx);
+  if (!ctx || !id128 || world < 1 || rank < 0 || rank >= world) return wc_fail(ctx, WC_ERR_ARG, "%s: null or out-of-range argument", __func__);
+  std::string err;
+  RcclApi *api = rccl_api(&err);
+  if (!api) return wc_fail(ctx, WC_ERR_HIP, "%s", err.c_str());
+  if (ctx->rccl) return wc_fail(ctx, WC_ERR_ARG, "wc_comm_rccl_init: the context already has an RCCL communicator");
+  ncclUniqueId id;
+  std::memcpy(&id, id128, 128);
+  RcclComm *c = new RcclComm{api, nullptr, ctx, rank, world};
+  const ncclResult_t rc = api->CommInitRank(&c->comm, world, id, rank);
+  if (rc != ncclSuccess) {
+    delete c;
+    return wc_fail(ctx, WC_ERR_HIP, "ncclCommInitRank failed: %s", api->GetErrorString(rc));
+  }
+  ctx->rccl = c;
+  wc_comm v;
+  std::memset(&v, 0, sizeof(v));
+  v.user = c, v.rank = rank, v.world = world;
+  v.allreduce_f64 = rc_allreduce, v.alltoallv = rc_alltoallv, v.allgatherv = rc_allgatherv;
+  v.stream_ordered = 1;
+  return wc_ctx_set_comm(ctx, &v);
+}
+
+extern "C" int wc_comm_rccl_destroy(wc_ctx *ctx) {
+  wc_dev_guard dg_(ctx);
+  if (!ctx) return WC_ERR_ARG;
+  if (!ctx->rccl) return WC_OK;
+  RcclComm *c = (RcclComm *)ctx->rccl;
+  (void)hipStreamSynchronize(ctx->stream);
+  (void)wc_ctx_set_comm(ctx, nullptr);
+  (void)c->api->CommDestroy(c->comm);
+  delete c;
+  ctx->rccl = nullptr;
+  return WC_OK;
+}

@@ -32,6 +32,7 @@ struct wc_ctx {
   // multi-GPU: the job's communicator (wc_ctx_set_comm / wc_comm_rccl_init)
   wc_comm comm{};
   bool have_comm = false;
+  void *rccl = nullptr;  // the in-library RCCL communicator (comm.hip), if any
   // pinned host mailbox
   uint32_t *h_status = nullptr;  // [0] n_emitted, [1] flags, ...
   double *h_mail = nullptr;      // pinned: 64 doubles of mailbox (costs etc.) + 4096 doubles of staging (the window's unknowns)

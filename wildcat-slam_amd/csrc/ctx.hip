@@ -89,12 +89,14 @@ extern "C" int wc_ctx_create(const wc_params *params, int device, wc_ctx **out) 
 }
 
 void wc_window_free(wc_ctx *ctx);  // window.hip
+extern "C" int wc_comm_rccl_destroy(wc_ctx *ctx);  // comm.hip
 
 extern "C" void wc_ctx_destroy(wc_ctx *ctx) {
   wc_dev_guard dg_(ctx);
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
+  (void)wc_comm_rccl_destroy(ctx);
   wc_window_free(ctx);
   wc_buf *all[] = {&ctx->b_keys[0],      &ctx->b_keys[1],     &ctx->b_vals[0],     &ctx->b_vals[1],      &ctx->b_sorttmp,
                    &ctx->b_slots,        &ctx->b_slot_ids,    &ctx->b_slot_keys[0], &ctx->b_slot_keys[1], &ctx->b_slot_idx[0],

@@ -190,12 +190,14 @@ template <int K>
 __global__ void __launch_bounds__(128, 4) k_knn_gate(const wc_surfel *q_surf, const wc_pose *q_pose, uint32_t nq, const double *sfeat,
                                                  const uint32_t *skeys, const uint32_t *sorig, const double *tworld, uint32_t nt,
                                                  MatchParams M, uint32_t *gated, uint32_t *knn_idx, double *knn_d2,
-                                                 const uint32_t *__restrict__ qorder) {
+                                                 const uint32_t *__restrict__ qorder, uint32_t q_begin, uint32_t q_end, uint32_t *gated_shard) {
   // qorder: the queries in the order of their grid cell (same-set matching: the sorted target permutation).  Neighbouring
   // threads then scan the same cell ranges: their feature loads hit the same cache lines and their trip counts agree.
   __shared__ uint2 s_rng[2 * kRowChunk][128];  // per thread: the candidate ranges of a chunk of rows (only its own column)
-  const uint32_t qi = blockIdx.x * blockDim.x + threadIdx.x;
-  if (qi >= nq) return;
+  // query-sharded call (several GPUs): this rank takes the positions [q_begin, q_end) of the cell order and writes its gated
+  // lists position-major into gated_shard (K words per position) - contiguous, so that ONE all-gather assembles all ranks'
+  const uint32_t qi = q_begin + blockIdx.x * blockDim.x + threadIdx.x;
+  if (qi >= q_end) return;
   const uint32_t q = qorder ? qorder[qi] : qi;
   double f[6];
   V3 cq, nq_w;
@@ -331,9 +333,26 @@ __global__ void __launch_bounds__(128, 4) k_knn_gate(const wc_surfel *q_surf, co
     const V3 nc = mk3(w[3], w[4], w[5]);
     if (acos(dot(nq_w, nc)) > M.ang_max) continue;                                    // cc:29, surfel.h:105-107
     if (fabs(dot(nq_w, cq - mk3(w[0], w[1], w[2]))) > M.dist_max) continue;           // cc:32
-    gated[(size_t)(out++) * nq + q] = c;
+    if (gated_shard)
+      gated_shard[(size_t)(qi - q_begin) * K + (out++)] = c;
+    else
+      gated[(size_t)(out++) * nq + q] = c;
   }
-  for (; out < (uint32_t)K; ++out) gated[(size_t)out * nq + q] = kNone;
+  for (; out < (uint32_t)K; ++out) {
+    if (gated_shard)
+      gated_shard[(size_t)(qi - q_begin) * K + out] = kNone;
+    else
+      gated[(size_t)out * nq + q] = kNone;
+  }
+}
+
+// the all-gathered, position-major gated lists of every rank -> the plane layout the resolve rounds read
+__global__ void __launch_bounds__(256) k_unpack_gated(const uint32_t *__restrict__ all, const uint32_t *__restrict__ qorder, uint32_t nq, int k,
+                                                     uint32_t *gated) {
+  const uint32_t qi = blockIdx.x * blockDim.x + threadIdx.x;
+  if (qi >= nq) return;
+  const uint32_t q = qorder ? qorder[qi] : qi;
+  for (int j = 0; j < k; ++j) gated[(size_t)j * nq + q] = all[(size_t)qi * k + j];
 }
 
 // choice(q) = first gated candidate c that is not already paired with q from c's own turn (c < q and choice(c) == q)
@@ -468,9 +487,24 @@ extern "C" int wc_match(wc_ctx *ctx, const wc_surfel *d_q_surf, const wc_pose *d
     WC_HIP(ctx, rocprim::radix_sort_pairs(ctx->b_sorttmp.p, tmp, k0, qk, v0, qo, (size_t)nq, 0u, 30u, st));
     qorder = qo;
   }
+  // several GPUs: the queries are independent (knn_surfel_matcher.cc:22-48), the targets are replicated;
+  // every rank searches a contiguous share of the queries (in cell order) and ONE all-gather of the gated lists (4 k bytes per
+  // query) gives every rank the whole table; the order-dependent de-duplication below then runs replicated
+  const bool sharded = ctx->have_comm && ctx->comm.world > 1 && ctx->comm.allgatherv && nq >= 4096 && !d_knn_idx && !d_knn_d2;
+  uint32_t q_begin = 0, q_end = nq;
+  uint32_t *gated_shard = nullptr;
+  if (sharded) {
+    const uint32_t w = (uint32_t)ctx->comm.world, r = (uint32_t)ctx->comm.rank;
+    q_begin = (uint32_t)(((uint64_t)nq * r) / w), q_end = (uint32_t)(((uint64_t)nq * (r + 1)) / w);
+    WC_TRY(wc_ensure(ctx, ctx->b_route[2], (size_t)nq * P.knn_k * 4));                     // all ranks' lists, position-major
+    WC_TRY(wc_ensure(ctx, ctx->b_route[3], (size_t)(q_end - q_begin + 1) * P.knn_k * 4));  // this rank's share
+    gated_shard = (uint32_t *)ctx->b_route[3].p;
+  }
+  const uint32_t nq_mine = q_end - q_begin;
 #define WC_KNN_LAUNCH(KK)                                                                                                        \
-  k_knn_gate<KK><<<(nq + 127) / 128, 128, 0, st>>>(d_q_surf, d_q_pose, nq, (const double *)b_sfeat.p, k1, v1, (const double *)b_world.p, \
-                                                  nt, M, (uint32_t *)b_gated.p, d_knn_idx, d_knn_d2, qorder)
+  if (nq_mine)                                                                                                                   \
+  k_knn_gate<KK><<<(nq_mine + 127) / 128, 128, 0, st>>>(d_q_surf, d_q_pose, nq, (const double *)b_sfeat.p, k1, v1, (const double *)b_world.p, \
+                                                  nt, M, (uint32_t *)b_gated.p, d_knn_idx, d_knn_d2, qorder, q_begin, q_end, gated_shard)
   switch (P.knn_k) {  // the reference's k = 10 gets its own instantiation (top-k in 30 registers)
     case 10: WC_KNN_LAUNCH(10); break;
     case 1: WC_KNN_LAUNCH(1); break;
@@ -491,6 +525,17 @@ extern "C" int wc_match(wc_ctx *ctx, const wc_surfel *d_q_surf, const wc_pose *d
   }
 #undef WC_KNN_LAUNCH
   WC_HIP(ctx, hipGetLastError());
+  if (sharded) {
+    const int w = ctx->comm.world;
+    std::vector<uint64_t> bytes((size_t)w);
+    for (int r = 0; r < w; ++r)
+      bytes[r] = (uint64_t)(((uint64_t)nq * (r + 1)) / w - ((uint64_t)nq * r) / w) * P.knn_k * 4;
+    if (!ctx->comm.stream_ordered) WC_HIP(ctx, hipStreamSynchronize(st));
+    if (ctx->comm.allgatherv(ctx->comm.user, gated_shard, (uint64_t)nq_mine * P.knn_k * 4, ctx->b_route[2].p, bytes.data()) != 0)
+      return wc_fail(ctx, WC_ERR_HIP, "wc_match: all-gather of the gated neighbour lists failed");
+    k_unpack_gated<<<(nq + 255) / 256, 256, 0, st>>>((const uint32_t *)ctx->b_route[2].p, qorder, nq, P.knn_k, (uint32_t *)b_gated.p);
+    WC_HIP(ctx, hipGetLastError());
+  }
   // 4. resolve the order-dependent "pair already seen" rule by fixed-point iteration
   uint32_t *choice[2] = {(uint32_t *)b_choice.p, (uint32_t *)b_choice.p + nq};
   uint32_t *flags = (uint32_t *)b_choice.p + 2 * (size_t)nq, *offsets = (uint32_t *)b_choice.p + 3 * (size_t)nq;

@@ -1740,10 +1740,20 @@ __global__ void __launch_bounds__(1024) k_post_reduce(const double *g, const dou
 }
 
 // multi-GPU hook: sum a device buffer over all ranks (RCCL through the caller); no-op on one GPU
+// (the callback installed with wc_window_set_allreduce, else the ctx's communicator - the in-library RCCL binding of comm.hip
+// enqueues ncclAllReduce on the ctx stream: no host synchronisation on that path)
+bool multi_gpu(const wc_ctx *ctx, const wc_window_state *W) {
+  return W->allreduce != nullptr || (ctx->have_comm && ctx->comm.world > 1 && ctx->comm.allreduce_f64 != nullptr);
+}
 int do_allreduce(wc_ctx *ctx, wc_window_state *W, double *d_buf, size_t count) {
-  if (!W->allreduce) return WC_OK;
-  WC_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  if (W->allreduce(W->allreduce_user, d_buf, (uint64_t)count) != 0) return wc_fail(ctx, WC_ERR_HIP, "all-reduce callback failed");
+  if (W->allreduce) {
+    WC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (W->allreduce(W->allreduce_user, d_buf, (uint64_t)count) != 0) return wc_fail(ctx, WC_ERR_HIP, "all-reduce callback failed");
+    return WC_OK;
+  }
+  if (!multi_gpu(ctx, W)) return WC_OK;
+  if (!ctx->comm.stream_ordered) WC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->comm.allreduce_f64(ctx->comm.user, d_buf, (uint64_t)count) != 0) return wc_fail(ctx, WC_ERR_HIP, "all-reduce failed");
   return WC_OK;
 }
 
@@ -1767,7 +1777,7 @@ int enqueue_linearize(wc_ctx *ctx, wc_window_state *W, const double *d_x, int ma
   ga.pieces = pcs, ga.heavy = (const uint32_t *)W->heavy.p, ga.partial = partial;
   // multi-GPU: the ranks reduce the upper block triangle only (pair order, 144 doubles per block pair, then g and the cost):
   // half the bytes of the dense matrix on the wire; one more kernel spreads the sum into both triangles
-  const bool packed = W->allreduce != nullptr;
+  const bool packed = multi_gpu(ctx, W);
   double *red = nullptr;
   const size_t red_count = (size_t)W->npairs * 144 + W->np + 2;
   if (packed) {
@@ -1806,7 +1816,7 @@ int enqueue_evaluate(wc_ctx *ctx, wc_window_state *W, const double *d_x, double 
   if (gi)
     k_eval_imu<<<gi, 256, 0, st>>>(W->wp, (const ImuRec *)W->irec.p, W->ni, d_x, (const double *)W->times_d.p,
                                   d_res ? d_res + W->nb + W->nu : nullptr, cp + gb + gu);
-  k_sum_blocks<<<1, 1024, 0, st>>>(cp, gb + gu + gi, (double *)W->mail.p, mail_slot, W->allreduce ? nullptr : host_mail);
+  k_sum_blocks<<<1, 1024, 0, st>>>(cp, gb + gu + gi, (double *)W->mail.p, mail_slot, multi_gpu(ctx, W) ? nullptr : host_mail);
   WC_HIP(ctx, hipGetLastError());
   WC_TRY(do_allreduce(ctx, W, (double *)W->mail.p + mail_slot, 1));
   return WC_OK;
@@ -1952,7 +1962,7 @@ extern "C" int wc_window_solve(wc_ctx *ctx, double *h_x_inout, wc_solve_summary 
       WC_TRY(enqueue_evaluate(ctx, W, xc, nullptr, 5, h_mail_dev));
       WC_HIP(ctx, hipGetLastError());
       // (one GPU: k_sum_blocks has stored the mailbox to pinned host memory itself; with an all-reduce behind it, copy)
-      if (W->allreduce || !h_mail_dev) WC_HIP(ctx, hipMemcpyAsync(ctx->h_mail, mail, 40 * 8, hipMemcpyDeviceToHost, st));
+      if (multi_gpu(ctx, W) || !h_mail_dev) WC_HIP(ctx, hipMemcpyAsync(ctx->h_mail, mail, 40 * 8, hipMemcpyDeviceToHost, st));
       WC_HIP(ctx, hipStreamSynchronize(st));
       if (lin_pending) {
         resolve_pending();

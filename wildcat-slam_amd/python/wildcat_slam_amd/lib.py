@@ -55,6 +55,15 @@ def default_params():
     return p
 
 
+def rccl_unique_id():
+    """128 opaque bytes from ncclGetUniqueId (rank 0 creates them, the launcher distributes them)"""
+    buf = C.create_string_buffer(128)
+    rc = load().wc_comm_rccl_unique_id(buf)
+    if rc != WC_OK:
+        raise WildcatError(rc, "wc_comm_rccl_unique_id failed (librccl.so not loadable?)")
+    return bytes(buf.raw)
+
+
 def route_owner(keys_xyz, world):
     """owner rank of every root voxel index (n x 3 int32) - wc_route_owner, needs no GPU"""
     keys_xyz = np.asarray(keys_xyz, np.int64).reshape(-1, 3)
@@ -266,9 +275,17 @@ class Context:
         ar = R.COMM_ALLREDUCE(guard(lambda user, p, n: comm.allreduce(p, n)))
         a2a = R.COMM_ALLTOALLV(guard(lambda user, s, sb, r, rb: comm.alltoallv(s, [sb[i] for i in range(world)], r, [rb[i] for i in range(world)])))
         ag = R.COMM_ALLGATHERV(guard(lambda user, s, n, r, rb: comm.allgatherv(s, n, r, [rb[i] for i in range(world)])))
-        c = R.Comm(None, comm.rank, world, ar, a2a, ag)
+        c = R.Comm(None, comm.rank, world, ar, a2a, ag, 0)
         self._comm = (c, ar, a2a, ag, comm)  # keep the trampolines alive
         self._ck(self.lib.wc_ctx_set_comm(self.h, C.byref(c)))
+
+    def comm_rccl_init(self, rank, world, unique_id):
+        """the in-library RCCL communicator (csrc/comm.hip); unique_id: the 128 bytes of rccl_unique_id() of rank 0"""
+        buf = C.create_string_buffer(bytes(unique_id), 128)
+        self._ck(self.lib.wc_comm_rccl_init(self.h, C.c_int(rank), C.c_int(world), buf))
+
+    def comm_rccl_destroy(self):
+        self._ck(self.lib.wc_comm_rccl_destroy(self.h))
 
     def route_partition(self, d_points, n, world):
         """-> (DeviceBuffer of wc_route_point[n], counts[world])"""

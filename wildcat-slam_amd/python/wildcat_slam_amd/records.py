@@ -88,6 +88,7 @@ class Comm(C.Structure):
         ("allreduce_f64", COMM_ALLREDUCE),
         ("alltoallv", COMM_ALLTOALLV),
         ("allgatherv", COMM_ALLGATHERV),
+        ("stream_ordered", C.c_int32),
     ]
 
 
