@@ -34,8 +34,9 @@ sys.path.insert(0, os.path.join(ROOT, "wildcat-slam_amd", "python"))
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
-STAGE_KERNELS = {"init": "k_init", "point_sort": "k_pt_runs + k_pt_bucket", "roots_stream": "k_roots<unsigned int, 1, true>",
-                 "roots_emit": "k_roots_emit<unsigned int, true>", "slot_order": "k_slot_emit"}
+# the five event-bracketed stages of wc_extract_stage_ms and the kernels of the DEFAULT (integer-moment) path inside them
+STAGE_KERNELS = {"init": "(none: the control block is cleared by the previous sweep's k_slot_emit)", "point_sort": "k_fx_acc<1>",
+                 "roots_stream": "k_fx_nodes<1>", "roots_emit": "k_fx_acc<2> + k_fx_nodes<2>", "slot_order": "k_slot_emit"}
 
 
 class _Ptr:
@@ -153,6 +154,12 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip firing_order / cloud_10m / odometry_step")
     ap.add_argument("--in-flight", type=int, default=3, help="sweeps in flight (contexts) of the extra pipelined measurement")
     args = ap.parse_args()
+
+    # stdout carries exactly ONE line, the JSON result: everything libraries print (RCCL greets with a version banner on
+    # stdout when its first communicator comes up) goes to stderr
+    real_stdout = os.fdopen(os.dup(1), "w")
+    sys.stdout.flush()
+    os.dup2(2, 1)
 
     import torch  # device memory + distributed plumbing only
     import torch.distributed as dist
@@ -279,6 +286,7 @@ def main():
                    "points_per_gpu": n_pts, "surfels_per_gpu": exp_surfels, "parallelism": "sweep-per-gpu x%d" % world},
         "roofline": roofline,
         "stages_ms": {k_: round(v, 5) for k_, v in stages.items()},
+        "stage_kernels": STAGE_KERNELS,
         "host": cpu_info(),
         "communicator": comm_kind,
     }
@@ -372,7 +380,8 @@ def main():
             result["odometry_step"] = {"error": repr(e)}
 
     if rank == 0:
-        print(json.dumps(result))
+        real_stdout.write(json.dumps(result) + "\n")
+        real_stdout.flush()
     ctx.close()
     if dist.is_initialized():
         dist.destroy_process_group()

@@ -3,7 +3,7 @@
 # passes (FETCH_SIZE / WRITE_SIZE cannot share a pass: TCC has 4 slots, MI355X_MICROARCH.md "rocprofv3 PMC slots").
 # Usage: gpurun -- 'bash profiles/collect.sh r1'   -> gpurun_out/<tag>/...; then python profiles/summarize.py <tag>
 set -u
-TAG=${1:-r1}
+TAG=${1:-r2}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/$TAG
 mkdir -p $O

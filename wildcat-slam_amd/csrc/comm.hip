@@ -38,10 +38,17 @@ RcclApi *rccl_api(std::string *err) {
   static bool tried = false, ok = false;
   if (!tried) {
     tried = true;
-    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-      api.so = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+    // an RCCL that the process has loaded already (e.g. the one bundled with PyTorch) is reused: two RCCL instances in one
+    // process would each bring up their own transport on the same GPUs
+    for (const char *name : {"librccl.so.1", "librccl.so"}) {
+      api.so = dlopen(name, RTLD_NOW | RTLD_NOLOAD);
       if (api.so) break;
     }
+    if (!api.so)
+      for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        api.so = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        if (api.so) break;
+      }
     if (api.so) {
       ok = true;
 #define WC_SYM(field, sym)                                   \
