@@ -190,17 +190,50 @@ def test_soa_point_layouts_match_the_aos_record(gpu, oracle, xyz_stride):
     """wc_points takes any (xyz pointer + stride, time pointer + stride): packed 12-byte xyz / padded 16-byte xyz with a
     separate time array must give bit-for-bit what the 48-byte hilti_ros::Point record gives (common.h:12-28)"""
     for pts in (synth.g2_lattice(300, m=32)[0], synth.g1_room(60_000)):
-        n = len(pts)
-        s_ref, id_ref = gpu.extract_surfels(pts)
-        xyz = np.zeros((n, xyz_stride // 4), np.float32)
-        xyz[:, 0], xyz[:, 1], xyz[:, 2] = pts["x"], pts["y"], pts["z"]
-        t = np.ascontiguousarray(pts["time"], np.float64)
-        d_xyz, d_t = gpu.to_device(xyz), gpu.to_device(t)
-        cap = max(1024, (3 * n) // 20 + 1)
-        d_out, d_ids = gpu.alloc(cap * 144), gpu.alloc(cap * 16)
-        desc = R.Points(d_xyz.ptr, d_t.ptr, xyz_stride, 8, n)
-        gpu.extract_enqueue(desc, d_out, d_ids, cap, float(t[0]), float(t[-1]))
-        m = gpu.extract_finish()
-        assert m == len(s_ref) > 0
-        s, ids = d_out.download(R.SURFEL, m), d_ids.download(R.SURFEL_ID, m)
-        assert s.tobytes() == s_ref.tobytes() and ids.tobytes() == id_ref.tobytes()
+        for exact in (True, False):
+            gpu.set_exact_sums(exact)  # (also resets the adaptive path choice: both calls below start from the same state)
+            try:
+                n = len(pts)
+                s_ref, id_ref = gpu.extract_surfels(pts)
+                ref_fast = gpu.extract_path_info()["fast"]
+                xyz = np.zeros((n, xyz_stride // 4), np.float32)
+                xyz[:, 0], xyz[:, 1], xyz[:, 2] = pts["x"], pts["y"], pts["z"]
+                t = np.ascontiguousarray(pts["time"], np.float64)
+                d_xyz, d_t = gpu.to_device(xyz), gpu.to_device(t)
+                cap = max(1024, (3 * n) // 20 + 1)
+                d_out, d_ids = gpu.alloc(cap * 144), gpu.alloc(cap * 16)
+                desc = R.Points(d_xyz.ptr, d_t.ptr, xyz_stride, 8, n)
+                gpu.set_exact_sums(exact)
+                gpu.extract_enqueue(desc, d_out, d_ids, cap, float(t[0]), float(t[-1]))
+                m = gpu.extract_finish()
+                assert m == len(s_ref) > 0
+                s, ids = d_out.download(R.SURFEL, m), d_ids.download(R.SURFEL_ID, m)
+                if exact or gpu.extract_path_info()["fast"] == ref_fast:  # same arithmetic on both layouts: same bytes
+                    assert s.tobytes() == s_ref.tobytes() and ids.tobytes() == id_ref.tobytes()
+                else:
+                    helpers.check_surfels(s, ids, s_ref, id_ref, tol=1e-6, t_tol=1e-4)
+            finally:
+                gpu.set_exact_sums(False)
+
+def test_default_path_backs_off_after_repeated_fall_backs(gpu, oracle):
+    """a sweep the default (integer-moment) path cannot finish - here: every node observed again after one second, more than its 16 time bins of 0.05 s -
+    is repeated on the exact path; when that keeps happening the library goes to the exact path directly for an exponentially
+    growing number of sweeps, and comes back to the default path afterwards.  Results are the oracle's all along."""
+    a, _ = synth.g2_lattice(60, m=32, t_start=synth.T0, duration=0.1)
+    b, _ = synth.g2_lattice(60, m=32, t_start=synth.T0 + 1.0, duration=0.1)  # the same voxels again, one second later
+    b["x"] += np.float32(0.001)
+    both = synth.concat_points(a, b)
+    s_ref, i_ref, _ = oracle.extract_surfels(both)
+    gpu.set_exact_sums(False)  # (also resets the adaptive state)
+    fast_flags = []
+    for _ in range(8):
+        s, i = gpu.extract_surfels(both)
+        helpers.check_surfels(s, i, s_ref, i_ref, tol=1e-6, t_tol=1e-4)
+        fast_flags.append(gpu.extract_path_info()["fast"])
+    info = gpu.extract_path_info()
+    assert not any(fast_flags)          # this cloud is never finished by the default path ...
+    assert 1 <= info["fallbacks"]       # ... which was tried ...
+    regular, _ = synth.g2_lattice(100, m=32)
+    gpu.set_exact_sums(False)
+    s, i = gpu.extract_surfels(regular)
+    assert gpu.extract_path_info()["fast"]  # ... and is back for a sweep it can handle

@@ -135,6 +135,7 @@ extern "C" int wc_ctx_set_params(wc_ctx *ctx, const wc_params *params) {
   if (!ctx || !params) return wc_fail(ctx, WC_ERR_ARG, "%s: null or out-of-range argument", __func__);
   WC_TRY(check_params(ctx, params));
   ctx->P = *params;
+  ctx->ex.fx_backoff = ctx->ex.fx_skip_calls = 0;  // new parameters: the adaptive path choice of the extraction starts afresh
   return WC_OK;
 }
 

@@ -2146,6 +2146,10 @@ extern "C" int wc_extract_surfels_enqueue(wc_ctx *ctx, const wc_points *pts, dou
   if (ctx->ex.general_calls > 0) --ctx->ex.general_calls;
   ctx->ex.order_general = false;
   ctx->ex.fx_active = fx_applicable(ctx, pts->n, t_lo, t_hi);
+  if (ctx->ex.fx_active && ctx->ex.fx_skip_calls > 0) {  // recent sweeps had to be repeated on the exact path: go there directly for a while
+    --ctx->ex.fx_skip_calls;
+    ctx->ex.fx_active = false;
+  }
   if (ctx->ex.fx_active) {
     const int rc = run_pipeline_fast(ctx, *pts, t_lo, t_hi, d_out, d_ids, cap);
     if (rc != WC_OK) ctx->ex.fx_dirty = true;
@@ -2181,6 +2185,10 @@ extern "C" int wc_extract_surfels_finish(wc_ctx *ctx, uint64_t *h_n_out) {
       // a decision too close to its threshold, a table at capacity, a node spanning > 16 time bins, ...: the tables are put
       // back to zero and the sweep is repeated on the exact path (below)
       ++ctx->ex.fx_fallbacks;
+      // exponential back-off: a sweep the default path cannot finish (a node spanning more than 16 time bins, more roots than
+      // blocks, ...) is usually followed by more of its kind; a gate that merely fell inside the noise band is not
+      ctx->ex.fx_backoff = std::min(32u, std::max(1u, ctx->ex.fx_backoff * 2u));
+      ctx->ex.fx_skip_calls = ctx->ex.fx_backoff - 1u;
       ctx->ex.fx_dirty = true;        // tables (a root at capacity, roots waiting for a layer-2 pass that never ran) ...
       ctx->ex.fx_ctrl_ready = false;  // ... and control blocks are set up anew by the next fast sweep
       ctx->ex.fx_active = false;
@@ -2191,6 +2199,7 @@ extern "C" int wc_extract_surfels_finish(wc_ctx *ctx, uint64_t *h_n_out) {
       const uint32_t n_fast = ctx->h_status[0];
       if (h_n_out) *h_n_out = n_fast;
       ctx->ex.fx_parity ^= 1;  // the other control block has been cleared by this sweep's k_slot_emit
+      ctx->ex.fx_backoff = 0;
       if (n_fast > ctx->ex.cap)
         return wc_fail(ctx, WC_ERR_CAPACITY, "output capacity %llu < %u surfels", (unsigned long long)ctx->ex.cap, n_fast);
       return WC_OK;
