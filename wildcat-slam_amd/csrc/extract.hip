@@ -1812,6 +1812,8 @@ int run_pipeline_fast(wc_ctx *ctx, const wc_points &pts, double t_lo, double t_h
   WC_TRY(fx_ensure_zero(ctx, ctx->b_fx[2], (size_t)tr * kFxBlockW * 8));
   WC_TRY(fx_ensure_zero(ctx, ctx->b_fx[3], (size_t)A.mq_per * kFxSub * kFxBlockW * 8));
   WC_TRY(wc_ensure(ctx, ctx->b_fx[4], (size_t)2 * A.rec_cap * kFxRecW * 8));  // records: reachable through list heads only, never cleared
+  const unsigned ngrid = std::min<unsigned>(256 * 16, std::max<unsigned>(64, (unsigned)(n / 256)));  // k_fx_nodes<1>; <2> uses fewer
+  WC_TRY(wc_ensure(ctx, ctx->b_fx[6], (size_t)ngrid * kFxJobCap * kFxJobW * 8));  // cluster jobs: written before they are read
   WC_TRY(wc_ensure(ctx, ctx->b_slots, total_slots * sizeof(wc_surfel)));
   WC_TRY(wc_ensure(ctx, ctx->b_slot_ids, total_slots * sizeof(wc_surfel_id)));
   WC_TRY(wc_ensure(ctx, ctx->b_slot_keys[1], (uint64_t)kBuckets * bin_cap * 8));
@@ -1838,6 +1840,7 @@ int run_pipeline_fast(wc_ctx *ctx, const wc_points &pts, double t_lo, double t_h
   A.rkey = (uint32_t *)ctx->b_fx[0].p, A.rlist = (uint32_t *)ctx->b_fx[1].p;
   A.blk = (unsigned long long *)ctx->b_fx[2].p, A.blk2 = (unsigned long long *)ctx->b_fx[3].p;
   A.rec = (unsigned long long *)ctx->b_fx[4].p;
+  A.jobs = (unsigned long long *)ctx->b_fx[6].p;
   A.status = ctrl + kCtrlStatus;
   A.cnt = ctrl + kCtrlFx;
   A.slots = (wc_surfel *)ctx->b_slots.p, A.slot_ids = (wc_surfel_id *)ctx->b_slot_ids.p;
@@ -1866,7 +1869,6 @@ int run_pipeline_fast(wc_ctx *ctx, const wc_points &pts, double t_lo, double t_h
   k_fx_acc<1><<<tiles, kFxThreads, 0, st>>>(A);
   dbg_sync("k_fx_acc<1>");
   mark(2);
-  const unsigned ngrid = std::min<unsigned>(256 * 16, std::max<unsigned>(64, (unsigned)(n / 256)));
   k_fx_nodes<1><<<ngrid, 64, 0, st>>>(A);
   dbg_sync("k_fx_nodes<1>");
   mark(3);
@@ -1891,7 +1893,8 @@ int fx_tail(wc_ctx *ctx, bool layer2) {
   if (layer2) {
     const unsigned tiles = (unsigned)((A.pts.n + kFxTile - 1) / kFxTile);
     k_fx_acc<2><<<tiles, kFxThreads, 0, st>>>(A);
-    k_fx_nodes<2><<<std::min(256u * 8u, std::max(64u, ctx->ex.last_splits)), 64, 0, st>>>(A);
+    const unsigned ngrid = std::min<unsigned>(256 * 16, std::max<unsigned>(64, (unsigned)(A.pts.n / 256)));  // (the job buffer's blocks)
+    k_fx_nodes<2><<<std::min(std::min(256u * 8u, ngrid), std::max(64u, ctx->ex.last_splits)), 64, 0, st>>>(A);
   }
   ctx->ex.layer2_done = layer2;
   mark(4);
