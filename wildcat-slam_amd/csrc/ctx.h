@@ -72,6 +72,7 @@ struct wc_ctx {
   wc_window_state *win = nullptr;
   // optional per-stage HIP events of the extraction pipeline (wc_extract_profile)
   bool ex_prof = false;
+  int ex_prof_mode = 0;
   hipEvent_t ex_ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 };
 

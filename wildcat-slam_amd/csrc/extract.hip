@@ -1849,7 +1849,7 @@ int run_pipeline_fast(wc_ctx *ctx, const wc_points &pts, double t_lo, double t_h
   A.slot_bins = (uint64_t *)ctx->b_slot_keys[1].p;
   A.slot_bin_cap = bin_cap;
   auto mark = [&](int i) {
-    if (ctx->ex_prof) (void)hipEventRecord(ctx->ex_ev[i], st);
+    if (ctx->ex_prof && (ctx->ex_prof_mode != 2 || i == 1 || i == 5)) (void)hipEventRecord(ctx->ex_ev[i], st);
   };
   mark(0);
   mark(1);
@@ -1888,7 +1888,7 @@ int fx_tail(wc_ctx *ctx, bool layer2) {
   FxArgs A;
   std::memcpy(&A, ctx->ex.roots_args, sizeof(A));
   auto mark = [&](int i) {
-    if (ctx->ex_prof) (void)hipEventRecord(ctx->ex_ev[i], st);
+    if (ctx->ex_prof && (ctx->ex_prof_mode != 2 || i == 1 || i == 5)) (void)hipEventRecord(ctx->ex_ev[i], st);
   };
   if (layer2) {
     const unsigned tiles = (unsigned)((A.pts.n + kFxTile - 1) / kFxTile);
@@ -1920,7 +1920,7 @@ int pipeline_tail(wc_ctx *ctx, bool layer2) {
   wc_surfel_id *d_ids = ctx->ex.d_ids;
   const uint64_t cap = ctx->ex.cap, total_slots = ctx->ex.total_slots;
   auto mark = [&](int i) {
-    if (ctx->ex_prof) (void)hipEventRecord(ctx->ex_ev[i], st);
+    if (ctx->ex_prof && (ctx->ex_prof_mode != 2 || i == 1 || i == 5)) (void)hipEventRecord(ctx->ex_ev[i], st);
   };
   if (layer2) {
     const unsigned grid2 = std::min(kRoots2Grid, std::max(64u, ctx->ex.last_splits));  // sized by the previous call's queue
@@ -2003,7 +2003,7 @@ int run_pipeline(wc_ctx *ctx, const wc_points &pts, double t_lo, double t_hi, wc
   uint32_t *status = (uint32_t *)ctx->b_ex_ctrl.p + kCtrlStatus;
 
   auto mark = [&](int i) {
-    if (ctx->ex_prof) (void)hipEventRecord(ctx->ex_ev[i], st);
+    if (ctx->ex_prof && (ctx->ex_prof_mode != 2 || i == 1 || i == 5)) (void)hipEventRecord(ctx->ex_ev[i], st);
   };
   mark(0);
   const bool fast_slots = fast_order && tbits <= 31 && total_slots < (1ull << 31);
@@ -2273,6 +2273,7 @@ extern "C" int wc_extract_profile(wc_ctx *ctx, int enable) {
   if (enable && !ctx->ex_ev[0])
     for (int i = 0; i < 8; ++i) WC_HIP(ctx, hipEventCreate(&ctx->ex_ev[i]));
   ctx->ex_prof = enable != 0;
+  ctx->ex_prof_mode = enable;  // 1: an event after every kernel group (each costs ~5 us of stream time); 2: first and last only
   return WC_OK;
 }
 
@@ -2280,6 +2281,11 @@ extern "C" int wc_extract_stage_ms(wc_ctx *ctx, float *h_ms5) {
   wc_dev_guard dg_(ctx);
   if (!ctx || !h_ms5 || !ctx->ex_ev[0]) return wc_fail(ctx, WC_ERR_ARG, "%s: null or out-of-range argument", __func__);
   WC_HIP(ctx, hipEventSynchronize(ctx->ex_ev[5]));
+  if (ctx->ex_prof_mode == 2) {  // bracket only: the whole stage in slot 1
+    for (int i = 0; i < 5; ++i) h_ms5[i] = 0.f;
+    WC_HIP(ctx, hipEventElapsedTime(&h_ms5[1], ctx->ex_ev[1], ctx->ex_ev[5]));
+    return WC_OK;
+  }
   for (int i = 0; i < 5; ++i) WC_HIP(ctx, hipEventElapsedTime(&h_ms5[i], ctx->ex_ev[i], ctx->ex_ev[i + 1]));
   return WC_OK;
 }
