@@ -62,6 +62,26 @@ with open(os.path.join(out, f"{tag}_pmc.md"), "w") as f:
 # per-kernel HBM traffic (x2-corrected reads + writes) for bench.py's roofline.traffic field
 json.dump({"source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, profiles/collect.sh {tag}; reads x2 (gfx950 correction)",
            "kernels": traffic}, open(os.path.join(out, f"{tag}_pmc.json"), "w"), indent=1)
+# derived metrics (one pass each): mean per kernel
+derived = collections.defaultdict(dict)
+for m in ("OccupancyPercent", "MeanOccupancyPerCU", "VALUBusy", "LDSBankConflict"):
+    p = os.path.join(src, "pmc_" + m, "b_counter_collection.csv")
+    if not os.path.exists(p):
+        continue
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(p)):
+        if r["Counter_Name"] == m:
+            acc[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
+    for k, v in acc.items():
+        derived[k][m] = sum(v) / len(v)
+if derived:
+    with open(os.path.join(out, f"{tag}_occupancy.md"), "w") as f:
+        f.write(f"# rocprofv3 --pmc OccupancyPercent / MeanOccupancyPerCU / VALUBusy / LDSBankConflict, one pass each ({tag})\n\n")
+        f.write("Mean over the dispatches of `python bench.py --steps 20 --warmup 5 --no-cpu-baseline --in-flight 1 --no-extras` "
+                "(C2 extraction + C4 window).\n\n| kernel | OccupancyPercent | MeanOccupancyPerCU | VALUBusy % | LDSBankConflict % |\n|---|---:|---:|---:|---:|\n")
+        for k in sorted(derived, key=lambda k: -agg.get(k, [0, 0.0])[1]):
+            d = derived[k]
+            f.write("| `%s` | %s | %s | %s | %s |\n" % (k, *("%.1f" % d[m] if m in d else "-" for m in ("OccupancyPercent", "MeanOccupancyPerCU", "VALUBusy", "LDSBankConflict"))))
 bj = os.path.join(src, "bench.json")
 if os.path.exists(bj):
     line = [l for l in open(bj) if l.startswith("{")][-1]

@@ -47,6 +47,16 @@ def test_g1_room_multires(gpu, oracle):
     print(res, list(st.nodes_plane))
 
 
+def test_g1_firing_order_full_size(gpu, oracle):
+    # the bench's second extraction entry: a 1 M-point sweep in firing order (five revolutions of the room: every node holds
+    # several temporal clusters, the busiest voxels have long record lists, octree layer 2 is in use) - counts and ids equal
+    # to the oracle's, geometry within 1e-6, completed by the default (integer-moment) path itself
+    pts = synth.g1_room(1_000_000, seed=synth.SEED + 3)
+    res, st = _run(gpu, oracle, pts, expect_fast=True)
+    assert res["n"] > 10_000 and st.nodes_plane[2] > 0
+    print(res, list(st.nodes_plane))
+
+
 def test_g1_no_time_hint(gpu, oracle):
     pts = synth.g1_room(100_000, seed=7)
     _run(gpu, oracle, pts, hint=False)
