@@ -161,6 +161,7 @@ def main():
     ap.add_argument("--window-patches", type=int, default=50000, help="surfels per sweep (C4: 50 000 -> 1 M surfels)")
     ap.add_argument("--no-window", action="store_true", help="skip the LM-window section")
     ap.add_argument("--no-extras", action="store_true", help="skip firing_order / cloud_10m / odometry_step")
+    ap.add_argument("--no-clouds", action="store_true", help="skip firing_order / cloud_10m only (profiling the odometry step)")
     ap.add_argument("--in-flight", type=int, default=3, help="sweeps in flight (contexts) of the extra pipelined measurement")
     args = ap.parse_args()
 
@@ -371,7 +372,7 @@ def main():
                                   "cpu": result["host"]["model"],
                                   "sample": "%d full C2 sweeps (%d pts each), %.1f s of single-thread oracle (oracle/extract.cc)" % (reps, n_pts, t_cpu)}
 
-    if not args.no_extras:
+    if not args.no_extras and not args.no_clouds:
         for name, fn in (("firing_order", bench_firing_order), ("cloud_10m", bench_cloud_10m)):
             try:
                 result[name] = fn(ctx, args, world, rank, dev, torch, dist, to_dev)

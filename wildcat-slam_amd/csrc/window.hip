@@ -420,6 +420,8 @@ __global__ void __launch_bounds__(256) k_seg_heads(const uint32_t *keys, uint32_
 }
 
 // ---- assembly: one workgroup per piece ------------------------------------------------------------------------------
+// (tried: workgroups of 256 / 128 / 64 threads by the size of the piece - a third of C4's binary pieces holds <= 64 records.
+// No gain: phase A is bound by its fp64 arithmetic per WAVEFRONT, and a small piece already keeps only one wavefront busy.)
 // Phase A: thread k evaluates record k of the piece (residual + W-wide Jacobian row) into LDS (row k of V = [J r]).
 // Phase B: the Gram matrix V^T V ((W+1)^2, packed upper triangle; the corner (W,W) carries the piece's cost instead of
 //          sum r^2) in 4x4 register blocks: thread = (block of the upper block triangle, slice of the records); per
@@ -434,9 +436,11 @@ __global__ void __launch_bounds__(kPiece) k_lin_surfel(WinParams wp, const Piece
   constexpr int NB = (T + 3) / 4;            // 4-column blocks of V
   constexpr int NBLK = NB * (NB + 1) / 2;    // blocks (bi <= bj) of the Gram matrix
   constexpr int NS = kPiece / NBLK;          // record slices
-  constexpr int VSZ = kPiece * T + 4;        // + 4: the padded columns of the last block read past the last row
-  constexpr int PSZ = NS * NBLK * 16;
-  __shared__ double sV[VSZ > PSZ ? VSZ : PSZ];  // V, later the per-slice partial blocks
+  constexpr int TS = T + (T & 1);            // row stride in LDS: even, so that a row's 4-column blocks are 16-byte aligned (ds_read_b128)
+  constexpr int VSZ = kPiece * TS + 4;       // + 4: the padded columns of the last block read past the last row
+  constexpr int PB = 17;                     // doubles per partial block in LDS: 16 + 1 (a stride of 16 doubles puts every second lane on the same banks)
+  constexpr int PSZ = NS * NBLK * PB;
+  __shared__ __attribute__((aligned(16))) double sV[VSZ > PSZ ? VSZ : PSZ];  // V, later the per-slice partial blocks
   __shared__ double sC[kPiece / 64];
   const Piece pc = pieces[blockIdx.x];
   const int tid = threadIdx.x;
@@ -466,8 +470,8 @@ __global__ void __launch_bounds__(kPiece) k_lin_surfel(WinParams wp, const Piece
     else
       eval_binary(wp, rv, 1, 0, pc.key, x, r, c, v);
 #pragma unroll
-    for (int i = 0; i < W; ++i) sV[tid * T + i] = v[i];
-    sV[tid * T + W] = r;
+    for (int i = 0; i < W; ++i) sV[tid * TS + i] = v[i];
+    sV[tid * TS + W] = r;
   }
   // cost of the piece: fixed shuffle tree per wavefront, the four wavefront sums are added in the tail
 #pragma unroll
@@ -491,15 +495,16 @@ __global__ void __launch_bounds__(kPiece) k_lin_surfel(WinParams wp, const Piece
   if (slice < NS) {
     // the slices partition the piece's records [0, count); columns past T (last block) belong to the next record (or, for
     // the last record, to unwritten storage): those products land in accumulator entries that are never read
-    const int sl = ((int)pc.count + NS - 1) / NS;
-    const int k0 = slice * sl, k1 = min(k0 + sl, (int)pc.count);
+    const int sl = (((int)pc.count + NS - 1) / NS) | 1;  // odd: the slices that share a wavefront then start on different banks
+    const int k0 = min(slice * sl, (int)pc.count), k1 = min(k0 + sl, (int)pc.count);
     const double *pi = sV + 4 * bi, *pj = sV + 4 * bj;
     for (int k = k0; k < k1; ++k) {
       double a[4], c4[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        a[q] = pi[k * T + q];
-        c4[q] = pj[k * T + q];
+      {
+        const double2 a01 = *(const double2 *)(pi + k * TS), a23 = *(const double2 *)(pi + k * TS + 2);
+        const double2 c01 = *(const double2 *)(pj + k * TS), c23 = *(const double2 *)(pj + k * TS + 2);
+        a[0] = a01.x, a[1] = a01.y, a[2] = a23.x, a[3] = a23.y;
+        c4[0] = c01.x, c4[1] = c01.y, c4[2] = c23.x, c4[3] = c23.y;
       }
 #pragma unroll
       for (int p = 0; p < 4; ++p)
@@ -515,7 +520,7 @@ __global__ void __launch_bounds__(kPiece) k_lin_surfel(WinParams wp, const Piece
 #pragma unroll
     for (int p = 0; p < 4; ++p)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) sV[(slice * NBLK + blk) * 16 + p * 4 + q] = acc[p][q];
+      for (int q = 0; q < 4; ++q) sV[(slice * NBLK + blk) * PB + p * 4 + q] = acc[p][q];
   }
   __syncthreads();
   constexpr int NOUT = T * (T + 1) / 2;
@@ -532,8 +537,8 @@ __global__ void __launch_bounds__(kPiece) k_lin_surfel(WinParams wp, const Piece
     } else {
       const int ti = i >> 2, tj = j >> 2;
       const int q = ti * NB - ti * (ti - 1) / 2 + (tj - ti);  // index of block (ti, tj) in the ti <= tj enumeration
-      const int off = q * 16 + (i & 3) * 4 + (j & 3);
-      for (int sl = 0; sl < NS; ++sl) out += sV[sl * NBLK * 16 + off];
+      const int off = q * PB + (i & 3) * 4 + (j & 3);
+      for (int sl = 0; sl < NS; ++sl) out += sV[sl * NBLK * PB + off];
     }
     partial[pc.part_off + e] = out;
   }
@@ -1625,6 +1630,17 @@ extern "C" int wc_window_build(wc_ctx *ctx, const wc_surfel *d_sld_surf, const w
   cut(segs_i, 37, false);
   W->npiece_i = (uint32_t)pieces.size() - W->npiece_b - W->npiece_u;
   W->npart_doubles = off;
+  if (getenv("WC_WIN_DEBUG")) {  // piece sizes per family
+    uint32_t hist[3][6] = {{0}};
+    for (size_t i = 0; i < pieces.size(); ++i) {
+      const int fam = i < W->npiece_b ? 0 : (i < W->npiece_b + W->npiece_u ? 1 : 2);
+      const uint32_t c = pieces[i].count;
+      hist[fam][c <= 16 ? 0 : c <= 32 ? 1 : c <= 64 ? 2 : c <= 128 ? 3 : c < (uint32_t)kPiece ? 4 : 5]++;
+    }
+    for (int fam = 0; fam < 3; ++fam)
+      fprintf(stderr, "[win] family %d pieces by count <=16 %u, <=32 %u, <=64 %u, <=128 %u, <%d %u, full %u\n", fam, hist[fam][0], hist[fam][1], hist[fam][2],
+              hist[fam][3], kPiece, hist[fam][4], hist[fam][5]);
+  }
 
   const uint32_t npairs = (uint32_t)(ns * (ns + 1) / 2);
   W->npairs = npairs;
