@@ -73,6 +73,23 @@ def test_small_timestamps_and_temporal_clusters(gpu, oracle):
     assert st.clusters_total == 2 * 8 * 200  # two temporal clusters per layer-1 plane node
 
 
+@pytest.mark.parametrize("revisits,fast", [(6, True), (9, None)])
+def test_many_temporal_clusters_per_node(gpu, oracle, revisits, fast):
+    # the same lattice observed 6 / 9 times inside one sweep, 0.08 s apart: every layer-1 node is a plane with that many
+    # temporal clusters.  k_fx_nodes puts every closed cluster aside as a job (512 per wavefront of 64 nodes): 6 x 64 fit - the
+    # default path completes the sweep itself; 9 x 64 do not - the sweep must be handed to the exact path, same result
+    parts = []
+    for r in range(revisits):
+        a, _ = synth.g2_lattice(150, m=32, t_start=0.08 * r, duration=0.02)
+        a["x"] += np.float32(0.0005 * r)
+        parts.append(a)
+    pts = synth.concat_points(*parts)
+    res, st = _run(gpu, oracle, pts, expect_fast=fast)
+    assert res["n"] == revisits * 8 * 150 and st.clusters_total == revisits * 8 * 150
+    if fast is None:
+        assert not res["fast"]["fast_path"]
+
+
 def test_empty_and_tiny_inputs(gpu, oracle):
     s, i = gpu.extract_surfels(np.zeros(0, R.POINT))
     assert len(s) == 0
