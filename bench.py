@@ -162,6 +162,7 @@ def main():
     ap.add_argument("--no-window", action="store_true", help="skip the LM-window section")
     ap.add_argument("--no-extras", action="store_true", help="skip firing_order / cloud_10m / odometry_step")
     ap.add_argument("--no-clouds", action="store_true", help="skip firing_order / cloud_10m only (profiling the odometry step)")
+    ap.add_argument("--extras-timeout", type=float, default=420.0, help="N > 1: seconds the sections after the headline may take")
     ap.add_argument("--in-flight", type=int, default=3, help="sweeps in flight (contexts) of the extra pipelined measurement")
     args = ap.parse_args()
 
@@ -372,22 +373,42 @@ def main():
                                   "cpu": result["host"]["model"],
                                   "sample": "%d full C2 sweeps (%d pts each), %.1f s of single-thread oracle (oracle/extract.cc)" % (reps, n_pts, t_cpu)}
 
-    if not args.no_extras and not args.no_clouds:
-        for name, fn in (("firing_order", bench_firing_order), ("cloud_10m", bench_cloud_10m)):
+    def extras():
+        torch.cuda.set_device(dev)  # (N > 1: this runs in a worker thread, and the current device is per thread)
+        if not args.no_extras and not args.no_clouds:
+            for name, fn in (("firing_order", bench_firing_order), ("cloud_10m", bench_cloud_10m)):
+                try:
+                    result[name] = fn(ctx, args, world, rank, dev, torch, dist, to_dev)
+                except Exception as e:
+                    result[name] = {"error": repr(e)}
+        if not args.no_window:
             try:
-                result[name] = fn(ctx, args, world, rank, dev, torch, dist, to_dev)
+                result["window"] = bench_window(ctx, args, world, rank, dev, torch, dist, cpu=cpu)
+            except Exception as e:  # the headline line must survive a failure of the extra section
+                result["window"] = {"error": repr(e)}
+        if not args.no_extras:
+            try:
+                result["odometry_step"] = bench_odometry_step(ctx, args, world, rank, dev, torch, dist, cpu=cpu)
             except Exception as e:
-                result[name] = {"error": repr(e)}
-    if not args.no_window:
-        try:
-            result["window"] = bench_window(ctx, args, world, rank, dev, torch, dist, cpu=cpu)
-        except Exception as e:  # the headline line must survive a failure of the extra section
-            result["window"] = {"error": repr(e)}
-    if not args.no_extras:
-        try:
-            result["odometry_step"] = bench_odometry_step(ctx, args, world, rank, dev, torch, dist, cpu=cpu)
-        except Exception as e:
-            result["odometry_step"] = {"error": repr(e)}
+                result["odometry_step"] = {"error": repr(e)}
+
+    if world == 1:
+        extras()
+    else:
+        # Several ranks: the extra sections use collectives (routed extraction, sharded window).  A collective that never returns
+        # must not cost the headline line: the sections run in a worker thread, and a rank that waits longer than --extras-timeout
+        # prints what it has and leaves.
+        import threading
+
+        th = threading.Thread(target=extras, daemon=True)
+        th.start()
+        th.join(args.extras_timeout)
+        if th.is_alive():
+            result["extras_timeout_s"] = args.extras_timeout
+            if rank == 0:
+                real_stdout.write(json.dumps(result, default=repr) + "\n")
+                real_stdout.flush()
+            os._exit(0)
 
     if rank == 0:
         real_stdout.write(json.dumps(result) + "\n")

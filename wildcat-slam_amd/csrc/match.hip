@@ -541,12 +541,12 @@ extern "C" int wc_match(wc_ctx *ctx, const wc_surfel *d_q_surf, const wc_pose *d
   uint32_t *flags = (uint32_t *)b_choice.p + 2 * (size_t)nq, *offsets = (uint32_t *)b_choice.p + 3 * (size_t)nq;
   WC_HIP(ctx, hipMemsetAsync(choice[0], 0xFF, (size_t)nq * 4, st));
   int cur = 0;
-  // rounds are issued four at a time between host checks (a round past the fixed point changes nothing, so the extra ones
+  // rounds are issued eight at a time between host checks (a round past the fixed point changes nothing, so the extra ones
   // are harmless); round r of a batch reports into changed[r] and only the last word is read back
   bool converged = false;
   for (int batch = 0; batch < 250000 && !converged; ++batch) {
-    const int rounds = same_set ? 4 : 1;
-    WC_HIP(ctx, hipMemsetAsync(changed, 0, 16, st));
+    const int rounds = same_set ? 8 : 1;
+    WC_HIP(ctx, hipMemsetAsync(changed, 0, 32, st));
     for (int r = 0; r < rounds; ++r) {
       k_resolve<<<(nq + 255) / 256, 256, 0, st>>>((const uint32_t *)b_gated.p, nq, P.knn_k, same_set, choice[cur], choice[cur ^ 1], changed + r);
       cur ^= 1;
