@@ -156,6 +156,23 @@ def test_queries_outside_the_target_box_and_pruned_shells(gpu, oracle):
     assert np.array_equal(pairs, oracle.match(q, qp, t, tp, False))
 
 
+@pytest.mark.parametrize("order", ["centre", "normal"])
+def test_both_orders_of_the_candidate_halves(gpu, oracle, order, monkeypatch):
+    """k_knn_gate tests one half of a candidate's six components before it loads the other; which half goes first is chosen
+    per call from the previous call's k-th distances (WC_KNN_ORDER pins it here).  Neighbour lists, distances (bit for bit)
+    and pairs must not depend on it: random normals (the normal half prunes), coherent normals (the centre half does)"""
+    monkeypatch.setenv("WC_KNN_ORDER", order)
+    rng = np.random.default_rng(4711)
+    t, tp = _random_surfels(rng, 6000, 12.0)
+    q, qp = _random_surfels(rng, 3000, 14.0, t0=10.0)
+    pairs, idx, d2 = gpu.match(q, qp, t, tp, False, want_knn=True)
+    ridx, rd2 = oracle.knn6(_feat(t), _feat(q), 10)
+    assert np.array_equal(idx.astype(np.int64), ridx.astype(np.int64)) and np.array_equal(d2, rd2)
+    assert np.array_equal(pairs, oracle.match(q, qp, t, tp, False))
+    w = synth.surfel_window(4, 300, seed=21)
+    assert np.array_equal(gpu.match(w["surf"], w["pose"], w["surf"], w["pose"], True), oracle.match(w["surf"], w["pose"], w["surf"], w["pose"], True))
+
+
 @pytest.mark.parametrize("k", [1, 3, 16])
 def test_other_neighbour_counts(gpu, oracle, k):
     """knn_k is a parameter (the reference hard-codes 10, knn_surfel_matcher.h:17): every instantiation of the top-k kernel"""

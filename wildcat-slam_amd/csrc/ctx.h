@@ -28,7 +28,8 @@ struct wc_ctx {
   // scratch buffers (device), grown on demand and kept for the lifetime of the ctx
   wc_buf b_ex_ctrl;  // the extraction's control block (status words, bucket / bin counters): never shared, cleared ahead of time
   wc_buf b_keys[2], b_vals[2], b_sorttmp, b_slots, b_slot_ids, b_slot_keys[2], b_slot_idx[2], b_cand, b_cand_meta,
-      b_status, b_misc[8], b_route[4], b_fx[7];
+      b_status, b_misc[8], b_route[4], b_fx[7], b_match_stat;
+  bool match_nf[2] = {false, false};  // wc_match: normal half of a candidate first (per kind of call: other set / same set)
   // multi-GPU: the job's communicator (wc_ctx_set_comm / wc_comm_rccl_init)
   wc_comm comm{};
   bool have_comm = false;

@@ -108,6 +108,7 @@ extern "C" void wc_ctx_destroy(wc_ctx *ctx) {
     if (b.p) (void)hipFree(b.p);
   for (wc_buf &b : ctx->b_route)
     if (b.p) (void)hipFree(b.p);
+  if (ctx->b_match_stat.p) (void)hipFree(ctx->b_match_stat.p);
   for (wc_buf &b : ctx->b_fx)
     if (b.p) (void)hipFree(b.p);
   if (ctx->h_status) (void)hipHostFree(ctx->h_status);

@@ -186,11 +186,12 @@ constexpr int kRowChunk = 4;  // rows of a shell whose candidate ranges are look
 
 // exact k-NN + gates.  gated[j][q] (plane j of nq entries: the resolve rounds read plane 0 coalesced and rarely more) =
 // j-th neighbour of q passing the first three gates (kNone-terminated).
-template <int K>
+template <int K, bool NF>
 __global__ void __launch_bounds__(128, 4) k_knn_gate(const wc_surfel *q_surf, const wc_pose *q_pose, uint32_t nq, const double *sfeat,
                                                  const uint32_t *skeys, const uint32_t *sorig, const double *tworld, uint32_t nt,
                                                  MatchParams M, uint32_t *gated, uint32_t *knn_idx, double *knn_d2,
-                                                 const uint32_t *__restrict__ qorder, uint32_t q_begin, uint32_t q_end, uint32_t *gated_shard) {
+                                                 const uint32_t *__restrict__ qorder, uint32_t q_begin, uint32_t q_end, uint32_t *gated_shard,
+                                                 double *kth_stat) {
   // qorder: the queries in the order of their grid cell (same-set matching: the sorted target permutation).  Neighbouring
   // threads then scan the same cell ranges: their feature loads hit the same cache lines and their trip counts agree.
   __shared__ uint2 s_rng[2 * kRowChunk][128];  // per thread: the candidate ranges of a chunk of rows (only its own column)
@@ -278,37 +279,76 @@ __global__ void __launch_bounds__(128, 4) k_knn_gate(const wc_surfel *q_surf, co
 #ifdef WC_PROF_KNN
           pc_ += e - b, pr_ += (e > b);
 #endif
-          // Candidates in groups of four: the centre parts of a group are requested together (one candidate per trip of a
-          // load - test - insert loop costs a full round trip to L2 each), then tested in order.  The running sum only
-          // grows: a candidate whose centre part already exceeds the current k-th distance cannot enter the list (ties
-          // are decided on the full sum, hence the strict test) - its normal part and its index are not loaded.
-          auto visit = [&](uint32_t i, double s) {
-            if (s > top.worst()) return;
-            const double *p = sfeat + (size_t)i * 6;
+          // Candidates in groups of four: ONE half of the six components of a group is requested together (one candidate per
+          // trip of a load - test - insert loop costs a full round trip to L2 each), then tested in order; the other half and
+          // the index are only loaded for the candidates whose first half does not already exceed the current k-th distance.
+          // Which half goes first is decided per CALL from the k-th distances of the previous call on this context (NF): the
+          // centre part while the k-th distance is small
+          // against the cells (targets whose neighbours share their normal: most of a cell's candidates lie outside the
+          // sphere), the normal part when it is not (normals that differ: 5 degrees are one unit, the 6-D k-th distance is
+          // several cells and the centre part of nearly every candidate lies below it - 16 % of the kernel).  Either way
+          // the full sum is formed in flann::L2_Simple's order (plain running sum of squared differences, component by
+          // component), and a half that exceeds the k-th distance on its own bounds the full sum from below in floating
+          // point too (adding non-negative terms is monotone): the same candidates enter the list.
+          if (!NF) {
+            auto visit = [&](uint32_t i, double s) {
+              if (s > top.worst()) return;
+              const double *p = sfeat + (size_t)i * 6;
 #pragma unroll
-            for (int d = 3; d < 6; ++d) {  // flann::L2_Simple: plain running sum of squared differences
-              const double df = f[d] - p[d];
-              s += df * df;
+              for (int d = 3; d < 6; ++d) {
+                const double df = f[d] - p[d];
+                s += df * df;
+              }
+              if (s > top.worst()) return;
+              top.push(s, sorig[i]);
+            };
+            uint32_t i = b;
+            for (; i + 4 <= e; i += 4) {
+              const double *p = sfeat + (size_t)i * 6;
+              double s4[4];
+#pragma unroll
+              for (int u = 0; u < 4; ++u) {
+                const double d0 = f[0] - p[6 * u], d1 = f[1] - p[6 * u + 1], d2 = f[2] - p[6 * u + 2];
+                s4[u] = (0.0 + d0 * d0 + d1 * d1) + d2 * d2;
+              }
+#pragma unroll
+              for (int u = 0; u < 4; ++u) visit(i + u, s4[u]);
             }
-            if (s > top.worst()) return;
-            top.push(s, sorig[i]);
-          };
-          uint32_t i = b;
-          for (; i + 4 <= e; i += 4) {
-            const double *p = sfeat + (size_t)i * 6;
-            double s4[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-              const double d0 = f[0] - p[6 * u], d1 = f[1] - p[6 * u + 1], d2 = f[2] - p[6 * u + 2];
-              s4[u] = (0.0 + d0 * d0 + d1 * d1) + d2 * d2;
+            for (; i < e; ++i) {
+              const double *p = sfeat + (size_t)i * 6;
+              const double d0 = f[0] - p[0], d1 = f[1] - p[1], d2 = f[2] - p[2];
+              visit(i, (0.0 + d0 * d0 + d1 * d1) + d2 * d2);
             }
+          } else {
+            auto visit = [&](uint32_t i, double np, double e3, double e4, double e5) {
+              if (np > top.worst()) return;
+              const double *p = sfeat + (size_t)i * 6;
+              const double d0 = f[0] - p[0], d1 = f[1] - p[1], d2 = f[2] - p[2];
+              double s = (0.0 + d0 * d0 + d1 * d1) + d2 * d2;
+              s += e3;
+              s += e4;
+              s += e5;
+              if (s > top.worst()) return;
+              top.push(s, sorig[i]);
+            };
+            uint32_t i = b;
+            for (; i + 4 <= e; i += 4) {
+              const double *p = sfeat + (size_t)i * 6;
+              double n4[4], q3[4], q4[4], q5[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) visit(i + u, s4[u]);
-          }
-          for (; i < e; ++i) {
-            const double *p = sfeat + (size_t)i * 6;
-            const double d0 = f[0] - p[0], d1 = f[1] - p[1], d2 = f[2] - p[2];
-            visit(i, (0.0 + d0 * d0 + d1 * d1) + d2 * d2);
+              for (int u = 0; u < 4; ++u) {
+                const double d3 = f[3] - p[6 * u + 3], d4 = f[4] - p[6 * u + 4], d5 = f[5] - p[6 * u + 5];
+                q3[u] = d3 * d3, q4[u] = d4 * d4, q5[u] = d5 * d5;
+                n4[u] = (q3[u] + q4[u]) + q5[u];
+              }
+#pragma unroll
+              for (int u = 0; u < 4; ++u) visit(i + u, n4[u], q3[u], q4[u], q5[u]);
+            }
+            for (; i < e; ++i) {
+              const double *p = sfeat + (size_t)i * 6;
+              const double d3 = f[3] - p[3], d4 = f[4] - p[4], d5 = f[5] - p[5];
+              visit(i, (d3 * d3 + d4 * d4) + d5 * d5, d3 * d3, d4 * d4, d5 * d5);
+            }
           }
         }
       }
@@ -319,6 +359,15 @@ __global__ void __launch_bounds__(128, 4) k_knn_gate(const wc_surfel *q_surf, co
 #ifdef WC_PROF_KNN
   atomicAdd(&g_knn_prof[0], pc_), atomicAdd(&g_knn_prof[1], pr_), atomicAdd(&g_knn_prof[2], ps_), atomicAdd(&g_knn_prof[3], 1ull);
 #endif
+  if (kth_stat && (blockIdx.x & 15u) == 0u && q_begin + (blockIdx.x + 1u) * blockDim.x <= q_end) {  // (full workgroups only)  // a sample of the k-th distances (in cells^2): the next call's order of the halves
+    double v = top.cnt == K ? fmin(top.worst() / (M.h * M.h), 1e6) : 0.0, c1 = top.cnt == K ? 1.0 : 0.0;
+    for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m), c1 += __shfl_xor(c1, m);
+    if ((threadIdx.x & 63) == 0) {
+      double *slot = kth_stat + ((blockIdx.x >> 4) & 15u) * 16u;  // 16 slots, 128 bytes apart
+      atomicAdd(slot, v);
+      atomicAdd(slot + 1, c1);
+    }
+  }
   // Q10: FLANN leaves the tail of the result untouched (zero-initialised) when fewer than k targets exist
   uint32_t out = 0;
 #pragma unroll
@@ -501,10 +550,21 @@ extern "C" int wc_match(wc_ctx *ctx, const wc_surfel *d_q_surf, const wc_pose *d
     gated_shard = (uint32_t *)ctx->b_route[3].p;
   }
   const uint32_t nq_mine = q_end - q_begin;
+  // order of the two halves of a candidate (see k_knn_gate): from the k-th distances of the previous call of this kind on this context
+  bool nf = ctx->match_nf[same_set ? 1 : 0];
+  if (const char *o = getenv("WC_KNN_ORDER")) nf = o[0] == 'n';  // "normal" / "centre": tests pin each instantiation
+  WC_TRY(wc_ensure(ctx, ctx->b_match_stat, 16 * 16 * 8));
+  double *kth_stat = (double *)ctx->b_match_stat.p;
+  WC_HIP(ctx, hipMemsetAsync(kth_stat, 0, 16 * 16 * 8, st));
 #define WC_KNN_LAUNCH(KK)                                                                                                        \
-  if (nq_mine)                                                                                                                   \
-  k_knn_gate<KK><<<(nq_mine + 127) / 128, 128, 0, st>>>(d_q_surf, d_q_pose, nq, (const double *)b_sfeat.p, k1, v1, (const double *)b_world.p, \
-                                                  nt, M, (uint32_t *)b_gated.p, d_knn_idx, d_knn_d2, qorder, q_begin, q_end, gated_shard)
+  if (nq_mine) {                                                                                                                 \
+    if (nf)                                                                                                                      \
+      k_knn_gate<KK, true><<<(nq_mine + 127) / 128, 128, 0, st>>>(d_q_surf, d_q_pose, nq, (const double *)b_sfeat.p, k1, v1, (const double *)b_world.p, \
+                                                            nt, M, (uint32_t *)b_gated.p, d_knn_idx, d_knn_d2, qorder, q_begin, q_end, gated_shard, kth_stat); \
+    else                                                                                                                         \
+      k_knn_gate<KK, false><<<(nq_mine + 127) / 128, 128, 0, st>>>(d_q_surf, d_q_pose, nq, (const double *)b_sfeat.p, k1, v1, (const double *)b_world.p, \
+                                                             nt, M, (uint32_t *)b_gated.p, d_knn_idx, d_knn_d2, qorder, q_begin, q_end, gated_shard, kth_stat); \
+  }
   switch (P.knn_k) {  // the reference's k = 10 gets its own instantiation (top-k in 30 registers)
     case 10: WC_KNN_LAUNCH(10); break;
     case 1: WC_KNN_LAUNCH(1); break;
@@ -568,8 +628,15 @@ extern "C" int wc_match(wc_ctx *ctx, const wc_surfel *d_q_surf, const wc_pose *d
   }
   k_emit_pairs<<<(nq + 255) / 256, 256, 0, st>>>(choice[cur], offsets, nq, d_q_surf, (const double *)b_world.p, same_set, d_pairs, cap, status);
   WC_HIP(ctx, hipGetLastError());
+  double h_stat[16 * 16];
+  WC_HIP(ctx, hipMemcpyAsync(h_stat, kth_stat, sizeof(h_stat), hipMemcpyDeviceToHost, st));
   WC_HIP(ctx, hipMemcpyAsync(ctx->h_status, status, 8, hipMemcpyDeviceToHost, st));
   WC_HIP(ctx, hipStreamSynchronize(st));
+  {
+    double sum = 0.0, cnt = 0.0;
+    for (int s = 0; s < 16; ++s) sum += h_stat[16 * s], cnt += h_stat[16 * s + 1];
+    if (cnt > 0.0) ctx->match_nf[same_set ? 1 : 0] = sum / cnt > 2.25;  // mean k-th distance beyond 1.5 cells: the centre half prunes little
+  }
 #ifdef WC_PROF_KNN
   {
     unsigned long long h[4], z[4] = {0, 0, 0, 0};
