@@ -88,7 +88,9 @@ int wc_extract_surfels_enqueue(wc_ctx *ctx, const wc_points *pts, double t_lo, d
 int wc_extract_surfels_finish(wc_ctx *ctx, uint64_t *h_n_out);
 /* per-stage device time of the LAST enqueued extraction, measured with HIP events on the ctx stream:
  * h_ms5 = {per-call fills, voxel grouping of the points, root + layer-1 streaming, node tests + emission (+ layer 2),
- * time ordering + gather of the surfels}.  Enable first. */
+ * time ordering + gather of the surfels}.  Enable first: 1 = an event after every kernel group (each event costs ~5 us of
+ * stream time), 2 = one pair of events around the whole stage (the stage's time is then reported in h_ms5[1], the other
+ * entries are 0), 0 = off. */
 int wc_extract_profile(wc_ctx *ctx, int enable);
 int wc_extract_stage_ms(wc_ctx *ctx, float *h_ms5);
 /* raw status words of the last extraction (profiling aid; words 16.. hold per-section cycle sums when the library
