@@ -30,6 +30,7 @@
 
 #include <algorithm>
 #include <cfloat>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -1573,6 +1574,9 @@ extern "C" int wc_window_build(wc_ctx *ctx, const wc_surfel *d_sld_surf, const w
   std::vector<Seg> segs_b, segs_u;
   W->nb = (uint32_t)n_pairs_sld;
   W->nu = (uint32_t)n_pairs_fix;
+  const bool tdbg = getenv("WC_WIN_DEBUG") != nullptr;
+  auto tnow = [] { return std::chrono::steady_clock::now(); };
+  auto t_a = tnow();
   WC_TRY(build_family(ctx, W, false, d_sld_surf, d_sld_pose, d_sld_surf, d_sld_pose, d_pairs_sld, W->nb, W->brec, W->bkey,
                       W->borig, segs_b));
   WC_TRY(build_family(ctx, W, true, d_fix_surf, d_fix_pose, d_sld_surf, d_sld_pose, d_pairs_fix, W->nu, W->urec, W->ukey,
@@ -1600,6 +1604,7 @@ extern "C" int wc_window_build(wc_ctx *ctx, const wc_surfel *d_sld_surf, const w
   W->ni = (uint32_t)irecs.size();
   WC_TRY(upload(ctx, W->irec, irecs));
 
+  auto t_b = tnow();
   // pieces + the CSR source lists of the gather
   uint32_t off = 0;
   auto cut = [&](const std::vector<Seg> &segs, uint32_t T, bool split) {
@@ -1706,6 +1711,7 @@ extern "C" int wc_window_build(wc_ctx *ctx, const wc_surfel *d_sld_surf, const w
     fprintf(stderr, "gather: %u pairs, %u heavy, %zu sources (max %u per pair), %zu g-sources, %zu pieces\n", npairs, W->nheavy, src.size(), mx,
             gsrc.size(), pieces.size());
   }
+  auto t_c = tnow();
   WC_TRY(upload(ctx, W->heavy, heavy));
   WC_TRY(upload(ctx, W->pieces, pieces));
   WC_TRY(upload(ctx, W->src, src));
@@ -1728,6 +1734,10 @@ extern "C" int wc_window_build(wc_ctx *ctx, const wc_surfel *d_sld_surf, const w
   const size_t ncb = (W->nb + 255) / 256 + (W->nu + 255) / 256 + (W->ni + 255) / 256 + 8;
   WC_TRY(wc_ensure(ctx, W->cost_part, ncb * 8));
   WC_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the uploads above read host vectors of this scope
+  if (tdbg) {
+    auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+    fprintf(stderr, "[win] build: families + imu %.0f us, pieces + source lists (host) %.0f us, uploads + sync %.0f us\n", us(t_a, t_b), us(t_b, t_c), us(t_c, tnow()));
+  }
   W->built = true;
   return WC_OK;
 }
