@@ -23,6 +23,7 @@
 // sweeps without run structure or with overfull bins, 21-bit keys for wide sweeps, radix sort of the slot keys.
 // The path is HBM/latency bound (20 B read per point, 144 B written per surfel); no MFMA.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 
 #include <cstdlib>
 #include <cstring>
