@@ -58,6 +58,7 @@ struct wc_ctx {
     bool fx_active = false;      // this call runs on the fast (integer-moment) path
     bool fx_dirty = false;       // the fast path's tables may hold garbage (an aborted sweep): memset before the next use
     uint32_t fx_last_flags = 0, fx_fallbacks = 0;
+    bool fx_long_lists = false;  // the last fast sweep walked long record lists: k_fx_merge runs before k_fx_nodes
     uint32_t fx_backoff = 0, fx_skip_calls = 0;  // sweeps that go straight to the exact path after fall-backs (exponential)
     bool fx_ctrl_ready = false;  // the fast path's two control blocks are initialised
     int fx_parity = 0;           // which of them the next fast sweep uses

@@ -1870,6 +1870,7 @@ int run_pipeline_fast(wc_ctx *ctx, const wc_points &pts, double t_lo, double t_h
   k_fx_acc<1><<<tiles, kFxThreads, 0, st>>>(A);
   dbg_sync("k_fx_acc<1>");
   mark(2);
+  if (ctx->ex.fx_long_lists) k_fx_merge<1><<<std::min<unsigned>(ngrid * 2u, 8192u), 128, 0, st>>>(A);
   k_fx_nodes<1><<<ngrid, 64, 0, st>>>(A);
   dbg_sync("k_fx_nodes<1>");
   mark(3);
@@ -1895,6 +1896,7 @@ int fx_tail(wc_ctx *ctx, bool layer2) {
     const unsigned tiles = (unsigned)((A.pts.n + kFxTile - 1) / kFxTile);
     k_fx_acc<2><<<tiles, kFxThreads, 0, st>>>(A);
     const unsigned ngrid = std::min<unsigned>(256 * 16, std::max<unsigned>(64, (unsigned)(A.pts.n / 256)));  // (the job buffer's blocks)
+    if (ctx->ex.fx_long_lists) k_fx_merge<2><<<std::min(8192u, std::max(64u, ctx->ex.last_splits)), 128, 0, st>>>(A);
     k_fx_nodes<2><<<std::min(std::min(256u * 8u, ngrid), std::max(64u, ctx->ex.last_splits)), 64, 0, st>>>(A);
   }
   ctx->ex.layer2_done = layer2;
@@ -2201,6 +2203,7 @@ extern "C" int wc_extract_surfels_finish(wc_ctx *ctx, uint64_t *h_n_out) {
       WC_TRY(wait());
     } else {
       const uint32_t n_fast = ctx->h_status[0];
+      ctx->ex.fx_long_lists = ctx->h_status[15] != 0u;  // lists of several records per (node, time slot): merged first next time
       if (h_n_out) *h_n_out = n_fast;
       ctx->ex.fx_parity ^= 1;  // the other control block has been cleared by this sweep's k_slot_emit
       ctx->ex.fx_backoff = 0;
