@@ -57,6 +57,26 @@ def test_g1_firing_order_full_size(gpu, oracle):
     print(res, list(st.nodes_plane))
 
 
+def test_long_record_lists_are_merged_from_the_second_sweep_on(gpu, oracle):
+    # sweeps in firing order leave several records per (node, time slot) list; a sweep that met such lists makes the next one run
+    # k_fx_merge (one lane per list) in front of k_fx_nodes: every sweep of the series must equal the oracle, the flag must be up
+    # after the first one, and a run-structured sweep must take it down again
+    gpu.set_exact_sums(False)
+    room = synth.g1_room(500_000, seed=31)
+    s_ref, i_ref, st = oracle.extract_surfels(room)
+    for k in range(3):
+        s, i = gpu.extract_surfels(room)
+        info = gpu.extract_path_info()
+        assert info["fast"] and info["long_lists"], (k, info)
+        helpers.check_surfels(s, i, s_ref, i_ref, tol=1e-6, t_tol=1e-4)
+    lat, _ = synth.g2_lattice(600, m=32)
+    l_ref, li_ref, _ = oracle.extract_surfels(lat)
+    for k in range(2):
+        s, i = gpu.extract_surfels(lat)
+        helpers.check_surfels(s, i, l_ref, li_ref, tol=1e-6, t_tol=1e-4)
+    assert not gpu.extract_path_info()["long_lists"]
+
+
 def test_g1_no_time_hint(gpu, oracle):
     pts = synth.g1_room(100_000, seed=7)
     _run(gpu, oracle, pts, hint=False)

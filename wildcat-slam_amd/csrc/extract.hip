@@ -2299,6 +2299,7 @@ extern "C" int wc_debug_status(wc_ctx *ctx, uint32_t *h_out64) {
   if (!ctx || !h_out64) return wc_fail(ctx, WC_ERR_ARG, "%s: null or out-of-range argument", __func__);
   // (the device copy has been cleared for the next call already: words 0..15 come from the host mailbox of the last call)
   for (int i = 0; i < 64; ++i) h_out64[i] = i < 16 ? ctx->h_status[i] : 0u;
+  h_out64[59] = ctx->ex.fx_long_lists ? 1u : 0u;  // the next fast sweep runs k_fx_merge (the last one had long record lists)
   h_out64[60] = ctx->ex.fx_fallbacks;  // sweeps the fast path handed to the exact path so far
   h_out64[61] = ctx->ex.fx_active ? 1u : 0u;  // the last sweep was completed by the fast (integer-moment) path
   h_out64[62] = ctx->ex.fx_last_flags;

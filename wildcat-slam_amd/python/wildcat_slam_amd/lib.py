@@ -220,10 +220,11 @@ class Context:
         self.set_params(self.params)
 
     def extract_path_info(self):
-        """-> dict(fast=the last sweep was completed by the fast path, fallbacks=sweeps handed to the exact path so far, flags)"""
+        """-> dict(fast=the last sweep was completed by the fast path, fallbacks=sweeps handed to the exact path so far, flags,
+        long_lists=the last fast sweep had long record lists: the next one merges them first (k_fx_merge))"""
         w = (C.c_uint32 * 64)()
         self._ck(self.lib.wc_debug_status(self.h, w))
-        return dict(fast=bool(w[61]), fallbacks=int(w[60]), flags=int(w[62]))
+        return dict(fast=bool(w[61]), fallbacks=int(w[60]), flags=int(w[62]), long_lists=bool(w[59]))
 
     def extract_profile(self, enable=True):
         """True / 1: HIP events after every kernel group of the stage (each event costs ~5 us of stream time); 2: only the first
