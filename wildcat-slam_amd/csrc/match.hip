@@ -182,6 +182,7 @@ struct TopK {
   }
 };
 
+constexpr int kKeep = 16;      // notes per lane (k_knn_gate)
 constexpr int kRowChunk = 4;  // rows of a shell whose candidate ranges are looked up together
 
 // exact k-NN + gates.  gated[j][q] (plane j of nq entries: the resolve rounds read plane 0 coalesced and rarely more) =
@@ -195,6 +196,7 @@ __global__ void __launch_bounds__(128, 4) k_knn_gate(const wc_surfel *q_surf, co
   // qorder: the queries in the order of their grid cell (same-set matching: the sorted target permutation).  Neighbouring
   // threads then scan the same cell ranges: their feature loads hit the same cache lines and their trip counts agree.
   __shared__ uint2 s_rng[2 * kRowChunk][128];  // per thread: the candidate ranges of a chunk of rows (only its own column)
+  __shared__ uint32_t s_keep[kKeep][128];      // per thread: candidates noted for the next drain
   // query-sharded call (several GPUs): this rank takes the positions [q_begin, q_end) of the cell order and writes its gated
   // lists position-major into gated_shard (K words per position) - contiguous, so that ONE all-gather assembles all ranks'
   const uint32_t qi = q_begin + blockIdx.x * blockDim.x + threadIdx.x;
@@ -221,6 +223,30 @@ __global__ void __launch_bounds__(128, 4) k_knn_gate(const wc_surfel *q_surf, co
 #ifdef WC_PROF_KNN
   unsigned long long pc_ = 0, pr_ = 0, ps_ = 0;
 #endif
+  // Candidates whose first half does not exceed the current k-th distance are only NOTED (their index, in LDS: up to kKeep per
+  // lane); when some lane's notes are nearly full all lanes of the wavefront finish theirs together: all six components in
+  // one round trip, the exact sum in flann::L2_Simple's order (plain running sum of squared differences, component by
+  // component), insertion.  Finishing a candidate on the spot costs the WAVEFRONT the index load's round trip and a pass through
+  // the insertion code whenever ANY of its 64 lanes has one - measured with clocks around the call: ~1.8 k clocks each, ~800
+  // times per wavefront, most of the kernel.  The k-th distance used by the first look may be stale by a few notes: more notes,
+  // same result.
+  uint32_t bcnt = 0;
+  auto drain = [&]() {
+    for (uint32_t j = 0; __ballot(j < bcnt); ++j) {
+      if (j < bcnt) {
+        const uint32_t ci = s_keep[j][threadIdx.x];
+        const double *p = sfeat + (size_t)ci * 6;
+        double s = 0.0;
+#pragma unroll
+        for (int d = 0; d < 6; ++d) {
+          const double df = f[d] - p[d];
+          s += df * df;
+        }
+        if (!(s > top.worst())) top.push(s, sorig[ci]);
+      }
+    }
+    bcnt = 0;
+  };
   for (int r = 0; r <= rmax; ++r) {
 #ifdef WC_PROF_KNN
     ++ps_;
@@ -280,78 +306,35 @@ __global__ void __launch_bounds__(128, 4) k_knn_gate(const wc_surfel *q_surf, co
           pc_ += e - b, pr_ += (e > b);
 #endif
           // Candidates in groups of four: ONE half of the six components of a group is requested together (one candidate per
-          // trip of a load - test - insert loop costs a full round trip to L2 each), then tested in order; the other half and
-          // the index are only loaded for the candidates whose first half does not already exceed the current k-th distance.
-          // Which half goes first is decided per CALL from the k-th distances of the previous call on this context (NF): the
-          // centre part while the k-th distance is small
-          // against the cells (targets whose neighbours share their normal: most of a cell's candidates lie outside the
-          // sphere), the normal part when it is not (normals that differ: 5 degrees are one unit, the 6-D k-th distance is
-          // several cells and the centre part of nearly every candidate lies below it - 16 % of the kernel).  Either way
-          // the full sum is formed in flann::L2_Simple's order (plain running sum of squared differences, component by
-          // component), and a half that exceeds the k-th distance on its own bounds the full sum from below in floating
-          // point too (adding non-negative terms is monotone): the same candidates enter the list.
-          if (!NF) {
-            auto visit = [&](uint32_t i, double s) {
-              if (s > top.worst()) return;
-              const double *p = sfeat + (size_t)i * 6;
+          // trip of a load - test loop costs a full round trip to L2 each).  Which half is decided per CALL from the k-th
+          // distances of the previous call on this context (NF): the centre part while the k-th distance is small against the
+          // cells (targets whose neighbours share their normal: most of a cell's candidates lie outside the sphere), the
+          // normal part when it is not (normals that differ: 5 degrees are one unit, the 6-D k-th distance is several cells
+          // and the centre part of nearly every candidate lies below it).  A half that exceeds the k-th distance on its own
+          // bounds the full sum from below in floating point too (adding non-negative terms is monotone).
+          uint32_t i = b;
+          for (; i + 4 <= e; i += 4) {
+            const double *p = sfeat + (size_t)i * 6 + (NF ? 3 : 0);
+            double h4[4];
 #pragma unroll
-              for (int d = 3; d < 6; ++d) {
-                const double df = f[d] - p[d];
-                s += df * df;
-              }
-              if (s > top.worst()) return;
-              top.push(s, sorig[i]);
-            };
-            uint32_t i = b;
-            for (; i + 4 <= e; i += 4) {
-              const double *p = sfeat + (size_t)i * 6;
-              double s4[4];
-#pragma unroll
-              for (int u = 0; u < 4; ++u) {
-                const double d0 = f[0] - p[6 * u], d1 = f[1] - p[6 * u + 1], d2 = f[2] - p[6 * u + 2];
-                s4[u] = (0.0 + d0 * d0 + d1 * d1) + d2 * d2;
-              }
-#pragma unroll
-              for (int u = 0; u < 4; ++u) visit(i + u, s4[u]);
+            for (int u = 0; u < 4; ++u) {
+              const double d0 = f[NF ? 3 : 0] - p[6 * u], d1 = f[NF ? 4 : 1] - p[6 * u + 1], d2 = f[NF ? 5 : 2] - p[6 * u + 2];
+              h4[u] = (0.0 + d0 * d0 + d1 * d1) + d2 * d2;
             }
-            for (; i < e; ++i) {
-              const double *p = sfeat + (size_t)i * 6;
-              const double d0 = f[0] - p[0], d1 = f[1] - p[1], d2 = f[2] - p[2];
-              visit(i, (0.0 + d0 * d0 + d1 * d1) + d2 * d2);
-            }
-          } else {
-            auto visit = [&](uint32_t i, double np, double e3, double e4, double e5) {
-              if (np > top.worst()) return;
-              const double *p = sfeat + (size_t)i * 6;
-              const double d0 = f[0] - p[0], d1 = f[1] - p[1], d2 = f[2] - p[2];
-              double s = (0.0 + d0 * d0 + d1 * d1) + d2 * d2;
-              s += e3;
-              s += e4;
-              s += e5;
-              if (s > top.worst()) return;
-              top.push(s, sorig[i]);
-            };
-            uint32_t i = b;
-            for (; i + 4 <= e; i += 4) {
-              const double *p = sfeat + (size_t)i * 6;
-              double n4[4], q3[4], q4[4], q5[4];
 #pragma unroll
-              for (int u = 0; u < 4; ++u) {
-                const double d3 = f[3] - p[6 * u + 3], d4 = f[4] - p[6 * u + 4], d5 = f[5] - p[6 * u + 5];
-                q3[u] = d3 * d3, q4[u] = d4 * d4, q5[u] = d5 * d5;
-                n4[u] = (q3[u] + q4[u]) + q5[u];
-              }
-#pragma unroll
-              for (int u = 0; u < 4; ++u) visit(i + u, n4[u], q3[u], q4[u], q5[u]);
-            }
-            for (; i < e; ++i) {
-              const double *p = sfeat + (size_t)i * 6;
-              const double d3 = f[3] - p[3], d4 = f[4] - p[4], d5 = f[5] - p[5];
-              visit(i, (d3 * d3 + d4 * d4) + d5 * d5, d3 * d3, d4 * d4, d5 * d5);
-            }
+            for (int u = 0; u < 4; ++u)
+              if (!(h4[u] > top.worst())) s_keep[bcnt++][threadIdx.x] = i + u;
+            if (__ballot(bcnt >= (uint32_t)(kKeep - 4))) drain();
+          }
+          for (; i < e; ++i) {
+            const double *p = sfeat + (size_t)i * 6 + (NF ? 3 : 0);
+            const double d0 = f[NF ? 3 : 0] - p[0], d1 = f[NF ? 4 : 1] - p[1], d2 = f[NF ? 5 : 2] - p[2];
+            if (!((0.0 + d0 * d0 + d1 * d1) + d2 * d2 > top.worst())) s_keep[bcnt++][threadIdx.x] = i;
+            if (__ballot(bcnt >= (uint32_t)(kKeep - 4))) drain();
           }
         }
       }
+    drain();
     // everything not yet scanned is at least `bound` away from the query (in 3-D, hence in 6-D)
     const double bound = r * M.h + in_cell;
     if (top.cnt == K && top.worst() < bound * bound) break;
