@@ -1374,13 +1374,29 @@ __global__ void __launch_bounds__(256) k_slot_emit(const uint32_t *__restrict__ 
   __shared__ uint32_t s_red[4];
   const int t = threadIdx.x, w = t >> 6, lane = t & 63;
   const uint32_t b0 = blockIdx.x * 4u;
+  // everything this workgroup reads before it knows its counts goes out in ONE round of loads: the counts in front of it
+  // (exactly blockIdx.x uint4's, at most four per thread), its own four counts and - speculatively - the first 64 entries
+  // of its wavefront's bin.  (A loop of dependent 4-byte loads here was the kernel's critical path: 16 round trips for
+  // the last workgroups.)
+  static_assert(kBuckets / 4 <= 4 * 256, "four uint4 loads per thread cover the counts");
+  const uint4 *c4 = (const uint4 *)counts;
+  uint4 v[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const uint32_t i = (uint32_t)t + 256u * k;
+    v[k] = i < blockIdx.x ? c4[i] : make_uint4(0u, 0u, 0u, 0u);
+  }
+  const uint4 own = c4[blockIdx.x];
+  const uint64_t *bin = bins + (size_t)(b0 + w) * bin_cap;
+  const uint64_t first = (uint32_t)lane < bin_cap ? bin[lane] : 0ull;
   uint32_t part = 0;
-  for (uint32_t i = t; i < b0; i += 256) part += counts[i];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) part += v[k].x + v[k].y + v[k].z + v[k].w;
   for (int off = 32; off >= 1; off >>= 1) part += __shfl_xor(part, off);
   if (lane == 0) s_red[w] = part;
   __syncthreads();
   uint32_t base = s_red[0] + s_red[1] + s_red[2] + s_red[3];
-  const uint32_t c0 = counts[b0], c1 = counts[b0 + 1], c2 = counts[b0 + 2], c3 = counts[b0 + 3];
+  const uint32_t c0 = own.x, c1 = own.y, c2 = own.z, c3 = own.w;
   if (blockIdx.x == gridDim.x - 1 && t == 0) {
     status[0] = base + c0 + c1 + c2 + c3;  // surfels emitted
     uint32_t *hm = host_mailbox(status);
@@ -1400,35 +1416,62 @@ __global__ void __launch_bounds__(256) k_slot_emit(const uint32_t *__restrict__ 
     if (lane == 0) raise_flag(status, kFlagSlotBinOverflow);
     return;
   }
-  const uint64_t *bin = bins + (size_t)(b0 + w) * bin_cap;
-  for (uint32_t i = lane; i < c; i += 64) s_item[w][i] = bin[i];
-  __builtin_amdgcn_wave_barrier();
-  for (uint32_t i = lane; i < c; i += 64) {
-    const uint64_t mine = s_item[w][i];
+  // equal keys: the time stamps themselves (a key of the fast path is a 32-bit fraction of the sweep), then - equal
+  // stamps - the canonical order, not the slot order
+  auto before = [&](uint64_t other, uint64_t mine) -> bool {
+    if ((other >> 32) == (mine >> 32) && other != mine) {
+      const double to = slots[(uint32_t)other].t, tm = slots[(uint32_t)mine].t;
+      return to < tm || (to == tm && surfel_id_less(slot_ids[(uint32_t)other], slot_ids[(uint32_t)mine]));
+    }
+    return other < mine;
+  };
+  if (c <= 64u) {  // the usual bucket: the items stay in registers, a lane reads the others with v_readlane
+    const uint32_t lo = (uint32_t)first, hi = (uint32_t)(first >> 32);
     uint32_t rank = 0;
     for (uint32_t j = 0; j < c; ++j) {  // composites are unique (slot index)
-      const uint64_t other = s_item[w][j];
-      bool less = other < mine;
-      if ((other >> 32) == (mine >> 32) && other != mine) {  // equal keys: the time stamps themselves (a key of the fast path
-        // is a 32-bit fraction of the sweep), then - equal stamps - the canonical order, not the slot order
-        const double to = slots[(uint32_t)other].t, tm = slots[(uint32_t)mine].t;
-        less = to < tm || (to == tm && surfel_id_less(slot_ids[(uint32_t)other], slot_ids[(uint32_t)mine]));
-      }
-      rank += less ? 1u : 0u;
+      const uint64_t other = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)hi, (int)j) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)lo, (int)j);
+      if ((uint32_t)lane < c) rank += before(other, first) ? 1u : 0u;
     }
-    s_sorted[w][rank] = (uint32_t)mine;
+    if ((uint32_t)lane < c) s_sorted[w][rank] = lo;
+  } else {
+    s_item[w][lane] = first;
+    for (uint32_t i = lane + 64; i < c; i += 64) s_item[w][i] = bin[i];
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t i = lane; i < c; i += 64) {
+      const uint64_t mine = s_item[w][i];
+      uint32_t rank = 0;
+      for (uint32_t j = 0; j < c; ++j) rank += before(s_item[w][j], mine) ? 1u : 0u;
+      s_sorted[w][rank] = (uint32_t)mine;
+    }
   }
   __builtin_amdgcn_wave_barrier();
   const int sub = lane / 10, piece = lane - sub * 10;  // six records per pass, ten 16-byte pieces per record
   if (sub >= 6) return;
-  for (uint32_t r = sub; r < c; r += 6) {
-    const uint64_t o = (uint64_t)base + r;
-    if (o >= cap) break;
+  auto load = [&](uint32_t r, bool on) -> double2 {
+    double2 d = make_double2(0.0, 0.0);
+    if (!on) return d;
     const uint32_t sl = s_sorted[w][r];
     if (piece < 9)
-      ((double2 *)(out + o))[piece] = ((const double2 *)(slots + sl))[piece];
+      d = ((const double2 *)(slots + sl))[piece];
+    else if (out_ids) {
+      const uint4 q = *(const uint4 *)(slot_ids + sl);
+      d = *(const double2 *)&q;
+    }
+    return d;
+  };
+  auto store = [&](uint32_t r, bool on, const double2 &d) {
+    if (!on) return;
+    const uint64_t o = (uint64_t)base + r;
+    if (piece < 9)
+      ((double2 *)(out + o))[piece] = d;
     else if (out_ids)
-      *(uint4 *)(out_ids + o) = *(const uint4 *)(slot_ids + sl);
+      *(double2 *)(out_ids + o) = d;
+  };
+  for (uint32_t r = sub; r < c; r += 12) {  // two passes' loads in flight before the first store
+    const bool on0 = (uint64_t)base + r < cap, on1 = r + 6 < c && (uint64_t)base + r + 6 < cap;
+    const double2 d0 = load(r, on0), d1 = load(r + 6, on1);
+    store(r, on0, d0);
+    store(r + 6, on1, d1);
   }
 }
 
