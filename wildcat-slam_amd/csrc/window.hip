@@ -253,9 +253,64 @@ __device__ __forceinline__ StateCorr state_corr(const double *x, const double *t
   c.ba = (1 - c.f) * ld3(l + 9) + c.f * ld3(r + 9);
   return c;
 }
-__device__ __forceinline__ M3 Ffun(Q4 L, Q4 R, V3 r) {  // cost_functor.h:446-448
-  const V3 lg = so3_log(qmul(qmul(L, so3_exp(r)), R));
-  return (so3_Jr_inv(lg) * qmat(qconj(R))) * so3_Jr(r);
+// The IMU factor evaluates Exp of the same two rotation vectors five times, Jr of them three times and Jr^-1 of two
+// logarithms (cost_functor.h:286-321, :446-448): twenty fp64 sin / cos calls and three atan2 in ONE thread's dependent
+// chain (44 k clocks per factor, `-DWC_PROF`-style clocks).  Here: Exp and Jr of a vector from one sincos of the half angle
+// (as surfel_side does), and Jr^-1 of a logarithm from the quaternion itself - |log q| = 2 |atan2(n, w)|,
+// cos(|log q| / 2) = |w|, sin(|log q| / 2) = n - so the factor costs two sincos and three atan2.
+struct ExpJr {
+  Q4 E;
+  M3 Jr;
+};
+__device__ __forceinline__ ExpJr exp_jr(V3 r) {
+  ExpJr o;
+  const double th2 = dot(r, r);
+  if (th2 < 1e-10 * 1e-10) {  // so3.hpp:705-712, utils.h:47
+    o.E = so3_exp(r);
+    o.Jr = m3_identity();
+    return o;
+  }
+  const double ith = rsqrt_nr(th2), th = th2 * ith;
+  double sh, ch;
+  sincos(0.5 * th, &sh, &ch);
+  const double imag = sh * ith;
+  o.E = {ch, imag * r.x, imag * r.y, imag * r.z};
+  const double s2 = (sh + sh) * ith, s = s2 * ch, omc = s2 * sh;  // sin th / th, (1 - cos th) / th
+  const V3 a = ith * r;
+  o.Jr = s * m3_identity() + (1 - s) * outer(a, a) + (-omc) * hat(a);  // Jr(r) = Jl(-r), utils.h:46-58
+  return o;
+}
+// so3_log (so3.hpp:264-311) and, if Jri != null, so3_Jr_inv of the result (utils.h:32-43)
+__device__ __forceinline__ V3 log_jr_inv(Q4 q, M3 *Jri) {
+  const double nn = sqrt(q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z);
+  q = {q.w / nn, q.x / nn, q.y / nn, q.z / nn};
+  const double sq = q.x * q.x + q.y * q.y + q.z * q.z, w = q.w;
+  if (sq < 1e-10 * 1e-10) {
+    const double k = 2.0 / w - (2.0 / 3.0) * sq / (w * (w * w));
+    const V3 lg = mk3(k * q.x, k * q.y, k * q.z);
+    if (Jri) *Jri = so3_Jr_inv(lg);
+    return lg;
+  }
+  const double n = sqrt(sq);
+  const double at = (w < 0) ? atan2(-n, -w) : atan2(n, w);
+  const double k = 2.0 * at / n;
+  const V3 lg = mk3(k * q.x, k * q.y, k * q.z);
+  if (Jri) {
+    const double th = 2.0 * fabs(at);
+    if (th > 1e-10) {
+      const M3 H = hat(-lg);
+      const double kk = 1 - th * fabs(w) / 2 / n;  // 1 - th cos(th / 2) / 2 / sin(th / 2)
+      *Jri = m3_identity() + (-0.5) * H + (kk / (th * th)) * (H * H);
+    } else {
+      *Jri = m3_identity();
+    }
+  }
+  return lg;
+}
+__device__ __forceinline__ M3 Ffun(Q4 L, Q4 E, Q4 R, const M3 &Jr) {  // cost_functor.h:446-448
+  M3 Jri;
+  log_jr_inv(qmul(qmul(L, E), R), &Jri);
+  return (Jri * qmat(qconj(R))) * Jr;
 }
 
 // IMU factor: 12 residuals; if rows != null also the 12 x 36 Jacobian, written as rows[row * stride + col]
@@ -269,8 +324,9 @@ __device__ void eval_imu(const WinParams &wp, const ImuRec &f, const double *x, 
   const Q4 R1{f.i1.quat[0], f.i1.quat[1], f.i1.quat[2], f.i1.quat[3]};
   const Q4 R2{f.i2.quat[0], f.i2.quat[1], f.i2.quat[2], f.i2.quat[3]};
   const V3 p1 = ld3(f.i1.pos), p2 = ld3(f.i2.pos), p3 = ld3(f.i3.pos);
-  const Q4 E1R1 = qmul(so3_exp(c1.r), R1), E2R2 = qmul(so3_exp(c2.r), R2);
-  const V3 gyr_est = so3_log(qmul(qconj(E1R1), E2R2)) / dt;
+  const ExpJr X1 = exp_jr(c1.r), X2 = exp_jr(c2.r);
+  const Q4 E1R1 = qmul(X1.E, R1), E2R2 = qmul(X2.E, R2);
+  const V3 gyr_est = log_jr_inv(qmul(qconj(E1R1), E2R2), nullptr) / dt;
   const V3 acc_est = (((c3.t + p3) + (c1.t + p1)) - 2 * (c2.t + p2)) / (dt * dt);
   const V3 grav = mk3(wp.grav[0], wp.grav[1], wp.grav[2]);
   const V3 r0 = wp.w_gyr * (((ld3(f.i1.gyr) + ld3(f.i2.gyr)) / 2 - gyr_est) - c1.bg);
@@ -303,10 +359,10 @@ __device__ void eval_imu(const WinParams &wp, const ImuRec &f, const double *x, 
       }
   };
   const M3 I = m3_identity();
-  const M3 F1 = Ffun(qconj(R1), E2R2, c1.r), F2 = Ffun(qconj(E1R1), R2, c2.r);
+  const M3 F1 = Ffun(qconj(R1), X1.E, E2R2, X1.Jr), F2 = Ffun(qconj(E1R1), X2.E, R2, X2.Jr);
   group(0, 0, F1, wp.w_gyr * (1 / dt), &F2, -wp.w_gyr * (1 / dt), nullptr, 0.0);
   group(0, 6, I, -wp.w_gyr, wp.quirks ? &I : nullptr, -wp.w_gyr, nullptr, 0.0);  // Q3 (cost_functor.h:314)
-  group(3, 0, (qmat(so3_exp(c1.r)) * hat(qrot(R1, ld3(f.i1.acc) - c1.ba))) * so3_Jr(c1.r), -wp.w_acc, nullptr, 0.0, nullptr, 0.0);
+  group(3, 0, (qmat(X1.E) * hat(qrot(R1, ld3(f.i1.acc) - c1.ba))) * X1.Jr, -wp.w_acc, nullptr, 0.0, nullptr, 0.0);
   group(3, 3, I, -wp.w_acc * (1 / dt / dt), &I, wp.w_acc * (2 / dt / dt), &I, -wp.w_acc * (1 / dt / dt));
   group(3, 9, qmat(E1R1), -wp.w_acc, nullptr, 0.0, nullptr, 0.0);
   group(6, 6, I, wp.w_bg, &I, -wp.w_bg, nullptr, 0.0);
@@ -552,6 +608,8 @@ __global__ void __launch_bounds__(kPiece) k_lin_surfel(WinParams wp, const Piece
 #endif
 }
 
+using f64x4 = __attribute__((ext_vector_type(4))) double;
+
 // IMU factors of one sample interval: <= kImuMax factors x 12 residual rows, 36-wide Jacobian
 constexpr int kImuMax = 8;  // (16: 30 us at C4, 8: 24 us - one round of 252 workgroups, 4: 37 us - two rounds)
 __global__ void __launch_bounds__(256) k_lin_imu(WinParams wp, const Piece *pieces, const ImuRec *recs, const double *x,
@@ -574,6 +632,9 @@ __global__ void __launch_bounds__(256) k_lin_imu(WinParams wp, const Piece *piec
     sC[tid] = 0.5 * c;  // TrivialLoss
   }
   __syncthreads();
+  // Gram matrix of the piece's rows.  Every entry is summed over the rows in row order (the fp64 matrix cores do this
+  // phase in a fifth of the time, but sum in groups of four: the facade parity test, which amplifies last-bit differences
+  // over 16 sweeps, then leaves its 5e-6 band); twelve rows' operands are requested before the first product is needed.
   constexpr int NOUT = T * (T + 1) / 2;
   const int nrows = (int)pc.count * 12;
   for (int e = tid; e < NOUT; e += 256) {
@@ -587,7 +648,13 @@ __global__ void __launch_bounds__(256) k_lin_imu(WinParams wp, const Piece *piec
     if (i == 36) {
       for (uint32_t k = 0; k < pc.count; ++k) acc += sC[k];
     } else {
-      for (int k = 0; k < nrows; ++k) acc += sV[k * T + i] * sV[k * T + j];
+      for (int k0 = 0; k0 < nrows; k0 += 12) {
+        double a[12], b[12];
+#pragma unroll
+        for (int q = 0; q < 12; ++q) a[q] = sV[(k0 + q) * T + i], b[q] = sV[(k0 + q) * T + j];
+#pragma unroll
+        for (int q = 0; q < 12; ++q) acc += a[q] * b[q];
+      }
     }
     partial[pc.part_off + e] = acc;
   }
@@ -926,7 +993,6 @@ __device__ __forceinline__ double readlane_d(double v, int src_lane) {  // src_l
 // redundantly in registers (no communication), 32 threads solve their row of the 4-column panel, 32 threads form the
 // four new rows of L^-1 (forward substitution on 4-row blocks, one column each), then everybody applies the rank-4 update.
 // in: sB rows 0..31 (lower part).  out: sB = L (lower, zeros above), sXi = L^-1.  Returns false on a non-positive pivot.
-using f64x4 = __attribute__((ext_vector_type(4))) double;
 
 __device__ __forceinline__ double rsqrt_nr(double a) {
   double inv = __builtin_amdgcn_rsq(a);  // ~2^-26 relative; one Newton step squares that, the second is insurance the
