@@ -66,8 +66,11 @@ int wc_timer_stop_ms(wc_ctx *ctx, float *h_ms);
  * host instantiation of the same header (ctx may be NULL).
  *   wc_selftest_so3 : out52 = Exp(v) quat (w,x,y,z) | Log(Exp(v)) | Jl | Jl_inv | Jr | Jr_inv | Hat   (3x3 row-major)
  *   wc_selftest_eig3: a9 symmetric row-major -> out12 = ascending eigenvalues | eigenvectors in columns (row-major)
- *   wc_selftest_quat: in12 = a(4) b(4) f p(3) -> out11 = slerp(a,f,b) | a*p (rotation) | a*b */
+ *   wc_selftest_quat: in12 = a(4) b(4) f p(3) -> out11 = slerp(a,f,b) | a*p (rotation) | a*b
+ *   wc_selftest_so3_fused (device only): the fused forms the factor kernels evaluate (csrc/so3_fused.h) ->
+ *                     out25 = Exp(v) quat | Jr(v) | Log(Exp(v)) | Jr_inv(Log(Exp(v))) */
 int wc_selftest_so3(wc_ctx *ctx, const double v[3], int on_device, double out52[52]);
+int wc_selftest_so3_fused(wc_ctx *ctx, const double v[3], double out25[25]);
 int wc_selftest_eig3(wc_ctx *ctx, const double a9[9], int on_device, double out12[12]);
 int wc_selftest_quat(wc_ctx *ctx, const double in12[12], int on_device, double out11[11]);
 

@@ -59,3 +59,28 @@ def test_eig3_and_quaternions_on_the_device(gpu):
         Rm = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)], [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
                        [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
         assert np.allclose(od[4:7], Rm @ p, atol=1e-14)
+
+
+def test_fused_so3_forms_of_the_factor_kernels(gpu):
+    """csrc/so3_fused.h (Exp + Jr from one sincos, Jr^-1 of a logarithm from the quaternion: what k_lin_imu / k_eval_imu
+    evaluate instead of cost_functor.h:286-321's separate calls) against the dmath.h helpers the reference's KATs pin,
+    on the device, from the series branch (|v| < 1e-10) to rotations close to pi.  The Jr^-1 coefficient 1 - th cot(th/2) / 2
+    cancels for small th in BOTH forms (utils.h:38), hence the absolute tolerance on it."""
+    rng = np.random.default_rng(23)
+    vs = [np.array([1.0, 2.0, 3.0]) / np.sqrt(14.0) * 3.0, np.zeros(3), np.array([3.1, 0.0, 0.0])]
+    vs += [rng.normal(size=3) * s for s in (1e-12, 1e-9, 1e-6, 1e-3, 0.1, 1.0) for _ in range(8)]
+    for v in vs:
+        n = np.linalg.norm(v)
+        if n > 3.1:
+            v = v * (3.1 / n)
+        d = so3_device(gpu, v)
+        out = np.zeros(25)
+        gpu._ck(gpu.lib.wc_selftest_so3_fused(gpu.h, R.ptr(np.ascontiguousarray(v, float)), R.ptr(out)))
+        assert np.allclose(out[0:4], d["exp"], rtol=0, atol=4e-16), v
+        # (utils.h:52 forms (1 - cos th) / th: zero below th = 1.5e-8 and ~1e-16 / th of rounding noise above; the fused form
+        # 2 sin^2(th / 2) / th has neither, so the two differ by exactly that)
+        assert np.allclose(out[4:13].reshape(3, 3), d["jr"], rtol=0, atol=2e-15 + (min(0.5 * n, 4e-16 / n) if n > 0 else 0.0)), v
+        assert np.allclose(out[13:16], d["log_exp"], rtol=0, atol=1e-15 * max(1.0, n)), v
+        assert np.allclose(out[16:25].reshape(3, 3), d["jr_inv"], rtol=0, atol=1e-9), v
+        # Jr_inv(v) Jr(v) = I (utils_test.cc:5-12 with v -> -v)
+        assert np.allclose(out[16:25].reshape(3, 3) @ out[4:13].reshape(3, 3), np.eye(3), atol=1e-9), v

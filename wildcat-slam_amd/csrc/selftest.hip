@@ -7,6 +7,7 @@
 // CPU test-suite can run it without a GPU).
 #include "ctx.h"
 #include "dmath.h"
+#include "so3_fused.h"
 
 using namespace wc;
 
@@ -73,6 +74,20 @@ WC_HD void quat_all(const double *in12, QuatOut *o) {  // in = a(4), b(4), f, p(
 
 __global__ void k_selftest_quat(const double *in12, QuatOut *o) { quat_all(in12, o); }
 
+struct FusedOut {  // 25 doubles: the fused device forms of so3_fused.h (what the IMU / surfel factor kernels evaluate)
+  double exp_q[4], jr[9];          // exp_jr(v)
+  double log_exp[3], jr_inv[9];    // log_jr_inv(exp_jr(v).E)
+};
+__global__ void k_selftest_fused(const double *v3, FusedOut *o) {
+  const ExpJr X = exp_jr(mk3(v3[0], v3[1], v3[2]));
+  o->exp_q[0] = X.E.w, o->exp_q[1] = X.E.x, o->exp_q[2] = X.E.y, o->exp_q[3] = X.E.z;
+  store9(X.Jr, o->jr);
+  M3 Jri;
+  const V3 l = log_jr_inv(X.E, &Jri);
+  o->log_exp[0] = l.x, o->log_exp[1] = l.y, o->log_exp[2] = l.z;
+  store9(Jri, o->jr_inv);
+}
+
 template <typename Out, typename Kern, typename HostFn>
 int run_selftest(wc_ctx *ctx, const double *h_in, size_t n_in, int on_device, double *h_out, Kern kern, HostFn host_fn) {
   if (!h_in || !h_out) return wc_fail(ctx, WC_ERR_ARG, "wc_selftest: null argument");
@@ -100,6 +115,11 @@ int run_selftest(wc_ctx *ctx, const double *h_in, size_t n_in, int on_device, do
 
 extern "C" int wc_selftest_so3(wc_ctx *ctx, const double v[3], int on_device, double out52[52]) {
   return run_selftest<So3Out>(ctx, v, 3, on_device, out52, k_selftest_so3, so3_all);
+}
+
+extern "C" int wc_selftest_so3_fused(wc_ctx *ctx, const double v[3], double out25[25]) {
+  if (!ctx) return WC_ERR_ARG;
+  return run_selftest<FusedOut>(ctx, v, 3, 1, out25, k_selftest_fused, [](const double *, FusedOut *) {});
 }
 
 extern "C" int wc_selftest_eig3(wc_ctx *ctx, const double a9[9], int on_device, double out12[12]) {

@@ -41,6 +41,7 @@
 
 #include "ctx.h"
 #include "dmath.h"
+#include "so3_fused.h"
 
 using namespace wc;
 
@@ -116,7 +117,6 @@ __device__ __forceinline__ V3 qrotf(double w, V3 u, V3 v) {
   const V3 ut = crossf(u, t);
   return mk3(fma(w, t.x, v.x) + ut.x, fma(w, t.y, v.y) + ut.y, fma(w, t.z, v.z) + ut.z);
 }
-__device__ __forceinline__ double rsqrt_nr(double a);
 
 // one surfel side: correction interpolated between two sample blocks (cost_functor.h:124-136), rotated lever arm
 // and, if wanted, the 1x6 Jacobian w.r.t. the interpolated (rot_cor, pos_cor)  (cost_functor.h:147-150, :162-165)
@@ -252,60 +252,6 @@ __device__ __forceinline__ StateCorr state_corr(const double *x, const double *t
   c.bg = (1 - c.f) * ld3(l + 6) + c.f * ld3(r + 6);
   c.ba = (1 - c.f) * ld3(l + 9) + c.f * ld3(r + 9);
   return c;
-}
-// The IMU factor evaluates Exp of the same two rotation vectors five times, Jr of them three times and Jr^-1 of two
-// logarithms (cost_functor.h:286-321, :446-448): twenty fp64 sin / cos calls and three atan2 in ONE thread's dependent
-// chain (44 k clocks per factor, `-DWC_PROF`-style clocks).  Here: Exp and Jr of a vector from one sincos of the half angle
-// (as surfel_side does), and Jr^-1 of a logarithm from the quaternion itself - |log q| = 2 |atan2(n, w)|,
-// cos(|log q| / 2) = |w|, sin(|log q| / 2) = n - so the factor costs two sincos and three atan2.
-struct ExpJr {
-  Q4 E;
-  M3 Jr;
-};
-__device__ __forceinline__ ExpJr exp_jr(V3 r) {
-  ExpJr o;
-  const double th2 = dot(r, r);
-  if (th2 < 1e-10 * 1e-10) {  // so3.hpp:705-712, utils.h:47
-    o.E = so3_exp(r);
-    o.Jr = m3_identity();
-    return o;
-  }
-  const double ith = rsqrt_nr(th2), th = th2 * ith;
-  double sh, ch;
-  sincos(0.5 * th, &sh, &ch);
-  const double imag = sh * ith;
-  o.E = {ch, imag * r.x, imag * r.y, imag * r.z};
-  const double s2 = (sh + sh) * ith, s = s2 * ch, omc = s2 * sh;  // sin th / th, (1 - cos th) / th
-  const V3 a = ith * r;
-  o.Jr = s * m3_identity() + (1 - s) * outer(a, a) + (-omc) * hat(a);  // Jr(r) = Jl(-r), utils.h:46-58
-  return o;
-}
-// so3_log (so3.hpp:264-311) and, if Jri != null, so3_Jr_inv of the result (utils.h:32-43)
-__device__ __forceinline__ V3 log_jr_inv(Q4 q, M3 *Jri) {
-  const double nn = sqrt(q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z);
-  q = {q.w / nn, q.x / nn, q.y / nn, q.z / nn};
-  const double sq = q.x * q.x + q.y * q.y + q.z * q.z, w = q.w;
-  if (sq < 1e-10 * 1e-10) {
-    const double k = 2.0 / w - (2.0 / 3.0) * sq / (w * (w * w));
-    const V3 lg = mk3(k * q.x, k * q.y, k * q.z);
-    if (Jri) *Jri = so3_Jr_inv(lg);
-    return lg;
-  }
-  const double n = sqrt(sq);
-  const double at = (w < 0) ? atan2(-n, -w) : atan2(n, w);
-  const double k = 2.0 * at / n;
-  const V3 lg = mk3(k * q.x, k * q.y, k * q.z);
-  if (Jri) {
-    const double th = 2.0 * fabs(at);
-    if (th > 1e-10) {
-      const M3 H = hat(-lg);
-      const double kk = 1 - th * fabs(w) / 2 / n;  // 1 - th cos(th / 2) / 2 / sin(th / 2)
-      *Jri = m3_identity() + (-0.5) * H + (kk / (th * th)) * (H * H);
-    } else {
-      *Jri = m3_identity();
-    }
-  }
-  return lg;
 }
 __device__ __forceinline__ M3 Ffun(Q4 L, Q4 E, Q4 R, const M3 &Jr) {  // cost_functor.h:446-448
   M3 Jri;
@@ -994,11 +940,6 @@ __device__ __forceinline__ double readlane_d(double v, int src_lane) {  // src_l
 // four new rows of L^-1 (forward substitution on 4-row blocks, one column each), then everybody applies the rank-4 update.
 // in: sB rows 0..31 (lower part).  out: sB = L (lower, zeros above), sXi = L^-1.  Returns false on a non-positive pivot.
 
-__device__ __forceinline__ double rsqrt_nr(double a) {
-  double inv = __builtin_amdgcn_rsq(a);  // ~2^-26 relative; one Newton step squares that, the second is insurance the
-  const double h = 0.5 * inv;             // pivot chain cannot afford (every dependent fp64 op costs ~25-30 clk here)
-  return fma(h, fma(-a * inv, inv, 1.0), inv);  // inv + inv/2 (1 - a inv^2)
-}
 
 struct Piv4 {  // Cholesky factor of a 4x4 pivot block and its inverse (both lower triangular)
   double l00, l10, l11, l20, l21, l22, l30, l31, l32, l33;
