@@ -93,6 +93,10 @@ struct wc_window_state {
   int (*allreduce)(void *, double *, uint64_t) = nullptr;
   void *allreduce_user = nullptr;
   wc_buf x, xc, scale, diag, A, y, mail, cost_part, keys_tmp[2], vals_tmp[2], heads, status;
+  // pinned staging of the two families' segment heads + status words, and the events that say a family's copy has landed
+  void *h_pin = nullptr;
+  size_t h_pin_cap = 0;
+  hipEvent_t fam_done[2] = {nullptr, nullptr};
   bool built = false;
 };
 
@@ -1469,25 +1473,30 @@ struct Seg {
   uint32_t start, count, key;
 };
 
-// sorted keys -> segments (device head detection, host ordering)
-int find_segments(wc_ctx *ctx, wc_window_state *W, const uint32_t *d_keys, uint32_t n, uint32_t max_heads, uint32_t st[4],
-                  std::vector<Seg> &segs) {
+// One family's segment search in flight: head detection and the copy of (status words, head slots) into pinned memory are
+// enqueued by build_family; collect_family waits for the family's event and orders the heads on the host.  Both families
+// are enqueued before the first wait (one idle gap of the device per build instead of two; the host picks the IMU factors
+// in the meantime).
+struct FamilyJob {
+  uint32_t n = 0, cap = 0;
+  const uint32_t *h_st = nullptr;
+  const std::pair<uint32_t, uint32_t> *h_heads = nullptr;
+  hipEvent_t done = nullptr;
+};
+
+int collect_family(wc_ctx *ctx, const FamilyJob &J, std::vector<Seg> &segs) {
   segs.clear();
-  if (n == 0) return WC_OK;
-  WC_TRY(wc_ensure(ctx, W->heads, (size_t)n * 8));
-  k_seg_heads<<<(n + 1023) / 1024, 1024, 0, ctx->stream>>>(d_keys, n, (uint32_t *)W->heads.p, (uint32_t *)W->status.p);
-  // ONE round trip: the status words (also k_pair_keys' flags) and as many head slots as there can be distinct keys
-  const uint32_t cap = std::min(n, max_heads);
-  std::vector<std::pair<uint32_t, uint32_t>> heads(cap);
-  WC_HIP(ctx, hipMemcpyAsync(st, W->status.p, 16, hipMemcpyDeviceToHost, ctx->stream));
-  WC_HIP(ctx, hipMemcpyAsync(heads.data(), W->heads.p, (size_t)cap * 8, hipMemcpyDeviceToHost, ctx->stream));
-  WC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (J.n == 0) return WC_OK;
+  WC_HIP(ctx, hipEventSynchronize(J.done));
+  const uint32_t *st = J.h_st;
+  if (st[1] & 2u) return wc_fail(ctx, WC_ERR_ORDER, "correspondence is not (older, newer)");
+  if (st[1] & 1u) return wc_fail(ctx, WC_ERR_RANGE, "surfel timestamp outside the sample-state range");
   const uint32_t nh = st[2];
-  if (nh > cap) return wc_fail(ctx, WC_ERR_RANGE, "more key segments (%u) than distinct keys (%u)", nh, cap);
-  heads.resize(nh);
+  if (nh > J.cap) return wc_fail(ctx, WC_ERR_RANGE, "more key segments (%u) than distinct keys (%u)", nh, J.cap);
+  std::vector<std::pair<uint32_t, uint32_t>> heads(J.h_heads, J.h_heads + nh);
   std::sort(heads.begin(), heads.end());
   for (uint32_t i = 0; i < nh; ++i) {
-    const uint32_t end = (i + 1 < nh) ? heads[i + 1].first : n;
+    const uint32_t end = (i + 1 < nh) ? heads[i + 1].first : J.n;
     segs.push_back({heads[i].first, end - heads[i].first, heads[i].second});
   }
   return WC_OK;
@@ -1503,19 +1512,25 @@ void wc_window_free(wc_ctx *ctx) {
                    &W->mail, &W->cost_part, &W->keys_tmp[0], &W->keys_tmp[1], &W->vals_tmp[0], &W->vals_tmp[1], &W->heads, &W->status};
   for (wc_buf *b : all)
     if (b->p) (void)hipFree(b->p);
+  if (W->h_pin) (void)hipHostFree(W->h_pin);
+  for (hipEvent_t e : W->fam_done)
+    if (e) (void)hipEventDestroy(e);
   delete W;
   ctx->win = nullptr;
 }
 
 namespace {
 
-// build one family of surfel records (binary or unary): keys -> sort -> packed records -> segments -> pieces
+// enqueue one family of surfel records (binary or unary): keys -> sort -> packed records -> segment heads -> copy to the
+// family's half of the pinned staging area
 int build_family(wc_ctx *ctx, wc_window_state *W, bool unary, const wc_surfel *s1, const wc_pose *p1, const wc_surfel *s2,
-                 const wc_pose *p2, const wc_pair *pairs, uint32_t n, wc_buf &rec, wc_buf &key, wc_buf &orig,
-                 std::vector<Seg> &segs) {
-  segs.clear();
+                 const wc_pose *p2, const wc_pair *pairs, uint32_t n, wc_buf &rec, wc_buf &key, wc_buf &orig, FamilyJob &J) {
+  J = FamilyJob{};
   if (n == 0) return WC_OK;
+  const int fam = unary ? 1 : 0;
   const int nf = unary ? 11 : 15;
+  const uint64_t maxkey = unary ? (uint64_t)W->ns : (uint64_t)W->ns * W->ns;
+  const uint32_t cap = (uint32_t)std::min<uint64_t>(n, maxkey + 1);  // as many head slots as there can be distinct keys
   WC_TRY(wc_ensure(ctx, W->keys_tmp[0], (size_t)n * 4));
   WC_TRY(wc_ensure(ctx, W->keys_tmp[1], (size_t)n * 4));
   WC_TRY(wc_ensure(ctx, W->vals_tmp[0], (size_t)n * 4));
@@ -1524,24 +1539,29 @@ int build_family(wc_ctx *ctx, wc_window_state *W, bool unary, const wc_surfel *s
   WC_TRY(wc_ensure(ctx, key, (size_t)n * 4));
   WC_TRY(wc_ensure(ctx, orig, (size_t)n * 4));
   WC_TRY(wc_ensure(ctx, W->status, 64 * 4));
-  WC_HIP(ctx, hipMemsetAsync(W->status.p, 0, 64 * 4, ctx->stream));
+  if (!W->fam_done[fam]) WC_HIP(ctx, hipEventCreateWithFlags(&W->fam_done[fam], hipEventDisableTiming));
+  uint32_t *d_st = (uint32_t *)W->status.p + 16 * fam;  // (k_pair_keys: word 1 = flags, k_seg_heads: word 2 = heads)
+  WC_HIP(ctx, hipMemsetAsync(d_st, 0, 16 * 4, ctx->stream));
   const unsigned grid = (n + 255) / 256;
   k_pair_keys<<<grid, 256, 0, ctx->stream>>>(s1, s2, pairs, n, (const double *)W->times_d.p, W->ns, unary ? 1 : 0,
-                                            (uint32_t *)W->keys_tmp[0].p, (uint32_t *)W->vals_tmp[0].p, (uint32_t *)W->status.p);
+                                            (uint32_t *)W->keys_tmp[0].p, (uint32_t *)W->vals_tmp[0].p, d_st);
   // (k_pair_keys' flags are read back with the segment heads: a flagged record gets key 0, so everything downstream is safe)
   unsigned bits = 1;
-  const uint64_t maxkey = unary ? (uint64_t)W->ns : (uint64_t)W->ns * W->ns;
   while ((1ull << bits) < maxkey + 1) ++bits;
   WC_TRY(sort_u32(ctx, W, (uint32_t *)W->keys_tmp[0].p, (uint32_t *)W->keys_tmp[1].p, (uint32_t *)W->vals_tmp[0].p,
                   (uint32_t *)W->vals_tmp[1].p, n, bits));
   k_build_records<<<grid, 256, 0, ctx->stream>>>(s1, p1, s2, p2, pairs, (const uint32_t *)W->vals_tmp[1].p,
                                                 (const uint32_t *)W->keys_tmp[1].p, n, (const double *)W->times_d.p, W->ns,
                                                 unary ? 1 : 0, W->wp.sigma0_sq, (double *)rec.p, (uint32_t *)key.p, (uint32_t *)orig.p);
+  // heads of family 0 / 1 in the two halves of W->heads (n_b and n_u entries at most)
+  uint32_t *d_heads = (uint32_t *)W->heads.p + (unary ? 2 * (size_t)W->nb : 0);
+  k_seg_heads<<<(n + 1023) / 1024, 1024, 0, ctx->stream>>>((const uint32_t *)key.p, n, d_heads, d_st);
   WC_HIP(ctx, hipGetLastError());
-  uint32_t st[4] = {0, 0, 0, 0};
-  WC_TRY(find_segments(ctx, W, (const uint32_t *)key.p, n, (uint32_t)maxkey + 1, st, segs));
-  if (st[1] & 2u) return wc_fail(ctx, WC_ERR_ORDER, "correspondence is not (older, newer)");
-  if (st[1] & 1u) return wc_fail(ctx, WC_ERR_RANGE, "surfel timestamp outside the sample-state range");
+  char *h = (char *)W->h_pin + (size_t)fam * (W->h_pin_cap / 2);
+  WC_HIP(ctx, hipMemcpyAsync(h, d_st, 16, hipMemcpyDeviceToHost, ctx->stream));
+  WC_HIP(ctx, hipMemcpyAsync(h + 64, d_heads, (size_t)cap * 8, hipMemcpyDeviceToHost, ctx->stream));
+  WC_HIP(ctx, hipEventRecord(W->fam_done[fam], ctx->stream));
+  J.n = n, J.cap = cap, J.h_st = (const uint32_t *)h, J.h_heads = (const std::pair<uint32_t, uint32_t> *)(h + 64), J.done = W->fam_done[fam];
   return WC_OK;
 }
 
@@ -1591,10 +1611,21 @@ extern "C" int wc_window_build(wc_ctx *ctx, const wc_surfel *d_sld_surf, const w
   const bool tdbg = getenv("WC_WIN_DEBUG") != nullptr;
   auto tnow = [] { return std::chrono::steady_clock::now(); };
   auto t_a = tnow();
+  {  // staging for both families' (status, heads); heads of both in one device buffer
+    const size_t half = 64 + ((size_t)ns * ns + 1) * 8, need = 2 * ((half + 127) / 128 * 128);
+    if (W->h_pin_cap < need) {
+      if (W->h_pin) (void)hipHostFree(W->h_pin);
+      W->h_pin = nullptr, W->h_pin_cap = 0;
+      WC_HIP(ctx, hipHostMalloc(&W->h_pin, need));
+      W->h_pin_cap = need;
+    }
+    WC_TRY(wc_ensure(ctx, W->heads, std::max<size_t>(((size_t)W->nb + W->nu) * 8, 16)));
+  }
+  FamilyJob job_b, job_u;
   WC_TRY(build_family(ctx, W, false, d_sld_surf, d_sld_pose, d_sld_surf, d_sld_pose, d_pairs_sld, W->nb, W->brec, W->bkey,
-                      W->borig, segs_b));
+                      W->borig, job_b));
   WC_TRY(build_family(ctx, W, true, d_fix_surf, d_fix_pose, d_sld_surf, d_sld_pose, d_pairs_fix, W->nu, W->urec, W->ukey,
-                      W->uorig, segs_u));
+                      W->uorig, job_u));
 
   // IMU factors (BuildImuResiduals, lidar_odometry.cc:319-363), selected on the host: a few thousand records
   std::vector<Seg> segs_i;
@@ -1617,6 +1648,8 @@ extern "C" int wc_window_build(wc_ctx *ctx, const wc_surfel *d_sld_surf, const w
   }
   W->ni = (uint32_t)irecs.size();
   WC_TRY(upload(ctx, W->irec, irecs));
+  WC_TRY(collect_family(ctx, job_b, segs_b));
+  WC_TRY(collect_family(ctx, job_u, segs_u));
 
   auto t_b = tnow();
   // pieces + the CSR source lists of the gather
