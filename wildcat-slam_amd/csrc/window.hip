@@ -1201,12 +1201,18 @@ __global__ void __launch_bounds__(256) k_chol_step(double *A, int ld, int k, int
   // corner of tile (0, 0) - panel solve of the next diagonal block's rows, its update - and factors + inverts that block
   // right away; a quarter of a tile's matrix-core work (fp64 MFMA runs at the vector rate: 64 clk per 16x16x4) and no
   // write-back stand between the launch and the factor.
-  if (blockIdx.y == 0) {
-    if (blockIdx.x == 0) chol_lead(A, ld, k, nblk, Lmat, Linv, fail, sA, sX, sLi, sLj);
+  // Linear grid: workgroup 0 is the lead, workgroup 1 + ti (ti + 1) / 2 + tj the tile (ti, tj) of the lower triangle.  (A
+  // tiles x (tiles + 1) grid whose upper half returned at once had up to 600 workgroups for 277 real ones: with more than
+  // 256 of them the dispatcher put a tile onto the lead's CU and the lead took 9 us instead of 7 - the first 17 steps.)
+  if (blockIdx.x == 0) {
+    chol_lead(A, ld, k, nblk, Lmat, Linv, fail, sA, sX, sLi, sLj);
     return;
   }
-  const int ti = blockIdx.y - 1, tj = blockIdx.x;
-  if (tj > ti) return;
+  const int b_ = (int)blockIdx.x - 1;
+  int ti = (int)((sqrtf(8.0f * (float)b_ + 1.0f) - 1.0f) * 0.5f);
+  while ((ti + 1) * (ti + 2) / 2 <= b_) ++ti;
+  while (ti * (ti + 1) / 2 > b_) --ti;
+  const int tj = b_ - ti * (ti + 1) / 2;
   const int failed = *fail;  // tested after the first barrier: one round trip together with the tile's loads, not before them
   const int tid = threadIdx.x;
   const int nrow = nblk * kNB;
@@ -2019,7 +2025,7 @@ extern "C" int wc_window_solve(wc_ctx *ctx, double *h_x_inout, wc_solve_summary 
       k_chol_first<<<1, 256, 0, st>>>(A, ld, Lmat, (double *)W->Linv.p, fail);
       for (int k = 0; k + 1 < nblk; ++k) {
         const int tiles = ((nblk - k - 1) * kNB + 63) / 64;
-        k_chol_step<<<dim3(tiles, tiles + 1), 256, 0, st>>>(A, ld, k, nblk, Lmat, (double *)W->Linv.p, fail);
+        k_chol_step<<<1 + tiles * (tiles + 1) / 2, 256, 0, st>>>(A, ld, k, nblk, Lmat, (double *)W->Linv.p, fail);
       }
       {  // back substitution, chunk by chunk from the last block row
         const double *zsrc = Lmat + (size_t)n * ld;
