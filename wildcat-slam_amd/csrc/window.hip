@@ -567,6 +567,25 @@ __global__ void __launch_bounds__(kPiece) k_lin_surfel(WinParams wp, const Piece
 
 using f64x4 = __attribute__((ext_vector_type(4))) double;
 
+// Entries (i <= j) of the IMU piece's 37 x 37 Gram matrix in the order of their row support.  A Jacobian column of class
+// rot / pos / bg / ba (column % 12 / 3) is non-zero only in the residual groups {gyr, acc} / {acc} / {gyr, bg} / {acc, ba}
+// (the group() calls of eval_imu: cost_functor.h:301-321), the residual column 36 in all four; bit g of the support of an
+// entry = residual group g (rows 3 g .. 3 g + 2 of every factor) contributes.  ent = i | j << 6 | support << 12.
+struct ImuGramOrder {
+  uint16_t ent[37 * 38 / 2];
+  constexpr ImuGramOrder() : ent() {
+    constexpr uint32_t sup[5] = {0x3u, 0x2u, 0x5u, 0xAu, 0xFu};
+    int n = 0;
+    for (uint32_t want = 0; want < 16; ++want)  // entries of equal support next to each other
+      for (int i = 0; i < 37; ++i)
+        for (int j = i; j < 37; ++j) {
+          const uint32_t m = sup[i == 36 ? 4 : (i % 12) / 3] & sup[j == 36 ? 4 : (j % 12) / 3];
+          if (m == want) ent[n++] = (uint16_t)((uint32_t)i | ((uint32_t)j << 6) | (m << 12));
+        }
+  }
+};
+__constant__ const ImuGramOrder kImuGram{};
+
 // IMU factors of one sample interval: <= kImuMax factors x 12 residual rows, 36-wide Jacobian
 constexpr int kImuMax = 8;  // (16: 30 us at C4, 8: 24 us - one round of 252 workgroups, 4: 37 us - two rounds)
 __global__ void __launch_bounds__(256) k_lin_imu(WinParams wp, const Piece *pieces, const ImuRec *recs, const double *x,
@@ -591,29 +610,31 @@ __global__ void __launch_bounds__(256) k_lin_imu(WinParams wp, const Piece *piec
   __syncthreads();
   // Gram matrix of the piece's rows.  Every entry is summed over the rows in row order (the fp64 matrix cores do this
   // phase in a fifth of the time, but sum in groups of four: the facade parity test, which amplifies last-bit differences
-  // over 16 sweeps, then leaves its 5e-6 band); twelve rows' operands are requested before the first product is needed.
+  // over 16 sweeps, then leaves its 5e-6 band).  Only the row groups in which BOTH columns can be non-zero are visited
+  // (a skipped term is + 0.0 * 0.0; see ImuGramOrder): 3.4 of 12 rows on average, and the entries are handed out in the
+  // order of their support, so that the lanes of a wavefront skip the same groups.
   constexpr int NOUT = T * (T + 1) / 2;
-  const int nrows = (int)pc.count * 12;
-  for (int e = tid; e < NOUT; e += 256) {
-    int i = 0, rem = e;
-    while (rem >= T - i) {
-      rem -= T - i;
-      ++i;
-    }
-    const int j = i + rem;
+  for (int e0 = tid; e0 < NOUT; e0 += 256) {
+    const uint32_t ent = kImuGram.ent[e0];
+    const int i = (int)(ent & 63u), j = (int)((ent >> 6) & 63u);
+    const uint32_t m = ent >> 12;
     double acc = 0.0;
     if (i == 36) {
       for (uint32_t k = 0; k < pc.count; ++k) acc += sC[k];
     } else {
-      for (int k0 = 0; k0 < nrows; k0 += 12) {
-        double a[12], b[12];
+      for (int k = 0; k < (int)pc.count; ++k) {
 #pragma unroll
-        for (int q = 0; q < 12; ++q) a[q] = sV[(k0 + q) * T + i], b[q] = sV[(k0 + q) * T + j];
-#pragma unroll
-        for (int q = 0; q < 12; ++q) acc += a[q] * b[q];
+        for (int g4 = 0; g4 < 4; ++g4)
+          if ((m >> g4) & 1u) {
+            const double *ra = &sV[(k * 12 + 3 * g4) * T];
+            const double a0 = ra[i], a1 = ra[T + i], a2 = ra[2 * T + i], b0 = ra[j], b1 = ra[T + j], b2 = ra[2 * T + j];
+            acc += a0 * b0;
+            acc += a1 * b1;
+            acc += a2 * b2;
+          }
       }
     }
-    partial[pc.part_off + e] = acc;
+    partial[pc.part_off + tri_index((uint32_t)i, (uint32_t)j, (uint32_t)T)] = acc;
   }
 }
 
