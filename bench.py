@@ -509,12 +509,11 @@ def bench_window(ctx, args, world, rank, dev, torch, dist, cpu=False):
     # the gated neighbour lists all-gathered (csrc/match.hip)
     d_pairs, d_pf = ctx.alloc(8 * n_s), ctx.alloc(8 * n_s)
     # (one untimed pass first: the library's scratch buffers are allocated on first use)
-    ctx.match_device(d_surf, d_pose, n_s, d_surf, d_pose, n_s, True, d_pairs, n_s)
-    ctx.match_device(d_surf, d_pose, n_s, d_fs, d_fp, len(w["fix_surf"]), False, d_pf, n_s)
+    # (wc_match_pair: both searches side by side on one GPU, one after the other when the matcher is query-sharded)
+    ctx.match_pair_device(d_surf, d_pose, n_s, d_fs, d_fp, len(w["fix_surf"]), d_pairs, n_s, d_pf, n_s)
     ctx.sync()
     t0 = time.perf_counter()
-    n_b = ctx.match_device(d_surf, d_pose, n_s, d_surf, d_pose, n_s, True, d_pairs, n_s)
-    n_u = ctx.match_device(d_surf, d_pose, n_s, d_fs, d_fp, len(w["fix_surf"]), False, d_pf, n_s)
+    n_b, n_u = ctx.match_pair_device(d_surf, d_pose, n_s, d_fs, d_fp, len(w["fix_surf"]), d_pairs, n_s, d_pf, n_s)
     t_match = time.perf_counter() - t0
     # shard the correspondences (contiguous slices) and the IMU factors
     lo_b, cnt_b = wdist.shard_range(n_b, rank, world)
@@ -602,7 +601,7 @@ def bench_window(ctx, args, world, rank, dev, torch, dist, cpu=False):
 def bench_odometry_step(ctx, args, world, rank, dev, torch, dist, cpu=False):
     """north_star's headline workload, one FULL odometry step (LidarOdometry::AddLidarScan, lidar_odometry.cc:523-566) through the
     C-ABI on a 10-sweep window of 1 M-point sweeps (10 x C2): 9 sweeps are already in the window (extracted, posed; the two oldest
-    form the fixed window), the step takes the newest sweep: BuildSurfels -> UpdateSurfelPoses -> 2 x KnnSurfelMatcher -> problem
+    form the fixed window), the step takes the newest sweep: BuildSurfels -> UpdateSurfelPoses -> 2 x KnnSurfelMatcher (wc_match_pair) -> problem
     construction -> solve -> UpdateSurfelPoses.  Single GPU (the N > 1 legs of its stages are `window` and `cloud_10m`)."""
     from wildcat_slam_amd import records as R, synth
 
@@ -654,8 +653,7 @@ def bench_odometry_step(ctx, args, world, rank, dev, torch, dist, cpu=False):
         ctx.update_surfel_poses(d_imu, len(imu), sld_s, sld_p, sld_b, n_sld)
         T["pose_update"] = time.perf_counter() - t1
         t1 = time.perf_counter()
-        nb = ctx.match_device(sld_s, sld_p, n_sld, sld_s, sld_p, n_sld, True, d_pb, cap_all)
-        nu = ctx.match_device(sld_s, sld_p, n_sld, d_surf, d_pose, n_fix, False, d_pu, cap_all)
+        nb, nu = ctx.match_pair_device(sld_s, sld_p, n_sld, d_surf, d_pose, n_fix, d_pb, cap_all, d_pu, cap_all)  # (both searches side by side)
         T["match"] = time.perf_counter() - t1
         t1 = time.perf_counter()
         ctx.window_build(sld_s, sld_p, d_pb, nb, imu, w["sample_times"], w["grav"], False, d_surf, d_pose, d_pu, nu)

@@ -168,6 +168,18 @@ int wc_match(wc_ctx *ctx, const wc_surfel *d_q_surf, const wc_pose *d_q_pose, ui
              const wc_pose *d_t_pose, uint64_t nt, int same_set, wc_pair *d_pairs, uint64_t cap, uint64_t *h_n_pairs,
              uint32_t *d_knn_idx, double *d_knn_d2);
 
+/* Both correspondence searches of one outer iteration (the two KnnSurfelMatcher objects of lidar_odometry.cc:530-538) at
+ * once.  Same results, bit for bit, as
+ *   wc_match(ctx, sld, sld_pose, n_sld, sld, sld_pose, n_sld, 1, d_pairs_sld, ...) followed by
+ *   wc_match(ctx, sld, sld_pose, n_sld, fix, fix_pose, n_fix, 0, d_pairs_fix, ...),
+ * but the fixed-window search runs on a helper context of its own (own stream and scratch, created on first use, ordered
+ * behind the work already enqueued on the ctx stream): one search is a single round of wavefronts whose durations differ by
+ * 3x, so the wavefronts of the other fill the slots the early finishers leave.  With a communicator installed (sharded
+ * matcher: collectives on the ctx stream) the two searches run one after the other. */
+int wc_match_pair(wc_ctx *ctx, const wc_surfel *d_sld_surf, const wc_pose *d_sld_pose, uint64_t n_sld,
+                  const wc_surfel *d_fix_surf, const wc_pose *d_fix_pose, uint64_t n_fix, wc_pair *d_pairs_sld, uint64_t cap_sld,
+                  uint64_t *h_n_pairs_sld, wc_pair *d_pairs_fix, uint64_t cap_fix, uint64_t *h_n_pairs_fix);
+
 /* window problem: factors + Levenberg-Marquardt ----------------------------------------------------------------- */
 /* Replaces the ceres::Problem construction of lidar_odometry.cc:541-545:
  *   BuildSldWinLidarResiduals (cc:254-297) — d_pairs_sld index the sliding-window surfels (older, newer),

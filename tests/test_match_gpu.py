@@ -233,3 +233,26 @@ def test_query_sharded_match_equals_unsharded(gpu):
         assert out[r][0].tobytes() == ref_b.tobytes() and out[r][1].tobytes() == ref_u.tobytes()
     for c in ctxs:
         c.close()
+
+
+@pytest.mark.parametrize("serial", [False, True])
+def test_match_pair_equals_the_two_searches_and_the_oracle(gpu, oracle, serial, monkeypatch):
+    """wc_match_pair (both KnnSurfelMatcher objects of lidar_odometry.cc:530-538 side by side, the fixed-window search on a helper
+    context and host thread) against two wc_match calls and against the oracle; several calls in a row reuse the helper."""
+    if serial:
+        monkeypatch.setenv("WC_MATCH_PAIR_SERIAL", "1")
+    w = synth.surfel_window(4, 2000, seed=31, fixed_patches=1500)
+    ns, nf = len(w["surf"]), len(w["fix_surf"])
+    d_s, d_p = gpu.to_device(w["surf"]), gpu.to_device(w["pose"])
+    d_fs, d_fp = gpu.to_device(w["fix_surf"]), gpu.to_device(w["fix_pose"])
+    d_b, d_u = gpu.alloc(8 * ns), gpu.alloc(8 * ns)
+    ref_b = oracle.match(w["surf"], w["pose"], w["surf"], w["pose"], True)
+    ref_u = oracle.match(w["surf"], w["pose"], w["fix_surf"], w["fix_pose"], False)
+    one_b = gpu.match(w["surf"], w["pose"], w["surf"], w["pose"], True)
+    one_u = gpu.match(w["surf"], w["pose"], w["fix_surf"], w["fix_pose"], False)
+    for _ in range(3):
+        nb, nu = gpu.match_pair_device(d_s, d_p, ns, d_fs, d_fp, nf, d_b, ns, d_u, ns)
+        got_b, got_u = d_b.download(R.PAIR, nb), d_u.download(R.PAIR, nu)
+        assert np.array_equal(got_b, one_b) and np.array_equal(got_u, one_u)
+        assert np.array_equal(got_b, ref_b) and np.array_equal(got_u, ref_u)
+    assert len(ref_b) > 1000 and len(ref_u) > 500

@@ -72,6 +72,8 @@ struct wc_ctx {
     bool fast_slots;
   } ex;
   wc_window_state *win = nullptr;
+  wc_ctx *aux = nullptr;  // helper context of wc_match_pair (second stream + scratch), owned by this ctx
+  hipEvent_t ev_aux = nullptr;  // orders the helper's stream behind the ctx stream
   // optional per-stage HIP events of the extraction pipeline (wc_extract_profile)
   bool ex_prof = false;
   int ex_prof_mode = 0;

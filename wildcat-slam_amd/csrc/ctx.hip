@@ -96,6 +96,11 @@ extern "C" void wc_ctx_destroy(wc_ctx *ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->aux) {
+    wc_ctx_destroy(ctx->aux);
+    ctx->aux = nullptr;
+  }
+  if (ctx->ev_aux) (void)hipEventDestroy(ctx->ev_aux);
   (void)wc_comm_rccl_destroy(ctx);
   wc_window_free(ctx);
   wc_buf *all[] = {&ctx->b_keys[0],      &ctx->b_keys[1],     &ctx->b_vals[0],     &ctx->b_vals[1],      &ctx->b_sorttmp,

@@ -14,6 +14,7 @@
 
 #include <cmath>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 #include <rocprim/rocprim.hpp>
@@ -646,3 +647,38 @@ extern "C" int wc_match(wc_ctx *ctx, const wc_surfel *d_q_surf, const wc_pose *d
   if (ctx->h_status[0] > cap) return wc_fail(ctx, WC_ERR_CAPACITY, "pair capacity %llu < %u", (unsigned long long)cap, ctx->h_status[0]);
   return WC_OK;
 }
+
+// The two searches of an outer iteration side by side (see include/wildcat_hip.h).  wc_match is synchronous and talks to the
+// host between its launches (the fixed-point rounds of the pair rule), so the second search gets its own context AND its own
+// host thread; both only read the surfels.
+extern "C" int wc_match_pair(wc_ctx *ctx, const wc_surfel *d_sld_surf, const wc_pose *d_sld_pose, uint64_t n_sld,
+                             const wc_surfel *d_fix_surf, const wc_pose *d_fix_pose, uint64_t n_fix, wc_pair *d_pairs_sld,
+                             uint64_t cap_sld, uint64_t *h_n_pairs_sld, wc_pair *d_pairs_fix, uint64_t cap_fix,
+                             uint64_t *h_n_pairs_fix) {
+  if (!ctx || !h_n_pairs_sld || !h_n_pairs_fix) return wc_fail(ctx, WC_ERR_ARG, "%s: null or out-of-range argument", __func__);
+  if (ctx->have_comm || n_sld == 0 || n_fix == 0 || getenv("WC_MATCH_PAIR_SERIAL")) {
+    WC_TRY(wc_match(ctx, d_sld_surf, d_sld_pose, n_sld, d_sld_surf, d_sld_pose, n_sld, 1, d_pairs_sld, cap_sld, h_n_pairs_sld, nullptr, nullptr));
+    return wc_match(ctx, d_sld_surf, d_sld_pose, n_sld, d_fix_surf, d_fix_pose, n_fix, 0, d_pairs_fix, cap_fix, h_n_pairs_fix, nullptr, nullptr);
+  }
+  wc_dev_guard dg_(ctx);
+  if (!ctx->aux) {
+    const int rc = wc_ctx_create(&ctx->P, ctx->device, &ctx->aux);
+    if (rc != WC_OK) return wc_fail(ctx, rc, "wc_match_pair: no helper context");
+  }
+  wc_ctx *aux = ctx->aux;
+  WC_TRY(wc_ctx_set_params(aux, &ctx->P));
+  // the helper's stream starts behind everything already enqueued on the ctx stream (the producers of the surfels and poses)
+  if (!ctx->ev_aux) WC_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_aux, hipEventDisableTiming));
+  WC_HIP(ctx, hipEventRecord(ctx->ev_aux, ctx->stream));
+  WC_HIP(ctx, hipStreamWaitEvent(aux->stream, ctx->ev_aux, 0));
+  int rc_fix = WC_OK;
+  std::thread helper([&] {
+    rc_fix = wc_match(aux, d_sld_surf, d_sld_pose, n_sld, d_fix_surf, d_fix_pose, n_fix, 0, d_pairs_fix, cap_fix, h_n_pairs_fix, nullptr, nullptr);
+  });
+  const int rc_sld = wc_match(ctx, d_sld_surf, d_sld_pose, n_sld, d_sld_surf, d_sld_pose, n_sld, 1, d_pairs_sld, cap_sld, h_n_pairs_sld, nullptr, nullptr);
+  helper.join();
+  if (rc_sld != WC_OK) return rc_sld;
+  if (rc_fix != WC_OK) return wc_fail(ctx, rc_fix, "wc_match_pair (fixed window): %s", wc_last_error(aux));
+  return WC_OK;
+}
+

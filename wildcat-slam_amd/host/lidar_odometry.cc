@@ -410,11 +410,9 @@ void LidarOdometry::AddLidarScan(const pcl::PointCloud<hilti_ros::Point>::Ptr &m
     const size_t n_sld = n_surfels_ - sld_begin_;
     // correspondences (:530-538)
     uint64_t n_b = 0, n_u = 0;
-    WC_CALL(wc_match(ctx_, d_surf_ + sld_begin_, d_pose_ + sld_begin_, n_sld, d_surf_ + sld_begin_, d_pose_ + sld_begin_, n_sld, 1,
-                     d_pairs_sld_, cap_surfels_, &n_b, nullptr, nullptr));
     const size_t n_fix = fix_end_ - fix_start_;
-    WC_CALL(wc_match(ctx_, d_surf_ + sld_begin_, d_pose_ + sld_begin_, n_sld, d_fix_surf_ + fix_start_, d_fix_pose_ + fix_start_, n_fix, 0,
-                     d_pairs_fix_, cap_surfels_, &n_u, nullptr, nullptr));
+    WC_CALL(wc_match_pair(ctx_, d_surf_ + sld_begin_, d_pose_ + sld_begin_, n_sld, d_fix_surf_ + fix_start_, d_fix_pose_ + fix_start_, n_fix,
+                          d_pairs_sld_, cap_surfels_, &n_b, d_pairs_fix_, cap_surfels_, &n_u));
     last_corr_[0] = n_b, last_corr_[1] = n_u;
     // 5. solve poses in windows (:541-562)
     std::vector<double> ts, x;

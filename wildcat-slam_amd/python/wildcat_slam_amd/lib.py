@@ -428,6 +428,14 @@ class Context:
                                    C.byref(n), C.c_void_p(d_knn_idx.ptr if d_knn_idx else 0), C.c_void_p(d_knn_d2.ptr if d_knn_d2 else 0)))
         return int(n.value)
 
+    def match_pair_device(self, d_sld_surf, d_sld_pose, n_sld, d_fix_surf, d_fix_pose, n_fix, d_pairs_sld, cap_sld, d_pairs_fix, cap_fix):
+        """both searches of an outer iteration side by side (wc_match_pair) -> (n_pairs_sld, n_pairs_fix)"""
+        nb, nu = C.c_uint64(0), C.c_uint64(0)
+        self._ck(self.lib.wc_match_pair(self.h, C.c_void_p(d_sld_surf.ptr), C.c_void_p(d_sld_pose.ptr), C.c_uint64(n_sld), C.c_void_p(d_fix_surf.ptr),
+                                        C.c_void_p(d_fix_pose.ptr), C.c_uint64(n_fix), C.c_void_p(d_pairs_sld.ptr), C.c_uint64(cap_sld), C.byref(nb),
+                                        C.c_void_p(d_pairs_fix.ptr), C.c_uint64(cap_fix), C.byref(nu)))
+        return int(nb.value), int(nu.value)
+
     def match(self, q_surf, q_pose, t_surf, t_pose, same_set, want_knn=False):
         """host convenience -> pairs[PAIR] (and the raw k-NN table if want_knn)"""
         nq, nt = len(q_surf), len(t_surf)
