@@ -649,6 +649,9 @@ __global__ void __launch_bounds__(256) k_lin_imu(WinParams wp, const Piece *piec
 // Every source costs two dependent loads (descriptor, value): four (heavy pairs: sixteen) sources are in flight per thread, added in list order
 // (bitwise reproducible, no atomics).
 constexpr int kGG = 7;
+constexpr int kLightSets = 2;  // block pairs per group of a light gather workgroup
+constexpr int kHeavyIlp = 8;   // sources in flight per thread of a heavy pair (with the next eight descriptors: 48 VGPRs -
+                               // above 64 only ONE 1008-thread workgroup fits a CU; 16 in flight measured no faster)
 struct GatherArgs {
   const Src *src;
   const uint32_t *src_begin;
@@ -668,8 +671,8 @@ struct GatherArgs {
 // one (they only depend on the list position), so a list of n sources is 1 + n / ILP round trips deep instead of 2 n / ILP:
 // the kernel lasts as long as its longest heavy pair (350 sources, 50 per group), 39.7 us of 41 by per-workgroup stamps.
 template <int STRIDE, int ILP>
-__device__ __forceinline__ double gather_pair_sum(const Src *src, const double *partial, uint32_t s0, uint32_t eend, int u, int v) {
-  double acc = 0.0;
+__device__ __forceinline__ double gather_pair_sum(const Src *src, const double *partial, uint32_t s0, uint32_t eend, int u, int v,
+                                                  double acc = 0.0) {
   const uint2 *src2 = (const uint2 *)src;
   static_assert(sizeof(Src) == 8, "descriptor = two words");
   uint2 d[ILP];
@@ -709,10 +712,10 @@ __device__ __forceinline__ double gather_pair_sum(const Src *src, const double *
   return acc;
 }
 
-__global__ void __launch_bounds__(144 * kGG) k_gather(GatherArgs a) {
+__global__ void __launch_bounds__(144 * kGG, 8) k_gather(GatherArgs a) {
   __shared__ double sred[kGG * 144];
   const int tid = threadIdx.x;
-  const uint32_t nlight = (a.npairs + kGG - 1) / kGG;
+  const uint32_t nlight = (a.npairs + kGG * kLightSets - 1) / (kGG * kLightSets);
   // dispatch order: g and the cost first (few workgroups with the longest chains of dependent loads), then the heavy pairs,
   // then the rest - dispatched last they only started when everything else had drained (47 us instead of ~30)
   const uint32_t nfirst = (uint32_t)a.ns + 1u;
@@ -721,54 +724,102 @@ __global__ void __launch_bounds__(144 * kGG) k_gather(GatherArgs a) {
     const bool heavy = blk < a.nheavy;
     const int grp = tid / 144, e = tid % 144;
     const int u = e / 12, v = e % 12;
-    const uint32_t pid = heavy ? a.heavy[blk] : (blk - a.nheavy) * kGG + grp;
-    double acc = 0.0;
-    bool write = false;
-    if (pid < a.npairs) {
-      const uint32_t b = a.src_begin[pid], eend = a.src_begin[pid + 1];
-      if (heavy) {
-        acc = gather_pair_sum<kGG, 16>(a.src, a.partial, b + grp, eend, u, v);  // (up to 350 sources: 50 per group)
-      } else if (eend - b <= kHeavySrc) {
-        acc = gather_pair_sum<1, 4>(a.src, a.partial, b, eend, u, v);
-        write = true;
-      }
-    }
+    // A heavy workgroup sums ONE pair; a light one kLightSets x kGG pairs, kLightSets per group, whose first four sources
+    // are requested together: a light pair is a chain of three round trips (list bounds, descriptors, values) and hardly any
+    // arithmetic, and with one pair per group the 1 162 light workgroups of C4 queued for the 512 workgroup slots of the chip
+    // behind the heavy ones (median start 21 us into a 35 us kernel, per-workgroup stamps).  Two sets: with four the kernel
+    // needs more than 64 VGPRs (or spills) and loses the second workgroup per CU.
+    uint32_t pidk[kLightSets];
+    double acck[kLightSets];
+    bool writek[kLightSets];
     if (heavy) {
+      const uint32_t pid = a.heavy[blk];
+      const uint32_t b = a.src_begin[pid], eend = a.src_begin[pid + 1];
+      double acc = gather_pair_sum<kGG, kHeavyIlp>(a.src, a.partial, b + grp, eend, u, v);  // (up to 350 sources: 50 per group)
       sred[grp * 144 + e] = acc;
       __syncthreads();
       if (grp == 0) {
         acc = 0.0;
         for (int q = 0; q < kGG; ++q) acc += sred[q * 144 + e];
-        write = true;
+      }
+#pragma unroll
+      for (int k = 0; k < kLightSets; ++k) pidk[k] = pid, acck[k] = acc, writek[k] = k == 0 && grp == 0;
+    } else {
+      const uint32_t set0 = (blk - a.nheavy) * kLightSets;
+      uint32_t bk[kLightSets], ek[kLightSets];
+#pragma unroll
+      for (int k = 0; k < kLightSets; ++k) {
+        pidk[k] = (set0 + k) * kGG + grp;
+        const bool valid = pidk[k] < a.npairs;
+        bk[k] = valid ? a.src_begin[pidk[k]] : 0u, ek[k] = valid ? a.src_begin[pidk[k] + 1] : 0u;
+        writek[k] = valid && ek[k] - bk[k] <= kHeavySrc;  // (a pair with more sources is summed by its heavy workgroup)
+      }
+      const uint2 *src2 = (const uint2 *)a.src;
+      uint2 d[kLightSets][4];
+#pragma unroll
+      for (int k = 0; k < kLightSets; ++k)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) d[k][q] = src2[(writek[k] && bk[k] + q < ek[k]) ? bk[k] + q : 0u];
+      double val[kLightSets][4];
+      bool ok[kLightSets][4];
+#pragma unroll
+      for (int k = 0; k < kLightSets; ++k)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const uint32_t part_off = d[k][q].x, sp = d[k][q].y & 0xFFu, sq_ = (d[k][q].y >> 8) & 0xFFu, sw = (d[k][q].y >> 16) & 0xFFu, sT = d[k][q].y >> 24;
+          ok[k][q] = writek[k] && bk[k] + q < ek[k] && (uint32_t)u < sw && (uint32_t)v < sw;
+          uint32_t r = sp * sw + u, c = sq_ * sw + v;
+          if (r > c) {
+            const uint32_t t = r;
+            r = c, c = t;
+          }
+          val[k][q] = a.partial[ok[k][q] ? part_off + tri_index(r, c, sT) : 0u];
+        }
+#pragma unroll
+      for (int k = 0; k < kLightSets; ++k) {
+        double acc = 0.0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (ok[k][q]) acc += val[k][q];
+        if (writek[k] && ek[k] - bk[k] > 4u) acc = gather_pair_sum<1, 8>(a.src, a.partial, bk[k] + 4u, ek[k], u, v, acc);  // (same order: onto acc)
+        acck[k] = acc;
       }
     }
-    // invert pid = I*ns - I(I-1)/2 + (J-I)
     const int ns = a.ns;
-    int I = 0, J = 0;
-    if (write) {
-      const float f = 2.f * ns + 1.f;
-      I = (int)((f - sqrtf(fmaxf(f * f - 8.f * (float)pid, 0.f))) * 0.5f);
-      I = max(0, min(I, ns - 1));
-      while (I > 0 && (uint32_t)(I * ns - I * (I - 1) / 2) > pid) --I;
-      while ((uint32_t)((I + 1) * ns - (I + 1) * I / 2) <= pid) ++I;
-      J = I + (int)(pid - (uint32_t)(I * ns - I * (I - 1) / 2));
-    }
     const int n = 12 * ns;
-    const int gi = I * 12 + u, gj = J * 12 + v;
-    if (a.fix_first && ((gi >= 3 && gi < 6) || (gj >= 3 && gj < 6))) acc = 0.0;  // SubsetParameterization(12,{3,4,5})
-    if (a.packed) {
-      if (write) a.H[(size_t)pid * 144 + e] = acc;
-      return;
-    }
-    // block (I, J) row by row, and its transpose as block (J, I) ALSO row by row: the transposed entries come through
-    // LDS (written straight from the registers the mirror block is 144 scattered 8-byte stores per pair, 9 MB of them)
     const int slot = heavy ? 0 : grp;
-    __syncthreads();  // (heavy: every group has read the partial sums)
-    if (write) sred[slot * 144 + e] = acc;
-    __syncthreads();
-    if (!write) return;
-    a.H[(size_t)gi * n + gj] = acc;
-    a.H[(size_t)(J * 12 + u) * n + I * 12 + v] = sred[slot * 144 + v * 12 + u];
+#pragma unroll
+    for (int k = 0; k < kLightSets; ++k) {
+      if (heavy && k > 0) break;
+      const uint32_t pid = pidk[k];
+      const bool write = writek[k];
+      double acc = acck[k];
+      // invert pid = I*ns - I(I-1)/2 + (J-I)
+      int I = 0, J = 0;
+      if (write) {
+        const float f = 2.f * ns + 1.f;
+        I = (int)((f - sqrtf(fmaxf(f * f - 8.f * (float)pid, 0.f))) * 0.5f);
+        I = max(0, min(I, ns - 1));
+        while (I > 0 && (uint32_t)(I * ns - I * (I - 1) / 2) > pid) --I;
+        while ((uint32_t)((I + 1) * ns - (I + 1) * I / 2) <= pid) ++I;
+        J = I + (int)(pid - (uint32_t)(I * ns - I * (I - 1) / 2));
+      }
+      const int gi = I * 12 + u, gj = J * 12 + v;
+      if (a.fix_first && ((gi >= 3 && gi < 6) || (gj >= 3 && gj < 6))) acc = 0.0;  // SubsetParameterization(12,{3,4,5})
+      if (a.packed) {
+        if (write) a.H[(size_t)pid * 144 + e] = acc;
+        continue;
+      }
+      // block (I, J) row by row, and its transpose as block (J, I) ALSO row by row: the transposed entries come through
+      // LDS (written straight from the registers the mirror block is 144 scattered 8-byte stores per pair, 9 MB of them)
+      __syncthreads();  // (heavy: every group has read the partial sums; light: the previous set's mirror has been read)
+      if (write) sred[slot * 144 + e] = acc;
+      __syncthreads();
+      if (write) {
+        a.H[(size_t)gi * n + gj] = acc;
+        a.H[(size_t)(J * 12 + u) * n + I * 12 + v] = sred[slot * 144 + v * 12 + u];
+      }
+    }
     return;
   }
   blk -= a.nheavy + nlight;
@@ -808,6 +859,13 @@ __global__ void __launch_bounds__(144 * kGG) k_gather(GatherArgs a) {
   {  // cost: deterministic sum of the cost slots of all partials
     constexpr int NT = 144 * kGG;
     double acc = 0.0;
+    // (the piece descriptors of the next trip are requested behind this trip's values, as in gather_pair_sum)
+    uint32_t off[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const uint32_t p = (uint32_t)tid + q * NT;
+      off[q] = a.pieces[p < a.npieces ? p : 0u].part_off;
+    }
     for (uint32_t p0 = tid; p0 < a.npieces; p0 += 4 * NT) {
       double val[4];
       bool ok[4];
@@ -817,7 +875,12 @@ __global__ void __launch_bounds__(144 * kGG) k_gather(GatherArgs a) {
         ok[q] = p < a.npieces;
         const uint32_t pp = ok[q] ? p : p0;
         const uint32_t T = pp < a.nb_pieces ? 25 : (pp < a.nb_pieces + a.nu_pieces ? 13 : 37);
-        val[q] = a.partial[a.pieces[pp].part_off + T * (T + 1) / 2 - 1];
+        val[q] = a.partial[ok[q] ? off[q] + T * (T + 1) / 2 - 1 : 0u];
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const uint32_t p = p0 + 4 * NT + q * NT;
+        off[q] = a.pieces[p < a.npieces ? p : 0u].part_off;
       }
 #pragma unroll
       for (int q = 0; q < 4; ++q)
@@ -1910,7 +1973,7 @@ int enqueue_linearize(wc_ctx *ctx, wc_window_state *W, const double *d_x, int ma
   ga.packed = packed ? 1 : 0;
   ga.nheavy = W->nheavy, ga.npairs = W->npairs, ga.npieces = W->npiece_b + W->npiece_u + W->npiece_i;
   ga.nb_pieces = W->npiece_b, ga.nu_pieces = W->npiece_u, ga.ns = W->ns, ga.fix_first = W->wp.fix_first;
-  k_gather<<<W->nheavy + (W->npairs + kGG - 1) / kGG + W->ns + 1, 144 * kGG, 0, st>>>(ga);
+  k_gather<<<W->nheavy + (W->npairs + kGG * kLightSets - 1) / (kGG * kLightSets) + W->ns + 1, 144 * kGG, 0, st>>>(ga);
   WC_HIP(ctx, hipGetLastError());
   if (packed) {
     WC_TRY(do_allreduce(ctx, W, red, red_count));  // the ONE collective of a linearisation
