@@ -1768,8 +1768,6 @@ extern "C" int wc_window_build(wc_ctx *ctx, const wc_surfel *d_sld_surf, const w
   }
   W->ni = (uint32_t)irecs.size();
   WC_TRY(upload(ctx, W->irec, irecs));
-  WC_TRY(collect_family(ctx, job_b, segs_b));
-  WC_TRY(collect_family(ctx, job_u, segs_u));
 
   auto t_b = tnow();
   // pieces + the CSR source lists of the gather
@@ -1793,9 +1791,30 @@ extern "C" int wc_window_build(wc_ctx *ctx, const wc_surfel *d_sld_surf, const w
     for (size_t i = first; i < pieces.size(); ++i) out[pos[kPiece - pieces[i].count]++] = pieces[i];
     std::copy(out.begin(), out.end(), pieces.begin() + first);
   };
+  // the binary family's pieces are cut, ordered and counted into the source lists while the device still works on the
+  // unary family's records
+  WC_TRY(collect_family(ctx, job_b, segs_b));
   cut(segs_b, 25, true);
   W->npiece_b = (uint32_t)pieces.size();
   by_size(0);
+  const uint32_t npairs = (uint32_t)(ns * (ns + 1) / 2);
+  W->npairs = npairs;
+  src_begin.assign(npairs + 1, 0), gsrc_begin.assign(ns + 1, 0);
+  auto pair_id = [&](int I, int J) { return (uint32_t)(I * ns - I * (I - 1) / 2 + (J - I)); };
+  for (size_t pi = 0; pi < pieces.size(); ++pi) {  // (binary pieces only: blocks_of below, first branch)
+    const Piece &pc = pieces[pi];
+    const int sp1l = pc.key & 0xFFFF, sp2l = pc.key >> 16;
+    int blk[4] = {sp1l, sp1l + 1, 0, 0}, nblk = 2;
+    if (sp2l > sp1l + 1)
+      blk[2] = sp2l, blk[3] = sp2l + 1, nblk = 4;
+    else if (sp2l == sp1l + 1)
+      blk[2] = sp2l + 1, nblk = 3;
+    for (int p = 0; p < nblk; ++p) {
+      gsrc_begin[blk[p] + 1]++;
+      for (int q = p; q < nblk; ++q) src_begin[pair_id(blk[p], blk[q]) + 1]++;
+    }
+  }
+  WC_TRY(collect_family(ctx, job_u, segs_u));
   cut(segs_u, 13, true);
   W->npiece_u = (uint32_t)pieces.size() - W->npiece_b;
   by_size(W->npiece_b);
@@ -1814,9 +1833,6 @@ extern "C" int wc_window_build(wc_ctx *ctx, const wc_surfel *d_sld_surf, const w
               hist[fam][3], kPiece, hist[fam][4], hist[fam][5]);
   }
 
-  const uint32_t npairs = (uint32_t)(ns * (ns + 1) / 2);
-  W->npairs = npairs;
-  auto pair_id = [&](int I, int J) { return (uint32_t)(I * ns - I * (I - 1) / 2 + (J - I)); };
   // CSR source lists in two passes over the pieces (count, fill): sources of a pair / block in piece order
   auto blocks_of = [&](size_t pi, int blk[4], uint8_t &w, uint8_t &T) -> int {
     const Piece &pc = pieces[pi];
@@ -1842,8 +1858,7 @@ extern "C" int wc_window_build(wc_ctx *ctx, const wc_surfel *d_sld_surf, const w
     blk[0] = (int)pc.key, blk[1] = (int)pc.key + 1, blk[2] = (int)pc.key + 2;
     return ((int)pc.key + 1 == ns - 1) ? 2 : 3;
   };
-  src_begin.assign(npairs + 1, 0), gsrc_begin.assign(ns + 1, 0);
-  for (size_t pi = 0; pi < pieces.size(); ++pi) {
+  for (size_t pi = W->npiece_b; pi < pieces.size(); ++pi) {  // (the binary pieces have been counted above)
     int blk[4];
     uint8_t w, T;
     const int nblk = blocks_of(pi, blk, w, T);
