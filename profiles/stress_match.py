@@ -23,5 +23,13 @@ for scans, patches, fixed, seed in ((20, 2500, 2500, 7), (10, 8000, 20000, 8), (
     got_f = ctx.match(w["surf"], w["pose"], w["fix_surf"], w["fix_pose"], False)
     assert np.array_equal(got_s, ref_s) and np.array_equal(got_f, ref_f), (scans, patches, fixed)
     assert (np.diff(d2, axis=1) >= 0).all() and (idx[:, 0] == np.arange(len(idx))).all()
+    # both searches side by side (wc_match_pair: helper context + host thread), three times in a row
+    from wildcat_slam_amd import records as R
+    ns, nf = len(w["surf"]), len(w["fix_surf"])
+    d_s, d_p, d_fs, d_fp = ctx.to_device(w["surf"]), ctx.to_device(w["pose"]), ctx.to_device(w["fix_surf"]), ctx.to_device(w["fix_pose"])
+    d_b, d_u = ctx.alloc(8 * ns), ctx.alloc(8 * ns)
+    for _ in range(3):
+        nb, nu = ctx.match_pair_device(d_s, d_p, ns, d_fs, d_fp, nf, d_b, ns, d_u, ns)
+        assert np.array_equal(d_b.download(R.PAIR, nb), ref_s) and np.array_equal(d_u.download(R.PAIR, nu), ref_f), (scans, patches, fixed, "pair")
     print(f"{scans:3d} sweeps x {patches:6d} patches, {fixed:6d} fixed: {len(ref_s):7d} + {len(ref_f):7d} pairs identical (oracle {t_cpu:.1f} s)")
 print("all windows agree with the oracle")
