@@ -1442,9 +1442,54 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // of it, one workgroup per 32 columns.  Inside the chunk: y_k = Linv_kk^T z_k (32x32 products + column sums), then
 // z_j -= L[block k rows][j] . y_k for the chunk's j left of block k; L and Linv of a step do not depend on y and are
 // loaded before the step's first barrier.
+// candidate point and the scalars the trust-region logic needs:
+//   xc = x - y * scale ; mail[2] = model_cost_change = (y.gs + sum D y^2) / 2 ; mail[3] = |step| ; mail[4] = |x|
+//   mail[0] = cost, mail[1] = max |g| of the linearisation this step starts from (what k_post_reduce writes after a
+//   stand-alone linearisation; inside the LM loop that launch is saved)
+// Runs at the end of the LAST back-substitution launch (the workgroup that has just finished y; a launch of its own was 5 - 6 us
+// of every LM iteration).
+struct StepArgs {
+  const double *x, *scale, *g, *diag, *lin_cost;
+  double *xc, *mail, *host_xc;
+  int on;
+};
+__device__ __forceinline__ void lm_step(const double *x, const double *y, const double *scale, const double *g, const double *diag, int n,
+                                        double *xc, double *mail, double *host_xc, const double *lin_cost) {
+  __shared__ double s0[1024], s1[1024], s2[1024], s3[1024];
+  const int tid = threadIdx.x;
+  double mc = 0.0, sn = 0.0, xn = 0.0, gm = 0.0;
+  for (int i = tid; i < n; i += 1024) {
+    const double d = -y[i] * scale[i];
+    xc[i] = x[i] + d;
+    host_xc[i] = x[i] + d;  // pinned host staging: an accepted candidate is host state (|x|, best point) without a copy node
+    mc += y[i] * (g[i] * scale[i]) + diag[i] * y[i] * y[i];
+    sn += d * d;
+    xn += x[i] * x[i];
+    gm = fmax(gm, fabs(g[i]));
+  }
+  s0[tid] = mc, s1[tid] = sn, s2[tid] = xn, s3[tid] = gm;
+  __syncthreads();
+  for (int st = 512; st > 0; st >>= 1) {
+    if (tid < st) {
+      s0[tid] += s0[tid + st];
+      s1[tid] += s1[tid + st];
+      s2[tid] += s2[tid + st];
+      s3[tid] = fmax(s3[tid], s3[tid + st]);
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    mail[2] = 0.5 * s0[0];
+    mail[3] = sqrt(s1[0]);
+    mail[4] = sqrt(s2[0]);
+    mail[0] = lin_cost[0];
+    mail[1] = s3[0];
+  }
+}
+
 constexpr int kBackChunk = 8;
 __global__ void __launch_bounds__(1024) k_chol_back_chunk(const double *A, int ld, int n, const double *Linv, const double *zsrc,
-                                                         double *y, int lo_blk, int hi_blk) {
+                                                         double *y, int lo_blk, int hi_blk, StepArgs S) {
   __shared__ double sz[kBackChunk * kNB];
   __shared__ double sP[kNB][kNB + 1];
   __shared__ double sQ[4][kBackChunk * kNB];
@@ -1499,6 +1544,10 @@ __global__ void __launch_bounds__(1024) k_chol_back_chunk(const double *A, int l
     for (int rr = 0; rr < 8; ++rr) lv[rr] = lv_n[rr];
   }
   if (tid < span && base + tid < n) y[base + tid] = sz[tid];
+  if (S.on) {  // the last chunk: y is complete (the other chunks' parts were written by the launches before this one)
+    __syncthreads();
+    lm_step(S.x, y, S.scale, S.g, S.diag, n, S.xc, S.mail, S.host_xc, S.lin_cost);
+  }
 }
 
 // y[j] = zsrc[j] - sum_{r in chunk} L[r][j] y[r] for the 32 columns j of this workgroup (all left of the chunk):
@@ -1528,45 +1577,6 @@ __global__ void __launch_bounds__(1024) k_chol_back_gemv(const double *A, int ld
     for (int q = 0; q < kNB; ++q) t += sP[q][tid];
     const int jj = blockIdx.x * kNB + tid;
     y[jj] = zsrc[jj] - t;
-  }
-}
-
-// candidate point and the scalars the trust-region logic needs:
-//   xc = x - y * scale ; mail[2] = model_cost_change = (y.gs + sum D y^2) / 2 ; mail[3] = |step| ; mail[4] = |x|
-//   mail[0] = cost, mail[1] = max |g| of the linearisation this step starts from (what k_post_reduce writes after a
-//   stand-alone linearisation; inside the LM loop that launch is saved)
-__global__ void __launch_bounds__(1024) k_step(const double *x, const double *y, const double *scale, const double *g,
-                                              const double *diag, int n, double *xc, double *mail, double *host_xc,
-                                              const double *lin_cost) {
-  __shared__ double s0[1024], s1[1024], s2[1024], s3[1024];
-  const int tid = threadIdx.x;
-  double mc = 0.0, sn = 0.0, xn = 0.0, gm = 0.0;
-  for (int i = tid; i < n; i += 1024) {
-    const double d = -y[i] * scale[i];
-    xc[i] = x[i] + d;
-    host_xc[i] = x[i] + d;  // pinned host staging: an accepted candidate is host state (|x|, best point) without a copy node
-    mc += y[i] * (g[i] * scale[i]) + diag[i] * y[i] * y[i];
-    sn += d * d;
-    xn += x[i] * x[i];
-    gm = fmax(gm, fabs(g[i]));
-  }
-  s0[tid] = mc, s1[tid] = sn, s2[tid] = xn, s3[tid] = gm;
-  __syncthreads();
-  for (int st = 512; st > 0; st >>= 1) {
-    if (tid < st) {
-      s0[tid] += s0[tid + st];
-      s1[tid] += s1[tid + st];
-      s2[tid] += s2[tid + st];
-      s3[tid] = fmax(s3[tid], s3[tid + st]);
-    }
-    __syncthreads();
-  }
-  if (tid == 0) {
-    mail[2] = 0.5 * s0[0];
-    mail[3] = sqrt(s1[0]);
-    mail[4] = sqrt(s2[0]);
-    mail[0] = lin_cost[0];
-    mail[1] = s3[0];
   }
 }
 
@@ -2004,7 +2014,7 @@ int enqueue_linearize(wc_ctx *ctx, wc_window_state *W, const double *d_x, int ma
     WC_TRY(do_allreduce(ctx, W, red, red_count));  // the ONE collective of a linearisation
     k_expand_pairs<<<W->npairs + 1, 144, 0, st>>>(red, W->npairs, W->ns, W->np, lin_H(W), lin_g(W));
   }
-  // (inside the LM loop the next k_step forms cost / max |g| of this linearisation itself: post = false)
+  // (inside the LM loop the next lm_step forms cost / max |g| of this linearisation itself: post = false)
   if (post) k_post_reduce<<<1, 1024, 0, st>>>(lin_g(W), lin_cost(W), W->n, (double *)W->mail.p, mail_slot);
   WC_HIP(ctx, hipGetLastError());
   return WC_OK;
@@ -2160,13 +2170,13 @@ extern "C" int wc_window_solve(wc_ctx *ctx, double *h_x_inout, wc_solve_summary 
         const double *zsrc = Lmat + (size_t)n * ld;
         for (int hi = (n + kNB - 1) / kNB; hi > 0;) {
           const int lo = std::max(0, hi - kBackChunk);
-          k_chol_back_chunk<<<1, 1024, 0, st>>>(Lmat, ld, n, (const double *)W->Linv.p, zsrc, y, lo, hi);
+          const StepArgs sa{x, scale, g, diag, lin_cost(W), xc, mail, h_stage_dev, lo == 0 ? 1 : 0};
+          k_chol_back_chunk<<<1, 1024, 0, st>>>(Lmat, ld, n, (const double *)W->Linv.p, zsrc, y, lo, hi, sa);
           if (lo > 0) k_chol_back_gemv<<<lo, 1024, 0, st>>>(Lmat, ld, n, zsrc, y, lo, hi);
           zsrc = y;
           hi = lo;
         }
       }
-      k_step<<<1, 1024, 0, st>>>(x, y, scale, g, diag, n, xc, mail, h_stage_dev, lin_cost(W));
       WC_TRY(enqueue_evaluate(ctx, W, xc, nullptr, 5, h_mail_dev));
       WC_HIP(ctx, hipGetLastError());
       // (one GPU: k_sum_blocks has stored the mailbox to pinned host memory itself; with an all-reduce behind it, copy)
@@ -2198,7 +2208,7 @@ extern "C" int wc_window_solve(wc_ctx *ctx, double *h_x_inout, wc_solve_summary 
         first_recorded = true;
         summary->first_step[0] = step_norm;
         if (h_first_step)
-          for (int i = 0; i < n; ++i) h_first_step[i] = ctx->h_mail[64 + i] - cur[i];  // (the candidate k_step staged)
+          for (int i = 0; i < n; ++i) h_first_step[i] = ctx->h_mail[64 + i] - cur[i];  // (the candidate lm_step staged)
       }
       if (step_norm <= 1e-8 * (x_norm + 1e-8)) {  // ParameterToleranceReached
         summary->termination = 0;
@@ -2214,7 +2224,7 @@ extern "C" int wc_window_solve(wc_ctx *ctx, double *h_x_inout, wc_solve_summary 
         std::swap(W->x, W->xc);
         x = (double *)W->x.p, xc = (double *)W->xc.p;
         WC_TRY(enqueue_linearize(ctx, W, x, 0, /*post=*/false));
-        // the accepted point = the candidate k_step staged in pinned memory (|x| and the best point are host state)
+        // the accepted point = the candidate lm_step staged in pinned memory (|x| and the best point are host state)
         std::memcpy(cur.data(), ctx->h_mail + 64, (size_t)n * 8);
         x_norm = 0.0;
         for (int i = 0; i < n; ++i) x_norm += cur[i] * cur[i];
@@ -2232,7 +2242,7 @@ extern "C" int wc_window_solve(wc_ctx *ctx, double *h_x_inout, wc_solve_summary 
       }
     }
   }
-  if (lin_pending) {  // the last accepted point's linearisation is still in flight (and no k_step follows it)
+  if (lin_pending) {  // the last accepted point's linearisation is still in flight (and no lm_step follows it)
     k_post_reduce<<<1, 1024, 0, st>>>(lin_g(W), lin_cost(W), W->n, mail, 0);
     WC_HIP(ctx, hipMemcpyAsync(ctx->h_mail, mail, 2 * 8, hipMemcpyDeviceToHost, st));
     WC_HIP(ctx, hipStreamSynchronize(st));
