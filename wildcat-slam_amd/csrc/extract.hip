@@ -1844,6 +1844,7 @@ int run_pipeline_fast(wc_ctx *ctx, const wc_points &pts, double t_lo, double t_h
   uint32_t tr = 2048;  // hash slots = root blocks: one per four points
   while ((uint64_t)tr * 4 < n) tr *= 2;
   A.tr_mask = tr - 1;
+  A.static_map = n <= 2000000ull ? 1u : 0u;  // (up to ~2 M points the node wavefronts are one round)
   const unsigned tiles = (unsigned)((n + kFxTile - 1) / kFxTile);
   A.rec_tiles = tiles;
   A.spill_per = (uint32_t)std::max<uint64_t>(1024, n / 32);
