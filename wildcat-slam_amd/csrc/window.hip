@@ -264,27 +264,39 @@ __device__ __forceinline__ M3 Ffun(Q4 L, Q4 E, Q4 R, const M3 &Jr) {  // cost_fu
 }
 
 // IMU factor: 12 residuals; if rows != null also the 12 x 36 Jacobian, written as rows[row * stride + col]
-// (cost_functor.h:272-355)
+// (cost_functor.h:272-355).  ROLE < 0: all of it.  ROLE 0 .. 3: the share of one of k_lin_imu's four wavefronts - the factor is
+// a single thread's chain of dependent fp64 operations (20.7 k clocks), and different code only runs side by side in
+// different wavefronts: 0 = residuals + the identity groups, 1 = F1 and its term of the group (0, 0), 2 = F2 (handed back in
+// `late`: its term is added to the group after a barrier, the same two operations in the same order), 3 = the groups (3, 0) and
+// (3, 9).  Every value is formed by the expressions of the full version.
+struct ImuLate {
+  M3 F2;
+  double w2[3];
+};
+template <int ROLE>
 __device__ void eval_imu(const WinParams &wp, const ImuRec &f, const double *x, const double *times, double res[12],
-                         double *rows, int stride) {
+                         double *rows, int stride, ImuLate *late = nullptr) {
+  constexpr bool kAll = ROLE < 0;
   const double dt = wp.dt;
   const StateCorr c1 = state_corr(x, times, f.sp1, f.mode, f.i1.t);
   const StateCorr c2 = state_corr(x, times, f.sp1, f.mode, f.i2.t);
   const StateCorr c3 = state_corr(x, times, f.sp1, f.mode, f.i3.t);
   const Q4 R1{f.i1.quat[0], f.i1.quat[1], f.i1.quat[2], f.i1.quat[3]};
   const Q4 R2{f.i2.quat[0], f.i2.quat[1], f.i2.quat[2], f.i2.quat[3]};
-  const V3 p1 = ld3(f.i1.pos), p2 = ld3(f.i2.pos), p3 = ld3(f.i3.pos);
   const ExpJr X1 = exp_jr(c1.r), X2 = exp_jr(c2.r);
   const Q4 E1R1 = qmul(X1.E, R1), E2R2 = qmul(X2.E, R2);
-  const V3 gyr_est = log_jr_inv(qmul(qconj(E1R1), E2R2), nullptr) / dt;
-  const V3 acc_est = (((c3.t + p3) + (c1.t + p1)) - 2 * (c2.t + p2)) / (dt * dt);
-  const V3 grav = mk3(wp.grav[0], wp.grav[1], wp.grav[2]);
-  const V3 r0 = wp.w_gyr * (((ld3(f.i1.gyr) + ld3(f.i2.gyr)) / 2 - gyr_est) - c1.bg);
-  const V3 r1 = wp.w_acc * ((qrot(E1R1, ld3(f.i1.acc) - c1.ba) - acc_est) + grav);
-  const V3 r2 = wp.w_bg * (c1.bg - c2.bg);
-  const V3 r3 = wp.w_ba * (c1.ba - c2.ba);
-  res[0] = r0.x, res[1] = r0.y, res[2] = r0.z, res[3] = r1.x, res[4] = r1.y, res[5] = r1.z;
-  res[6] = r2.x, res[7] = r2.y, res[8] = r2.z, res[9] = r3.x, res[10] = r3.y, res[11] = r3.z;
+  if (kAll || ROLE == 0) {
+    const V3 p1 = ld3(f.i1.pos), p2 = ld3(f.i2.pos), p3 = ld3(f.i3.pos);
+    const V3 gyr_est = log_jr_inv(qmul(qconj(E1R1), E2R2), nullptr) / dt;
+    const V3 acc_est = (((c3.t + p3) + (c1.t + p1)) - 2 * (c2.t + p2)) / (dt * dt);
+    const V3 grav = mk3(wp.grav[0], wp.grav[1], wp.grav[2]);
+    const V3 r0 = wp.w_gyr * (((ld3(f.i1.gyr) + ld3(f.i2.gyr)) / 2 - gyr_est) - c1.bg);
+    const V3 r1 = wp.w_acc * ((qrot(E1R1, ld3(f.i1.acc) - c1.ba) - acc_est) + grav);
+    const V3 r2 = wp.w_bg * (c1.bg - c2.bg);
+    const V3 r3 = wp.w_ba * (c1.ba - c2.ba);
+    res[0] = r0.x, res[1] = r0.y, res[2] = r0.z, res[3] = r1.x, res[4] = r1.y, res[5] = r1.z;
+    res[6] = r2.x, res[7] = r2.y, res[8] = r2.z, res[9] = r3.x, res[10] = r3.y, res[11] = r3.z;
+  }
   if (!rows) return;
   // tau Jacobians (cost_functor.h:301-321) scattered with (1 - f), f onto the bracketing blocks (:402-444).  The caller has
   // zeroed the rows; every 3x3 group is summed in registers over the states that contribute to it (in the reference's
@@ -309,14 +321,22 @@ __device__ void eval_imu(const WinParams &wp, const ImuRec &f, const double *x, 
       }
   };
   const M3 I = m3_identity();
-  const M3 F1 = Ffun(qconj(R1), X1.E, E2R2, X1.Jr), F2 = Ffun(qconj(E1R1), X2.E, R2, X2.Jr);
-  group(0, 0, F1, wp.w_gyr * (1 / dt), &F2, -wp.w_gyr * (1 / dt), nullptr, 0.0);
-  group(0, 6, I, -wp.w_gyr, wp.quirks ? &I : nullptr, -wp.w_gyr, nullptr, 0.0);  // Q3 (cost_functor.h:314)
-  group(3, 0, (qmat(X1.E) * hat(qrot(R1, ld3(f.i1.acc) - c1.ba))) * X1.Jr, -wp.w_acc, nullptr, 0.0, nullptr, 0.0);
-  group(3, 3, I, -wp.w_acc * (1 / dt / dt), &I, wp.w_acc * (2 / dt / dt), &I, -wp.w_acc * (1 / dt / dt));
-  group(3, 9, qmat(E1R1), -wp.w_acc, nullptr, 0.0, nullptr, 0.0);
-  group(6, 6, I, wp.w_bg, &I, -wp.w_bg, nullptr, 0.0);
-  group(9, 9, I, wp.w_ba, &I, -wp.w_ba, nullptr, 0.0);
+  if (kAll) {
+    const M3 F1 = Ffun(qconj(R1), X1.E, E2R2, X1.Jr), F2 = Ffun(qconj(E1R1), X2.E, R2, X2.Jr);
+    group(0, 0, F1, wp.w_gyr * (1 / dt), &F2, -wp.w_gyr * (1 / dt), nullptr, 0.0);
+  } else if (ROLE == 1) {  // acc = va * w1[b]; wavefront 2 adds vb * w2[b] behind the barrier
+    const M3 F1 = Ffun(qconj(R1), X1.E, E2R2, X1.Jr);
+    group(0, 0, F1, wp.w_gyr * (1 / dt), nullptr, 0.0, nullptr, 0.0);
+  } else if (ROLE == 2) {
+    late->F2 = Ffun(qconj(E1R1), X2.E, R2, X2.Jr);
+    for (int b = 0; b < 3; ++b) late->w2[b] = w2[b];
+  }
+  if (kAll || ROLE == 0) group(0, 6, I, -wp.w_gyr, wp.quirks ? &I : nullptr, -wp.w_gyr, nullptr, 0.0);  // Q3 (cost_functor.h:314)
+  if (kAll || ROLE == 3) group(3, 0, (qmat(X1.E) * hat(qrot(R1, ld3(f.i1.acc) - c1.ba))) * X1.Jr, -wp.w_acc, nullptr, 0.0, nullptr, 0.0);
+  if (kAll || ROLE == 0) group(3, 3, I, -wp.w_acc * (1 / dt / dt), &I, wp.w_acc * (2 / dt / dt), &I, -wp.w_acc * (1 / dt / dt));
+  if (kAll || ROLE == 3) group(3, 9, qmat(E1R1), -wp.w_acc, nullptr, 0.0, nullptr, 0.0);
+  if (kAll || ROLE == 0) group(6, 6, I, wp.w_bg, &I, -wp.w_bg, nullptr, 0.0);
+  if (kAll || ROLE == 0) group(9, 9, I, wp.w_ba, &I, -wp.w_ba, nullptr, 0.0);
 }
 
 __device__ __forceinline__ uint32_t tri_index(uint32_t i, uint32_t j, uint32_t T) {  // i <= j, row-major upper
@@ -597,15 +617,40 @@ __global__ void __launch_bounds__(256) k_lin_imu(WinParams wp, const Piece *piec
   const int tid = threadIdx.x;
   for (int e = tid; e < (int)pc.count * 12 * T; e += 256) sV[e] = 0.0;  // eval_imu stores the non-zero 3x3 groups only
   __syncthreads();
-  if (tid < (int)pc.count) {
-    double res[12];
-    eval_imu(wp, recs[pc.begin + tid], x, times, res, &sV[tid * 12 * T], T);
-    double c = 0;
-    for (int r = 0; r < 12; ++r) {
-      sV[(tid * 12 + r) * T + 36] = res[r];
-      c += res[r] * res[r];
+  {  // the factor's evaluation, one share per wavefront (see eval_imu); lane = factor
+    const int wv = tid >> 6, ln = tid & 63;
+    const bool act = ln < (int)pc.count;
+    ImuLate late;
+    if (act) {
+      const ImuRec &f = recs[pc.begin + ln];
+      double *rows = &sV[ln * 12 * T];
+      double res[12];
+      if (wv == 0) {
+        eval_imu<0>(wp, f, x, times, res, rows, T);
+        double c = 0;
+        for (int r = 0; r < 12; ++r) {
+          rows[r * T + 36] = res[r];
+          c += res[r] * res[r];
+        }
+        sC[ln] = 0.5 * c;  // TrivialLoss
+      } else if (wv == 1) {
+        eval_imu<1>(wp, f, x, times, res, rows, T);
+      } else if (wv == 2) {
+        eval_imu<2>(wp, f, x, times, res, rows, T, &late);
+      } else {
+        eval_imu<3>(wp, f, x, times, res, rows, T);
+      }
     }
-    sC[tid] = 0.5 * c;  // TrivialLoss
+    __syncthreads();
+    if (act && wv == 2) {  // group (0, 0): + (sb F2[i][j]) w2[b] onto wavefront 1's va w1[b]
+      double *rows = &sV[ln * 12 * T];
+      const double sb = -wp.w_gyr * (1 / wp.dt);
+      for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+          const double vb = sb * late.F2.m[i][j];
+          for (int b = 0; b < 3; ++b) rows[i * T + b * 12 + j] += vb * late.w2[b];
+        }
+    }
   }
   __syncthreads();
   // Gram matrix of the piece's rows.  Every entry is summed over the rows in row order (the fp64 matrix cores do this
@@ -962,7 +1007,7 @@ __global__ void __launch_bounds__(256) k_eval_imu(WinParams wp, const ImuRec *re
   double c = 0.0;
   if (k < n) {
     double res[12];
-    eval_imu(wp, recs[k], x, times, res, nullptr, 0);
+    eval_imu<-1>(wp, recs[k], x, times, res, nullptr, 0);
     for (int r = 0; r < 12; ++r) {
       c += res[r] * res[r];
       if (residuals) residuals[(size_t)k * 12 + r] = res[r];
