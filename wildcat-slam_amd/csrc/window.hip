@@ -266,9 +266,8 @@ __device__ __forceinline__ M3 Ffun(Q4 L, Q4 E, Q4 R, const M3 &Jr) {  // cost_fu
 // IMU factor: 12 residuals; if rows != null also the 12 x 36 Jacobian, written as rows[row * stride + col]
 // (cost_functor.h:272-355).  ROLE < 0: all of it.  ROLE 0 .. 3: the share of one of k_lin_imu's four wavefronts - the factor is
 // a single thread's chain of dependent fp64 operations (20.7 k clocks), and different code only runs side by side in
-// different wavefronts: 0 = residuals + the identity groups, 1 = F1 and its term of the group (0, 0), 2 = F2 (handed back in
-// `late`: its term is added to the group after a barrier, the same two operations in the same order), 3 = the groups (3, 0) and
-// (3, 9).  Every value is formed by the expressions of the full version.
+// different wavefronts: 0 = residuals, 1 = F1 and its term of the group (0, 0), 2 = F2 (handed back in `late`: its term is added
+// to the group after a barrier, the same two operations in the same order), 3 = every other group.  Every value is formed by the expressions of the full version.
 struct ImuLate {
   M3 F2;
   double w2[3];
@@ -331,12 +330,12 @@ __device__ void eval_imu(const WinParams &wp, const ImuRec &f, const double *x, 
     late->F2 = Ffun(qconj(E1R1), X2.E, R2, X2.Jr);
     for (int b = 0; b < 3; ++b) late->w2[b] = w2[b];
   }
-  if (kAll || ROLE == 0) group(0, 6, I, -wp.w_gyr, wp.quirks ? &I : nullptr, -wp.w_gyr, nullptr, 0.0);  // Q3 (cost_functor.h:314)
+  if (kAll || ROLE == 3) group(0, 6, I, -wp.w_gyr, wp.quirks ? &I : nullptr, -wp.w_gyr, nullptr, 0.0);  // Q3 (cost_functor.h:314)
   if (kAll || ROLE == 3) group(3, 0, (qmat(X1.E) * hat(qrot(R1, ld3(f.i1.acc) - c1.ba))) * X1.Jr, -wp.w_acc, nullptr, 0.0, nullptr, 0.0);
-  if (kAll || ROLE == 0) group(3, 3, I, -wp.w_acc * (1 / dt / dt), &I, wp.w_acc * (2 / dt / dt), &I, -wp.w_acc * (1 / dt / dt));
+  if (kAll || ROLE == 3) group(3, 3, I, -wp.w_acc * (1 / dt / dt), &I, wp.w_acc * (2 / dt / dt), &I, -wp.w_acc * (1 / dt / dt));
   if (kAll || ROLE == 3) group(3, 9, qmat(E1R1), -wp.w_acc, nullptr, 0.0, nullptr, 0.0);
-  if (kAll || ROLE == 0) group(6, 6, I, wp.w_bg, &I, -wp.w_bg, nullptr, 0.0);
-  if (kAll || ROLE == 0) group(9, 9, I, wp.w_ba, &I, -wp.w_ba, nullptr, 0.0);
+  if (kAll || ROLE == 3) group(6, 6, I, wp.w_bg, &I, -wp.w_bg, nullptr, 0.0);
+  if (kAll || ROLE == 3) group(9, 9, I, wp.w_ba, &I, -wp.w_ba, nullptr, 0.0);
 }
 
 __device__ __forceinline__ uint32_t tri_index(uint32_t i, uint32_t j, uint32_t T) {  // i <= j, row-major upper
@@ -659,7 +658,10 @@ __global__ void __launch_bounds__(256) k_lin_imu(WinParams wp, const Piece *piec
   // (a skipped term is + 0.0 * 0.0; see ImuGramOrder): 3.4 of 12 rows on average, and the entries are handed out in the
   // order of their support, so that the lanes of a wavefront skip the same groups.
   constexpr int NOUT = T * (T + 1) / 2;
-  for (int e0 = tid; e0 < NOUT; e0 += 256) {
+  for (int round = 0; round < (NOUT + 255) / 256; ++round) {
+    // (the table is ordered by support = by cost: the 64-entry groups go to the wavefronts in a snake, light and heavy alternating)
+    const int wv = tid >> 6, e0 = ((round & 1) ? 4 * round + (3 - wv) : 4 * round + wv) * 64 + (tid & 63);
+    if (e0 >= NOUT) continue;
     const uint32_t ent = kImuGram.ent[e0];
     const int i = (int)(ent & 63u), j = (int)((ent >> 6) & 63u);
     const uint32_t m = ent >> 12;
