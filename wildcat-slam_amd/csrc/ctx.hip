@@ -101,6 +101,8 @@ extern "C" void wc_ctx_destroy(wc_ctx *ctx) {
     ctx->aux = nullptr;
   }
   if (ctx->ev_aux) (void)hipEventDestroy(ctx->ev_aux);
+  for (hipEvent_t e : ctx->ev_knn)
+    if (e) (void)hipEventDestroy(e);
   (void)wc_comm_rccl_destroy(ctx);
   wc_window_free(ctx);
   wc_buf *all[] = {&ctx->b_keys[0],      &ctx->b_keys[1],     &ctx->b_vals[0],     &ctx->b_vals[1],      &ctx->b_sorttmp,

@@ -542,9 +542,27 @@ extern "C" int wc_match(wc_ctx *ctx, const wc_surfel *d_q_surf, const wc_pose *d
     gated_shard = (uint32_t *)ctx->b_route[3].p;
   }
   const uint32_t nq_mine = q_end - q_begin;
-  // order of the two halves of a candidate (see k_knn_gate): from the k-th distances of the previous call of this kind on this context
-  bool nf = ctx->match_nf[same_set ? 1 : 0];
+  // order of the two halves of a candidate (see k_knn_gate).  First guess: from the k-th distances of the previous call of this
+  // kind on this context.  That rule is wrong for windows whose 6-D distances are dominated by the normals' noise (the facade's
+  // room stream: the k-th neighbour lies within 1.5 cells, yet the normal half first is 1.6 x faster), so the device time of
+  // the search is measured and, once both orders have been tried, the faster one is used; the other is tried again every 16th
+  // call.  The lists do not depend on the order.
+  const int kind = same_set ? 1 : 0;
+  bool nf = ctx->match_nf[kind];
+  {
+    const double t0 = ctx->match_ns_per_q[kind][0], t1 = ctx->match_ns_per_q[kind][1];
+    const uint32_t call = ctx->match_calls[kind]++;
+    if (t0 > 0.0 && t1 > 0.0) {
+      nf = t1 < t0;
+      if ((call & 15u) == 15u) nf = !nf;
+    } else if (call > 0 && (t0 > 0.0 || t1 > 0.0)) {
+      nf = !(t1 > 0.0);  // the order not yet tried
+    }
+  }
   if (const char *o = getenv("WC_KNN_ORDER")) nf = o[0] == 'n';  // "normal" / "centre": tests pin each instantiation
+  for (hipEvent_t &e : ctx->ev_knn)
+    if (!e) WC_HIP(ctx, hipEventCreate(&e));
+  WC_HIP(ctx, hipEventRecord(ctx->ev_knn[0], st));
   WC_TRY(wc_ensure(ctx, ctx->b_match_stat, 16 * 16 * 8));
   double *kth_stat = (double *)ctx->b_match_stat.p;
   WC_HIP(ctx, hipMemsetAsync(kth_stat, 0, 16 * 16 * 8, st));
@@ -577,6 +595,7 @@ extern "C" int wc_match(wc_ctx *ctx, const wc_surfel *d_q_surf, const wc_pose *d
   }
 #undef WC_KNN_LAUNCH
   WC_HIP(ctx, hipGetLastError());
+  WC_HIP(ctx, hipEventRecord(ctx->ev_knn[1], st));
   if (sharded) {
     const int w = ctx->comm.world;
     std::vector<uint64_t> bytes((size_t)w);
@@ -632,6 +651,12 @@ extern "C" int wc_match(wc_ctx *ctx, const wc_surfel *d_q_surf, const wc_pose *d
     double sum = 0.0, cnt = 0.0;
     for (int s = 0; s < 16; ++s) sum += h_stat[16 * s], cnt += h_stat[16 * s + 1];
     if (cnt > 0.0) ctx->match_nf[same_set ? 1 : 0] = sum / cnt > 2.25;  // mean k-th distance beyond 1.5 cells: the centre half prunes little
+    float ms = 0.f;
+    if (nq_mine >= 4096 && hipEventElapsedTime(&ms, ctx->ev_knn[0], ctx->ev_knn[1]) == hipSuccess && ms > 0.f) {
+      double &t = ctx->match_ns_per_q[kind][nf ? 1 : 0];
+      const double now = (double)ms * 1e6 / (double)nq_mine;
+      t = t > 0.0 ? 0.5 * (t + now) : now;
+    }
   }
 #ifdef WC_PROF_KNN
   {
