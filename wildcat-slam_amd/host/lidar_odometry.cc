@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 
 #include "../csrc/dmath.h"
@@ -372,6 +373,16 @@ void LidarOdometry::AddLidarScan(const pcl::PointCloud<hilti_ros::Point>::Ptr &m
   double sweep_endtime = point_times_.front() + config_.sweep_duration;
   if (point_times_.back() < sweep_endtime || imu_buff_.empty() || imu_buff_.back().timestamp < sweep_endtime) return;
 
+  // (WC_ODOM_DEBUG=1: wall time of the stages of a completed sweep on stderr)
+  static const bool dbg_t = getenv("WC_ODOM_DEBUG") != nullptr;
+  auto t_prev = std::chrono::steady_clock::now();
+  double t_stage[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  auto lap = [&](int i) {
+    if (!dbg_t) return;
+    const auto now = std::chrono::steady_clock::now();
+    t_stage[i] += std::chrono::duration<double, std::milli>(now - t_prev).count();
+    t_prev = now;
+  };
   // 2. integrate IMU poses in windows (:512-513)
   PredictImuStatesAndSampleStates(sweep_endtime);
   sweep_endtime = samples_.back().timestamp;
@@ -390,6 +401,7 @@ void LidarOdometry::AddLidarScan(const pcl::PointCloud<hilti_ros::Point>::Ptr &m
   UploadImuStates();
   WC_CALL(wc_undistort_sweep(ctx_, (const char *)d_pts_[pts_cur_] + pts_begin_ * sizeof(hilti_ros::Point), n_sweep, d_imu_, imu_states_.size(), d_sweep_));
   DropBufferedPoints(n_sweep);
+  lap(0);
 
   // 4. ---- hot path: extract surfels, attach poses (:523-527) ----
   const size_t max_new = (3 * n_sweep) / 20 + 1;
@@ -405,6 +417,7 @@ void LidarOdometry::AddLidarScan(const pcl::PointCloud<hilti_ros::Point>::Ptr &m
     n_surfels_ += n_new;
   }
   UpdateSurfelPosesOnDevice();
+  lap(1);
 
   for (int iter = 0; iter < config_.outer_iter_num_max; ++iter) {
     const size_t n_sld = n_surfels_ - sld_begin_;
@@ -414,6 +427,7 @@ void LidarOdometry::AddLidarScan(const pcl::PointCloud<hilti_ros::Point>::Ptr &m
     WC_CALL(wc_match_pair(ctx_, d_surf_ + sld_begin_, d_pose_ + sld_begin_, n_sld, d_fix_surf_ + fix_start_, d_fix_pose_ + fix_start_, n_fix,
                           d_pairs_sld_, cap_surfels_, &n_b, d_pairs_fix_, cap_surfels_, &n_u));
     last_corr_[0] = n_b, last_corr_[1] = n_u;
+    lap(2);
     // 5. solve poses in windows (:541-562)
     std::vector<double> ts, x;
     for (const Sample &s : samples_) {
@@ -424,13 +438,20 @@ void LidarOdometry::AddLidarScan(const pcl::PointCloud<hilti_ros::Point>::Ptr &m
     const bool fix_first = first_sample_known_ && samples_.front().timestamp == first_sample_time_;  // :556-560
     WC_CALL(wc_window_build(ctx_, d_surf_ + sld_begin_, d_pose_ + sld_begin_, d_pairs_sld_, n_b, d_fix_surf_ + fix_start_, d_fix_pose_ + fix_start_, d_pairs_fix_, n_u,
                             flat.data(), flat.size(), ts.data(), ts.size(), samples_.back().grav, fix_first ? 1 : 0));
+    lap(3);
     WC_CALL(wc_window_solve(ctx_, x.data(), &last_summary_, nullptr));
+    lap(4);
     for (size_t i = 0; i < samples_.size(); ++i) std::memcpy(samples_[i].cor, &x[12 * i], 96);
     // state update (:564-566)
     UpdateImuPoses();
     UpdateSurfelPosesOnDevice();
     UpdateSamplePoses();
+    lap(5);
   }
   ShrinkToFit();  // :574-580
+  lap(6);
+  if (dbg_t)
+    fprintf(stderr, "[odom] sweep %d: predict + undistort %.2f, extract + poses %.2f, match %.2f, build %.2f, solve %.2f (%d iterations), update %.2f, shrink %.2f ms\n",
+            (int)sweep_id_, t_stage[0], t_stage[1], t_stage[2], t_stage[3], t_stage[4], (int)last_summary_.iterations, t_stage[5], t_stage[6]);
   ++sweep_id_;
 }
