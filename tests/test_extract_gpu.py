@@ -150,6 +150,17 @@ def test_c2_full_size_properties(gpu, oracle):
     print(res["fast"])
 
 
+def test_c5_cloud_full_size_on_one_gpu(gpu, oracle):
+    """BASELINE config C5's cloud (9 999 872 points) on ONE GPU, both arithmetic modes against the oracle: the sizes at which
+    k_fx_nodes hands its parents out sub-list after sub-list (more than 2 M points) and a time bucket of the slot order holds
+    more than 64 surfels (k_slot_emit's LDS ranking)."""
+    pts, info = synth.g2_lattice(39062, m=32)
+    assert len(pts) == 9_999_872
+    res, st = _run(gpu, oracle, pts, expect_fast=True)
+    assert st.surfels == 8 * 39062
+    print(res["fast"])
+
+
 def test_dense_voxels_overflow_fast_sort_and_fall_back(gpu, oracle):
     # 3 root voxels with ~9 000 points each: a bucket of the fast (bucket) sort overflows and the general radix path
     # must take over transparently; huge roots also exercise the multi-chunk streaming of k_roots
