@@ -233,7 +233,10 @@ void shrink_to_fit(wco_odom *o) {
     o->fix.push_front(o->sld.front());  // oldest first, each to the FRONT: the fixed window ends up newest-first (Q11)
     o->sld.pop_front();
   }
-  // cc:247-249 compares back() with itself: the fixed window is never trimmed (Q11)
+  // cc:247-249 compares back() with itself: the fixed window is never trimmed (Q11).  With the quirks switched off (not a
+  // reference mode: the intended behaviour the facade's reference_quirks = false implements) it is cut from its old end.
+  if (!o->P.reference_quirks)
+    while (!o->fix.empty() && o->fix.front().s.t - o->fix.back().s.t > o->fixed_window_duration) o->fix.pop_back();
 }
 
 }  // namespace
@@ -360,6 +363,23 @@ extern "C" void wco_odom_add_scan(wco_odom *o, const void *points48, uint64_t n)
   ++o->sweep_id;
 }
 
+extern "C" void wco_odom_set_quirks(wco_odom *o, int on) { o->P.reference_quirks = on ? 1 : 0; }
+// the window's states for a re-synchronised comparison: 23 doubles per sample state (timestamp, cor[12], grav[3], quat[4],
+// pos[3]) and the IMU states; counts[2] = their numbers (nothing is written beyond the capacities)
+extern "C" void wco_odom_export_state(const wco_odom *o, double *samples23, uint64_t cap_s, wc_imu_state *imu, uint64_t cap_i,
+                                      uint64_t counts[2]) {
+  counts[0] = o->samples.size(), counts[1] = o->imu_states.size();
+  for (uint64_t i = 0; i < o->samples.size() && i < cap_s; ++i) {
+    const Sample &s = o->samples[i];
+    double *p = samples23 + 23 * i;
+    p[0] = s.timestamp;
+    std::memcpy(p + 1, s.cor, 96);
+    std::memcpy(p + 13, s.grav, 24);
+    std::memcpy(p + 16, s.quat, 32);
+    std::memcpy(p + 20, s.pos, 24);
+  }
+  for (uint64_t i = 0; i < o->imu_states.size() && i < cap_i; ++i) imu[i] = o->imu_states[i];
+}
 extern "C" int wco_odom_sweeps(const wco_odom *o) { return o->sweep_id; }
 extern "C" uint64_t wco_odom_num_samples(const wco_odom *o) { return o->samples.size(); }
 // out[15] = t, pos[3], quat[4] (w,x,y,z), bg[3], ba[3], spare

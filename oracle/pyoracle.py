@@ -259,6 +259,17 @@ class Odometry:
         err = lib().wco_odom_error(self._h)
         assert err == 0, f"a reference CHECK would have fired (oracle/odometry.cc:{err})"
 
+    def set_quirks(self, on):
+        lib().wco_odom_set_quirks(self._h, C.c_int(1 if on else 0))
+
+    def export_state(self):
+        """(samples (ns, 23): timestamp, cor[12], grav[3], quat[4], pos[3]; imu states as R.IMU_STATE records)"""
+        cnt = (C.c_uint64 * 2)()
+        lib().wco_odom_export_state(self._h, None, C.c_uint64(0), None, C.c_uint64(0), cnt)
+        s, imu = np.zeros((max(cnt[0], 1), 23)), np.zeros(max(cnt[1], 1), dtype=R.IMU_STATE)
+        lib().wco_odom_export_state(self._h, R.ptr(s), C.c_uint64(cnt[0]), R.ptr(imu), C.c_uint64(cnt[1]), cnt)
+        return s[: cnt[0]], imu[: cnt[1]]
+
     def sweeps(self):
         return int(lib().wco_odom_sweeps(self._h))
 

@@ -107,6 +107,9 @@ void wco_odom_destroy(wco_odom *o);
 int wco_odom_error(const wco_odom *o); /* non-zero: a CHECK of the reference would have aborted */
 void wco_odom_add_imu(wco_odom *o, double t, const double acc[3], const double gyr[3]);  /* AddImuData cc:607-611 */
 void wco_odom_add_scan(wco_odom *o, const void *points48, uint64_t n);                  /* AddLidarScan cc:487-605 */
+void wco_odom_set_quirks(wco_odom *o, int on); /* 0: Q1/Q3 Jacobians accumulated, fixed window trimmed (not a reference mode) */
+void wco_odom_export_state(const wco_odom *o, double *samples23, uint64_t cap_s, wc_imu_state *imu, uint64_t cap_i,
+                           uint64_t counts[2]);
 int wco_odom_sweeps(const wco_odom *o);
 uint64_t wco_odom_num_samples(const wco_odom *o);
 int wco_odom_sample(const wco_odom *o, uint64_t i, double *out15);

@@ -47,6 +47,24 @@ def test_g1_room_multires(gpu, oracle):
     print(res, list(st.nodes_plane))
 
 
+def test_sparse_firing_order_sweep_stays_on_the_default_path(gpu, oracle):
+    # what the host facade hands over every 0.5 s: ~75 k points of a room in firing order, nearly every point of a 1024-point tile
+    # in a cell of its own.  Three quarters of the tile's partial sums overflow its 256-cell LDS hash into the spill pool; round 2
+    # sized that pool at n / 32 per bank, so every such sweep silently fell back to the exact path (and the facade never ran the
+    # kernels the bench measures).  The sweep must be completed by the default path on a FRESH context, first call.
+    from wildcat_slam_amd import lib
+
+    msgs, _, _ = synth.raw_stream(1.0, pts_per_s=150_000, t_start=1000.0)
+    ctx = lib.Context(0)
+    try:
+        for k in (0, 5):
+            pts = synth.concat_points(*msgs[k : k + 5])
+            res, st = helpers.check_fast_and_exact(ctx, oracle, pts, expect_fast=True)
+            assert res["fast"]["n"] > 300 and ctx.extract_path_info()["fallbacks"] == 0
+    finally:
+        ctx.close()
+
+
 def test_g1_firing_order_full_size(gpu, oracle):
     # the bench's second extraction entry: a 1 M-point sweep in firing order (five revolutions of the room: every node holds
     # several temporal clusters, the busiest voxels have long record lists, octree layer 2 is in use) - counts and ids equal

@@ -62,7 +62,8 @@ struct wc_ctx {
     // the layer-2 launch and roots were queued for it after all
     bool fx_active = false;      // this call runs on the fast (integer-moment) path
     bool fx_dirty = false;       // the fast path's tables may hold garbage (an aborted sweep): memset before the next use
-    uint32_t fx_last_flags = 0, fx_fallbacks = 0;
+    uint32_t fx_last_flags = 0, fx_fallbacks = 0, fx_last_why = 0;
+    bool fx_spill_full = false;  // the spill pool of the fast path overflowed once: sized for the worst case from then on
     bool fx_long_lists = false;  // the last fast sweep walked long record lists: k_fx_merge runs before k_fx_nodes
     uint32_t fx_backoff = 0, fx_skip_calls = 0;  // sweeps that go straight to the exact path after fall-backs (exponential)
     bool fx_ctrl_ready = false;  // the fast path's two control blocks are initialised

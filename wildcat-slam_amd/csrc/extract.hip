@@ -1847,7 +1847,12 @@ int run_pipeline_fast(wc_ctx *ctx, const wc_points &pts, double t_lo, double t_h
   A.static_map = n <= 2000000ull ? 1u : 0u;  // (up to ~2 M points the node wavefronts are one round)
   const unsigned tiles = (unsigned)((n + kFxTile - 1) / kFxTile);
   A.rec_tiles = tiles;
-  A.spill_per = (uint32_t)std::max<uint64_t>(1024, n / 32);
+  // spill pool (partials the tile's 256-cell LDS hash could not take): eight banks by tile index.  A tile spills at most one
+  // record per point, so ceil(tiles / 8) x 1024 records per bank can never overflow - used for sweeps up to 2 M points (a sparse
+  // sweep in firing order, e.g. 75 k points of a 40 m room, puts three quarters of its points there) and, sticky, on any context
+  // whose pool has overflowed once; larger clouds start with n / 32 per bank
+  const uint64_t spill_full = ((uint64_t)tiles + 7) / 8 * kFxTile;
+  A.spill_per = (uint32_t)((n <= 2000000ull || ctx->ex.fx_spill_full) ? spill_full : std::max<uint64_t>(1024, n / 32));
   A.rec_cap = tiles * (uint32_t)kFxRecTile + 8u * A.spill_per;
   const uint64_t total_slots = (n * (uint64_t)(P.max_layer + 1)) / (uint64_t)P.cluster_min_points + 1;
   uint32_t bin_cap = 64;
@@ -2235,6 +2240,10 @@ extern "C" int wc_extract_surfels_finish(wc_ctx *ctx, uint64_t *h_n_out) {
       // a decision too close to its threshold, a table at capacity, a node spanning > 16 time bins, ...: the tables are put
       // back to zero and the sweep is repeated on the exact path (below)
       ++ctx->ex.fx_fallbacks;
+      ctx->ex.fx_last_why = 0;
+      for (int i = 0; i < 24; ++i)
+        if (ctx->h_status[32 + i]) ctx->ex.fx_last_why |= 1u << i;
+      if (ctx->ex.fx_last_why & (1u << 4)) ctx->ex.fx_spill_full = true;  // the spill pool overflowed: full size from now on
       // exponential back-off: a sweep the default path cannot finish (a node spanning more than 16 time bins, more roots than
       // blocks, ...) is usually followed by more of its kind; a gate that merely fell inside the noise band is not
       ctx->ex.fx_backoff = std::min(32u, std::max(1u, ctx->ex.fx_backoff * 2u));
@@ -2347,6 +2356,7 @@ extern "C" int wc_debug_status(wc_ctx *ctx, uint32_t *h_out64) {
   h_out64[60] = ctx->ex.fx_fallbacks;  // sweeps the fast path handed to the exact path so far
   h_out64[61] = ctx->ex.fx_active ? 1u : 0u;  // the last sweep was completed by the fast (integer-moment) path
   h_out64[62] = ctx->ex.fx_last_flags;
+  h_out64[63] = ctx->ex.fx_last_why;  // bit i: call site i of fx_fallback() fired in the last sweep that fell back
 #ifdef WC_PROF_ROOTS
   // average the per-root section timers into words [16, 24), number of timed roots in word 24
   const size_t nslots = ctx->ex.pts.n / (size_t)(ctx->P.min_points + 1) + 1;

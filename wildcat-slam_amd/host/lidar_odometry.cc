@@ -71,18 +71,52 @@ void LidarOdometry::Fatal(const char *what, int rc) const {
 
 LidarOdometry::LidarOdometry() : LidarOdometry(0) {}
 
+// the library parameters that follow LioConfig: solver iterations, the quirk Jacobians (Q1 / Q3) and the extraction arithmetic
+static void ParamsFromConfig(const LioConfig &c, wc_params *P) {
+  wc_params_default(P);
+  P->max_iterations = c.inner_iter_num_max;
+  P->reference_quirks = c.reference_quirks ? 1 : 0;
+  P->exact_sums = c.exact_sums ? 1 : 0;
+  P->imu_dt = 1 / c.imu_rate;
+}
+
 LidarOdometry::LidarOdometry(int device) {
   wc_params P;
-  wc_params_default(&P);
-  P.max_iterations = config_.inner_iter_num_max;
-  P.reference_quirks = config_.reference_quirks ? 1 : 0;
-  P.exact_sums = config_.reference_quirks ? 1 : 0;  // the reference's summation order too: sample states match the CPU path to 1e-6
+  ParamsFromConfig(config_, &P);
   int rc = wc_ctx_create(&P, device, &ctx_);
   if (rc != WC_OK) {
     std::fprintf(stderr, "[wildcat] FATAL: no MI355X context (rc=%d); there is no CPU fallback\n", rc);
     std::abort();
   }
   stq(ext_quat_, quat_from_matrix(config_.ext_rotation));
+}
+
+// config() hands out a mutable LioConfig; the values the library holds a copy of (wc_params) and the extrinsic quaternion are
+// re-derived here.  Call after changing config() and before the next AddLidarScan.
+void LidarOdometry::ApplyConfig() {
+  wc_params P;
+  ParamsFromConfig(config_, &P);
+  WC_CALL(wc_ctx_set_params(ctx_, &P));
+  stq(ext_quat_, quat_from_matrix(config_.ext_rotation));
+}
+
+// test hook (not in the reference): overwrite the window's sample states and IMU states with another run's (23 doubles per
+// sample state: timestamp, cor[12], grav[3], quat[4], pos[3]) and re-attach the surfel poses, so that every sweep of a
+// comparison starts from the same states.  The counts must equal the facade's own.
+bool LidarOdometry::ImportState(const double *samples23, size_t ns, const wc_imu_state *imu, size_t n_imu) {
+  if (ns != samples_.size() || n_imu != imu_states_.size()) return false;
+  for (size_t i = 0; i < ns; ++i) {
+    const double *p = samples23 + 23 * i;
+    Sample &s = samples_[i];
+    if (s.timestamp != p[0]) return false;
+    std::memcpy(s.cor, p + 1, 96);
+    std::memcpy(s.grav, p + 13, 24);
+    std::memcpy(s.quat, p + 16, 32);
+    std::memcpy(s.pos, p + 20, 24);
+  }
+  for (size_t i = 0; i < n_imu; ++i) imu_states_[i] = imu[i];
+  UpdateSurfelPosesOnDevice();
+  return true;
 }
 
 LidarOdometry::~LidarOdometry() {
@@ -409,6 +443,11 @@ void LidarOdometry::AddLidarScan(const pcl::PointCloud<hilti_ros::Point>::Ptr &m
   wc_points desc{d_sweep_, (const char *)d_sweep_ + WC_HILTI_POINT_TIME_OFFSET, WC_HILTI_POINT_BYTES, WC_HILTI_POINT_BYTES, n_sweep};
   uint64_t n_new = 0;
   WC_CALL(wc_extract_surfels(ctx_, &desc, sweep_t0, sweep_t1, d_surf_ + n_surfels_, nullptr, max_new, &n_new));
+  {
+    uint32_t st[64];
+    WC_CALL(wc_debug_status(ctx_, st));
+    ++(st[61] ? sweeps_fast_ : sweeps_exact_);  // which arithmetic completed this sweep (read-out for tests / logs)
+  }
   if (n_new) {
     WC_CALL(wc_memset(ctx_, d_inbody_ + n_surfels_, 0, n_new));
     std::vector<double> fresh(n_new);  // only the timestamps travel (8 of 144 bytes per surfel)

@@ -51,7 +51,13 @@ class LidarOdometry {
   const std::deque<double> &fixed_window_times() const { return fix_times_; }
   const wc_solve_summary &last_solve() const { return last_summary_; }
   uint64_t last_correspondences(int which) const { return last_corr_[which]; }
+  // sweeps whose extraction was completed by the default (integer-moment) path / by the reference-order path (configured, or
+  // fallen back to because a gate lay inside the reference's own rounding noise)
+  int sweeps_fast_path() const { return sweeps_fast_; }
+  int sweeps_exact_path() const { return sweeps_exact_; }
   LioConfig &config() { return config_; }
+  void ApplyConfig();  // push config() changes (quirks, extraction arithmetic, iteration cap, extrinsics) into the device context
+  bool ImportState(const double *samples23, size_t ns, const wc_imu_state *imu, size_t n_imu);  // test hook, see .cc
 
  private:
   struct Sample {  // reference SampleState (surfel.h:9-23)
@@ -89,7 +95,7 @@ class LidarOdometry {
   double ext_quat_[4];
   bool init_sld_win_ = false, sync_done_ = false, first_sample_known_ = false;
   double first_sample_time_ = 0.0;
-  int sweep_id_ = 0;
+  int sweep_id_ = 0, sweeps_fast_ = 0, sweeps_exact_ = 0;
   // sliding window in HBM, time ordered: d_surf_[sld_begin_ .. n_surfels_) ([0, sld_begin_) has moved to the fixed window and
   // is dropped at the next reallocation).  Fixed window: d_fix_surf_[fix_start_ .. fix_end_), NEWEST first - the array is
   // filled from the back because the reference push_front()s (lidar_odometry.cc:243-246, Q11)

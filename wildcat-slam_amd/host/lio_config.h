@@ -29,4 +29,7 @@ struct LioConfig {
   // not in the reference: true = reproduce its quirks (Q1/Q3 Jacobians, Q11 fixed window never trimmed); false = the
   // mathematically intended behaviour (accumulated Jacobians, fixed window trimmed to fixed_window_duration)
   bool reference_quirks = true;
+  // not in the reference: surfel-extraction arithmetic (wc_params.exact_sums).  false (default) = the order-independent integer
+  // moments every benchmark number is quoted on (ids / counts exact, geometry ~1e-9); true = every sum in the reference's order
+  bool exact_sums = false;
 };

@@ -54,13 +54,31 @@ void wc_odom_stats(void *h, double *stats) {
   stats[7] = o->last_solve().termination;
 }
 
+// out[2] = sweeps extracted by the default (integer-moment) arithmetic, sweeps extracted in the reference's summation order
+void wc_odom_extract_paths(void *h, int out[2]) {
+  out[0] = ((LidarOdometry *)h)->sweeps_fast_path();
+  out[1] = ((LidarOdometry *)h)->sweeps_exact_path();
+}
+
 // timestamps of the fixed window in its stored order (newest first, Q11); returns the window size
 uint64_t wc_odom_fixed_times(void *h, double *out, uint64_t cap) {
   const std::deque<double> &t = ((LidarOdometry *)h)->fixed_window_times();
   for (uint64_t i = 0; i < t.size() && i < cap; ++i) out[i] = t[i];
   return t.size();
 }
-void wc_odom_set_quirks(void *h, int on) { ((LidarOdometry *)h)->config().reference_quirks = on != 0; }
+// both setters re-derive the device context's parameters (Q1 / Q3 Jacobians, extraction arithmetic), not only the host flags
+void wc_odom_set_quirks(void *h, int on) {
+  ((LidarOdometry *)h)->config().reference_quirks = on != 0;
+  ((LidarOdometry *)h)->ApplyConfig();
+}
+void wc_odom_set_exact_sums(void *h, int on) {
+  ((LidarOdometry *)h)->config().exact_sums = on != 0;
+  ((LidarOdometry *)h)->ApplyConfig();
+}
+// test hook: start the next sweep from another run's states (LidarOdometry::ImportState); 0 = done, 1 = the counts differ
+int wc_odom_import_state(void *h, const double *samples23, uint64_t ns, const wc_imu_state *imu, uint64_t n_imu) {
+  return ((LidarOdometry *)h)->ImportState(samples23, ns, imu, n_imu) ? 0 : 1;
+}
 
 // ---- known-answer hooks for the host-side product code (the g++ instantiation of csrc/dmath.h, the facade's spline, the
 // resampler): the reference's own unit tests are run against these in tests/test_host_kat.py -------------------------------

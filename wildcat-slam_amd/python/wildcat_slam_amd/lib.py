@@ -224,7 +224,7 @@ class Context:
         long_lists=the last fast sweep had long record lists: the next one merges them first (k_fx_merge))"""
         w = (C.c_uint32 * 64)()
         self._ck(self.lib.wc_debug_status(self.h, w))
-        return dict(fast=bool(w[61]), fallbacks=int(w[60]), flags=int(w[62]), long_lists=bool(w[59]))
+        return dict(fast=bool(w[61]), fallbacks=int(w[60]), flags=int(w[62]), why=int(w[63]), long_lists=bool(w[59]))
 
     def extract_profile(self, enable=True):
         """True / 1: HIP events after every kernel group of the stage (each event costs ~5 us of stream time); 2: only the first
@@ -240,6 +240,7 @@ class Context:
         """host convenience: upload POINT array, extract, download -> (surfels, ids).  hint: True = the sweep's own time range,
         False = none (the library reads it back), (t_lo, t_hi) = explicit range"""
         n = len(points)
+        assert points.dtype.itemsize == 48, "POINT records are 48 bytes (np.concatenate packs the dtype: use synth.concat_points)"
         cap = cap or max(1024, (3 * n) // 20 + 1)
         d_pts = self.to_device(points) if n else self.alloc(48)
         d_out, d_ids = self.alloc(cap * 144), self.alloc(cap * 16)
@@ -478,6 +479,26 @@ class Odometry:
     def add_scan(self, points):
         assert points.dtype == R.POINT
         self.lib.wc_odom_add_scan(self.h, R.ptr(points), C.c_uint64(len(points)))
+
+    def extract_paths(self):
+        """(sweeps extracted by the default integer-moment path, sweeps extracted in the reference's summation order)"""
+        out = (C.c_int * 2)()
+        self.lib.wc_odom_extract_paths(self.h, out)
+        return out[0], out[1]
+
+    def set_quirks(self, on):
+        self.lib.wc_odom_set_quirks(self.h, C.c_int(1 if on else 0))
+
+    def set_exact_sums(self, on):
+        self.lib.wc_odom_set_exact_sums(self.h, C.c_int(1 if on else 0))
+
+    def import_state(self, samples23, imu):
+        """test hook: continue from another run's sample / IMU states (LidarOdometry::ImportState)"""
+        samples23 = np.ascontiguousarray(samples23, dtype=np.float64)
+        imu = np.ascontiguousarray(imu)
+        assert samples23.shape[1] == 23 and imu.dtype == R.IMU_STATE
+        rc = self.lib.wc_odom_import_state(self.h, R.ptr(samples23), C.c_uint64(len(samples23)), R.ptr(imu), C.c_uint64(len(imu)))
+        assert rc == 0, "import_state: the window's sample / IMU state counts differ"
 
     def sweeps(self):
         return int(self.lib.wc_odom_sweeps(self.h))
