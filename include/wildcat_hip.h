@@ -137,9 +137,23 @@ int wc_gather_surfels(wc_ctx *ctx, const wc_surfel *d_local, const wc_surfel_id 
 int wc_prefilter_points(wc_ctx *ctx, const void *d_pts_in, uint64_t n, const double ext_quat[4], const double ext_t[3],
                         double min_range, double max_range, const double blind_min[3], const double blind_max[3],
                         void *d_pts_out, uint64_t cap, uint64_t *h_n_out);
+/* The same loop including its CHECK(points_buff_.empty() || pt.time >= points_buff_.back().time) (:491), evaluated on the device
+ * for EVERY incoming point against the last point buffered at that moment: prev_time = stamp of the last buffered point before this
+ * message (-INFINITY: buffer empty).  *h_monotonic = 0 when the CHECK would have fired.  d_kept_times (may be NULL, capacity
+ * `cap`): the survivors' stamps, packed - the only thing a host-side window bookkeeping needs back. */
+int wc_prefilter_points_checked(wc_ctx *ctx, const void *d_pts_in, uint64_t n, const double ext_quat[4], const double ext_t[3],
+                                double min_range, double max_range, const double blind_min[3], const double blind_max[3],
+                                void *d_pts_out, uint64_t cap, uint64_t *h_n_out, double prev_time, double *d_kept_times,
+                                int *h_monotonic);
 /* Replaces UndistortSweep(sweep_in, imu_states, sweep_out) (src/odometry/lidar_odometry.cc:143-158).
  * WC_ERR_RANGE mirrors the CHECK at :149. */
 int wc_undistort_sweep(wc_ctx *ctx, const void *d_pts_in, uint64_t n, const wc_imu_state *d_imu, uint64_t n_imu, void *d_pts_out);
+/* The same, but the sweep leaves as the 20 bytes per point BuildSurfels reads (surfel_extraction.cc:317-324 copies x, y, z, time
+ * and nothing else): d_xyz_out = n x 3 floats, d_time_out = n doubles, i.e. the wc_points {d_xyz_out, d_time_out, 12, 8, n}.
+ * The undistorted 48-byte records are never written or read: 48 + 20 + 20 bytes of traffic per point up to and including the
+ * extraction's pass instead of 48 + 48 + 48. */
+int wc_undistort_sweep_packed(wc_ctx *ctx, const void *d_pts_in, uint64_t n, const wc_imu_state *d_imu, uint64_t n_imu, float *d_xyz_out,
+                              double *d_time_out);
 
 /* surfel pose update --------------------------------------------------------------------------------------------- */
 /* Replaces UpdateSurfelPoses(const std::deque<ImuState>&, std::deque<Surfel::Ptr>&) (src/odometry/lidar_odometry.cc:160-170)

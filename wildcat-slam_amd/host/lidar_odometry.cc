@@ -121,7 +121,7 @@ bool LidarOdometry::ImportState(const double *samples23, size_t ns, const wc_imu
 
 LidarOdometry::~LidarOdometry() {
   if (!ctx_) return;
-  void *bufs[] = {d_surf_, d_pose_, d_inbody_, d_pairs_sld_, d_pairs_fix_, d_imu_, d_sweep_, d_scan_raw_, d_pts_[0], d_pts_[1], d_fix_surf_, d_fix_pose_};
+  void *bufs[] = {d_surf_, d_pose_, d_inbody_, d_pairs_sld_, d_pairs_fix_, d_imu_, d_sweep_xyz_, d_sweep_t_, d_kept_t_, d_scan_raw_, d_pts_[0], d_pts_[1], d_fix_surf_, d_fix_pose_};
   for (void *b : bufs)
     if (b) wc_dev_free(ctx_, b);
   wc_ctx_destroy(ctx_);
@@ -213,19 +213,20 @@ void LidarOdometry::AppendScanOnDevice(const pcl::PointCloud<hilti_ros::Point> &
   }
   uint64_t kept = 0;
   char *dst = (char *)d_pts_[pts_cur_] + pts_end_ * sizeof(hilti_ros::Point);
-  WC_CALL(wc_prefilter_points(ctx_, d_scan_raw_, n, ext_quat_, config_.ext_translation, config_.min_range, config_.max_range, config_.blind_min,
-                              config_.blind_max, dst, cap_pts_[pts_cur_] - pts_end_, &kept));
-  std::vector<double> kt(kept);
-  WC_CALL(wc_d2h_strided(ctx_, kt.data(), dst + WC_HILTI_POINT_TIME_OFFSET, 8, sizeof(hilti_ros::Point), kept));
-  // CHECK(points_buff_.empty() || pt.time >= points_buff_.back().time) (:491): every incoming point, filtered or not, against
-  // the last BUFFERED point at that moment
-  double prev = point_times_.empty() ? -INFINITY : point_times_.back();
-  size_t k = 0;
-  for (const hilti_ros::Point &pt : msg) {
-    WC_CHECK(pt.time >= prev);
-    if (k < kept && kt[k] == pt.time) prev = pt.time, ++k;
+  if (n > cap_kept_t_) {
+    if (d_kept_t_) WC_CALL(wc_dev_free(ctx_, d_kept_t_));
+    cap_kept_t_ = n + n / 2;
+    WC_CALL(wc_dev_alloc(ctx_, cap_kept_t_ * sizeof(double), &d_kept_t_));
   }
-  WC_CHECK(k == kept);
+  // CHECK(points_buff_.empty() || pt.time >= points_buff_.back().time) (:491) runs on the device too: every incoming point,
+  // filtered or not, against the last BUFFERED point at that moment; the survivors' stamps come back packed
+  int monotonic = 1;
+  WC_CALL(wc_prefilter_points_checked(ctx_, d_scan_raw_, n, ext_quat_, config_.ext_translation, config_.min_range, config_.max_range,
+                                      config_.blind_min, config_.blind_max, dst, cap_pts_[pts_cur_] - pts_end_, &kept,
+                                      point_times_.empty() ? -INFINITY : point_times_.back(), (double *)d_kept_t_, &monotonic));
+  WC_CHECK(monotonic);
+  std::vector<double> kt(kept);
+  if (kept) WC_CALL(wc_d2h(ctx_, kt.data(), d_kept_t_, kept * sizeof(double)));
   point_times_.insert(point_times_.end(), kt.begin(), kt.end());
   pts_end_ += kept;
 }
@@ -425,22 +426,26 @@ void LidarOdometry::AddLidarScan(const pcl::PointCloud<hilti_ros::Point>::Ptr &m
   WC_CHECK(n_sweep > 0);
   const double sweep_t0 = point_times_.front(), sweep_t1 = point_times_[n_sweep - 1];
 
-  // 3. undistort sweep by IMU poses (:519-520) — wc_undistort_sweep replaces UndistortSweep :143-158; neither the raw nor
-  //    the undistorted sweep ever comes back to the host, extraction reads it where it lies
+  // 3. undistort sweep by IMU poses (:519-520) — wc_undistort_sweep_packed replaces UndistortSweep :143-158 and leaves the
+  //    sweep as the 20 bytes per point BuildSurfels reads (x, y, z, time: surfel_extraction.cc:317-324); neither the raw nor the
+  //    undistorted sweep ever comes back to the host, and the undistorted 48-byte records are never formed
   if (n_sweep > cap_sweep_) {
-    if (d_sweep_) WC_CALL(wc_dev_free(ctx_, d_sweep_));
+    if (d_sweep_xyz_) WC_CALL(wc_dev_free(ctx_, d_sweep_xyz_));
+    if (d_sweep_t_) WC_CALL(wc_dev_free(ctx_, d_sweep_t_));
     cap_sweep_ = n_sweep * 2;
-    WC_CALL(wc_dev_alloc(ctx_, cap_sweep_ * sizeof(hilti_ros::Point), &d_sweep_));
+    WC_CALL(wc_dev_alloc(ctx_, cap_sweep_ * 3 * sizeof(float), &d_sweep_xyz_));
+    WC_CALL(wc_dev_alloc(ctx_, cap_sweep_ * sizeof(double), &d_sweep_t_));
   }
   UploadImuStates();
-  WC_CALL(wc_undistort_sweep(ctx_, (const char *)d_pts_[pts_cur_] + pts_begin_ * sizeof(hilti_ros::Point), n_sweep, d_imu_, imu_states_.size(), d_sweep_));
+  WC_CALL(wc_undistort_sweep_packed(ctx_, (const char *)d_pts_[pts_cur_] + pts_begin_ * sizeof(hilti_ros::Point), n_sweep, d_imu_, imu_states_.size(),
+                                    (float *)d_sweep_xyz_, (double *)d_sweep_t_));
   DropBufferedPoints(n_sweep);
   lap(0);
 
   // 4. ---- hot path: extract surfels, attach poses (:523-527) ----
   const size_t max_new = (3 * n_sweep) / 20 + 1;
   EnsureSurfelCapacity(max_new);
-  wc_points desc{d_sweep_, (const char *)d_sweep_ + WC_HILTI_POINT_TIME_OFFSET, WC_HILTI_POINT_BYTES, WC_HILTI_POINT_BYTES, n_sweep};
+  wc_points desc{d_sweep_xyz_, d_sweep_t_, 3 * sizeof(float), sizeof(double), n_sweep};
   uint64_t n_new = 0;
   WC_CALL(wc_extract_surfels(ctx_, &desc, sweep_t0, sweep_t1, d_surf_ + n_surfels_, nullptr, max_new, &n_new));
   {

@@ -108,7 +108,9 @@ class LidarOdometry {
   uint8_t *d_inbody_ = nullptr;
   wc_pair *d_pairs_sld_ = nullptr, *d_pairs_fix_ = nullptr;
   wc_imu_state *d_imu_ = nullptr;
-  void *d_sweep_ = nullptr;
+  void *d_sweep_xyz_ = nullptr, *d_sweep_t_ = nullptr;  // the undistorted sweep, packed: 3 floats | 1 double per point
+  void *d_kept_t_ = nullptr;  // stamps of the points the pre-filter kept (scratch of AppendScanOnDevice)
+  size_t cap_kept_t_ = 0;
   size_t cap_surfels_ = 0, n_surfels_ = 0, sld_begin_ = 0, cap_imu_ = 0, cap_sweep_ = 0;
   std::deque<double> surfel_times_;  // host copy of the sliding window's surfel timestamps (window bookkeeping only)
   wc_solve_summary last_summary_{};

@@ -343,6 +343,29 @@ class Context:
                                               C.c_double(max_range), v(blind_min), v(blind_max), C.c_void_p(d_out.ptr), C.c_uint64(n), C.byref(m)))
         return d_out.download(R.POINT, int(m.value))
 
+    def prefilter_points_checked(self, points, ext_quat, ext_t, min_range, max_range, blind_min, blind_max, prev_time=-np.inf):
+        """-> (survivors, their stamps as the library packed them, the reference's CHECK at lidar_odometry.cc:491 held)"""
+        n = len(points)
+        d_in, d_out, d_t = self.to_device(points), self.alloc(48 * max(n, 1)), self.alloc(8 * max(n, 1))
+        m, mono = C.c_uint64(0), C.c_int(1)
+        v = lambda a: R.ptr(np.ascontiguousarray(a, np.float64))  # noqa: E731
+        self._ck(self.lib.wc_prefilter_points_checked(self.h, C.c_void_p(d_in.ptr), C.c_uint64(n), v(ext_quat), v(ext_t), C.c_double(min_range),
+                                                      C.c_double(max_range), v(blind_min), v(blind_max), C.c_void_p(d_out.ptr), C.c_uint64(n),
+                                                      C.byref(m), C.c_double(prev_time), C.c_void_p(d_t.ptr), C.byref(mono)))
+        k = int(m.value)
+        return d_out.download(R.POINT, k), d_t.download(np.float64, k), bool(mono.value)
+
+    def undistort_sweep_packed(self, points, imu, keep_on_device=False):
+        """-> (xyz float32 (n, 3), time float64 (n,)): the 20 bytes per point the extraction reads"""
+        n = len(points)
+        d_in, d_imu = self.to_device(points), self.to_device(imu)
+        d_xyz, d_t = self.alloc(12 * max(n, 1)), self.alloc(8 * max(n, 1))
+        self._ck(self.lib.wc_undistort_sweep_packed(self.h, C.c_void_p(d_in.ptr), C.c_uint64(n), C.c_void_p(d_imu.ptr), C.c_uint64(len(imu)),
+                                                    C.c_void_p(d_xyz.ptr), C.c_void_p(d_t.ptr)))
+        if keep_on_device:
+            return d_xyz, d_t
+        return d_xyz.download(np.float32, 3 * n).reshape(-1, 3), d_t.download(np.float64, n)
+
     def undistort_sweep(self, points, imu):
         n = len(points)
         d_in, d_out, d_imu = self.to_device(points), self.alloc(48 * max(n, 1)), self.to_device(imu)
