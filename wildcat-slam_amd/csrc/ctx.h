@@ -28,7 +28,7 @@ struct wc_ctx {
   // scratch buffers (device), grown on demand and kept for the lifetime of the ctx
   wc_buf b_ex_ctrl;  // the extraction's control block (status words, bucket / bin counters): never shared, cleared ahead of time
   wc_buf b_keys[2], b_vals[2], b_sorttmp, b_slots, b_slot_ids, b_slot_keys[2], b_slot_idx[2], b_cand, b_cand_meta,
-      b_status, b_misc[8], b_route[4], b_fx[7], b_match_stat;
+      b_status, b_misc[8], b_route[4], b_fx[10], b_match_stat;
   bool match_nf[2] = {false, false};  // wc_match: normal half of a candidate first (per kind of call: other set / same set)
   // ... and what the two orders cost on this context's calls (device time of k_knn_gate per query, smoothed; 0 = not yet tried):
   // once both are known the faster one is used, and the other is tried again every 16th call
@@ -63,7 +63,8 @@ struct wc_ctx {
     bool fx_active = false;      // this call runs on the fast (integer-moment) path
     bool fx_dirty = false;       // the fast path's tables may hold garbage (an aborted sweep): memset before the next use
     uint32_t fx_last_flags = 0, fx_fallbacks = 0, fx_last_why = 0;
-    bool fx_spill_full = false;  // the spill pool of the fast path overflowed once: sized for the worst case from then on
+    bool fx_spill_full = false;
+    bool fx_split = false;  // the node stage of the current sweep runs as k_fx_walk + k_fx_test (extract_split.inc)  // the spill pool of the fast path overflowed once: sized for the worst case from then on
     bool fx_long_lists = false;  // the last fast sweep walked long record lists: k_fx_merge runs before k_fx_nodes
     uint32_t fx_backoff = 0, fx_skip_calls = 0;  // sweeps that go straight to the exact path after fall-backs (exponential)
     bool fx_ctrl_ready = false;  // the fast path's two control blocks are initialised

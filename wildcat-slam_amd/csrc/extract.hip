@@ -1790,6 +1790,7 @@ int sort_pairs(wc_ctx *ctx, K *kin, K *kout, uint32_t *vin, uint32_t *vout, size
 }
 
 #include "extract_fast.inc"
+#include "extract_split.inc"
 
 // ---- host side of the fast path ------------------------------------------------------------------------------------------
 // grow-only buffer that is ZERO when it is (re)allocated: the fast path's tables are zero at rest
@@ -1864,6 +1865,20 @@ int run_pipeline_fast(wc_ctx *ctx, const wc_points &pts, double t_lo, double t_h
   WC_TRY(wc_ensure(ctx, ctx->b_fx[4], (size_t)2 * A.rec_cap * kFxRecW * 8));  // records: reachable through list heads only, never cleared
   const unsigned ngrid = std::min<unsigned>(256 * 16, std::max<unsigned>(64, (unsigned)(n / 256)));  // k_fx_nodes<1>; <2> uses fewer
   WC_TRY(wc_ensure(ctx, ctx->b_fx[6], (size_t)ngrid * kFxJobCap * kFxJobW * 8));  // cluster jobs: written before they are read
+  // node stage as two kernels (extract_split.inc) where one round of wavefronts does not hold the sweep's parents: above 2 M points
+  // (WC_FX_SPLIT=0 / 1 pins the choice: tests run both forms on the same clouds)
+  {
+    static const char *env = getenv("WC_FX_SPLIT");
+    ctx->ex.fx_split = env ? atoi(env) != 0 : !A.static_map;
+  }
+  if (ctx->ex.fx_split) {
+    A.static_map = 0u;
+    A.jobpool_per = (uint32_t)std::max<uint64_t>(4096, n / (uint64_t)std::max(1, P.cluster_min_points) / 2);  // 8 sub-pools: 4 x the worst case
+    WC_TRY(wc_ensure(ctx, ctx->b_fx[7], ((size_t)mr / 8 + 2) * kFxNodeW * 64 * 8));
+    WC_TRY(wc_ensure(ctx, ctx->b_fx[8], ((size_t)mr / 8 + 2) * kFxDescW * 4));
+    WC_TRY(wc_ensure(ctx, ctx->b_fx[9], (size_t)8 * A.jobpool_per * kFxJobW * 8));
+    A.nodes = (unsigned long long *)ctx->b_fx[7].p, A.wdesc = (uint32_t *)ctx->b_fx[8].p, A.jobpool = (unsigned long long *)ctx->b_fx[9].p;
+  }
   WC_TRY(wc_ensure(ctx, ctx->b_slots, total_slots * sizeof(wc_surfel)));
   WC_TRY(wc_ensure(ctx, ctx->b_slot_ids, total_slots * sizeof(wc_surfel_id)));
   WC_TRY(wc_ensure(ctx, ctx->b_slot_keys[1], (uint64_t)kBuckets * bin_cap * 8));
@@ -1920,7 +1935,13 @@ int run_pipeline_fast(wc_ctx *ctx, const wc_points &pts, double t_lo, double t_h
   dbg_sync("k_fx_acc<1>");
   mark(2);
   if (ctx->ex.fx_long_lists) k_fx_merge<1><<<std::min<unsigned>(ngrid * 2u, 8192u), 128, 0, st>>>(A);
-  k_fx_nodes<1><<<ngrid, 64, 0, st>>>(A);
+  if (ctx->ex.fx_split) {
+    k_fx_walk<1><<<ngrid, 64, 0, st>>>(A);
+    dbg_sync("k_fx_walk<1>");
+    k_fx_test<1><<<ngrid, 64, 0, st>>>(A);
+  } else {
+    k_fx_nodes<1><<<ngrid, 64, 0, st>>>(A);
+  }
   dbg_sync("k_fx_nodes<1>");
   mark(3);
   static_assert(sizeof(FxArgs) <= sizeof(ctx->ex.roots_args), "ctx.h: roots_args too small");
@@ -1946,7 +1967,13 @@ int fx_tail(wc_ctx *ctx, bool layer2) {
     k_fx_acc<2><<<tiles, kFxThreads, 0, st>>>(A);
     const unsigned ngrid = std::min<unsigned>(256 * 16, std::max<unsigned>(64, (unsigned)(A.pts.n / 256)));  // (the job buffer's blocks)
     if (ctx->ex.fx_long_lists) k_fx_merge<2><<<std::min(8192u, std::max(64u, ctx->ex.last_splits)), 128, 0, st>>>(A);
-    k_fx_nodes<2><<<std::min(std::min(256u * 8u, ngrid), std::max(64u, ctx->ex.last_splits)), 64, 0, st>>>(A);
+    const unsigned g2 = std::min(std::min(256u * 8u, ngrid), std::max(64u, ctx->ex.last_splits));
+    if (ctx->ex.fx_split) {
+      k_fx_walk<2><<<g2, 64, 0, st>>>(A);
+      k_fx_test<2><<<g2, 64, 0, st>>>(A);
+    } else {
+      k_fx_nodes<2><<<g2, 64, 0, st>>>(A);
+    }
   }
   ctx->ex.layer2_done = layer2;
   mark(4);
