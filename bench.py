@@ -510,22 +510,19 @@ def bench_window(ctx, args, world, rank, dev, torch, dist, cpu=False):
     d_pairs, d_pf = ctx.alloc(8 * n_s), ctx.alloc(8 * n_s)
     # (one untimed pass first: the library's scratch buffers are allocated on first use)
     # (wc_match_pair: both searches side by side on one GPU, one after the other when the matcher is query-sharded)
-    ctx.match_pair_device(d_surf, d_pose, n_s, d_fs, d_fp, len(w["fix_surf"]), d_pairs, n_s, d_pf, n_s)
+    ctx.match_pair_device(d_surf, d_pose, n_s, d_fs, d_fp, len(w["fix_surf"]), d_pairs, n_s, d_pf, n_s, sharded=world > 1)
     ctx.sync()
     t0 = time.perf_counter()
-    n_b, n_u = ctx.match_pair_device(d_surf, d_pose, n_s, d_fs, d_fp, len(w["fix_surf"]), d_pairs, n_s, d_pf, n_s)
+    n_b, n_u = ctx.match_pair_device(d_surf, d_pose, n_s, d_fs, d_fp, len(w["fix_surf"]), d_pairs, n_s, d_pf, n_s, sharded=world > 1)
     t_match = time.perf_counter() - t0
-    # shard the correspondences (contiguous slices) and the IMU factors
-    lo_b, cnt_b = wdist.shard_range(n_b, rank, world)
-    lo_u, cnt_u = wdist.shard_range(n_u, rank, world)
-    # (N > 1: every linearisation ends in ONE all-reduce through the ctx's communicator, installed in main())
-    imu_r = wdist.shard_imu(w["imu"], rank, world)  # IMU factors: a contiguous share of the state triples per rank
-    build_args = (d_surf, d_pose, _Ptr(d_pairs.ptr + 8 * lo_b), cnt_b, imu_r if len(imu_r) >= 3 else None, w["sample_times"], w["grav"],
-                  False, d_fs, d_fp, _Ptr(d_pf.ptr + 8 * lo_u), cnt_u)
-    ctx.window_build(*build_args)  # (first call allocates)
+    # N > 1: wc_window_build_sharded - every rank passes the same replicated lists, the library takes this rank's contiguous share of
+    # the correspondences and of the IMU triples; every linearisation then ends in ONE all-reduce through the ctx's communicator
+    build_args = (d_surf, d_pose, d_pairs, n_b, w["imu"], w["sample_times"], w["grav"], False, d_fs, d_fp, d_pf, n_u)
+    build_kw = {"sharded": world > 1}
+    ctx.window_build(*build_args, **build_kw)  # (first call allocates)
     ctx.sync()
     t0 = time.perf_counter()
-    ctx.window_build(*build_args)  # once per solve: interval keys, sort, packed records, pieces, gather lists
+    ctx.window_build(*build_args, **build_kw)  # once per solve: interval keys, sort, packed records, pieces, gather lists
     ctx.sync()
     t_build = time.perf_counter() - t0
     ns = len(w["sample_times"])
@@ -598,83 +595,41 @@ def bench_window(ctx, args, world, rank, dev, torch, dist, cpu=False):
     return out
 
 
+def ring_allreduce_model_us(nbytes, world):
+    """modelled time of a ring all-reduce over xGMI (MI355X_MICROARCH.md: point-to-point links, ~153 GB/s each direction per
+    link; a ring moves 2 (N-1)/N of the payload over every rank's one link to its ring neighbour) - a printed estimate, not a
+    measurement"""
+    if world < 2 or not nbytes:
+        return 0.0
+    return 2.0 * (world - 1) / world * nbytes / 153e9 * 1e6 + 2 * (world - 1) * 1.5  # + ~1.5 us per hop
+
+
 def bench_odometry_step(ctx, args, world, rank, dev, torch, dist, cpu=False):
     """north_star's headline workload, one FULL odometry step (LidarOdometry::AddLidarScan, lidar_odometry.cc:523-566) through the
     C-ABI on a 10-sweep window of 1 M-point sweeps (10 x C2): 9 sweeps are already in the window (extracted, posed; the two oldest
-    form the fixed window), the step takes the newest sweep: BuildSurfels -> UpdateSurfelPoses -> 2 x KnnSurfelMatcher (wc_match_pair) -> problem
-    construction -> solve -> UpdateSurfelPoses.  Single GPU (the N > 1 legs of its stages are `window` and `cloud_10m`)."""
+    form the fixed window), the step takes the newest sweep: BuildSurfels -> UpdateSurfelPoses -> 2 x KnnSurfelMatcher -> problem
+    construction -> solve -> UpdateSurfelPoses (wildcat_slam_amd/step.py).  N > 1: the SAME step with every stage sharded over the
+    ranks (strong scaling: one window, N GPUs) - routed extraction of the newest sweep + gather, query-sharded matcher, sharded
+    factors with one all-reduce per linearisation; the time is the slowest rank's."""
     from wildcat_slam_amd import records as R, synth
+    from wildcat_slam_amd.step import StepWindow
 
     K, roots = 10, args.roots
     w = synth.g2_scan_sequence(K, roots, m=32, seed=synth.SEED + 21)
-    imu = w["imu"]
-    d_imu = ctx.to_device(imu)
-    n_pts = len(w["scans"][-1])
-    cap_all = K * 8 * roots + 4096
-    d_surf, d_pose, d_inb = ctx.alloc(144 * cap_all), ctx.alloc(56 * cap_all), ctx.alloc(cap_all)
-    ctx._ck(ctx.lib.wc_memset(ctx.h, ctx_ptr(d_inb), 0, ctx_size(cap_all)))
-    counts, d_scans = [], []
-    for s in w["scans"]:
-        d_scans.append(ctx.to_device(s))
-    n_have = 0
-    for k in range(K - 1):  # the window before the step: sweeps 0 .. K-2
-        s = w["scans"][k]
-        desc = ctx.points_desc(d_scans[k], len(s))
-        ctx.extract_enqueue(desc, _Ptr(d_surf.ptr + 144 * n_have), None, cap_all - n_have, float(s["time"][0]), float(s["time"][-1]))
-        m = ctx.extract_finish()
-        counts.append(m)
-        n_have += m
-    ctx.update_surfel_poses(d_imu, len(imu), d_surf, d_pose, d_inb, n_have)
-    n_fix = counts[0] + counts[1]  # the two oldest sweeps: fixed window (constant world pose)
-    d_pb, d_pu = ctx.alloc(8 * cap_all), ctx.alloc(8 * cap_all)
-    newest = w["scans"][-1]
-    desc_new = ctx.points_desc(d_scans[-1], n_pts)
-    ns = len(w["sample_times"])
-    x0 = np.zeros(12 * ns)
-    # a copy of the window state so that every timed repetition starts from the same window
-    keep = (ctx.alloc(144 * n_have), ctx.alloc(56 * n_have))
-    ctx._ck(ctx.lib.wc_d2d(ctx.h, ctx_ptr(keep[0]), ctx_ptr(d_surf), ctx_size(144 * n_have)))
-    ctx._ck(ctx.lib.wc_d2d(ctx.h, ctx_ptr(keep[1]), ctx_ptr(d_pose), ctx_size(56 * n_have)))
-
-    def one_step(timed):
-        ctx._ck(ctx.lib.wc_d2d(ctx.h, ctx_ptr(d_surf), ctx_ptr(keep[0]), ctx_size(144 * n_have)))
-        ctx._ck(ctx.lib.wc_d2d(ctx.h, ctx_ptr(d_pose), ctx_ptr(keep[1]), ctx_size(56 * n_have)))
-        ctx._ck(ctx.lib.wc_memset(ctx.h, ctx_ptr(_Ptr(d_inb.ptr + n_have)), 0, ctx_size(cap_all - n_have)))
-        ctx.sync()
-        T = {}
-        t0 = time.perf_counter()
-        ctx.extract_enqueue(desc_new, _Ptr(d_surf.ptr + 144 * n_have), None, cap_all - n_have, float(newest["time"][0]), float(newest["time"][-1]))
-        m = ctx.extract_finish()
-        T["extract"] = time.perf_counter() - t0
-        n_all = n_have + m
-        n_sld = n_all - n_fix
-        sld_s, sld_p, sld_b = _Ptr(d_surf.ptr + 144 * n_fix), _Ptr(d_pose.ptr + 56 * n_fix), _Ptr(d_inb.ptr + n_fix)
-        t1 = time.perf_counter()
-        ctx.update_surfel_poses(d_imu, len(imu), sld_s, sld_p, sld_b, n_sld)
-        T["pose_update"] = time.perf_counter() - t1
-        t1 = time.perf_counter()
-        nb, nu = ctx.match_pair_device(sld_s, sld_p, n_sld, d_surf, d_pose, n_fix, d_pb, cap_all, d_pu, cap_all)  # (both searches side by side)
-        T["match"] = time.perf_counter() - t1
-        t1 = time.perf_counter()
-        ctx.window_build(sld_s, sld_p, d_pb, nb, imu, w["sample_times"], w["grav"], False, d_surf, d_pose, d_pu, nu)
-        T["build"] = time.perf_counter() - t1
-        t1 = time.perf_counter()
-        x, summ, _ = ctx.window_solve(x0)
-        T["solve"] = time.perf_counter() - t1
-        t1 = time.perf_counter()
-        ctx.update_surfel_poses(d_imu, len(imu), sld_s, sld_p, sld_b, n_sld)  # (the IMU poses would carry the B-spline correction)
-        ctx.sync()
-        T["pose_update2"] = time.perf_counter() - t1
-        T["total"] = time.perf_counter() - t0
-        return T, dict(new_surfels=m, sld=n_sld, fix=n_fix, binary=nb, unary=nu, iters=summ.iterations, cost=[summ.initial_cost, summ.final_cost],
-                       term=summ.termination, imu=max(0, len(imu) - 2))
-
-    one_step(False)
-    one_step(False)
+    sw = StepWindow(ctx, w, rank=rank, world=world)
+    n_pts, ns = sw.n_pts, sw.ns
+    sw.step()
+    sw.step()
     reps = 9
     runs, info = [], None
     for _ in range(reps):
-        T, info = one_step(True)
+        if world > 1:
+            dist.barrier()
+        T, info, _ = sw.step()
+        if world > 1:  # the step lasts as long as its slowest rank
+            tt = torch.tensor([T[k_] for k_ in sorted(T)], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            T = dict(zip(sorted(T), [float(v) for v in tt.tolist()]))
         runs.append(T)
     runs.sort(key=lambda t: t["total"])
     T = runs[reps // 2]  # the median repetition (a repetition that meets a host hiccup - one in a few dozen - is 2x the others)
@@ -695,6 +650,13 @@ def bench_odometry_step(ctx, args, world, rank, dev, torch, dist, cpu=False):
                         "frac": round(total_b / T["total"] / 1e9 / HBM_PEAK_GBS, 5),
                         "algorithmic_bytes": {"extract": b_ext, "pose_update": b_pose, "match": b_match, "assembly_all_iterations": b_asm}},
            "timing": "wall clock around each C-ABI call (every call is synchronous on return), the median of %d repetitions from the same window state" % reps}
+    if world > 1:
+        out["scaling"] = "strong"
+        out["n_gpus"] = world
+        out["allreduce_bytes_per_linearisation"] = info["allreduce_bytes"]
+        out["allreduce_ring_model_us"] = round(ring_allreduce_model_us(info["allreduce_bytes"], world), 1)
+        out["collectives"] = ("extraction: one all-to-all of 24-byte point records by root voxel + one all-gather of the new surfels; matcher: one "
+                              "all-gather of the gated lists per search; window: one all-reduce per linearisation + one double per candidate cost")
     if cpu:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import pyoracle  # test infrastructure, used here ONLY as the timed CPU baseline

@@ -105,6 +105,8 @@ int wc_voxel_keys(wc_ctx *ctx, const wc_points *pts, int32_t *d_keys_xyz);
 /* one cloud over several GPUs (BASELINE config 5) --------------------------------------------------- */
 /* The reference has no counterpart (single thread): root voxels are independent after binning (surfel_extraction.cc:217-219,
  * :330-332) but each needs all its points in time order (:22-29), so a cloud shards by root voxel - see csrc/route.hip. */
+/* Installing a communicator makes NO existing entry point a collective: only the *_sharded calls (wc_extract_surfels_sharded,
+ * wc_gather_surfels, wc_match_sharded, wc_match_pair_sharded, wc_window_build_sharded and the solve of a problem built by it) use it. */
 int wc_ctx_set_comm(wc_ctx *ctx, const wc_comm *comm); /* NULL removes it */
 /* the in-library RCCL communicator (csrc/comm.hip; librccl.so is dlopen()ed): rank 0 creates the 128-byte unique id, the
  * launcher hands it to every rank, each rank calls wc_comm_rccl_init on its ctx.  Collectives run on the ctx's stream. */
@@ -182,14 +184,26 @@ int wc_match(wc_ctx *ctx, const wc_surfel *d_q_surf, const wc_pose *d_q_pose, ui
              const wc_pose *d_t_pose, uint64_t nt, int same_set, wc_pair *d_pairs, uint64_t cap, uint64_t *h_n_pairs,
              uint32_t *d_knn_idx, double *d_knn_d2);
 
+/* Multi-GPU form of wc_match (the queries are independent, knn_surfel_matcher.cc:22-48): a COLLECTIVE of the ctx's
+ * communicator - every rank calls it with the same replicated arguments; each searches a contiguous share of the queries (in
+ * grid-cell order) and ONE all-gather of the gated neighbour lists (4 k bytes per query) gives every rank the whole table, on
+ * which the order-dependent de-duplication (cc:35-38) runs replicated: every rank ends with the unsharded call's pairs, byte for
+ * byte.  wc_match itself is never a collective, whatever is installed on the ctx.  Without a communicator (or a world of one) this
+ * is wc_match. */
+int wc_match_sharded(wc_ctx *ctx, const wc_surfel *d_q_surf, const wc_pose *d_q_pose, uint64_t nq, const wc_surfel *d_t_surf,
+                     const wc_pose *d_t_pose, uint64_t nt, int same_set, wc_pair *d_pairs, uint64_t cap, uint64_t *h_n_pairs);
+/* both searches of an outer iteration as collectives (one after the other: their all-gathers share the ctx stream) */
+int wc_match_pair_sharded(wc_ctx *ctx, const wc_surfel *d_sld_surf, const wc_pose *d_sld_pose, uint64_t n_sld,
+                          const wc_surfel *d_fix_surf, const wc_pose *d_fix_pose, uint64_t n_fix, wc_pair *d_pairs_sld, uint64_t cap_sld,
+                          uint64_t *h_n_pairs_sld, wc_pair *d_pairs_fix, uint64_t cap_fix, uint64_t *h_n_pairs_fix);
+
 /* Both correspondence searches of one outer iteration (the two KnnSurfelMatcher objects of lidar_odometry.cc:530-538) at
  * once.  Same results, bit for bit, as
  *   wc_match(ctx, sld, sld_pose, n_sld, sld, sld_pose, n_sld, 1, d_pairs_sld, ...) followed by
  *   wc_match(ctx, sld, sld_pose, n_sld, fix, fix_pose, n_fix, 0, d_pairs_fix, ...),
  * but the fixed-window search runs on a helper context of its own (own stream and scratch, created on first use, ordered
  * behind the work already enqueued on the ctx stream): one search is a single round of wavefronts whose durations differ by
- * 3x, so the wavefronts of the other fill the slots the early finishers leave.  With a communicator installed (sharded
- * matcher: collectives on the ctx stream) the two searches run one after the other. */
+ * 3x, so the wavefronts of the other fill the slots the early finishers leave.  Never a collective (wc_match_pair_sharded is). */
 int wc_match_pair(wc_ctx *ctx, const wc_surfel *d_sld_surf, const wc_pose *d_sld_pose, uint64_t n_sld,
                   const wc_surfel *d_fix_surf, const wc_pose *d_fix_pose, uint64_t n_fix, wc_pair *d_pairs_sld, uint64_t cap_sld,
                   uint64_t *h_n_pairs_sld, wc_pair *d_pairs_fix, uint64_t cap_fix, uint64_t *h_n_pairs_fix);
@@ -208,7 +222,22 @@ int wc_window_build(wc_ctx *ctx, const wc_surfel *d_sld_surf, const wc_pose *d_s
                     uint64_t n_pairs_sld, const wc_surfel *d_fix_surf, const wc_pose *d_fix_pose, const wc_pair *d_pairs_fix,
                     uint64_t n_pairs_fix, const wc_imu_state *h_imu, uint64_t n_imu, const double *h_sample_times, uint64_t ns,
                     const double *h_grav, int fix_first_pos);
-/* counts[4] = {binary factors, unary factors, imu factors, assembly pieces} */
+/* Multi-GPU form (correspondences and IMU factors sharded, unknowns replicated): a COLLECTIVE of the ctx's
+ * communicator.  EVERY rank passes the SAME replicated arguments as it would to wc_window_build; the library takes this rank's
+ * contiguous share of both correspondence lists and of the IMU state triples, and one small all-reduce checks that the shares add
+ * up to the whole problem (WC_ERR_ARG otherwise).  From then on wc_window_linearize / _evaluate / _solve on this problem are
+ * collectives: ONE all-reduce per linearisation of {upper block pairs of H, g, cost} - 144 doubles per pair of sample blocks at
+ * most two apart, the 6 x 6 pose corner (36) of the others, which only surfel factors reach: 0.76 MB at 64 sample states, 2.7 MB
+ * at 127 - plus one double per candidate cost; every rank takes identical accept / reject decisions on identical numbers.
+ * A problem built with wc_window_build is never a collective, whatever is installed on the ctx (a caller that shards the factors
+ * itself opts in with wc_window_set_allreduce).  Without a communicator (or a world of one) this is wc_window_build. */
+int wc_window_build_sharded(wc_ctx *ctx, const wc_surfel *d_sld_surf, const wc_pose *d_sld_pose, const wc_pair *d_pairs_sld,
+                            uint64_t n_pairs_sld, const wc_surfel *d_fix_surf, const wc_pose *d_fix_pose, const wc_pair *d_pairs_fix,
+                            uint64_t n_pairs_fix, const wc_imu_state *h_imu, uint64_t n_imu, const double *h_sample_times, uint64_t ns,
+                            const double *h_grav, int fix_first_pos);
+/* counts[4] = {binary factors, unary factors, imu factors, assembly pieces} (of THIS rank's share for a sharded problem);
+ * wc_window_reduce_bytes: bytes one linearisation's all-reduce carries (0: the problem is not sharded) */
+uint64_t wc_window_reduce_bytes(wc_ctx *ctx);
 int wc_window_counts(wc_ctx *ctx, uint64_t counts[4]);
 /* problem.Evaluate(apply_loss_function = true) (lidar_odometry.cc:62-65): cost = 1/2 sum rho; d_residuals (may be NULL)
  * receives the loss-corrected residuals in the reference's block order: binary, unary, 12 per IMU factor.
@@ -219,9 +248,9 @@ int wc_window_linearize(wc_ctx *ctx, const double *h_x, double *d_H, double *d_g
 /* ceres::Solve with the reference's options (lidar_odometry.cc:551-561): trust-region LM, <= max_iterations.
  * h_x_inout: corrections in / optimised corrections out; h_first_step (may be NULL) receives the first LM increment. */
 int wc_window_solve(wc_ctx *ctx, double *h_x_inout, wc_solve_summary *summary, double *h_first_step);
-/* multi-GPU: install a "sum this device buffer over all ranks" callback (RCCL all-reduce); called once per
- * linearisation on the packed {upper block triangle of H (144 doubles per pair of sample blocks), g, cost} buffer and
- * once per candidate-cost evaluation (one double). */
+/* multi-GPU, for a caller that shards the factors ITSELF (each rank builds its own slices with wc_window_build): install a
+ * "sum this device buffer over all ranks" callback; called once per linearisation on the packed {upper block pairs of H, g, cost}
+ * buffer (layout: wc_window_build_sharded above) and once per candidate-cost evaluation (one double).  NULL removes it. */
 int wc_window_set_allreduce(wc_ctx *ctx, int (*fn)(void *user, double *d_buf, uint64_t count), void *user);
 
 #ifdef __cplusplus

@@ -194,10 +194,11 @@ def test_other_neighbour_counts(gpu, oracle, k):
 
 
 def test_query_sharded_match_equals_unsharded(gpu):
-    """SURVEY 8(e) row 2: the queries of KnnSurfelMatcher::Match are independent (knn_surfel_matcher.cc:22-48); with a
-    communicator installed every rank searches a contiguous share of the queries, ONE all-gather of the gated neighbour lists
+    """SURVEY 8(e) row 2: the queries of KnnSurfelMatcher::Match are independent (knn_surfel_matcher.cc:22-48); in
+    wc_match_sharded every rank searches a contiguous share of the queries, ONE all-gather of the gated neighbour lists
     gives every rank the whole table and the order-dependent pair de-duplication runs replicated.  Two ranks on one GPU
-    (dist.ThreadComm stands in for RCCL): both must return exactly the unsharded call's pairs, for both matchers."""
+    (dist.ThreadComm stands in for RCCL): both must return exactly the unsharded call's pairs, for both matchers.  wc_match
+    itself is NOT a collective with a communicator installed (no implicit collectives): rank 0 alone calls it."""
     import threading
 
     from wildcat_slam_amd import dist as wdist
@@ -215,8 +216,11 @@ def test_query_sharded_match_equals_unsharded(gpu):
     def run(r):
         try:
             ctxs[r].set_comm(wdist.ThreadComm(shared, r, ctxs[r]))
-            b = ctxs[r].match(w["surf"], w["pose"], w["surf"], w["pose"], True)
-            u = ctxs[r].match(w["surf"], w["pose"], w["fix_surf"], w["fix_pose"], False)
+            if r == 0:  # the plain call on ONE rank only: it must not wait for the others
+                alone = ctxs[r].match(w["surf"], w["pose"], w["surf"], w["pose"], True)
+                assert alone.tobytes() == ref_b.tobytes() and shared["calls"][0] == 0
+            b = ctxs[r].match(w["surf"], w["pose"], w["surf"], w["pose"], True, sharded=True)
+            u = ctxs[r].match(w["surf"], w["pose"], w["fix_surf"], w["fix_pose"], False, sharded=True)
             out[r] = (b, u)
         except Exception as e:  # pragma: no cover
             errors.append(e)

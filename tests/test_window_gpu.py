@@ -211,8 +211,11 @@ def test_two_rank_sharded_solve_on_one_gpu(gpu, oracle):
 
 
 def test_sharded_solve_through_the_ctx_communicator(gpu, oracle):
-    """the same lock-step solve, the all-reduce going through the ctx's wc_comm (the slot the in-library RCCL binding of
-    csrc/comm.hip fills with ncclAllReduce on the ctx stream) instead of the legacy callback"""
+    """the same lock-step solve through wc_window_build_sharded: every rank passes the SAME replicated arguments, the library
+    takes the rank's share of the correspondences and of the IMU triples and the all-reduce goes through the ctx's wc_comm (the
+    slot the in-library RCCL binding of csrc/comm.hip fills with ncclAllReduce on the ctx stream).  A problem built with the
+    plain wc_window_build is not a collective although the communicator is installed; ranks that pass different lists are
+    caught by the build's share check."""
     import threading
 
     from wildcat_slam_amd import dist as wdist
@@ -235,9 +238,18 @@ def test_sharded_solve_through_the_ctx_communicator(gpu, oracle):
         try:
             c = ctxs[r]
             c.set_comm(wdist.ThreadComm(shared, r, c))
-            lo, cnt = wdist.shard_range(len(pairs), r, world)
-            k = [c.to_device(w["surf"]), c.to_device(w["pose"]), c.to_device(pairs[lo:lo + cnt])]
-            c.window_build(k[0], k[1], k[2], cnt, w["imu"] if r == 0 else None, w["sample_times"], w["grav"], True)
+            k = [c.to_device(w["surf"]), c.to_device(w["pose"]), c.to_device(pairs)]
+            if r == 0:  # plain build + solve on ONE rank with the communicator installed: no collective, the whole problem
+                c.window_build(k[0], k[1], k[2], len(pairs), w["imu"], w["sample_times"], w["grav"], True)
+                xa, sa, _ = c.window_solve(x0)
+                assert shared["calls"][0] == 0 and np.array_equal(xa, x_ref) and c.window_reduce_bytes() == 0
+            # ranks that disagree about the problem: the share check of the build fails on every rank
+            with pytest.raises(lib.WildcatError):
+                c.window_build(k[0], k[1], k[2], len(pairs) - (7 if r == 1 else 0), w["imu"], w["sample_times"], w["grav"], True, sharded=True)
+            c.window_build(k[0], k[1], k[2], len(pairs), w["imu"], w["sample_times"], w["grav"], True, sharded=True)
+            nb, _, ni, _ = c.window_counts()
+            assert nb == wdist.shard_range(len(pairs), r, world)[1] and 0 < ni < len(w["imu"]) - 2
+            assert c.window_reduce_bytes() == 8 * wdist.packed_count(ns)
             res[r] = c.window_solve(x0) + (k,)
         except Exception as e:  # pragma: no cover
             errors.append(e)

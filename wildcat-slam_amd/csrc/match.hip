@@ -438,10 +438,11 @@ __global__ void __launch_bounds__(256) k_emit_pairs(const uint32_t *choice, cons
 
 }  // namespace
 
-// scratch lives in ctx->b_misc[1..7] slots to avoid another state struct
-extern "C" int wc_match(wc_ctx *ctx, const wc_surfel *d_q_surf, const wc_pose *d_q_pose, uint64_t nq_, const wc_surfel *d_t_surf,
-                        const wc_pose *d_t_pose, uint64_t nt_, int same_set, wc_pair *d_pairs, uint64_t cap, uint64_t *h_n_pairs,
-                        uint32_t *d_knn_idx, double *d_knn_d2) {
+// scratch lives in ctx->b_misc[1..7] slots to avoid another state struct.  want_shard: the call is a collective of the ctx's
+// communicator (wc_match_sharded) - every rank makes it with the same replicated arguments
+static int match_impl(wc_ctx *ctx, const wc_surfel *d_q_surf, const wc_pose *d_q_pose, uint64_t nq_, const wc_surfel *d_t_surf,
+                      const wc_pose *d_t_pose, uint64_t nt_, int same_set, wc_pair *d_pairs, uint64_t cap, uint64_t *h_n_pairs,
+                      uint32_t *d_knn_idx, double *d_knn_d2, bool want_shard) {
   wc_dev_guard dg_(ctx);
   if (!ctx || !h_n_pairs) return wc_fail(ctx, WC_ERR_ARG, "%s: null or out-of-range argument", __func__);
   *h_n_pairs = 0;
@@ -531,7 +532,8 @@ extern "C" int wc_match(wc_ctx *ctx, const wc_surfel *d_q_surf, const wc_pose *d
   // several GPUs: the queries are independent (knn_surfel_matcher.cc:22-48), the targets are replicated;
   // every rank searches a contiguous share of the queries (in cell order) and ONE all-gather of the gated lists (4 k bytes per
   // query) gives every rank the whole table; the order-dependent de-duplication below then runs replicated
-  const bool sharded = ctx->have_comm && ctx->comm.world > 1 && ctx->comm.allgatherv && nq >= 4096 && !d_knn_idx && !d_knn_d2;
+  // (the predicate only depends on arguments every rank shares: a rank-dependent one would leave the others in the all-gather)
+  const bool sharded = want_shard && ctx->have_comm && ctx->comm.world > 1 && ctx->comm.allgatherv && nq >= 4096;
   uint32_t q_begin = 0, q_end = nq;
   uint32_t *gated_shard = nullptr;
   if (sharded) {
@@ -673,6 +675,27 @@ extern "C" int wc_match(wc_ctx *ctx, const wc_surfel *d_q_surf, const wc_pose *d
   return WC_OK;
 }
 
+extern "C" int wc_match(wc_ctx *ctx, const wc_surfel *d_q_surf, const wc_pose *d_q_pose, uint64_t nq, const wc_surfel *d_t_surf,
+                        const wc_pose *d_t_pose, uint64_t nt, int same_set, wc_pair *d_pairs, uint64_t cap, uint64_t *h_n_pairs,
+                        uint32_t *d_knn_idx, double *d_knn_d2) {
+  return match_impl(ctx, d_q_surf, d_q_pose, nq, d_t_surf, d_t_pose, nt, same_set, d_pairs, cap, h_n_pairs, d_knn_idx, d_knn_d2, false);
+}
+
+extern "C" int wc_match_sharded(wc_ctx *ctx, const wc_surfel *d_q_surf, const wc_pose *d_q_pose, uint64_t nq, const wc_surfel *d_t_surf,
+                                const wc_pose *d_t_pose, uint64_t nt, int same_set, wc_pair *d_pairs, uint64_t cap, uint64_t *h_n_pairs) {
+  return match_impl(ctx, d_q_surf, d_q_pose, nq, d_t_surf, d_t_pose, nt, same_set, d_pairs, cap, h_n_pairs, nullptr, nullptr, true);
+}
+
+// both searches of an outer iteration as collectives, one after the other (their all-gathers share the ctx stream)
+extern "C" int wc_match_pair_sharded(wc_ctx *ctx, const wc_surfel *d_sld_surf, const wc_pose *d_sld_pose, uint64_t n_sld,
+                                     const wc_surfel *d_fix_surf, const wc_pose *d_fix_pose, uint64_t n_fix, wc_pair *d_pairs_sld,
+                                     uint64_t cap_sld, uint64_t *h_n_pairs_sld, wc_pair *d_pairs_fix, uint64_t cap_fix,
+                                     uint64_t *h_n_pairs_fix) {
+  if (!ctx || !h_n_pairs_sld || !h_n_pairs_fix) return wc_fail(ctx, WC_ERR_ARG, "%s: null or out-of-range argument", __func__);
+  WC_TRY(wc_match_sharded(ctx, d_sld_surf, d_sld_pose, n_sld, d_sld_surf, d_sld_pose, n_sld, 1, d_pairs_sld, cap_sld, h_n_pairs_sld));
+  return wc_match_sharded(ctx, d_sld_surf, d_sld_pose, n_sld, d_fix_surf, d_fix_pose, n_fix, 0, d_pairs_fix, cap_fix, h_n_pairs_fix);
+}
+
 // The two searches of an outer iteration side by side (see include/wildcat_hip.h).  wc_match is synchronous and talks to the
 // host between its launches (the fixed-point rounds of the pair rule), so the second search gets its own context AND its own
 // host thread; both only read the surfels.
@@ -681,7 +704,8 @@ extern "C" int wc_match_pair(wc_ctx *ctx, const wc_surfel *d_sld_surf, const wc_
                              uint64_t cap_sld, uint64_t *h_n_pairs_sld, wc_pair *d_pairs_fix, uint64_t cap_fix,
                              uint64_t *h_n_pairs_fix) {
   if (!ctx || !h_n_pairs_sld || !h_n_pairs_fix) return wc_fail(ctx, WC_ERR_ARG, "%s: null or out-of-range argument", __func__);
-  if (ctx->have_comm || n_sld == 0 || n_fix == 0 || getenv("WC_MATCH_PAIR_SERIAL")) {
+  static const bool serial = getenv("WC_MATCH_PAIR_SERIAL") != nullptr;
+  if (n_sld == 0 || n_fix == 0 || serial) {
     WC_TRY(wc_match(ctx, d_sld_surf, d_sld_pose, n_sld, d_sld_surf, d_sld_pose, n_sld, 1, d_pairs_sld, cap_sld, h_n_pairs_sld, nullptr, nullptr));
     return wc_match(ctx, d_sld_surf, d_sld_pose, n_sld, d_fix_surf, d_fix_pose, n_fix, 0, d_pairs_fix, cap_fix, h_n_pairs_fix, nullptr, nullptr);
   }
@@ -696,12 +720,29 @@ extern "C" int wc_match_pair(wc_ctx *ctx, const wc_surfel *d_sld_surf, const wc_
   if (!ctx->ev_aux) WC_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_aux, hipEventDisableTiming));
   WC_HIP(ctx, hipEventRecord(ctx->ev_aux, ctx->stream));
   WC_HIP(ctx, hipStreamWaitEvent(aux->stream, ctx->ev_aux, 0));
-  int rc_fix = WC_OK;
-  std::thread helper([&] {
-    rc_fix = wc_match(aux, d_sld_surf, d_sld_pose, n_sld, d_fix_surf, d_fix_pose, n_fix, 0, d_pairs_fix, cap_fix, h_n_pairs_fix, nullptr, nullptr);
-  });
-  const int rc_sld = wc_match(ctx, d_sld_surf, d_sld_pose, n_sld, d_sld_surf, d_sld_pose, n_sld, 1, d_pairs_sld, cap_sld, h_n_pairs_sld, nullptr, nullptr);
-  helper.join();
+  int rc_fix = WC_OK, rc_sld = WC_OK;
+  // no exception may cross the C boundary: a failed thread creation runs the second search on this thread, an allocation
+  // failure inside a search becomes a status code
+  auto guarded = [](int &rc, auto &&fn) {
+    try {
+      rc = fn();
+    } catch (...) {
+      rc = WC_ERR_HIP;
+    }
+  };
+  auto search_fix = [&] { return wc_match(aux, d_sld_surf, d_sld_pose, n_sld, d_fix_surf, d_fix_pose, n_fix, 0, d_pairs_fix, cap_fix, h_n_pairs_fix, nullptr, nullptr); };
+  std::thread helper;
+  bool threaded = true;
+  try {
+    helper = std::thread([&] { guarded(rc_fix, search_fix); });
+  } catch (...) {
+    threaded = false;
+  }
+  guarded(rc_sld, [&] { return wc_match(ctx, d_sld_surf, d_sld_pose, n_sld, d_sld_surf, d_sld_pose, n_sld, 1, d_pairs_sld, cap_sld, h_n_pairs_sld, nullptr, nullptr); });
+  if (threaded)
+    helper.join();
+  else
+    guarded(rc_fix, search_fix);
   if (rc_sld != WC_OK) return rc_sld;
   if (rc_fix != WC_OK) return wc_fail(ctx, rc_fix, "wc_match_pair (fixed window): %s", wc_last_error(aux));
   return WC_OK;

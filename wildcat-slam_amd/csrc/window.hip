@@ -89,7 +89,14 @@ struct wc_window_state {
   // device buffers
   wc_buf times_d, brec, bkey, borig, urec, ukey, uorig, irec, pieces, partial, src, src_begin, gsrc, gsrc_begin;
   wc_buf lin, Linv, heavy, Lmat, reduce;
-  uint32_t nheavy = 0;  // lin = [H (n*n) | g (np) | cost, spare]: ONE contiguous buffer, the unit of the multi-GPU all-reduce
+  uint32_t nheavy = 0;  // lin = [H (n*n) | g (np) | cost, spare]
+  // multi-GPU: sharded = this problem holds one rank's share of the factors (wc_window_build_sharded, or a caller that shards
+  // itself and installs wc_window_set_allreduce); only then are linearisation and cost evaluation collectives.  pair_off[pid] =
+  // offset of block pair pid in the reduction buffer: 144 doubles for a pair of sample blocks at most two apart (IMU factors
+  // reach that far, cost_functor.h:264-355), 36 - the pose x pose corner - for the others (surfel factors only, :16-179)
+  bool sharded = false;
+  wc_buf pair_off;
+  uint32_t red_H = 0;  // doubles of the reduction buffer in front of {g (np), cost, spare}
   int (*allreduce)(void *, double *, uint64_t) = nullptr;
   void *allreduce_user = nullptr;
   wc_buf x, xc, scale, diag, A, y, mail, cost_part, keys_tmp[2], vals_tmp[2], heads, status;
@@ -710,7 +717,9 @@ struct GatherArgs {
   double *H, *g, *cost;
   uint32_t nheavy, npairs, npieces, nb_pieces, nu_pieces;
   int ns, fix_first;
-  int packed;  // H = block pairs in pair order, 144 doubles each (the multi-GPU reduction buffer); else the dense n x n matrix
+  int packed;  // H = the multi-GPU reduction buffer: block pairs in pair order at pair_off[pid] (144 doubles, or the 6 x 6 pose
+               // corner of a pair more than two sample blocks apart); else the dense n x n matrix
+  const uint32_t *pair_off;
 };
 
 // Sum of the sources s0, s0 + STRIDE, ... of one entry (u, v) of a block pair, in list order.  A source costs two dependent
@@ -854,7 +863,12 @@ __global__ void __launch_bounds__(144 * kGG, 8) k_gather(GatherArgs a) {
       const int gi = I * 12 + u, gj = J * 12 + v;
       if (a.fix_first && ((gi >= 3 && gi < 6) || (gj >= 3 && gj < 6))) acc = 0.0;  // SubsetParameterization(12,{3,4,5})
       if (a.packed) {
-        if (write) a.H[(size_t)pid * 144 + e] = acc;
+        if (write) {
+          if (J - I <= 2)
+            a.H[(size_t)a.pair_off[pid] + e] = acc;
+          else if (u < 6 && v < 6)
+            a.H[(size_t)a.pair_off[pid] + u * 6 + v] = acc;  // (the rest of a far pair's block is zero: no IMU factor reaches it)
+        }
         continue;
       }
       // block (I, J) row by row, and its transpose as block (J, I) ALSO row by row: the transposed entries come through
@@ -951,11 +965,12 @@ __global__ void __launch_bounds__(144 * kGG, 8) k_gather(GatherArgs a) {
 
 // multi-GPU: the reduced block pairs (pair order, 144 doubles each) -> both triangles of the dense matrix; g and the cost
 // follow the pairs in the reduction buffer and are copied behind H
-__global__ void __launch_bounds__(144) k_expand_pairs(const double *packed, uint32_t npairs, int ns, int np, double *H, double *g) {
+__global__ void __launch_bounds__(144) k_expand_pairs(const double *packed, uint32_t npairs, int ns, int np, double *H, double *g,
+                                                     const uint32_t *pair_off, uint32_t red_H) {
   const uint32_t pid = blockIdx.x;
   const int e = threadIdx.x;
   if (pid == npairs) {  // tail: g (np doubles) + cost, spare
-    for (int i = e; i < np + 2; i += 144) g[i] = packed[(size_t)npairs * 144 + i];
+    for (int i = e; i < np + 2; i += 144) g[i] = packed[(size_t)red_H + i];
     return;
   }
   const float f = 2.f * ns + 1.f;
@@ -964,8 +979,12 @@ __global__ void __launch_bounds__(144) k_expand_pairs(const double *packed, uint
   while (I > 0 && (uint32_t)(I * ns - I * (I - 1) / 2) > pid) --I;
   while ((uint32_t)((I + 1) * ns - (I + 1) * I / 2) <= pid) ++I;
   const int J = I + (int)(pid - (uint32_t)(I * ns - I * (I - 1) / 2));
-  const int n = 12 * ns, gi = I * 12 + e / 12, gj = J * 12 + e % 12;
-  const double v = packed[(size_t)pid * 144 + e];
+  const int n = 12 * ns, u = e / 12, w = e % 12, gi = I * 12 + u, gj = J * 12 + w;
+  double v = 0.0;
+  if (J - I <= 2)
+    v = packed[(size_t)pair_off[pid] + e];
+  else if (u < 6 && w < 6)
+    v = packed[(size_t)pair_off[pid] + u * 6 + w];
   H[(size_t)gi * n + gj] = v;
   H[(size_t)gj * n + gi] = v;
 }
@@ -1744,10 +1763,10 @@ int build_family(wc_ctx *ctx, wc_window_state *W, bool unary, const wc_surfel *s
 
 }  // namespace
 
-extern "C" int wc_window_build(wc_ctx *ctx, const wc_surfel *d_sld_surf, const wc_pose *d_sld_pose, const wc_pair *d_pairs_sld,
-                               uint64_t n_pairs_sld, const wc_surfel *d_fix_surf, const wc_pose *d_fix_pose,
-                               const wc_pair *d_pairs_fix, uint64_t n_pairs_fix, const wc_imu_state *h_imu, uint64_t n_imu,
-                               const double *h_sample_times, uint64_t ns_, const double *h_grav, int fix_first_pos) {
+static int window_build_impl(wc_ctx *ctx, const wc_surfel *d_sld_surf, const wc_pose *d_sld_pose, const wc_pair *d_pairs_sld,
+                             uint64_t n_pairs_sld, const wc_surfel *d_fix_surf, const wc_pose *d_fix_pose,
+                             const wc_pair *d_pairs_fix, uint64_t n_pairs_fix, const wc_imu_state *h_imu, uint64_t n_imu,
+                             const double *h_sample_times, uint64_t ns_, const double *h_grav, int fix_first_pos, bool sharded) {
   wc_dev_guard dg_(ctx);
   if (!ctx || !h_sample_times || ns_ < 2 || ns_ > 340 || !h_grav) return wc_fail(ctx, WC_ERR_ARG, "%s: null or out-of-range argument", __func__);  // 12 ns <= 4096 unknowns: dense H (134 MB), the largest window the solve has been exercised on; the reference's default window has 82 sample states
   if (n_pairs_sld >= (1ull << 31) || n_pairs_fix >= (1ull << 31)) return wc_fail(ctx, WC_ERR_ARG, "%s: null or out-of-range argument", __func__);
@@ -1755,6 +1774,7 @@ extern "C" int wc_window_build(wc_ctx *ctx, const wc_surfel *d_sld_surf, const w
   if (!ctx->win) ctx->win = new wc_window_state;
   wc_window_state *W = ctx->win;
   W->built = false;
+  W->sharded = sharded;
   const wc_params &P = ctx->P;
   const int ns = (int)ns_;
   W->ns = ns;
@@ -1775,7 +1795,7 @@ extern "C" int wc_window_build(wc_ctx *ctx, const wc_surfel *d_sld_surf, const w
   std::vector<Piece> pieces;
   std::vector<Src> src;
   std::vector<GSrc> gsrc;
-  std::vector<uint32_t> src_begin, gsrc_begin, heavy;
+  std::vector<uint32_t> src_begin, gsrc_begin, heavy, pair_off;
   struct SyncGuard {
     hipStream_t s;
     ~SyncGuard() { (void)hipStreamSynchronize(s); }
@@ -1941,6 +1961,18 @@ extern "C" int wc_window_build(wc_ctx *ctx, const wc_surfel *d_sld_surf, const w
       }
     }
   }
+  pair_off.assign(npairs + 1, 0);
+  {
+    uint32_t o = 0, pid = 0;
+    for (int I = 0; I < ns; ++I)
+      for (int J = I; J < ns; ++J) {
+        pair_off[pid++] = o;
+        o += (J - I <= 2) ? 144u : 36u;
+      }
+    pair_off[npairs] = o;
+    W->red_H = o;
+  }
+  WC_TRY(upload(ctx, W->pair_off, pair_off));
   for (uint32_t i = 0; i < npairs; ++i)
     if (src_begin[i + 1] - src_begin[i] > kHeavySrc) heavy.push_back(i);
   W->nheavy = (uint32_t)heavy.size();
@@ -1981,6 +2013,73 @@ extern "C" int wc_window_build(wc_ctx *ctx, const wc_surfel *d_sld_surf, const w
   return WC_OK;
 }
 
+extern "C" int wc_window_build(wc_ctx *ctx, const wc_surfel *d_sld_surf, const wc_pose *d_sld_pose, const wc_pair *d_pairs_sld,
+                               uint64_t n_pairs_sld, const wc_surfel *d_fix_surf, const wc_pose *d_fix_pose,
+                               const wc_pair *d_pairs_fix, uint64_t n_pairs_fix, const wc_imu_state *h_imu, uint64_t n_imu,
+                               const double *h_sample_times, uint64_t ns_, const double *h_grav, int fix_first_pos) {
+  return window_build_impl(ctx, d_sld_surf, d_sld_pose, d_pairs_sld, n_pairs_sld, d_fix_surf, d_fix_pose, d_pairs_fix, n_pairs_fix, h_imu,
+                           n_imu, h_sample_times, ns_, h_grav, fix_first_pos, false);
+}
+
+namespace {
+int do_allreduce(wc_ctx *ctx, wc_window_state *W, double *d_buf, size_t count);
+}
+
+// The multi-GPU form (see include/wildcat_hip.h): the SAME replicated arguments on every rank; the library takes this rank's
+// contiguous share of both correspondence lists and of the IMU state triples (factor i = states i, i + 1, i + 2: a rank's share
+// of the factors is its states plus the two that follow), and checks with one small all-reduce that the ranks' shares add up
+// to the whole problem - ranks that were handed different lists, or a world in which not every rank made this call, fail here
+// instead of summing H, g and the cost a wrong number of times.
+extern "C" int wc_window_build_sharded(wc_ctx *ctx, const wc_surfel *d_sld_surf, const wc_pose *d_sld_pose, const wc_pair *d_pairs_sld,
+                                       uint64_t n_pairs_sld, const wc_surfel *d_fix_surf, const wc_pose *d_fix_pose,
+                                       const wc_pair *d_pairs_fix, uint64_t n_pairs_fix, const wc_imu_state *h_imu, uint64_t n_imu,
+                                       const double *h_sample_times, uint64_t ns_, const double *h_grav, int fix_first_pos) {
+  if (!ctx) return WC_ERR_ARG;
+  if (!ctx->have_comm || ctx->comm.world <= 1)  // one rank: the whole problem, no collective
+    return window_build_impl(ctx, d_sld_surf, d_sld_pose, d_pairs_sld, n_pairs_sld, d_fix_surf, d_fix_pose, d_pairs_fix, n_pairs_fix, h_imu,
+                             n_imu, h_sample_times, ns_, h_grav, fix_first_pos, false);
+  if (!ctx->comm.allreduce_f64) return wc_fail(ctx, WC_ERR_ARG, "%s: the communicator has no all-reduce", __func__);
+  const uint64_t w = (uint64_t)ctx->comm.world, r = (uint64_t)ctx->comm.rank;
+  auto share = [&](uint64_t n, uint64_t &lo, uint64_t &cnt) {
+    lo = (n * r) / w;
+    cnt = (n * (r + 1)) / w - lo;
+  };
+  uint64_t lo_b, n_b, lo_u, n_u, lo_i = 0, n_i = 0;
+  share(n_pairs_sld, lo_b, n_b);
+  share(n_pairs_fix, lo_u, n_u);
+  const uint64_t n_fac = (h_imu && n_imu >= 3) ? n_imu - 2 : 0;
+  share(n_fac, lo_i, n_i);
+  WC_TRY(window_build_impl(ctx, d_sld_surf, d_sld_pose, d_pairs_sld ? d_pairs_sld + lo_b : nullptr, n_b, d_fix_surf, d_fix_pose,
+                           d_pairs_fix ? d_pairs_fix + lo_u : nullptr, n_u, n_i ? h_imu + lo_i : nullptr, n_i ? n_i + 2 : 0, h_sample_times, ns_,
+                           h_grav, fix_first_pos, true));
+  wc_dev_guard dg_(ctx);
+  wc_window_state *W = ctx->win;
+  // the whole problem's IMU factor count, from the replicated states (the selection rule of BuildImuResiduals, cc:324-329)
+  uint64_t ni_all = 0;
+  for (uint64_t i = 0; i + 2 < n_imu && h_imu; ++i) {
+    if (h_imu[i].t < W->times.front()) continue;
+    if (h_imu[i + 2].t > W->times.back()) break;
+    ++ni_all;
+  }
+  const double mine[4] = {(double)W->nb, (double)W->nu, (double)W->ni, 1.0};
+  double *chk = (double *)W->mail.p + 48;
+  WC_HIP(ctx, hipMemcpyAsync(chk, mine, sizeof(mine), hipMemcpyHostToDevice, ctx->stream));
+  WC_HIP(ctx, hipStreamSynchronize(ctx->stream));  // (`mine` is a stack array)
+  WC_TRY(do_allreduce(ctx, W, chk, 4));
+  double all[4];
+  WC_HIP(ctx, hipMemcpyAsync(all, chk, sizeof(all), hipMemcpyDeviceToHost, ctx->stream));
+  WC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (all[0] != (double)n_pairs_sld || all[1] != (double)n_pairs_fix || all[2] != (double)ni_all || all[3] != (double)w) {
+    W->built = false;
+    return wc_fail(ctx, WC_ERR_ARG,
+                   "wc_window_build_sharded: the ranks' shares do not add up to the problem this rank was given (binary %.0f of %llu, unary %.0f of "
+                   "%llu, imu %.0f of %llu, ranks %.0f of %llu): every rank must pass the same replicated arguments",
+                   all[0], (unsigned long long)n_pairs_sld, all[1], (unsigned long long)n_pairs_fix, all[2], (unsigned long long)ni_all, all[3],
+                   (unsigned long long)w);
+  }
+  return WC_OK;
+}
+
 namespace {
 
 inline double *lin_H(wc_window_state *W) { return (double *)W->lin.p; }
@@ -2008,7 +2107,7 @@ __global__ void __launch_bounds__(1024) k_post_reduce(const double *g, const dou
 // (the callback installed with wc_window_set_allreduce, else the ctx's communicator - the in-library RCCL binding of comm.hip
 // enqueues ncclAllReduce on the ctx stream: no host synchronisation on that path)
 bool multi_gpu(const wc_ctx *ctx, const wc_window_state *W) {
-  return W->allreduce != nullptr || (ctx->have_comm && ctx->comm.world > 1 && ctx->comm.allreduce_f64 != nullptr);
+  return W->allreduce != nullptr || (W->sharded && ctx->have_comm && ctx->comm.world > 1 && ctx->comm.allreduce_f64 != nullptr);
 }
 int do_allreduce(wc_ctx *ctx, wc_window_state *W, double *d_buf, size_t count) {
   if (W->allreduce) {
@@ -2044,13 +2143,14 @@ int enqueue_linearize(wc_ctx *ctx, wc_window_state *W, const double *d_x, int ma
   // half the bytes of the dense matrix on the wire; one more kernel spreads the sum into both triangles
   const bool packed = multi_gpu(ctx, W);
   double *red = nullptr;
-  const size_t red_count = (size_t)W->npairs * 144 + W->np + 2;
+  const size_t red_count = (size_t)W->red_H + W->np + 2;
   if (packed) {
     WC_TRY(wc_ensure(ctx, W->reduce, red_count * 8));
     red = (double *)W->reduce.p;
   }
   ga.H = packed ? red : lin_H(W);
-  ga.g = packed ? red + (size_t)W->npairs * 144 : lin_g(W);
+  ga.g = packed ? red + (size_t)W->red_H : lin_g(W);
+  ga.pair_off = (const uint32_t *)W->pair_off.p;
   ga.cost = ga.g + W->np;
   ga.packed = packed ? 1 : 0;
   ga.nheavy = W->nheavy, ga.npairs = W->npairs, ga.npieces = W->npiece_b + W->npiece_u + W->npiece_i;
@@ -2059,7 +2159,7 @@ int enqueue_linearize(wc_ctx *ctx, wc_window_state *W, const double *d_x, int ma
   WC_HIP(ctx, hipGetLastError());
   if (packed) {
     WC_TRY(do_allreduce(ctx, W, red, red_count));  // the ONE collective of a linearisation
-    k_expand_pairs<<<W->npairs + 1, 144, 0, st>>>(red, W->npairs, W->ns, W->np, lin_H(W), lin_g(W));
+    k_expand_pairs<<<W->npairs + 1, 144, 0, st>>>(red, W->npairs, W->ns, W->np, lin_H(W), lin_g(W), (const uint32_t *)W->pair_off.p, W->red_H);
   }
   // (inside the LM loop the next lm_step forms cost / max |g| of this linearisation itself: post = false)
   if (post) k_post_reduce<<<1, 1024, 0, st>>>(lin_g(W), lin_cost(W), W->n, (double *)W->mail.p, mail_slot);
@@ -2101,6 +2201,11 @@ extern "C" int wc_window_counts(wc_ctx *ctx, uint64_t counts[4]) {
   counts[0] = ctx->win->nb, counts[1] = ctx->win->nu, counts[2] = ctx->win->ni;
   counts[3] = ctx->win->npiece_b + ctx->win->npiece_u + ctx->win->npiece_i;
   return WC_OK;
+}
+
+extern "C" uint64_t wc_window_reduce_bytes(wc_ctx *ctx) {
+  if (!ctx || !ctx->win || !ctx->win->built || !multi_gpu(ctx, ctx->win)) return 0;
+  return ((uint64_t)ctx->win->red_H + ctx->win->np + 2) * 8;
 }
 
 extern "C" int wc_window_evaluate(wc_ctx *ctx, const double *h_x, double *h_cost, double *d_residuals) {

@@ -26,40 +26,55 @@ def _padded(n):
     return ((n + 1 + 31) // 32) * 32
 
 
+def pair_offsets(ns):
+    """offset of every upper block pair (I <= J, pair order) in the reduction buffer, and the buffer's H part in doubles: 144
+    doubles for a pair of sample blocks at most two apart (IMU factors reach that far, cost_functor.h:264-355), the 6 x 6 pose
+    corner (36) for the others, which only surfel factors touch (csrc/window.hip: wc_window_state::pair_off)"""
+    off, o = {}, 0
+    for i in range(ns):
+        for j in range(i, ns):
+            off[(i, j)] = o
+            o += 144 if j - i <= 2 else 36
+    return off, o
+
+
 def packed_count(ns):
     """number of doubles in the reduction buffer {upper block pairs, g, cost, spare} of a window with ns sample states"""
-    return (ns * (ns + 1) // 2) * 144 + _padded(12 * ns) + 2
+    return pair_offsets(ns)[1] + _padded(12 * ns) + 2
 
 
 def pack(H, g, cost):
-    """dense H (n x n), g, cost -> the reduction buffer (the layout k_gather writes when an all-reduce is installed)"""
+    """dense H (n x n), g, cost -> the reduction buffer (the layout k_gather writes for a sharded problem)"""
     n = len(g)
     ns = n // 12
-    npairs = ns * (ns + 1) // 2
-    buf = np.zeros(npairs * 144 + _padded(n) + 2)
-    pid = 0
-    for i in range(ns):
-        for j in range(i, ns):
-            buf[pid * 144 : (pid + 1) * 144] = H[12 * i : 12 * i + 12, 12 * j : 12 * j + 12].reshape(-1)
-            pid += 1
-    buf[npairs * 144 : npairs * 144 + n] = g
-    buf[npairs * 144 + _padded(n)] = cost
+    off, nh = pair_offsets(ns)
+    buf = np.zeros(nh + _padded(n) + 2)
+    for (i, j), o in off.items():
+        blk = H[12 * i : 12 * i + 12, 12 * j : 12 * j + 12]
+        if j - i <= 2:
+            buf[o : o + 144] = blk.reshape(-1)
+        else:
+            assert not blk[6:, :].any() and not blk[:, 6:].any(), "a far pair has entries outside its pose corner"
+            buf[o : o + 36] = blk[:6, :6].reshape(-1)
+    buf[nh : nh + n] = g
+    buf[nh + _padded(n)] = cost
     return buf
 
 
 def unpack(buf, ns):
     """the reduction buffer -> dense symmetric H, g, cost (what k_expand_pairs does on the device)"""
     n = 12 * ns
-    npairs = ns * (ns + 1) // 2
+    off, nh = pair_offsets(ns)
     H = np.zeros((n, n))
-    pid = 0
-    for i in range(ns):
-        for j in range(i, ns):
-            blk = buf[pid * 144 : (pid + 1) * 144].reshape(12, 12)
-            H[12 * i : 12 * i + 12, 12 * j : 12 * j + 12] = blk
-            H[12 * j : 12 * j + 12, 12 * i : 12 * i + 12] = blk.T
-            pid += 1
-    return H, buf[npairs * 144 : npairs * 144 + n], float(buf[npairs * 144 + _padded(n)])
+    for (i, j), o in off.items():
+        blk = np.zeros((12, 12))
+        if j - i <= 2:
+            blk[:] = buf[o : o + 144].reshape(12, 12)
+        else:
+            blk[:6, :6] = buf[o : o + 36].reshape(6, 6)
+        H[12 * i : 12 * i + 12, 12 * j : 12 * j + 12] = blk
+        H[12 * j : 12 * j + 12, 12 * i : 12 * i + 12] = blk.T
+    return H, buf[nh : nh + n], float(buf[nh + _padded(n)])
 
 
 class DeviceView:

@@ -326,6 +326,13 @@ class Context:
                                            C.c_void_p(d_oid.ptr)))
         return d_out.download(R.SURFEL, n), d_oid.download(R.SURFEL_ID, n)
 
+    def gather_surfels_device(self, d_local, d_local_ids, n_local, d_out, d_out_ids, cap):
+        """wc_gather_surfels into caller buffers (device) -> number of surfels of the merged, replicated list"""
+        m = C.c_uint64(0)
+        self._ck(self.lib.wc_gather_surfels(self.h, C.c_void_p(d_local.ptr), C.c_void_p(d_local_ids.ptr), C.c_uint64(n_local), C.c_void_p(d_out.ptr),
+                                            C.c_void_p(d_out_ids.ptr if d_out_ids else 0), C.c_uint64(cap), C.byref(m)))
+        return int(m.value)
+
     def gather_surfels(self, d_local, d_local_ids, n_local, cap):
         d_out, d_oid = self.alloc(144 * max(cap, 1)), self.alloc(16 * max(cap, 1))
         m = C.c_uint64(0)
@@ -378,18 +385,25 @@ class Context:
                                                  C.c_void_p(d_in_body.ptr), C.c_uint64(n)))
 
     def window_build(self, d_surf, d_pose, d_pairs, n_pairs, imu, sample_times, grav, fix_first_pos, d_fix_surf=None, d_fix_pose=None,
-                     d_pairs_fix=None, n_pairs_fix=0):
-        """imu: host IMU_STATE array (or None); sample_times/grav: host arrays"""
+                     d_pairs_fix=None, n_pairs_fix=0, sharded=False):
+        """imu: host IMU_STATE array (or None); sample_times/grav: host arrays.  sharded: wc_window_build_sharded - a collective of
+        the ctx's communicator, every rank passes the SAME replicated arguments and the library takes this rank's share"""
         st = np.ascontiguousarray(sample_times, np.float64)
         gr = np.ascontiguousarray(grav, np.float64)
         self._ns = len(st)
         null = C.c_void_p(0)
-        self._ck(self.lib.wc_window_build(
+        fn = self.lib.wc_window_build_sharded if sharded else self.lib.wc_window_build
+        self._ck(fn(
             self.h, C.c_void_p(d_surf.ptr), C.c_void_p(d_pose.ptr), C.c_void_p(d_pairs.ptr) if d_pairs else null, C.c_uint64(n_pairs),
             C.c_void_p(d_fix_surf.ptr) if d_fix_surf else null, C.c_void_p(d_fix_pose.ptr) if d_fix_pose else null,
             C.c_void_p(d_pairs_fix.ptr) if d_pairs_fix else null, C.c_uint64(n_pairs_fix),
             R.ptr(imu) if imu is not None and len(imu) else null, C.c_uint64(len(imu) if imu is not None else 0), R.ptr(st), C.c_uint64(len(st)),
             R.ptr(gr), C.c_int(int(fix_first_pos))))
+
+    def window_reduce_bytes(self):
+        """bytes one linearisation's all-reduce carries (0: the problem is not sharded)"""
+        self.lib.wc_window_reduce_bytes.restype = C.c_uint64
+        return int(self.lib.wc_window_reduce_bytes(self.h))
 
     def window_counts(self):
         c = (C.c_uint64 * 4)()
@@ -445,22 +459,30 @@ class Context:
         self._ck(self.lib.wc_window_set_allreduce(self.h, self._cb, C.c_void_p(0)))
 
     # ---- correspondence ---------------------------------------------------------------------------------------------
-    def match_device(self, d_q_surf, d_q_pose, nq, d_t_surf, d_t_pose, nt, same_set, d_pairs, cap, d_knn_idx=None, d_knn_d2=None):
+    def match_device(self, d_q_surf, d_q_pose, nq, d_t_surf, d_t_pose, nt, same_set, d_pairs, cap, d_knn_idx=None, d_knn_d2=None, sharded=False):
+        """sharded: wc_match_sharded - a collective of the ctx's communicator (every rank, same replicated arguments)"""
         n = C.c_uint64(0)
+        if sharded:
+            self._ck(self.lib.wc_match_sharded(self.h, C.c_void_p(d_q_surf.ptr), C.c_void_p(d_q_pose.ptr), C.c_uint64(nq), C.c_void_p(d_t_surf.ptr),
+                                               C.c_void_p(d_t_pose.ptr), C.c_uint64(nt), C.c_int(1 if same_set else 0), C.c_void_p(d_pairs.ptr),
+                                               C.c_uint64(cap), C.byref(n)))
+            return int(n.value)
         self._ck(self.lib.wc_match(self.h, C.c_void_p(d_q_surf.ptr), C.c_void_p(d_q_pose.ptr), C.c_uint64(nq), C.c_void_p(d_t_surf.ptr),
                                    C.c_void_p(d_t_pose.ptr), C.c_uint64(nt), C.c_int(1 if same_set else 0), C.c_void_p(d_pairs.ptr), C.c_uint64(cap),
                                    C.byref(n), C.c_void_p(d_knn_idx.ptr if d_knn_idx else 0), C.c_void_p(d_knn_d2.ptr if d_knn_d2 else 0)))
         return int(n.value)
 
-    def match_pair_device(self, d_sld_surf, d_sld_pose, n_sld, d_fix_surf, d_fix_pose, n_fix, d_pairs_sld, cap_sld, d_pairs_fix, cap_fix):
-        """both searches of an outer iteration side by side (wc_match_pair) -> (n_pairs_sld, n_pairs_fix)"""
+    def match_pair_device(self, d_sld_surf, d_sld_pose, n_sld, d_fix_surf, d_fix_pose, n_fix, d_pairs_sld, cap_sld, d_pairs_fix, cap_fix, sharded=False):
+        """both searches of an outer iteration side by side (wc_match_pair; sharded: wc_match_pair_sharded, a collective)
+        -> (n_pairs_sld, n_pairs_fix)"""
         nb, nu = C.c_uint64(0), C.c_uint64(0)
-        self._ck(self.lib.wc_match_pair(self.h, C.c_void_p(d_sld_surf.ptr), C.c_void_p(d_sld_pose.ptr), C.c_uint64(n_sld), C.c_void_p(d_fix_surf.ptr),
+        fn = self.lib.wc_match_pair_sharded if sharded else self.lib.wc_match_pair
+        self._ck(fn(self.h, C.c_void_p(d_sld_surf.ptr), C.c_void_p(d_sld_pose.ptr), C.c_uint64(n_sld), C.c_void_p(d_fix_surf.ptr),
                                         C.c_void_p(d_fix_pose.ptr), C.c_uint64(n_fix), C.c_void_p(d_pairs_sld.ptr), C.c_uint64(cap_sld), C.byref(nb),
                                         C.c_void_p(d_pairs_fix.ptr), C.c_uint64(cap_fix), C.byref(nu)))
         return int(nb.value), int(nu.value)
 
-    def match(self, q_surf, q_pose, t_surf, t_pose, same_set, want_knn=False):
+    def match(self, q_surf, q_pose, t_surf, t_pose, same_set, want_knn=False, sharded=False):
         """host convenience -> pairs[PAIR] (and the raw k-NN table if want_knn)"""
         nq, nt = len(q_surf), len(t_surf)
         dq, dqp = self.to_device(q_surf), self.to_device(q_pose)
@@ -472,7 +494,7 @@ class Context:
         k = self.params.knn_k
         d_idx = self.alloc(4 * max(nq, 1) * k) if want_knn else None
         d_d2 = self.alloc(8 * max(nq, 1) * k) if want_knn else None
-        n = self.match_device(dq, dqp, nq, dt, dtp, nt, same_set, d_pairs, nq, d_idx, d_d2)
+        n = self.match_device(dq, dqp, nq, dt, dtp, nt, same_set, d_pairs, nq, d_idx, d_d2, sharded=sharded)
         pairs = d_pairs.download(R.PAIR, n)
         if want_knn:
             return pairs, d_idx.download(np.uint32, nq * k).reshape(nq, k), d_d2.download(np.float64, nq * k).reshape(nq, k)
