@@ -116,6 +116,7 @@ extern "C" void wc_ctx_destroy(wc_ctx *ctx) {
   for (wc_buf &b : ctx->b_route)
     if (b.p) (void)hipFree(b.p);
   if (ctx->b_match_stat.p) (void)hipFree(ctx->b_match_stat.p);
+  if (ctx->b_match_samp.p) (void)hipFree(ctx->b_match_samp.p);
   for (wc_buf &b : ctx->b_fx)
     if (b.p) (void)hipFree(b.p);
   if (ctx->h_status) (void)hipHostFree(ctx->h_status);

@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <thread>
@@ -88,6 +89,57 @@ __global__ void __launch_bounds__(256) k_features(const wc_surfel *surf, const w
     atomicMin(&bbox[threadIdx.x], min(min(s_mm[0][threadIdx.x], s_mm[1][threadIdx.x]), min(s_mm[2][threadIdx.x], s_mm[3][threadIdx.x])));
   else if (threadIdx.x < 6)
     atomicMax(&bbox[threadIdx.x], max(max(s_mm[0][threadIdx.x], s_mm[1][threadIdx.x]), max(s_mm[2][threadIdx.x], s_mm[3][threadIdx.x])));
+}
+
+// ---- the cell size of THIS call's data: a sampled look at the k-th 6-D distances ----------------------------------------------
+// The grid lives on the scaled centres only, so a query has to scan every cell within its k-th 6-D distance; the right cell size
+// is that distance, which depends on the window (1.4 m cells suit a sparse fixed window whose 10th neighbour is metres away, a
+// room seen by 40 sweeps has 280 surfels per cubic metre and its 10th neighbour 0.4 units away - one-metre cells there mean
+// 2 500 candidates per query).  kSampleQ queries, spread over the call's queries, count the targets inside 16 radii 2^(i/2 - 3)
+// (0.125 .. 22.6 units) - every target against every sample, a few GFLOP at most (large target sets are strided) - and the host
+// takes the median radius that holds k of them.  Only the speed of the search depends on it, never its result.
+constexpr int kSampleQ = 128, kSampleR = 16;
+__global__ void __launch_bounds__(128) k_sample_feats(const wc_surfel *surf, const wc_pose *pose, uint32_t n, double cs, double as, double *sf,
+                                                     uint32_t *counts) {
+  const int s = threadIdx.x;
+  const uint32_t i = (uint32_t)(((uint64_t)n * (2u * (uint32_t)s + 1u)) / (2u * (uint32_t)kSampleQ));  // evenly spread over the call's queries
+  double f[6];
+  V3 cw, nw;
+  feature6(surf[min(i, n - 1u)], pose[min(i, n - 1u)], cs, as, f, cw, nw);
+  for (int d = 0; d < 6; ++d) sf[s * 6 + d] = f[d];
+  for (int r = 0; r < kSampleR; ++r) counts[s * kSampleR + r] = 0u;
+}
+__global__ void __launch_bounds__(256) k_kth_sample(const double *__restrict__ feat, uint32_t nt, uint32_t stride, const double *__restrict__ sf,
+                                                   uint32_t *counts) {
+  __shared__ double s_f[kSampleQ][6];
+  __shared__ uint32_t s_cnt[kSampleQ][kSampleR];
+  for (int e = threadIdx.x; e < kSampleQ * 6; e += 256) (&s_f[0][0])[e] = sf[e];
+  for (int e = threadIdx.x; e < kSampleQ * kSampleR; e += 256) (&s_cnt[0][0])[e] = 0u;
+  __syncthreads();
+  const uint64_t i = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * stride;
+  if (i < nt) {
+    double t[6];
+    for (int d = 0; d < 6; ++d) t[d] = feat[i * 6 + d];
+    for (int s = 0; s < kSampleQ; ++s) {
+      double d2 = 0.0;
+#pragma unroll
+      for (int d = 0; d < 6; ++d) {
+        const double v = t[d] - s_f[s][d];
+        d2 = fma(v, v, d2);
+      }
+      if (d2 <= 512.0) {  // (rare: most targets are far from most samples)
+        int e = 0;
+        (void)frexp(d2, &e);  // d2 in [2^(e-1), 2^e): inside the radius with r^2 = 2^e
+        const int b = min(max(e + 6, 0), kSampleR - 1);
+        atomicAdd(&s_cnt[s][b], 1u);
+      }
+    }
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < kSampleQ * kSampleR; e += 256) {
+    const uint32_t c = (&s_cnt[0][0])[e];
+    if (c) atomicAdd(&counts[e], c);
+  }
 }
 
 __device__ __forceinline__ int cell_of(double v, double org, double h, int dim) {
@@ -474,7 +526,22 @@ static int match_impl(wc_ctx *ctx, const wc_surfel *d_q_surf, const wc_pose *d_q
   WC_HIP(ctx, hipMemsetAsync(status, 0, 64 * 4, st));
   k_features<<<(nt + 255) / 256, 256, 0, st>>>(d_t_surf, d_t_pose, nt, P.center_scale, P.angular_scale, (double *)b_feat.p,
                                               (double *)b_world.p, bbox);
+  // optional (WC_KNN_CELL=<factor> or WC_MATCH_DEBUG): the k-th 6-D distances of a sample of this call's queries (k_kth_sample),
+  // read back with the bounding box
+  static const char *cell_env = getenv("WC_KNN_CELL");
+  static const bool match_dbg = getenv("WC_MATCH_DEBUG") != nullptr;
+  const bool sample = (cell_env && cell_env[0] != 'v') || match_dbg;
+  const uint32_t samp_stride = (uint32_t)((nt + 262143u) / 262144u);  // at most 256 k targets are looked at
   unsigned long long hb[6];
+  uint32_t h_cnt[kSampleQ * kSampleR];
+  if (sample) {
+    WC_TRY(wc_ensure(ctx, ctx->b_match_samp, (size_t)kSampleQ * 6 * 8 + (size_t)kSampleQ * kSampleR * 4));
+    double *samp_f = (double *)ctx->b_match_samp.p;
+    uint32_t *samp_c = (uint32_t *)(samp_f + kSampleQ * 6);
+    k_sample_feats<<<1, kSampleQ, 0, st>>>(d_q_surf, d_q_pose, nq, P.center_scale, P.angular_scale, samp_f, samp_c);
+    k_kth_sample<<<(unsigned)(((nt + samp_stride - 1) / samp_stride + 255) / 256), 256, 0, st>>>((const double *)b_feat.p, nt, samp_stride, samp_f, samp_c);
+    WC_HIP(ctx, hipMemcpyAsync(h_cnt, samp_c, sizeof(h_cnt), hipMemcpyDeviceToHost, st));
+  }
   WC_HIP(ctx, hipMemcpyAsync(hb, bbox, sizeof(hb), hipMemcpyDeviceToHost, st));
   WC_HIP(ctx, hipStreamSynchronize(st));
   MatchParams M;
@@ -491,7 +558,42 @@ static int match_impl(wc_ctx *ctx, const wc_surfel *d_q_surf, const wc_pose *d_q
   // cell size: about 4 targets per occupied-volume cell, at most one scaled unit (= 1 m), at least extent / 1000
   double vol = 1.0;
   for (int d = 0; d < 3; ++d) vol *= std::max(hi[d] - lo[d], 0.05);
-  M.h = std::min(1.0, std::cbrt(4.0 * vol / (double)nt));
+  const double h_vol = std::min(1.0, std::cbrt(4.0 * vol / (double)nt));
+  M.h = h_vol;
+  // Round 3 tried to take the cell size from THIS call's data: kSampleQ queries measure their k-th 6-D distance
+  // (k_kth_sample) and the grid gets cells of a multiple of the median.  Measured (profiles/dev/time_match.py, time_facade.py;
+  // DESIGN 3.3): the bench windows (random normals, k-th distance 2 - 5.7 units) are fastest with the density rule's cells of a
+  // quarter of that distance; on the facade's room stream the MEDIAN is 0.18 - 0.25 units but the tail reaches 2.8 - 5.7 (surfels
+  // whose normal has no like within metres), and a query walks (k-th distance / h)^3 cells: cells of 2 x the median made the
+  // search 5 x slower (25 - 40 ms), of 0.5 x the median 2000 x.  The tail, not the median, sets the cost of a search, so the
+  // density rule stays the default and the sampled rule an experiment behind WC_KNN_CELL=<factor>.
+  if (sample) {
+    // median over the samples of the smallest radius that holds k targets (strided counts scaled up); samples that never
+    // reach k inside 22 units (fewer than k targets, or a target set far from the queries) vote for the largest radius
+    std::vector<double> rk;
+    for (int s = 0; s < kSampleQ; ++s) {
+      uint64_t c = 0;
+      int b = kSampleR;
+      for (int r = 0; r < kSampleR; ++r) {
+        c += (uint64_t)h_cnt[s * kSampleR + r] * samp_stride;
+        if (c >= (uint64_t)std::min<uint32_t>((uint32_t)P.knn_k, nt)) {
+          b = r;
+          break;
+        }
+      }
+      rk.push_back(std::ldexp(1.0, b - 6) > 0 ? std::sqrt(std::ldexp(1.0, b - 6)) : 0.125);
+    }
+    std::nth_element(rk.begin(), rk.begin() + rk.size() / 2, rk.end());
+    const double r_med = rk[rk.size() / 2];
+    const double factor = (cell_env && cell_env[0] != 'v') ? atof(cell_env) : 0.0;
+    if (factor > 0.0) M.h = std::min(h_vol, factor * r_med);
+    ctx->match_last_rk = r_med;
+    if (match_dbg) {
+      std::sort(rk.begin(), rk.end());
+      fprintf(stderr, "[match] nq %u nt %u same %d: sampled k-th distance p10 %.3f p50 %.3f p90 %.3f max %.3f; h_vol %.3f -> h %.3f\n", nq, nt, same_set,
+              rk[rk.size() / 10], rk[rk.size() / 2], rk[rk.size() * 9 / 10], rk.back(), h_vol, M.h);
+    }
+  }
   M.h = std::max(M.h, std::max(ext / 1000.0, 1e-3));
   for (int d = 0; d < 3; ++d) {
     M.org[d] = lo[d];
