@@ -46,6 +46,40 @@ def test_facade_multi_sweep(gpu):
     odo.close()
 
 
+def test_facade_residual_log(gpu):
+    """the reference's residual histograms (PrintSurfelResiduals / PrintImuResiduals, lidar_odometry.cc:56-94) before and after
+    every solve, off by default: one line block per factor family, counts = the problem's factor counts"""
+    from wildcat_slam_amd import lib
+
+    msgs, imu, _ = synth.raw_stream(2.2, pts_per_s=300_000, gyro_bias=(0.0, 0.0, 0.02), t_start=1000.0)
+    odo = lib.Odometry(0)
+    _drive(odo, msgs[:8], imu)
+    assert odo.residual_log() == ""
+    odo.set_residual_log(True)
+    k = 0
+    while k < len(imu["t"]) and imu["t"][k] <= msgs[7]["time"][-1] + 0.02:
+        k += 1
+    for m in msgs[8:]:
+        while k < len(imu["t"]) and imu["t"][k] <= m["time"][-1] + 0.02:
+            odo.add_imu(imu["t"][k], imu["acc"][k], imu["gyr"][k])
+            k += 1
+        odo.add_scan(m)
+    st, log = odo.stats(), odo.residual_log()
+    assert odo.sweeps() >= 3 and st["binary"] > 100
+    for when in ("[before solve] ", "[after update] "):
+        head = when + "Sliding Window Surfel residuals, cost: "
+        assert head in log
+        blk = log[log.index(head):]
+        assert "dist: Count: %d  Min: " % int(st["binary"]) in blk.split("\n")[0]
+        for kind in ("gyro", "acc", "gyro_bias", "acc_bias"):
+            assert when + "Imu residuals with type " + kind + ", cost: " in log
+    assert "Fixed Window" not in log  # (no fixed window yet: PrintSurfelResiduals returns on an empty block list, :57-59)
+    import re
+
+    assert len(re.findall(r"\n\[-?[0-9.]+, -?[0-9.]+[)\]]\t", log)) == 2 * 5 * 10  # ten buckets per histogram, five histograms, twice
+    odo.close()
+
+
 def _feed(odo, ref, msgs, imu, on_sweep):
     """the same raw stream into the facade and the orchestrated oracle; on_sweep(sweep number) after every completed sweep"""
     k = 0

@@ -171,3 +171,30 @@ def test_imu_resampler_kat(host):
     host.wc_host_resampler_add(h, C.c_double(2), R.ptr(acc1), R.ptr(gyr1))
     assert host.wc_host_resampler_advance(h, R.ptr(out)) == 1 and 1.0 <= out[0] <= 1.1 + 1e-12
     host.wc_host_resampler_destroy(h)
+
+
+def test_histogram_text_is_the_reference_utility(host):
+    """Histogram::ToString (src/common/histogram.cc:27-76, what PrintSurfelResiduals / PrintImuResiduals log, lidar_odometry.cc:70,
+    :91): Count / Min / Max / Mean in float arithmetic, equal-width buckets with the last one closed, a 20-character bar rounded to
+    nearest, count and running total with percentages.  Expected text worked out by hand from the reference's loop."""
+    host.wc_host_histogram.restype = C.c_uint64
+
+    def text(vals, buckets):
+        v = np.asarray(vals, np.float64)
+        buf = C.create_string_buffer(4096)
+        host.wc_host_histogram(v.ctypes.data_as(C.c_void_p), C.c_uint64(len(v)), C.c_int(buckets), buf, C.c_uint64(4096))
+        return buf.value.decode()
+
+    assert text([], 10) == "Count: 0"
+    assert text([0.25, 0.25], 10) == "Count: 2  Min: 0.25  Max: 0.25  Mean: 0.25"  # min == max: no buckets
+    got = text([1.0, 2.0, 3.0, 4.0], 2)
+    bar = " " * 10 + "#" * 10
+    want = ("Count: 4  Min: 1  Max: 4  Mean: 2.5"
+            "\n[1.000000, 2.500000)\t" + bar + "\tCount: 2 (50%)\tTotal: 2 (50%)"
+            "\n[2.500000, 4.000000]\t" + bar + "\tCount: 2 (50%)\tTotal: 4 (100%)")
+    assert got == want, got
+    # 10 buckets over [0, 1]: 0.95 and 1.0 share the closed last bucket, 0.05 sits in the first
+    lines = text([0.0, 0.05, 0.5, 0.95, 1.0], 10).split("\n")
+    assert len(lines) == 11 and lines[0].startswith("Count: 5  Min: 0  Max: 1  Mean: 0.5")
+    assert "Count: 2 (40%)" in lines[1] and "Count: 2 (40%)" in lines[10] and lines[10].endswith("Total: 5 (100%)")
+    assert lines[10].startswith("[0.900000, 1.000000]") and "Count: 1 (20%)" in lines[6]

@@ -304,7 +304,7 @@ def test_c3_window_size_independent_properties(gpu):
     assert np.abs(g_end).max() < 1e-2 * np.abs(g).max()
 
 
-def test_c4_window_full_size_properties(gpu):
+def test_c4_window_full_size_properties(gpu, oracle):
     """BASELINE config C4 at FULL size (20 sweeps x 50 000 patches = 1 M sliding-window surfels, 50 000 fixed-window surfels,
     IMU factors, ~2 M factors, 127 sample states) - the window bench.py times.  The oracle would need minutes, so: properties
     that hold at any size.  wc_window_counts equals the matcher's counts; the normal equations are symmetric, bitwise
@@ -345,6 +345,27 @@ def test_c4_window_full_size_properties(gpu):
     # IMU factors carry a TrivialLoss (lidar_odometry.cc:342,356): their residuals enter the cost as plain squares; surfel
     # residuals are Cauchy-corrected (sqrt(rho') r), so 1/2 r_c^2 <= 1/2 rho(r^2) for each of them
     assert 0.5 * float(np.dot(res, res)) <= cost * (1 + 1e-12)
+    # BY VALUE at full size: the oracle (oracle/window.cc, one factor at a time, dense accumulation) linearises the same 1 M + 1 M
+    # surfel factors + IMU factors - seconds on one core - at x = 0 and at a random point; this is the regime of 12 k pieces and
+    # gather lists of hundreds of sources that the smaller comparisons never reach (lidar_odometry.cc:254-317 -> cost_functor.h)
+    Wref = oracle.Window(w["sample_times"], w["grav"], False)
+    Wref.add_binary(w["surf"], w["pose"], pairs)
+    Wref.add_unary(w["fix_surf"], w["fix_pose"], w["surf"], w["pose"], pf)
+    Wref.add_imu(w["imu"])
+    assert Wref.num_residuals() == n_b + n_u + 12 * ni_
+    x1 = 2e-3 * np.random.default_rng(17).normal(size=12 * ns)
+    for xv, (Hg, gg, cg) in ((x0, (H, g, c0)), (x1, gpu.window_linearize(x1))):
+        Hr, gr, cr = Wref.linearize(xv)
+        assert abs(cg - cr) <= 1e-10 * cr
+        assert np.abs(Hg - Hr).max() <= 1e-9 * np.abs(Hr).max() and np.abs(gg - gr).max() <= 1e-9 * np.abs(gr).max()
+        # block by block: every 12 x 12 block pair relative to ITS OWN size (small far-apart blocks are not hidden by the diagonal)
+        Hb = np.abs(Hg - Hr).reshape(ns, 12, ns, 12).max(axis=(1, 3))
+        Hs = np.abs(Hr).reshape(ns, 12, ns, 12).max(axis=(1, 3))
+        assert np.all(Hb <= 1e-8 * np.maximum(Hs, 1e-300) + 1e-12 * np.abs(Hr).max())
+        assert np.array_equal(Hs == 0, np.abs(Hg).reshape(ns, 12, ns, 12).max(axis=(1, 3)) == 0)  # same block sparsity
+    cr1, res_ref = Wref.evaluate(x1, want_residuals=True)
+    c1, res1 = gpu.window_evaluate(x1, want_residuals=True)
+    assert abs(c1 - cr1) <= 1e-10 * cr1 and np.abs(res1 - res_ref).max() <= 1e-9 * np.abs(res_ref).max()
     x, s, _ = gpu.window_solve(x0)
     assert s.iterations >= 1 and s.successful_steps >= 1 and s.final_cost < s.initial_cost
     assert abs(s.initial_cost - c0) <= 1e-9 * c0

@@ -12,11 +12,24 @@
 // (torch.distributed / MPI / a file): 128 opaque bytes.
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
-#include <rccl/rccl.h>
 
 #include <cstring>
 
 #include "ctx.h"
+
+// The few names of RCCL's C API this file uses, declared here so that the library BUILDS without the rccl-dev headers (it is
+// only ever reached through dlopen): nccl.h of RCCL 2.x / ROCm 6-7 - ncclUniqueId is 128 opaque bytes, the enums below have
+// been stable since NCCL 2.0.  wc_comm_rccl_init checks ncclGetVersion() >= 2.0 before trusting them.
+extern "C" {
+typedef struct ncclComm *ncclComm_t;
+typedef struct {
+  char internal[128];
+} ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclInt8 = 0, ncclChar = 0, ncclUint8 = 1, ncclInt32 = 2, ncclUint32 = 3, ncclInt64 = 4, ncclUint64 = 5, ncclFloat16 = 6, ncclFloat32 = 7, ncclFloat64 = 8, ncclDouble = 8 } ncclDataType_t;
+typedef enum { ncclSum = 0 } ncclRedOp_t;
+}
+static_assert(sizeof(ncclUniqueId) == 128, "the 128-byte id of include/wildcat_hip.h");
 
 namespace {
 
@@ -31,6 +44,7 @@ struct RcclApi {
   ncclResult_t (*GroupStart)() = nullptr;
   ncclResult_t (*GroupEnd)() = nullptr;
   const char *(*GetErrorString)(ncclResult_t) = nullptr;
+  ncclResult_t (*GetVersion)(int *) = nullptr;
 };
 
 RcclApi *rccl_api(std::string *err) {
@@ -63,11 +77,14 @@ RcclApi *rccl_api(std::string *err) {
       WC_SYM(GroupStart, "ncclGroupStart")
       WC_SYM(GroupEnd, "ncclGroupEnd")
       WC_SYM(GetErrorString, "ncclGetErrorString")
+      WC_SYM(GetVersion, "ncclGetVersion")
 #undef WC_SYM
+      int ver = 0;
+      if (ok && (api.GetVersion(&ver) != ncclSuccess || ver < 2000)) ok = false;  // (the local declarations above describe 2.x)
     }
   }
   if (!ok) {
-    if (err) *err = api.so ? "librccl.so lacks an expected symbol" : (std::string("dlopen(librccl.so) failed: ") + (dlerror() ? dlerror() : "?"));
+    if (err) *err = api.so ? "librccl.so lacks an expected symbol or is older than 2.0" : (std::string("dlopen(librccl.so) failed: ") + (dlerror() ? dlerror() : "?"));
     return nullptr;
   }
   return &api;

@@ -11,6 +11,7 @@
 
 #include "../csrc/dmath.h"
 #include "cubic_bspline.h"
+#include "histogram.h"
 
 using namespace wc;
 
@@ -121,6 +122,7 @@ bool LidarOdometry::ImportState(const double *samples23, size_t ns, const wc_imu
 
 LidarOdometry::~LidarOdometry() {
   if (!ctx_) return;
+  if (d_res_) wc_dev_free(ctx_, d_res_);
   void *bufs[] = {d_surf_, d_pose_, d_inbody_, d_pairs_sld_, d_pairs_fix_, d_imu_, d_sweep_xyz_, d_sweep_t_, d_kept_t_, d_scan_raw_, d_pts_[0], d_pts_[1], d_fix_surf_, d_fix_pose_};
   for (void *b : bufs)
     if (b) wc_dev_free(ctx_, b);
@@ -314,6 +316,53 @@ void LidarOdometry::PredictImuStatesAndSampleStates(double end_time) {
   }
 }
 
+// PrintSurfelResiduals x 2 + PrintImuResiduals (:56-94) on the problem wc_window_build holds: ONE wc_window_evaluate (the
+// reference's three problem.Evaluate calls, each on one family's blocks, apply_loss_function = true) gives the loss-corrected
+// residuals in the reference's block order - binary, unary, 12 per IMU factor; a family's cost is half its squared norm.  The
+// text goes to last_residual_log() (and to stderr with WC_ODOM_DEBUG): the reference's LOG(INFO) lines, glog prefix aside.
+void LidarOdometry::LogResiduals(const std::vector<double> &x, const char *when) {
+  uint64_t cnt[4] = {0, 0, 0, 0};
+  WC_CALL(wc_window_counts(ctx_, cnt));
+  const size_t nb = cnt[0], nu = cnt[1], ni = cnt[2], nres = nb + nu + 12 * ni;
+  if (nres == 0) return;
+  if (nres > cap_res_) {
+    if (d_res_) WC_CALL(wc_dev_free(ctx_, d_res_));
+    cap_res_ = nres + nres / 2;
+    WC_CALL(wc_dev_alloc(ctx_, cap_res_ * sizeof(double), &d_res_));
+  }
+  double cost = 0;
+  WC_CALL(wc_window_evaluate(ctx_, x.data(), &cost, (double *)d_res_));
+  std::vector<double> r(nres);
+  WC_CALL(wc_d2h(ctx_, r.data(), d_res_, nres * sizeof(double)));
+  char buf[96];
+  auto surfel = [&](size_t first, size_t n, const char *window_type) {
+    if (n == 0) return;  // (:57-59)
+    Histogram hist;
+    double c = 0;
+    for (size_t i = first; i < first + n; ++i) hist.Add(r[i]), c += r[i] * r[i];
+    std::snprintf(buf, sizeof(buf), " Surfel residuals, cost: %g, dist: ", 0.5 * c);
+    residual_log_ += std::string(when) + window_type + buf + hist.ToString(10) + "\n";
+  };
+  surfel(0, nb, "Sliding Window");
+  surfel(nb, nu, "Fixed Window");
+  if (ni) {  // (:74-93)
+    Histogram hist[4];
+    const char *types[4] = {"gyro", "acc", "gyro_bias", "acc_bias"};
+    double c = 0;
+    for (size_t i = nb + nu; i < nres; i += 12)
+      for (int j = 0; j < 4; ++j) {
+        const double *p = &r[i + 3 * j];
+        const double s2 = p[0] * p[0] + p[1] * p[1] + p[2] * p[2];
+        hist[j].Add(std::sqrt(s2));
+        c += s2;
+      }
+    for (int j = 0; j < 4; ++j) {
+      std::snprintf(buf, sizeof(buf), ", cost: %g, dist: ", 0.5 * c);
+      residual_log_ += std::string(when) + "Imu residuals with type " + types[j] + buf + hist[j].ToString(10) + "\n";
+    }
+  }
+}
+
 void LidarOdometry::UploadImuStates() {
   const size_t n_imu = imu_states_.size();
   if (n_imu > cap_imu_) {
@@ -483,6 +532,10 @@ void LidarOdometry::AddLidarScan(const pcl::PointCloud<hilti_ros::Point>::Ptr &m
     WC_CALL(wc_window_build(ctx_, d_surf_ + sld_begin_, d_pose_ + sld_begin_, d_pairs_sld_, n_b, d_fix_surf_ + fix_start_, d_fix_pose_ + fix_start_, d_pairs_fix_, n_u,
                             flat.data(), flat.size(), ts.data(), ts.size(), samples_.back().grav, fix_first ? 1 : 0));
     lap(3);
+    if (config_.log_residual_histograms) {  // :547-549
+      residual_log_.clear();
+      LogResiduals(x, "[before solve] ");
+    }
     WC_CALL(wc_window_solve(ctx_, x.data(), &last_summary_, nullptr));
     lap(4);
     for (size_t i = 0; i < samples_.size(); ++i) std::memcpy(samples_[i].cor, &x[12 * i], 96);
@@ -490,6 +543,15 @@ void LidarOdometry::AddLidarScan(const pcl::PointCloud<hilti_ros::Point>::Ptr &m
     UpdateImuPoses();
     UpdateSurfelPosesOnDevice();
     UpdateSamplePoses();
+    if (config_.log_residual_histograms) {
+      // :568-570 - AFTER UpdateSamplePoses: the factors still hold the poses they were built with, the sample states' rotation
+      // and position corrections have just been zeroed (:176-177), the biases stay: the reference's second log shows the
+      // residuals at (0, 0, bg, ba), not at the optimum.  Reproduced as it is.
+      std::vector<double> x_after;
+      for (const Sample &s : samples_) x_after.insert(x_after.end(), s.cor, s.cor + 12);
+      LogResiduals(x_after, "[after update] ");
+      if (dbg_t) fputs(residual_log_.c_str(), stderr);
+    }
     lap(5);
   }
   ShrinkToFit();  // :574-580

@@ -13,6 +13,7 @@
 #include <cstdint>
 #include <deque>
 #include <memory>
+#include <string>
 #include <vector>
 
 #ifndef WC_HAVE_REFERENCE_TYPES
@@ -55,6 +56,8 @@ class LidarOdometry {
   // fallen back to because a gate lay inside the reference's own rounding noise)
   int sweeps_fast_path() const { return sweeps_fast_; }
   int sweeps_exact_path() const { return sweeps_exact_; }
+  // the residual histograms of the last completed sweep (config().log_residual_histograms; lidar_odometry.cc:56-94)
+  const std::string &last_residual_log() const { return residual_log_; }
   LioConfig &config() { return config_; }
   void ApplyConfig();  // push config() changes (quirks, extraction arithmetic, iteration cap, extrinsics) into the device context
   bool ImportState(const double *samples23, size_t ns, const wc_imu_state *imu, size_t n_imu);  // test hook, see .cc
@@ -70,6 +73,7 @@ class LidarOdometry {
   void PredictImuStatesAndSampleStates(double end_time);
   bool SyncHeadingMsgs();
   void UploadImuStates();
+  void LogResiduals(const std::vector<double> &x, const char *when);
   void UpdateImuPoses();
   void UpdateSamplePoses();
   void UpdateSurfelPosesOnDevice();
@@ -113,6 +117,9 @@ class LidarOdometry {
   size_t cap_kept_t_ = 0;
   size_t cap_surfels_ = 0, n_surfels_ = 0, sld_begin_ = 0, cap_imu_ = 0, cap_sweep_ = 0;
   std::deque<double> surfel_times_;  // host copy of the sliding window's surfel timestamps (window bookkeeping only)
+  std::string residual_log_;
+  void *d_res_ = nullptr;
+  size_t cap_res_ = 0;
   wc_solve_summary last_summary_{};
   uint64_t last_corr_[2] = {0, 0};
 };

@@ -29,6 +29,10 @@ struct LioConfig {
   // not in the reference: true = reproduce its quirks (Q1/Q3 Jacobians, Q11 fixed window never trimmed); false = the
   // mathematically intended behaviour (accumulated Jacobians, fixed window trimmed to fixed_window_duration)
   bool reference_quirks = true;
+  // not in the reference (which always does it): log the residual histograms of the three factor families before and
+  // after every solve (PrintSurfelResiduals / PrintImuResiduals, lidar_odometry.cc:56-94, :547-549, :568-570) - two more passes
+  // over the factors and a read-back of every residual per sweep
+  bool log_residual_histograms = false;
   // not in the reference: surfel-extraction arithmetic (wc_params.exact_sums).  false (default) = the order-independent integer
   // moments every benchmark number is quoted on (ids / counts exact, geometry ~1e-9); true = every sum in the reference's order
   bool exact_sums = false;

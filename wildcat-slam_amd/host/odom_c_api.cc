@@ -2,7 +2,10 @@
 // object wildcat_slam_node.cc would drive through its C++ interface.
 #include <cstring>
 
+#include <algorithm>
+
 #include "cubic_bspline.h"
+#include "histogram.h"
 #include "imu_resampler.h"
 #include "lidar_odometry.h"
 
@@ -75,6 +78,30 @@ void wc_odom_set_exact_sums(void *h, int on) {
   ((LidarOdometry *)h)->config().exact_sums = on != 0;
   ((LidarOdometry *)h)->ApplyConfig();
 }
+// the reference's residual log (PrintSurfelResiduals / PrintImuResiduals, lidar_odometry.cc:56-94): switch + the last sweep's text
+void wc_odom_set_residual_log(void *h, int on) { ((LidarOdometry *)h)->config().log_residual_histograms = on != 0; }
+uint64_t wc_odom_residual_log(void *h, char *out, uint64_t cap) {
+  const std::string &s = ((LidarOdometry *)h)->last_residual_log();
+  if (out && cap) {
+    const size_t n = std::min<size_t>(s.size(), cap - 1);
+    std::memcpy(out, s.data(), n);
+    out[n] = 0;
+  }
+  return s.size();
+}
+// Histogram::ToString (src/common/histogram.cc:27-76) through the facade's restatement, for a known-answer test
+uint64_t wc_host_histogram(const double *values, uint64_t n, int buckets, char *out, uint64_t cap) {
+  Histogram hst;
+  for (uint64_t i = 0; i < n; ++i) hst.Add(values[i]);
+  const std::string s = hst.ToString(buckets);
+  if (out && cap) {
+    const size_t m = std::min<size_t>(s.size(), cap - 1);
+    std::memcpy(out, s.data(), m);
+    out[m] = 0;
+  }
+  return s.size();
+}
+
 // test hook: start the next sweep from another run's states (LidarOdometry::ImportState); 0 = done, 1 = the counts differ
 int wc_odom_import_state(void *h, const double *samples23, uint64_t ns, const wc_imu_state *imu, uint64_t n_imu) {
   return ((LidarOdometry *)h)->ImportState(samples23, ns, imu, n_imu) ? 0 : 1;

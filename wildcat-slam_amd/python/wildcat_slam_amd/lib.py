@@ -531,6 +531,17 @@ class Odometry:
         self.lib.wc_odom_extract_paths(self.h, out)
         return out[0], out[1]
 
+    def set_residual_log(self, on):
+        """the reference's residual histograms before / after every solve (lidar_odometry.cc:56-94, :547-549, :568-570)"""
+        self.lib.wc_odom_set_residual_log(self.h, C.c_int(1 if on else 0))
+
+    def residual_log(self):
+        self.lib.wc_odom_residual_log.restype = C.c_uint64
+        n = int(self.lib.wc_odom_residual_log(self.h, None, C.c_uint64(0)))
+        buf = C.create_string_buffer(n + 1)
+        self.lib.wc_odom_residual_log(self.h, buf, C.c_uint64(n + 1))
+        return buf.value.decode()
+
     def set_quirks(self, on):
         self.lib.wc_odom_set_quirks(self.h, C.c_int(1 if on else 0))
 
