@@ -80,6 +80,34 @@ def test_facade_residual_log(gpu):
     odo.close()
 
 
+def test_facade_outputs_are_what_the_reference_publishes(gpu):
+    """config().fill_outputs: after a sweep LidarOdometry::last_outputs() holds what the reference hands to ROS at
+    lidar_odometry.cc:582-602 - one marker per sliding-window surfel (PubSurfels), the sweep undistorted with the FINAL poses as
+    a PointCloud2 payload stamped with its first point, and the world -> imu_link transform of the last sample state"""
+    from wildcat_slam_amd import lib
+
+    msgs, imu, truth = synth.raw_stream(1.7, pts_per_s=300_000, gyro_bias=(0.0, 0.0, 0.02), t_start=1000.0)
+    odo = lib.Odometry(0)
+    odo.set_fill_outputs(True)
+    _drive(odo, msgs, imu)
+    assert odo.sweeps() >= 2
+    o, st, s = odo.outputs(), odo.stats(), odo.samples()
+    assert len(o["markers"]) == int(st["sld_surfels"]) > 500
+    assert np.allclose(np.linalg.norm(o["markers"][:, 3:7], axis=1), 1.0, atol=1e-12) and np.all(o["markers"][:, 13] == 1.0)
+    sc = o["markers"][:, 7:10]
+    assert np.all(sc[np.isfinite(sc)] >= 0) and np.nanmin(sc[:, 0]) < 0.15  # 3 sigma of a plane patch along its normal: centimetres
+    # the sweep in the world frame: points of the room the synthetic scanner stands in (walls at +-20 m)
+    pts = o["scan"]
+    assert len(pts) > 100_000 and o["stamp"] == pts["time"][0] and np.all(np.diff(pts["time"]) >= 0)
+    assert np.abs(pts["x"]).max() < 21.5 and np.abs(pts["y"]).max() < 21.5
+    # tf = the last sample state, quaternion in tf's (x, y, z, w) order
+    assert o["tf"][0] == s[-1, 0] and np.array_equal(o["tf"][1:4], s[-1, 1:4])
+    assert np.array_equal(o["tf"][4:8], s[-1, [5, 6, 7, 4]])
+    p_true, _ = truth(np.array([s[-1, 0]]))
+    assert np.linalg.norm(o["tf"][1:4] - p_true[0]) < 0.25
+    odo.close()
+
+
 def _feed(odo, ref, msgs, imu, on_sweep):
     """the same raw stream into the facade and the orchestrated oracle; on_sweep(sweep number) after every completed sweep"""
     k = 0

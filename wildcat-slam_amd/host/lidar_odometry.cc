@@ -363,6 +363,37 @@ void LidarOdometry::LogResiduals(const std::vector<double> &x, const char *when)
   }
 }
 
+// what the reference hands to ROS at the end of AddLidarScan (:582-602), as plain data
+void LidarOdometry::FillOutputs(const void *d_raw_sweep, size_t n_sweep) {
+  // PubSurfels(surfels_sld_win_, ...) (:582, surfel_extraction.cc:360-434)
+  const size_t n = n_surfels_ - sld_begin_;
+  std::vector<wc_surfel> surf(n);
+  std::vector<wc_pose> pose(n);
+  if (n) {
+    WC_CALL(wc_d2h(ctx_, surf.data(), d_surf_ + sld_begin_, n * sizeof(wc_surfel)));
+    WC_CALL(wc_d2h(ctx_, pose.data(), d_pose_ + sld_begin_, n * sizeof(wc_pose)));
+  }
+  outputs_.markers.resize(n);
+  for (size_t i = 0; i < n; ++i) outputs_.markers[i] = wc_wire::MarkerFromSurfel(surf[i], pose[i]);
+  // the sweep, undistorted once more with the poses the solve left behind (:584-595)
+  std::vector<hilti_ros::Point> pts(n_sweep);
+  if (n_sweep) {
+    void *d_und = nullptr;
+    WC_CALL(wc_dev_alloc(ctx_, n_sweep * sizeof(hilti_ros::Point), &d_und));
+    UploadImuStates();
+    WC_CALL(wc_undistort_sweep(ctx_, d_raw_sweep, n_sweep, d_imu_, imu_states_.size(), d_und));
+    WC_CALL(wc_d2h(ctx_, pts.data(), d_und, n_sweep * sizeof(hilti_ros::Point)));
+    WC_CALL(wc_dev_free(ctx_, d_und));
+  }
+  wc_wire::Cloud2FromPoints(pts.data(), pts.size(), outputs_.scan_in_world);
+  outputs_.scan_stamp = n_sweep ? pts[0].time : 0.0;
+  // tf world -> imu_link (:596-602)
+  const Sample &b = samples_.back();
+  outputs_.tf.stamp = b.timestamp;
+  std::memcpy(outputs_.tf.origin, b.pos, 24);
+  outputs_.tf.rotation_xyzw[0] = b.quat[1], outputs_.tf.rotation_xyzw[1] = b.quat[2], outputs_.tf.rotation_xyzw[2] = b.quat[3], outputs_.tf.rotation_xyzw[3] = b.quat[0];
+}
+
 void LidarOdometry::UploadImuStates() {
   const size_t n_imu = imu_states_.size();
   if (n_imu > cap_imu_) {
@@ -488,6 +519,7 @@ void LidarOdometry::AddLidarScan(const pcl::PointCloud<hilti_ros::Point>::Ptr &m
   UploadImuStates();
   WC_CALL(wc_undistort_sweep_packed(ctx_, (const char *)d_pts_[pts_cur_] + pts_begin_ * sizeof(hilti_ros::Point), n_sweep, d_imu_, imu_states_.size(),
                                     (float *)d_sweep_xyz_, (double *)d_sweep_t_));
+  const void *d_raw_sweep = (const char *)d_pts_[pts_cur_] + pts_begin_ * sizeof(hilti_ros::Point);  // (stays where it is until the next scan arrives)
   DropBufferedPoints(n_sweep);
   lap(0);
 
@@ -555,6 +587,7 @@ void LidarOdometry::AddLidarScan(const pcl::PointCloud<hilti_ros::Point>::Ptr &m
     lap(5);
   }
   ShrinkToFit();  // :574-580
+  if (config_.fill_outputs) FillOutputs(d_raw_sweep, n_sweep);  // :582-602
   lap(6);
   if (dbg_t)
     fprintf(stderr, "[odom] sweep %d: predict + undistort %.2f, extract + poses %.2f, match %.2f, build %.2f, solve %.2f (%d iterations), update %.2f, shrink %.2f ms\n",

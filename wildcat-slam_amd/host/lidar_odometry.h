@@ -21,6 +21,7 @@
 #endif
 #include "../../include/wildcat_hip.h"
 #include "lio_config.h"
+#include "wire_formats.h"
 
 class LidarOdometry {
  public:
@@ -56,6 +57,14 @@ class LidarOdometry {
   // fallen back to because a gate lay inside the reference's own rounding noise)
   int sweeps_fast_path() const { return sweeps_fast_; }
   int sweeps_exact_path() const { return sweeps_exact_; }
+  // what the reference publishes after a sweep (lidar_odometry.cc:582-602), as plain data (config().fill_outputs)
+  struct SweepOutputs {
+    std::vector<wc_wire::SurfelMarker> markers;  // PubSurfels(surfels_sld_win_) (:582), one SPHERE per sliding-window surfel
+    wc_wire::PointCloud2 scan_in_world;          // the sweep undistorted with the final IMU poses (:584-595), frame "world"
+    double scan_stamp = 0;                       // msg.header.stamp = time of the sweep's first point (:592)
+    wc_wire::StampedTransform tf{};              // world -> imu_link at the last sample state (:596-602)
+  };
+  const SweepOutputs &last_outputs() const { return outputs_; }
   // the residual histograms of the last completed sweep (config().log_residual_histograms; lidar_odometry.cc:56-94)
   const std::string &last_residual_log() const { return residual_log_; }
   LioConfig &config() { return config_; }
@@ -117,6 +126,8 @@ class LidarOdometry {
   size_t cap_kept_t_ = 0;
   size_t cap_surfels_ = 0, n_surfels_ = 0, sld_begin_ = 0, cap_imu_ = 0, cap_sweep_ = 0;
   std::deque<double> surfel_times_;  // host copy of the sliding window's surfel timestamps (window bookkeeping only)
+  SweepOutputs outputs_;
+  void FillOutputs(const void *d_raw_sweep, size_t n_sweep);
   std::string residual_log_;
   void *d_res_ = nullptr;
   size_t cap_res_ = 0;

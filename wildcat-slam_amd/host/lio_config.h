@@ -33,6 +33,10 @@ struct LioConfig {
   // after every solve (PrintSurfelResiduals / PrintImuResiduals, lidar_odometry.cc:56-94, :547-549, :568-570) - two more passes
   // over the factors and a read-back of every residual per sweep
   bool log_residual_histograms = false;
+  // not in the reference (which always publishes): fill LidarOdometry::last_outputs() after every sweep with what the reference
+  // hands to ROS there (lidar_odometry.cc:582-602): the sliding window's surfel markers, the sweep undistorted with the final
+  // poses as a PointCloud2 payload, the world -> imu_link transform.  Costs a read-back of the window's surfels per sweep.
+  bool fill_outputs = false;
   // not in the reference: surfel-extraction arithmetic (wc_params.exact_sums).  false (default) = the order-independent integer
   // moments every benchmark number is quoted on (ids / counts exact, geometry ~1e-9); true = every sum in the reference's order
   bool exact_sums = false;

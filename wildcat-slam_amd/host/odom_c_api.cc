@@ -102,6 +102,75 @@ uint64_t wc_host_histogram(const double *values, uint64_t n, int buckets, char *
   return s.size();
 }
 
+// ---- the ROS-free wire formats (host/wire_formats.h) ------------------------------------------------------------------------
+void wc_odom_set_fill_outputs(void *h, int on) { ((LidarOdometry *)h)->config().fill_outputs = on != 0; }
+// markers of the last sweep: out = n x 14 doubles (position 3, orientation wxyz 4, scale 3, colour rgba 4); returns n
+uint64_t wc_odom_markers(void *h, double *out, uint64_t cap) {
+  const auto &m = ((LidarOdometry *)h)->last_outputs().markers;
+  for (uint64_t i = 0; i < m.size() && i < cap; ++i) {
+    double *o = out + 14 * i;
+    std::memcpy(o, m[i].position, 24);
+    std::memcpy(o + 3, m[i].orientation, 32);
+    std::memcpy(o + 7, m[i].scale, 24);
+    for (int c = 0; c < 4; ++c) o[10 + c] = m[i].color[c];
+  }
+  return m.size();
+}
+// the published sweep: its 48-byte point records (the PointCloud2 payload), header stamp; tf8 = stamp, origin, rotation xyzw
+uint64_t wc_odom_scan_in_world(void *h, void *points48, uint64_t cap, double *stamp, double tf8[8]) {
+  const LidarOdometry::SweepOutputs &o = ((LidarOdometry *)h)->last_outputs();
+  const uint64_t n = o.scan_in_world.width;
+  if (points48 && cap >= n && n) std::memcpy(points48, o.scan_in_world.data.data(), 48 * n);
+  if (stamp) *stamp = o.scan_stamp;
+  if (tf8) {
+    tf8[0] = o.tf.stamp;
+    std::memcpy(tf8 + 1, o.tf.origin, 24);
+    std::memcpy(tf8 + 4, o.tf.rotation_xyzw, 32);
+  }
+  return n;
+}
+// pcl::fromROSMsg for hilti_ros::Point on a described payload: nf fields (names: zero-terminated strings back to back),
+// returns the number of registered fields matched (-1: refused); out48 must hold width * height records
+int wc_host_cloud2_to_points(const char *names, const uint32_t *offsets, const uint8_t *datatypes, const uint32_t *counts, int nf, uint32_t width,
+                             uint32_t height, uint32_t point_step, uint32_t row_step, int is_bigendian, const uint8_t *data, uint64_t nbytes,
+                             void *out48) {
+  wc_wire::PointCloud2 msg;
+  msg.width = width, msg.height = height, msg.point_step = point_step, msg.row_step = row_step, msg.is_bigendian = is_bigendian != 0;
+  const char *p = names;
+  for (int f = 0; f < nf; ++f) {
+    msg.fields.push_back({std::string(p), offsets[f], datatypes[f], counts[f]});
+    p += std::strlen(p) + 1;
+  }
+  msg.data.assign(data, data + nbytes);
+  std::vector<hilti_ros::Point> pts;
+  const int m = wc_wire::PointsFromCloud2(msg, pts);
+  if (m >= 0 && !pts.empty()) std::memcpy(out48, pts.data(), 48 * pts.size());
+  return m;
+}
+// pcl::toROSMsg: the field table (6 x {offset, datatype, count}) and point_step for hilti_ros::Point; names_out gets
+// "x\0y\0z\0intensity\0timestamp\0ring\0"
+int wc_host_points_to_cloud2_layout(uint32_t table18[18], char *names_out, uint64_t cap) {
+  wc_wire::PointCloud2 msg;
+  wc_wire::Cloud2FromPoints(nullptr, 0, msg);
+  std::string names;
+  for (size_t f = 0; f < msg.fields.size(); ++f) {
+    table18[3 * f] = msg.fields[f].offset, table18[3 * f + 1] = msg.fields[f].datatype, table18[3 * f + 2] = msg.fields[f].count;
+    names += msg.fields[f].name;
+    names.push_back('\0');
+  }
+  if (names_out && cap >= names.size()) std::memcpy(names_out, names.data(), names.size());
+  return (int)msg.point_step;
+}
+// makeRightHanded (surfel_extraction.cc:340-358) and the marker of one surfel, for known-answer tests
+void wc_host_make_right_handed(double evec9[9], double eval3[3]) { wc_wire::MakeRightHanded(evec9, eval3); }
+void wc_host_marker(const wc_surfel *s, const wc_pose *p, double out14[14]) {
+  const wc_wire::SurfelMarker m = wc_wire::MarkerFromSurfel(*s, *p);
+  std::memcpy(out14, m.position, 24);
+  std::memcpy(out14 + 3, m.orientation, 32);
+  std::memcpy(out14 + 7, m.scale, 24);
+  for (int c = 0; c < 4; ++c) out14[10 + c] = m.color[c];
+}
+
 // test hook: start the next sweep from another run's states (LidarOdometry::ImportState); 0 = done, 1 = the counts differ
 int wc_odom_import_state(void *h, const double *samples23, uint64_t ns, const wc_imu_state *imu, uint64_t n_imu) {
   return ((LidarOdometry *)h)->ImportState(samples23, ns, imu, n_imu) ? 0 : 1;

@@ -531,6 +531,24 @@ class Odometry:
         self.lib.wc_odom_extract_paths(self.h, out)
         return out[0], out[1]
 
+    def set_fill_outputs(self, on):
+        """what the reference publishes after a sweep (lidar_odometry.cc:582-602) as plain data: markers, sweep, tf"""
+        self.lib.wc_odom_set_fill_outputs(self.h, C.c_int(1 if on else 0))
+
+    def outputs(self):
+        """-> dict(markers (n, 14): position, orientation wxyz, scale, rgba; scan: POINT records of the published sweep; stamp;
+        tf: stamp, origin (3), rotation xyzw (4))"""
+        self.lib.wc_odom_markers.restype = C.c_uint64
+        self.lib.wc_odom_scan_in_world.restype = C.c_uint64
+        n = int(self.lib.wc_odom_markers(self.h, None, C.c_uint64(0)))
+        m = np.zeros((max(n, 1), 14))
+        self.lib.wc_odom_markers(self.h, R.ptr(m), C.c_uint64(n))
+        k = int(self.lib.wc_odom_scan_in_world(self.h, None, C.c_uint64(0), None, None))
+        pts = np.zeros(max(k, 1), R.POINT)
+        stamp, tf = C.c_double(0), np.zeros(8)
+        self.lib.wc_odom_scan_in_world(self.h, R.ptr(pts), C.c_uint64(k), C.byref(stamp), R.ptr(tf))
+        return dict(markers=m[:n], scan=pts[:k], stamp=stamp.value, tf=tf)
+
     def set_residual_log(self, on):
         """the reference's residual histograms before / after every solve (lidar_odometry.cc:56-94, :547-549, :568-570)"""
         self.lib.wc_odom_set_residual_log(self.h, C.c_int(1 if on else 0))
