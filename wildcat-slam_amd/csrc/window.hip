@@ -95,6 +95,7 @@ struct wc_window_state {
   // offset of block pair pid in the reduction buffer: 144 doubles for a pair of sample blocks at most two apart (IMU factors
   // reach that far, cost_functor.h:264-355), 36 - the pose x pose corner - for the others (surfel factors only, :16-179)
   bool sharded = false;
+  wc_buf pcr_D[2], pcr_A[2], pcr_R[2], yred;  // bias elimination by parallel cyclic reduction (window_schur.inc)
   wc_buf pair_off;
   uint32_t red_H = 0;  // doubles of the reduction buffer in front of {g (np), cost, spare}
   int (*allreduce)(void *, double *, uint64_t) = nullptr;
@@ -1646,6 +1647,8 @@ __global__ void __launch_bounds__(1024) k_chol_back_gemv(const double *A, int ld
   }
 }
 
+#include "window_schur.inc"
+
 // ---- host helpers ----------------------------------------------------------------------------------------------------
 int sort_u32(wc_ctx *ctx, wc_window_state *W, uint32_t *kin, uint32_t *kout, uint32_t *vin, uint32_t *vout, size_t n,
              unsigned end_bit) {
@@ -1705,7 +1708,8 @@ void wc_window_free(wc_ctx *ctx) {
   if (!W) return;
   wc_buf *all[] = {&W->times_d, &W->brec, &W->bkey, &W->borig, &W->urec, &W->ukey, &W->uorig, &W->irec, &W->pieces, &W->partial,
                    &W->src, &W->src_begin, &W->gsrc, &W->gsrc_begin, &W->x, &W->xc, &W->lin, &W->Linv, &W->heavy, &W->Lmat, &W->reduce, &W->scale, &W->diag, &W->A, &W->y,
-                   &W->mail, &W->cost_part, &W->keys_tmp[0], &W->keys_tmp[1], &W->vals_tmp[0], &W->vals_tmp[1], &W->heads, &W->status};
+                   &W->mail, &W->cost_part, &W->keys_tmp[0], &W->keys_tmp[1], &W->vals_tmp[0], &W->vals_tmp[1], &W->heads, &W->status, &W->pair_off,
+                   &W->pcr_D[0], &W->pcr_D[1], &W->pcr_A[0], &W->pcr_A[1], &W->pcr_R[0], &W->pcr_R[1], &W->yred};
   for (wc_buf *b : all)
     if (b->p) (void)hipFree(b->p);
   if (W->h_pin) (void)hipHostFree(W->h_pin);
@@ -2260,6 +2264,17 @@ extern "C" int wc_window_solve(wc_ctx *ctx, double *h_x_inout, wc_solve_summary 
   double *mail = (double *)W->mail.p;
   int *fail = (int *)((double *)W->mail.p + 32);
   std::vector<double> best(h_x_inout, h_x_inout + n), cur(best);
+  static const bool lm_dense = getenv("WC_LM_DENSE") != nullptr;
+  const bool use_schur = !lm_dense && W->ns >= 4;
+  if (use_schur) {
+    const int npz = 6 * W->ns, M = (W->ns + 1) / 2, ldr = ((npz + 1 + 63) / 64) * 64;
+    for (int b = 0; b < 2; ++b) {
+      WC_TRY(wc_ensure(ctx, W->pcr_D[b], (size_t)M * 144 * 8));
+      WC_TRY(wc_ensure(ctx, W->pcr_A[b], (size_t)M * 144 * 8));
+      WC_TRY(wc_ensure(ctx, W->pcr_R[b], (size_t)M * kSB * ldr * 8));
+    }
+    WC_TRY(wc_ensure(ctx, W->yred, (size_t)(npz + kNB + 64) * 8));
+  }
 
   WC_HIP(ctx, hipMemcpyAsync(x, cur.data(), (size_t)n * 8, hipMemcpyHostToDevice, st));
   WC_TRY(enqueue_linearize(ctx, W, x, 0));
@@ -2309,24 +2324,57 @@ extern "C" int wc_window_solve(wc_ctx *ctx, double *h_x_inout, wc_solve_summary 
       }
       ++iter;
       // LevenbergMarquardtStrategy::ComputeStep on the device
-      {
-        dim3 grid((np + 255) / 256, np);
-        grid.y += 1;  // (+ the workgroup of the first diagonal block)
-        k_damp_first<<<grid, 256, 0, st>>>(H, g, scale, n, np, ld, radius, A, diag, Lmat, (double *)W->Linv.p, fail);
-      }
-      for (int k = 0; k + 1 < nblk; ++k) {
-        const int tiles = ((nblk - k - 1) * kNB + 63) / 64;
-        k_chol_step<<<1 + tiles * (tiles + 1) / 2, 256, 0, st>>>(A, ld, k, nblk, Lmat, (double *)W->Linv.p, fail);
-      }
-      {  // back substitution, chunk by chunk from the last block row
-        const double *zsrc = Lmat + (size_t)n * ld;
-        for (int hi = (n + kNB - 1) / kNB; hi > 0;) {
+      if (use_schur) {
+        // bias unknowns first, by parallel cyclic reduction (window_schur.inc); the dense panel steps run on the pose half
+        const int ns = W->ns, npz = 6 * ns, M = (ns + 1) / 2;
+        const int ldr = ((npz + 1 + 63) / 64) * 64, nch = (ldr + 255) / 256;
+        const int np2 = ((npz + 1 + kNB - 1) / kNB) * kNB, ld2 = np2, nblk2 = np2 / kNB;
+        double *Dp[2] = {(double *)W->pcr_D[0].p, (double *)W->pcr_D[1].p}, *Ap[2] = {(double *)W->pcr_A[0].p, (double *)W->pcr_A[1].p};
+        double *Rp[2] = {(double *)W->pcr_R[0].p, (double *)W->pcr_R[1].p}, *yred = (double *)W->yred.p;
+        k_pcr_init<<<dim3(M, nch), 256, 0, st>>>(H, g, scale, n, ns, radius, Dp[0], Ap[0], Rp[0], ldr, diag, fail);
+        int cur = 0;
+        for (int s = 1; s < M; s *= 2) {
+          k_pcr_level<<<dim3(M, nch), 256, 0, st>>>(s, M, Dp[cur], Ap[cur], Rp[cur], Dp[cur ^ 1], Ap[cur ^ 1], Rp[cur ^ 1], ldr, fail);
+          cur ^= 1;
+        }
+        double *X = Rp[cur ^ 1];
+        k_pcr_final<<<dim3(M, nch), 256, 0, st>>>(Dp[cur], Rp[cur], X, ldr, fail);
+        k_schur_form<<<dim3((np2 + 255) / 256, np2 + 1), 256, 0, st>>>(H, g, scale, X, n, ns, ldr, np2, ld2, radius, A, diag, Lmat, (double *)W->Linv.p, fail);
+        for (int k = 0; k + 1 < nblk2; ++k) {
+          const int tiles = ((nblk2 - k - 1) * kNB + 63) / 64;
+          k_chol_step<<<1 + tiles * (tiles + 1) / 2, 256, 0, st>>>(A, ld2, k, nblk2, Lmat, (double *)W->Linv.p, fail);
+        }
+        const StepArgs sa{x, scale, g, diag, lin_cost(W), xc, mail, h_stage_dev, 0};
+        const double *zsrc = Lmat + (size_t)npz * ld2;
+        for (int hi = (npz + kNB - 1) / kNB; hi > 0;) {
           const int lo = std::max(0, hi - kBackChunk);
-          const StepArgs sa{x, scale, g, diag, lin_cost(W), xc, mail, h_stage_dev, lo == 0 ? 1 : 0};
-          k_chol_back_chunk<<<1, 1024, 0, st>>>(Lmat, ld, n, (const double *)W->Linv.p, zsrc, y, lo, hi, sa);
-          if (lo > 0) k_chol_back_gemv<<<lo, 1024, 0, st>>>(Lmat, ld, n, zsrc, y, lo, hi);
-          zsrc = y;
+          k_chol_back_chunk<<<1, 1024, 0, st>>>(Lmat, ld2, npz, (const double *)W->Linv.p, zsrc, yred, lo, hi, sa);
+          if (lo > 0) k_chol_back_gemv<<<lo, 1024, 0, st>>>(Lmat, ld2, npz, zsrc, yred, lo, hi);
+          zsrc = yred;
           hi = lo;
+        }
+        k_schur_bias_y<<<(npz + 3) / 4, 256, 0, st>>>(X, yred, ns, ldr, y);
+        k_lm_step<<<1, 1024, 0, st>>>(sa, y, n);
+      } else {
+        {
+          dim3 grid((np + 255) / 256, np);
+          grid.y += 1;  // (+ the workgroup of the first diagonal block)
+          k_damp_first<<<grid, 256, 0, st>>>(H, g, scale, n, np, ld, radius, A, diag, Lmat, (double *)W->Linv.p, fail);
+        }
+        for (int k = 0; k + 1 < nblk; ++k) {
+          const int tiles = ((nblk - k - 1) * kNB + 63) / 64;
+          k_chol_step<<<1 + tiles * (tiles + 1) / 2, 256, 0, st>>>(A, ld, k, nblk, Lmat, (double *)W->Linv.p, fail);
+        }
+        {  // back substitution, chunk by chunk from the last block row
+          const double *zsrc = Lmat + (size_t)n * ld;
+          for (int hi = (n + kNB - 1) / kNB; hi > 0;) {
+            const int lo = std::max(0, hi - kBackChunk);
+            const StepArgs sa{x, scale, g, diag, lin_cost(W), xc, mail, h_stage_dev, lo == 0 ? 1 : 0};
+            k_chol_back_chunk<<<1, 1024, 0, st>>>(Lmat, ld, n, (const double *)W->Linv.p, zsrc, y, lo, hi, sa);
+            if (lo > 0) k_chol_back_gemv<<<lo, 1024, 0, st>>>(Lmat, ld, n, zsrc, y, lo, hi);
+            zsrc = y;
+            hi = lo;
+          }
         }
       }
       WC_TRY(enqueue_evaluate(ctx, W, xc, nullptr, 5, h_mail_dev));
