@@ -558,11 +558,14 @@ def bench_window(ctx, args, world, rank, dev, torch, dist, cpu=False):
         "assembly_roofline": {"bound": "hbm", "achieved": round(algo / (lin_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": round(algo / (lin_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "algorithmic_bytes_per_linearisation": algo,
                               "frac_of_measured_copy": round(algo / (lin_ms * 1e-3) / 1e9 / copy, 5) if copy else None},
-        # one LM iteration = one linearisation + one candidate-cost pass over the same records (2 x the bytes) + the
+        # one LM iteration = ONE pass over the factor records since round 3 (the candidate's cost comes from a linearisation at the
+        # candidate, which an accepted step keeps; round 2 made a cost-only pass and then a linearisation: 2 x the bytes) + the
         # replicated damped solve; the time is the whole iteration (wall clock of the solve / iterations)
-        "lm_roofline": {"bound": "hbm", "achieved": round(2 * algo / (it_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(2 * algo / (it_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "algorithmic_bytes_per_iteration": 2 * algo,
-                        "ms_per_iteration": round(it_ms, 4)},
+        "lm_roofline": {"bound": "hbm", "achieved": round(algo / (it_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(algo / (it_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "algorithmic_bytes_per_iteration": algo,
+                        "passes_over_the_factors": 1, "ms_per_iteration": round(it_ms, 4),
+                        "linear_solve": "bias unknowns eliminated by parallel cyclic reduction (12 x 12 super-blocks), dense blocked Cholesky (fp64 MFMA "
+                                        "panel steps) on the %d pose unknowns" % (6 * ns)},
         "build_ms": round(t_build * 1e3, 3), "match_s": round(t_match, 4), "match_surfels_per_s": round(2 * n_s / t_match, 1), "generate_s": round(t_gen, 2),
     }
     if cpu:

@@ -88,7 +88,8 @@ struct wc_window_state {
   std::vector<double> times;
   // device buffers
   wc_buf times_d, brec, bkey, borig, urec, ukey, uorig, irec, pieces, partial, src, src_begin, gsrc, gsrc_begin;
-  wc_buf lin, Linv, heavy, Lmat, reduce;
+  wc_buf lin, lin_alt, Linv, heavy, Lmat, reduce;  // lin_alt: the linearisation at the LM candidate (see wc_window_solve)
+  int lin_sel = 0;                                 // which of the two holds the linearisation at the current point
   uint32_t nheavy = 0;  // lin = [H (n*n) | g (np) | cost, spare]
   // multi-GPU: sharded = this problem holds one rank's share of the factors (wc_window_build_sharded, or a caller that shards
   // itself and installs wc_window_set_allreduce); only then are linearisation and cost evaluation collectives.  pair_off[pid] =
@@ -1707,7 +1708,7 @@ void wc_window_free(wc_ctx *ctx) {
   wc_window_state *W = ctx->win;
   if (!W) return;
   wc_buf *all[] = {&W->times_d, &W->brec, &W->bkey, &W->borig, &W->urec, &W->ukey, &W->uorig, &W->irec, &W->pieces, &W->partial,
-                   &W->src, &W->src_begin, &W->gsrc, &W->gsrc_begin, &W->x, &W->xc, &W->lin, &W->Linv, &W->heavy, &W->Lmat, &W->reduce, &W->scale, &W->diag, &W->A, &W->y,
+                   &W->src, &W->src_begin, &W->gsrc, &W->gsrc_begin, &W->x, &W->xc, &W->lin, &W->lin_alt, &W->Linv, &W->heavy, &W->Lmat, &W->reduce, &W->scale, &W->diag, &W->A, &W->y,
                    &W->mail, &W->cost_part, &W->keys_tmp[0], &W->keys_tmp[1], &W->vals_tmp[0], &W->vals_tmp[1], &W->heads, &W->status, &W->pair_off,
                    &W->pcr_D[0], &W->pcr_D[1], &W->pcr_A[0], &W->pcr_A[1], &W->pcr_R[0], &W->pcr_R[1], &W->yred};
   for (wc_buf *b : all)
@@ -1999,6 +2000,8 @@ static int window_build_impl(wc_ctx *ctx, const wc_surfel *d_sld_surf, const wc_
   WC_TRY(wc_ensure(ctx, W->x, n * 8));
   WC_TRY(wc_ensure(ctx, W->xc, n * 8));
   WC_TRY(wc_ensure(ctx, W->lin, (n * n + (size_t)W->np + 2) * 8));
+  WC_TRY(wc_ensure(ctx, W->lin_alt, (n * n + (size_t)W->np + 2) * 8));
+  W->lin_sel = 0;
   WC_TRY(wc_ensure(ctx, W->Linv, (size_t)W->np * kNB * 8));
   WC_TRY(wc_ensure(ctx, W->scale, n * 8));
   WC_TRY(wc_ensure(ctx, W->diag, n * 8));
@@ -2086,11 +2089,12 @@ extern "C" int wc_window_build_sharded(wc_ctx *ctx, const wc_surfel *d_sld_surf,
 
 namespace {
 
-inline double *lin_H(wc_window_state *W) { return (double *)W->lin.p; }
-inline double *lin_g(wc_window_state *W) { return (double *)W->lin.p + (size_t)W->n * W->n; }
-inline double *lin_cost(wc_window_state *W) { return lin_g(W) + W->np; }
+// lin = [H (n*n) | g (np) | cost, spare]; `other` = the buffer that does NOT hold the current point's linearisation
+inline double *lin_H(wc_window_state *W, bool other = false) { return (double *)(((W->lin_sel != 0) != other) ? W->lin_alt.p : W->lin.p); }
+inline double *lin_g(wc_window_state *W, bool other = false) { return lin_H(W, other) + (size_t)W->n * W->n; }
+inline double *lin_cost(wc_window_state *W, bool other = false) { return lin_g(W, other) + W->np; }
 
-__global__ void __launch_bounds__(1024) k_post_reduce(const double *g, const double *cost, int n, double *mail, int slot) {
+__global__ void __launch_bounds__(1024) k_post_reduce(const double *g, const double *cost, int n, double *mail, int slot, double *host_mail = nullptr) {
   __shared__ double s[1024];
   const int tid = threadIdx.x;
   double mx = 0.0;
@@ -2104,6 +2108,9 @@ __global__ void __launch_bounds__(1024) k_post_reduce(const double *g, const dou
   if (tid == 0) {
     mail[slot] = cost[0];
     mail[slot + 1] = s[0];
+    if (host_mail) {  // the whole mailbox to pinned host memory (as k_sum_blocks does on the evaluation path)
+      for (int i = 0; i < 40; ++i) host_mail[i] = (i == slot) ? cost[0] : (i == slot + 1 ? s[0] : mail[i]);
+    }
   }
 }
 
@@ -2126,7 +2133,8 @@ int do_allreduce(wc_ctx *ctx, wc_window_state *W, double *d_buf, size_t count) {
 }
 
 // all kernels of one linearisation at x (device): partials -> H, g ; cost -> mail[slot], max|g| -> mail[slot+1]
-int enqueue_linearize(wc_ctx *ctx, wc_window_state *W, const double *d_x, int mail_slot, bool post = true) {
+int enqueue_linearize(wc_ctx *ctx, wc_window_state *W, const double *d_x, int mail_slot, bool post = true, bool other = false,
+                      double *host_mail = nullptr) {
   hipStream_t st = ctx->stream;
   const Piece *pcs = (const Piece *)W->pieces.p;
   double *partial = (double *)W->partial.p;
@@ -2152,8 +2160,8 @@ int enqueue_linearize(wc_ctx *ctx, wc_window_state *W, const double *d_x, int ma
     WC_TRY(wc_ensure(ctx, W->reduce, red_count * 8));
     red = (double *)W->reduce.p;
   }
-  ga.H = packed ? red : lin_H(W);
-  ga.g = packed ? red + (size_t)W->red_H : lin_g(W);
+  ga.H = packed ? red : lin_H(W, other);
+  ga.g = packed ? red + (size_t)W->red_H : lin_g(W, other);
   ga.pair_off = (const uint32_t *)W->pair_off.p;
   ga.cost = ga.g + W->np;
   ga.packed = packed ? 1 : 0;
@@ -2163,10 +2171,10 @@ int enqueue_linearize(wc_ctx *ctx, wc_window_state *W, const double *d_x, int ma
   WC_HIP(ctx, hipGetLastError());
   if (packed) {
     WC_TRY(do_allreduce(ctx, W, red, red_count));  // the ONE collective of a linearisation
-    k_expand_pairs<<<W->npairs + 1, 144, 0, st>>>(red, W->npairs, W->ns, W->np, lin_H(W), lin_g(W), (const uint32_t *)W->pair_off.p, W->red_H);
+    k_expand_pairs<<<W->npairs + 1, 144, 0, st>>>(red, W->npairs, W->ns, W->np, lin_H(W, other), lin_g(W, other), (const uint32_t *)W->pair_off.p, W->red_H);
   }
   // (inside the LM loop the next lm_step forms cost / max |g| of this linearisation itself: post = false)
-  if (post) k_post_reduce<<<1, 1024, 0, st>>>(lin_g(W), lin_cost(W), W->n, (double *)W->mail.p, mail_slot);
+  if (post) k_post_reduce<<<1, 1024, 0, st>>>(lin_g(W, other), lin_cost(W, other), W->n, (double *)W->mail.p, mail_slot, host_mail);
   WC_HIP(ctx, hipGetLastError());
   return WC_OK;
 }
@@ -2265,7 +2273,7 @@ extern "C" int wc_window_solve(wc_ctx *ctx, double *h_x_inout, wc_solve_summary 
   int *fail = (int *)((double *)W->mail.p + 32);
   std::vector<double> best(h_x_inout, h_x_inout + n), cur(best);
   static const bool lm_dense = getenv("WC_LM_DENSE") != nullptr;
-  const bool use_schur = !lm_dense && W->ns >= 4;
+  const bool use_schur = !lm_dense && W->ns >= 4;  // (two super-blocks at least: the reduction has a level)
   if (use_schur) {
     const int npz = 6 * W->ns, M = (W->ns + 1) / 2, ldr = ((npz + 1 + 63) / 64) * 64;
     for (int b = 0; b < 2; ++b) {
@@ -2293,6 +2301,11 @@ extern "C" int wc_window_solve(wc_ctx *ctx, double *h_x_inout, wc_solve_summary 
   // region radius, which is known).  If that read-back shows a gradient below tolerance, the iteration that was enqueued
   // on top of it is discarded - the reference stops before it.
   bool lin_pending = false;
+  // Round 3: the candidate's cost comes from a LINEARISATION at the candidate (into the other {H, g, cost} buffer) instead of a
+  // cost-only pass over the same records: an accepted step - the rule - then needs no second pass (one pass over the factors
+  // per iteration instead of two, -0.05 ms of 0.6 at C4), a rejected one has formed an H nobody uses (+0.1 ms).  Its cost and
+  // max |g| arrive with the iteration's mailbox, so nothing is pending between iterations.  WC_LM_EVAL_PASS=1: round 2's flow.
+  static const bool cand_lin = getenv("WC_LM_EVAL_PASS") == nullptr;
   double *h_mail_dev = nullptr, *h_stage_dev = nullptr;  // device addresses of the pinned mailbox and of its staging area
   {
     void *dp = nullptr;
@@ -2331,15 +2344,28 @@ extern "C" int wc_window_solve(wc_ctx *ctx, double *h_x_inout, wc_solve_summary 
         const int np2 = ((npz + 1 + kNB - 1) / kNB) * kNB, ld2 = np2, nblk2 = np2 / kNB;
         double *Dp[2] = {(double *)W->pcr_D[0].p, (double *)W->pcr_D[1].p}, *Ap[2] = {(double *)W->pcr_A[0].p, (double *)W->pcr_A[1].p};
         double *Rp[2] = {(double *)W->pcr_R[0].p, (double *)W->pcr_R[1].p}, *yred = (double *)W->yred.p;
-        k_pcr_init<<<dim3(M, nch), 256, 0, st>>>(H, g, scale, n, ns, radius, Dp[0], Ap[0], Rp[0], ldr, diag, fail);
-        int cur = 0;
-        for (int s = 1; s < M; s *= 2) {
-          k_pcr_level<<<dim3(M, nch), 256, 0, st>>>(s, M, Dp[cur], Ap[cur], Rp[cur], Dp[cur ^ 1], Ap[cur ^ 1], Rp[cur ^ 1], ldr, fail);
+        const PcrSrc src{H, g, scale, n, ns, radius, diag};
+        int cur = 0, nlev = 0;
+        for (int s = 1; s < M; s *= 2) ++nlev;
+        double *X = nullptr;
+        k_pcr_init<<<dim3(M, nch), 256, 0, st>>>(src, Dp[0], Ap[0], Rp[0], ldr, fail);
+        for (int s = 1, lev = 0; lev < nlev; s *= 2, ++lev) {  // (ns >= 4: at least one level)
+          const bool first = false, last = lev == nlev - 1;
+          const dim3 grid(M, nch);
+#define WC_PCR(F, L) k_pcr_level<F, L><<<grid, 256, 0, st>>>(s, M, src, Dp[cur], Ap[cur], Rp[cur], Dp[cur ^ 1], Ap[cur ^ 1], Rp[cur ^ 1], ldr, fail)
+          if (first && last)
+            WC_PCR(true, true);
+          else if (first)
+            WC_PCR(true, false);
+          else if (last)
+            WC_PCR(false, true);
+          else
+            WC_PCR(false, false);
+#undef WC_PCR
           cur ^= 1;
         }
-        double *X = Rp[cur ^ 1];
-        k_pcr_final<<<dim3(M, nch), 256, 0, st>>>(Dp[cur], Rp[cur], X, ldr, fail);
-        k_schur_form<<<dim3((np2 + 255) / 256, np2 + 1), 256, 0, st>>>(H, g, scale, X, n, ns, ldr, np2, ld2, radius, A, diag, Lmat, (double *)W->Linv.p, fail);
+        X = Rp[cur];  // the last level wrote X = T^-1 [C | bB] where the others write R'
+        k_schur_form<<<dim3((np2 + 255) / 256, 1 + ns + (np2 - npz)), 256, 0, st>>>(H, g, scale, X, n, ns, ldr, np2, ld2, radius, A, diag, Lmat, (double *)W->Linv.p, fail);
         for (int k = 0; k + 1 < nblk2; ++k) {
           const int tiles = ((nblk2 - k - 1) * kNB + 63) / 64;
           k_chol_step<<<1 + tiles * (tiles + 1) / 2, 256, 0, st>>>(A, ld2, k, nblk2, Lmat, (double *)W->Linv.p, fail);
@@ -2377,7 +2403,10 @@ extern "C" int wc_window_solve(wc_ctx *ctx, double *h_x_inout, wc_solve_summary 
           }
         }
       }
-      WC_TRY(enqueue_evaluate(ctx, W, xc, nullptr, 5, h_mail_dev));
+      if (cand_lin)
+        WC_TRY(enqueue_linearize(ctx, W, xc, 5, /*post=*/true, /*other=*/true, multi_gpu(ctx, W) ? nullptr : h_mail_dev));  // mail[5] = cost, [6] = max |g| at the candidate
+      else
+        WC_TRY(enqueue_evaluate(ctx, W, xc, nullptr, 5, h_mail_dev));
       WC_HIP(ctx, hipGetLastError());
       // (one GPU: k_sum_blocks has stored the mailbox to pinned host memory itself; with an all-reduce behind it, copy)
       if (multi_gpu(ctx, W) || !h_mail_dev) WC_HIP(ctx, hipMemcpyAsync(ctx->h_mail, mail, 40 * 8, hipMemcpyDeviceToHost, st));
@@ -2423,13 +2452,23 @@ extern "C" int wc_window_solve(wc_ctx *ctx, double *h_x_inout, wc_solve_summary 
       if (rho > 1e-3) {  // HandleSuccessfulStep
         std::swap(W->x, W->xc);
         x = (double *)W->x.p, xc = (double *)W->xc.p;
-        WC_TRY(enqueue_linearize(ctx, W, x, 0, /*post=*/false));
         // the accepted point = the candidate lm_step staged in pinned memory (|x| and the best point are host state)
         std::memcpy(cur.data(), ctx->h_mail + 64, (size_t)n * 8);
         x_norm = 0.0;
         for (int i = 0; i < n; ++i) x_norm += cur[i] * cur[i];
         x_norm = std::sqrt(x_norm);
-        lin_pending = true;
+        if (cand_lin) {  // the candidate's linearisation IS the new point's
+          W->lin_sel ^= 1;
+          H = lin_H(W), g = lin_g(W);
+          cost = cand_cost, gmax = ctx->h_mail[6];
+          if (cost < min_cost) {
+            min_cost = cost;
+            best = cur;
+          }
+        } else {
+          WC_TRY(enqueue_linearize(ctx, W, x, 0, /*post=*/false));
+          lin_pending = true;
+        }
         summary->n_linearizations++;
         radius = radius / std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * rho - 1.0, 3));
         radius = std::min(1e16, radius);
