@@ -376,7 +376,7 @@ def main():
     def extras():
         torch.cuda.set_device(dev)  # (N > 1: this runs in a worker thread, and the current device is per thread)
         if not args.no_extras and not args.no_clouds:
-            for name, fn in (("firing_order", bench_firing_order), ("cloud_10m", bench_cloud_10m)):
+            for name, fn in (("firing_order", bench_firing_order), ("cloud_10m", bench_cloud_10m), ("batched_10x_c2", bench_batched)):
                 try:
                     result[name] = fn(ctx, args, world, rank, dev, torch, dist, to_dev)
                 except Exception as e:
@@ -442,6 +442,87 @@ def bench_firing_order(ctx, args, world, rank, dev, torch, dist, to_dev):
             "stages_ms": {k: round(v, 5) for k, v in stages.items()}}
 
 
+def bench_batched(ctx, args, world, rank, dev, torch, dist, to_dev):
+    """K = 10 C2 sweeps through ONE launch chain (wc_extract_surfels_batch_*: C3 / C4's windows hold 5 / 20 sweeps; a single
+    1 M-point sweep is launch-latency bound), as 48-byte records and as the 20 B / point layout; and the sweep-preparation chain
+    of the facade - wc_undistort_sweep_packed (lidar_odometry.cc:143-158) -> extraction of its 20 B / point output - on one sweep."""
+    from wildcat_slam_amd import records as R, synth
+
+    K = 10
+    sweeps = [synth.g2_lattice(args.roots, m=32, seed=synth.SEED + 300 + k)[0] for k in range(K)]
+    n = len(sweeps[0])
+    cap = (3 * n) // 20 + 1
+    exp = 8 * args.roots
+    keep, out = [], {}
+    for layout in ("aos", "soa"):
+        jobs = []
+        for p in sweeps:
+            d_o, d_i = torch.empty(cap * 144, dtype=torch.uint8, device=dev), torch.empty(cap * 16, dtype=torch.uint8, device=dev)
+            if layout == "aos":
+                d = to_dev(p)
+                desc = R.Points(d.data_ptr(), d.data_ptr() + 24, 48, 48, n)
+                keep.append((d, d_o, d_i))
+            else:
+                d_x = torch.from_numpy(np.stack([p["x"], p["y"], p["z"]], axis=1).astype(np.float32).reshape(-1)).to(dev)
+                d_t = torch.from_numpy(np.ascontiguousarray(p["time"], np.float64)).to(dev)
+                desc = R.Points(d_x.data_ptr(), d_t.data_ptr(), 12, 8, n)
+                keep.append((d_x, d_t, d_o, d_i))
+            jobs.append((desc, _Ptr(d_o.data_ptr()), _Ptr(d_i.data_ptr()), cap, float(p["time"][0]), float(p["time"][-1])))
+        enq, fin = ctx.extract_batch_prepare(jobs)
+        for _ in range(5):
+            enq()
+            counts = fin()
+        assert all(c == exp for c in counts) or os.environ.get("WC_DEBUG_SKIP"), counts
+        reps = max(5, args.steps // 10)
+        ctx.sync()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            enq()
+            fin()
+        ctx.sync()
+        sec = (time.perf_counter() - t0) / reps
+        dev_ms = 0.0
+        for _ in range(reps):  # device time of the chain: HIP events on the ctx stream around the batch's launches
+            ctx.timer_start()
+            enq()
+            dev_ms += ctx.timer_stop_ms()
+            fin()
+        dev_ms /= reps
+        algo = K * (20 * n + 144 * exp)
+        out[layout] = {"ms_per_batch": round(sec * 1e3, 5), "ms_per_sweep": round(sec * 1e3 / K, 5), "value": round(K * n / sec / 1e6, 2), "unit": "Mpts/s (this rank)",
+                       "stage_device_ms_per_batch": round(dev_ms, 5), "roofline_frac": round(algo / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                       "roofline_frac_wall_clock": round(algo / sec / 1e9 / HBM_PEAK_GBS, 5)}
+    out["workload"] = "%d C2 sweeps (%d points -> %d surfels each) enqueued together: one launch chain for all of them" % (K, n, exp)
+    # undistortion + extraction of one sweep, the facade's chain (48 B read + 20 B written, then 20 B read)
+    try:
+        p = sweeps[0]
+        imu, _ = synth.imu_states(float(p["time"][0]) - 0.0031, float(p["time"][-1]) + 0.01, t_origin=float(p["time"][0]))
+        d_raw, d_imu = ctx.to_device(p), ctx.to_device(imu)
+        d_xyz, d_t = ctx.alloc(12 * n), ctx.alloc(8 * n)
+        d_o, d_i = ctx.alloc(144 * cap), ctx.alloc(16 * cap)
+        import ctypes as C
+
+        def chain():
+            ctx._ck(ctx.lib.wc_undistort_sweep_packed(ctx.h, C.c_void_p(d_raw.ptr), C.c_uint64(n), C.c_void_p(d_imu.ptr), C.c_uint64(len(imu)),
+                                                      C.c_void_p(d_xyz.ptr), C.c_void_p(d_t.ptr)))
+            ctx.extract_enqueue(R.Points(d_xyz.ptr, d_t.ptr, 12, 8, n), d_o, d_i, cap, float(p["time"][0]), float(p["time"][-1]))
+            return ctx.extract_finish()
+
+        for _ in range(5):
+            m = chain()
+        ctx.sync()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            chain()
+        ctx.sync()
+        sec = (time.perf_counter() - t0) / 20
+        out["undistort_then_extract"] = {"ms_per_sweep": round(sec * 1e3, 5), "surfels": m, "value": round(n / sec / 1e6, 2), "unit": "Mpts/s",
+                                         "bytes_per_point": "48 read + 20 written (wc_undistort_sweep_packed), 20 read (extraction); round 2: 48 + 48 + 48"}
+    except Exception as e:
+        out["undistort_then_extract"] = {"error": repr(e)}
+    return out
+
+
 def bench_cloud_10m(ctx, args, world, rank, dev, torch, dist, to_dev):
     """BASELINE config 5's cloud: G2, 39 062 roots = 9 999 872 points.  N = 1: the whole cloud on this GPU.  N > 1: every rank
     holds a time-contiguous 1/N slice; wc_extract_surfels_sharded routes the points to the owner of their root voxel (ONE
@@ -465,9 +546,28 @@ def bench_cloud_10m(ctx, args, world, rank, dev, torch, dist, to_dev):
             return fin()
 
         stages, roof = extraction_stage(ctx, step, n, n_s, steps)
-        return {"workload": "C5 cloud on one GPU: %d points -> %d surfels" % (n, n_s), "ms_per_step": round(sec * 1e3, 5), "value": round(n / sec / 1e6, 2),
-                "unit": "Mpts/s", "stage_device_ms": roof["stage_device_ms"], "roofline_frac": roof["frac"], "dominant_kernel": roof["dominant_kernel"],
-                "stages_ms": {k: round(v, 5) for k, v in stages.items()}}
+        out = {"workload": "C5 cloud on one GPU: %d points -> %d surfels; input = 48-byte hilti_ros::Point records" % (n, n_s), "ms_per_step": round(sec * 1e3, 5),
+               "value": round(n / sec / 1e6, 2), "unit": "Mpts/s", "stage_device_ms": roof["stage_device_ms"], "roofline_frac": roof["frac"],
+               "dominant_kernel": roof["dominant_kernel"], "stages_ms": {k: round(v, 5) for k, v in stages.items()},
+               "node_stage": "two kernels (k_fx_walk + k_fx_test) above 2 M points"}
+        # the same cloud as the 20 bytes per point the extraction reads (what wc_undistort_sweep_packed leaves): never `value`
+        try:
+            d_xyz = torch.from_numpy(np.stack([pts["x"], pts["y"], pts["z"]], axis=1).astype(np.float32).reshape(-1)).to(dev)
+            d_t = torch.from_numpy(np.ascontiguousarray(pts["time"], np.float64)).to(dev)
+            desc2 = R.Points(d_xyz.data_ptr(), d_t.data_ptr(), 12, 8, n)
+            sec2, n_s2, (enq2, fin2) = time_extract(ctx, desc2, _Ptr(d_out.data_ptr()), _Ptr(d_ids.data_ptr()), cap, t_lo, t_hi, steps, 3, 8 * n_roots)
+
+            def step2():
+                enq2()
+                return fin2()
+
+            st2, roof2 = extraction_stage(ctx, step2, n, n_s2, steps)
+            out["soa_input"] = {"layout": "float32 xyz (stride 12) + float64 time (stride 8): 20 B / point", "ms_per_step": round(sec2 * 1e3, 5),
+                                "value": round(n / sec2 / 1e6, 2), "unit": "Mpts/s", "stage_device_ms": roof2["stage_device_ms"], "roofline_frac": roof2["frac"],
+                                "stages_ms": {k: round(v, 5) for k, v in st2.items()}}
+        except Exception as e:
+            out["soa_input"] = {"error": repr(e)}
+        return out
     lo, cnt = wdist.shard_range(n, rank, world)
     d_slice = ctx.to_device(pts[lo: lo + cnt])
     cap = (3 * n) // 20 // world * 2 + 4096

@@ -102,6 +102,15 @@ typedef struct wc_comm {
                              callback must have completed when it returns */
 } wc_comm;
 
+/* One sweep of a batched extraction (wc_extract_surfels_batch_*): the arguments of wc_extract_surfels_enqueue. */
+typedef struct wc_sweep_job {
+  wc_points pts;
+  double t_lo, t_hi;   /* time range hint of THIS sweep (t_lo > t_hi: read back from the device) */
+  wc_surfel *d_out;
+  wc_surfel_id *d_ids; /* may be NULL */
+  uint64_t cap;
+} wc_sweep_job;
+
 /* Hard-coded reference parameters of the path.  wc_params_default() fills the
  * reference values; tests may override them to reach edge cases. */
 typedef struct wc_params {

@@ -89,6 +89,14 @@ int wc_extract_surfels(wc_ctx *ctx, const wc_points *pts, double t_lo, double t_
 int wc_extract_surfels_enqueue(wc_ctx *ctx, const wc_points *pts, double t_lo, double t_hi, wc_surfel *d_out,
                                wc_surfel_id *d_ids, uint64_t cap);
 int wc_extract_surfels_finish(wc_ctx *ctx, uint64_t *h_n_out);
+/* K sweeps (1 <= K <= 64) through ONE launch chain: BuildSurfels is called once per sweep with a fresh GlobalMap
+ * (lidar_odometry.cc:523-525), so sweeps are independent; when several are known together (a window replayed from a log, C3 / C4's
+ * 5 / 20-sweep windows, several sensors) their kernels run as one launch each over all sweeps instead of three launches per
+ * sweep - a 1 M-point sweep is launch-latency bound on its own.  Every sweep gets its own output buffers, count and - should a
+ * gate fall inside the noise band - its own repetition on the exact path; results are those of K wc_extract_surfels calls, byte for
+ * byte.  enqueue returns without waiting; finish fills h_n_out[K]. */
+int wc_extract_surfels_batch_enqueue(wc_ctx *ctx, const wc_sweep_job *jobs, int K);
+int wc_extract_surfels_batch_finish(wc_ctx *ctx, uint64_t *h_n_out, int K);
 /* per-stage device time of the LAST enqueued extraction, measured with HIP events on the ctx stream:
  * h_ms5 = {per-call fills, voxel grouping of the points, root + layer-1 streaming, node tests + emission (+ layer 2),
  * time ordering + gather of the surfels}.  Enable first: 1 = an event after every kernel group (each event costs ~5 us of

@@ -313,3 +313,40 @@ def test_default_path_backs_off_after_repeated_fall_backs(gpu, oracle):
     gpu.set_exact_sums(False)
     s, i = gpu.extract_surfels(regular)
     assert gpu.extract_path_info()["fast"]  # ... and is back for a sweep it can handle
+
+
+def test_batched_sweeps_equal_single_sweeps(gpu, oracle):
+    """wc_extract_surfels_batch_*: K sweeps through ONE launch chain (every sweep its own tables, the kernels run once over all of
+    them) give, sweep by sweep, the bytes K wc_extract_surfels calls give - for sweeps with run structure, a sweep in firing order
+    (long record lists, layer 2 in use: its flags join the shared layer-2 launches from the second round on), a short and an EMPTY
+    sweep in one batch, twice in a row (the tables are clean again behind a batch)."""
+    from wildcat_slam_amd import lib
+
+    sweeps = [synth.g2_lattice(300, m=32, seed=synth.SEED + 40)[0], synth.g1_room(120_000, seed=synth.SEED + 41),
+              synth.g2_lattice(64, m=32, seed=synth.SEED + 42)[0], synth.g2_lattice(4, m=32, seed=3)[0][:0],
+              synth.g2_lattice(500, m=24, seed=synth.SEED + 43)[0]]
+    single = [gpu.extract_surfels(p) if len(p) else (np.zeros(0, R.SURFEL), np.zeros(0, R.SURFEL_ID)) for p in sweeps]
+    ctx = lib.Context(0)
+    try:
+        jobs, keep = [], []
+        for p in sweeps:
+            n = len(p)
+            cap = max(1024, (3 * n) // 20 + 1)
+            d_p = ctx.to_device(p) if n else ctx.alloc(48)
+            d_o, d_i = ctx.alloc(144 * cap), ctx.alloc(16 * cap)
+            keep.append((d_p, d_o, d_i))
+            t_lo, t_hi = (float(p["time"][0]), float(p["time"][-1])) if n else (1.0, 0.0)
+            jobs.append((ctx.points_desc(d_p, n), d_o, d_i, cap, t_lo, t_hi))
+        enq, fin = ctx.extract_batch_prepare(jobs)
+        for rnd in range(3):
+            enq()
+            counts = fin()
+            for k, (s_ref, id_ref) in enumerate(single):
+                assert counts[k] == len(s_ref), (rnd, k, counts[k], len(s_ref))
+                s_b, id_b = keep[k][1].download(R.SURFEL, counts[k]), keep[k][2].download(R.SURFEL_ID, counts[k])
+                assert s_b.tobytes() == s_ref.tobytes() and id_b.tobytes() == id_ref.tobytes(), (rnd, k)
+        # and against the oracle, for the sweep in firing order
+        s_o, id_o, _ = oracle.extract_surfels(sweeps[1])
+        helpers.check_surfels(keep[1][1].download(R.SURFEL, counts[1]), keep[1][2].download(R.SURFEL_ID, counts[1]), s_o, id_o, tol=1e-6, t_tol=1e-4)
+    finally:
+        ctx.close()

@@ -34,7 +34,9 @@ struct wc_ctx {
   // once both are known the faster one is used, and the other is tried again every 16th call
   double match_ns_per_q[2][2] = {{0.0, 0.0}, {0.0, 0.0}};  // [kind][normal first]
   uint32_t match_calls[2] = {0u, 0u};
-  double match_last_rk = 0.0;  // median sampled k-th 6-D distance of the last wc_match call (scaled units): what set its cell size
+  double match_last_rk = 0.0;
+  std::vector<wc_ctx *> batch_subs;  // sub-contexts of wc_extract_surfels_batch_* (own scratch, the parent's stream)
+  wc_buf b_batch;  // median sampled k-th 6-D distance of the last wc_match call (scaled units): what set its cell size
   hipEvent_t ev_knn[2] = {nullptr, nullptr};
   // multi-GPU: the job's communicator (wc_ctx_set_comm / wc_comm_rccl_init)
   wc_comm comm{};
@@ -65,7 +67,11 @@ struct wc_ctx {
     bool fx_dirty = false;       // the fast path's tables may hold garbage (an aborted sweep): memset before the next use
     uint32_t fx_last_flags = 0, fx_fallbacks = 0, fx_last_why = 0;
     bool fx_spill_full = false;
-    bool fx_split = false;  // the node stage of the current sweep runs as k_fx_walk + k_fx_test (extract_split.inc)  // the spill pool of the fast path overflowed once: sized for the worst case from then on
+    bool fx_split = false;
+    // batched extraction (wc_extract_surfels_batch_*): a sub-context prepares its sweep - tables, control block, kernel arguments
+    // in roots_args - and leaves the launches to the parent, which runs K sweeps' kernels as one launch chain
+    bool batch_defer = false, deferred = false;
+    unsigned fx_tiles = 0, fx_ngrid = 0;  // the node stage of the current sweep runs as k_fx_walk + k_fx_test (extract_split.inc)  // the spill pool of the fast path overflowed once: sized for the worst case from then on
     bool fx_long_lists = false;  // the last fast sweep walked long record lists: k_fx_merge runs before k_fx_nodes
     uint32_t fx_backoff = 0, fx_skip_calls = 0;  // sweeps that go straight to the exact path after fall-backs (exponential)
     bool fx_ctrl_ready = false;  // the fast path's two control blocks are initialised

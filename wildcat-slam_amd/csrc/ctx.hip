@@ -117,6 +117,9 @@ extern "C" void wc_ctx_destroy(wc_ctx *ctx) {
     if (b.p) (void)hipFree(b.p);
   if (ctx->b_match_stat.p) (void)hipFree(ctx->b_match_stat.p);
   if (ctx->b_match_samp.p) (void)hipFree(ctx->b_match_samp.p);
+  if (ctx->b_batch.p) (void)hipFree(ctx->b_batch.p);
+  for (wc_ctx *sub : ctx->batch_subs) wc_ctx_destroy(sub);
+  ctx->batch_subs.clear();
   for (wc_buf &b : ctx->b_fx)
     if (b.p) (void)hipFree(b.p);
   if (ctx->h_status) (void)hipHostFree(ctx->h_status);

@@ -1361,21 +1361,43 @@ __global__ void __launch_bounds__(256) k_fix_ties(const uint64_t *__restrict__ k
 // in front of its four buckets: 16 KB out of L2, cheaper than a separate scan launch), the order inside a bucket (rank by
 // counting, one wavefront per bucket, a handful of surfels each) and the 160-byte copy slot -> output, 16 B per lane.
 constexpr int kSlotBinMax = 512;
-__global__ void __launch_bounds__(256) k_slot_emit(const uint32_t *__restrict__ counts, const uint64_t *__restrict__ bins, uint32_t bin_cap,
-                                                  const wc_surfel *__restrict__ slots, const wc_surfel_id *__restrict__ slot_ids,
-                                                  uint32_t *status, wc_surfel *out, wc_surfel_id *out_ids, uint64_t cap, uint32_t *next_ctrl,
-                                                  uint32_t next_words) {
+struct SlotEmitArgs {
+  const uint32_t *counts;
+  const uint64_t *bins;
+  uint32_t bin_cap;
+  const wc_surfel *slots;
+  const wc_surfel_id *slot_ids;
+  uint32_t *status;
+  wc_surfel *out;
+  wc_surfel_id *out_ids;
+  uint64_t cap;
+  uint32_t *next_ctrl;
+  uint32_t next_words;
+};
+// (bid / nblk: the workgroup's index and the grid of ITS sweep - the kernel proper, or one sweep's share of a batched launch)
+__device__ __forceinline__ void slot_emit_body(const SlotEmitArgs &E, const uint32_t bid, const uint32_t nblk) {
+  const uint32_t *__restrict__ counts = E.counts;
+  const uint64_t *__restrict__ bins = E.bins;
+  const uint32_t bin_cap = E.bin_cap;
+  const wc_surfel *__restrict__ slots = E.slots;
+  const wc_surfel_id *__restrict__ slot_ids = E.slot_ids;
+  uint32_t *status = E.status;
+  wc_surfel *out = E.out;
+  wc_surfel_id *out_ids = E.out_ids;
+  const uint64_t cap = E.cap;
+  uint32_t *next_ctrl = E.next_ctrl;
+  const uint32_t next_words = E.next_words;
   __shared__ uint64_t s_item[4][kSlotBinMax];
   if (next_ctrl) {  // fast path: the control block of the NEXT sweep (the other of two) is cleared here, off the host's path
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t i = bid * 256u + threadIdx.x;
     if (i < next_words) next_ctrl[i] = (i == 8u || i == 9u) ? status[i] : 0u;  // (words 8, 9: the mailbox address)
   }
   __shared__ uint32_t s_sorted[4][kSlotBinMax];
   __shared__ uint32_t s_red[4];
   const int t = threadIdx.x, w = t >> 6, lane = t & 63;
-  const uint32_t b0 = blockIdx.x * 4u;
+  const uint32_t b0 = bid * 4u;
   // everything this workgroup reads before it knows its counts goes out in ONE round of loads: the counts in front of it
-  // (exactly blockIdx.x uint4's, at most four per thread), its own four counts and - speculatively - the first 64 entries
+  // (exactly bid uint4's, at most four per thread), its own four counts and - speculatively - the first 64 entries
   // of its wavefront's bin.  (A loop of dependent 4-byte loads here was the kernel's critical path: 16 round trips for
   // the last workgroups.)
   static_assert(kBuckets / 4 <= 4 * 256, "four uint4 loads per thread cover the counts");
@@ -1384,9 +1406,9 @@ __global__ void __launch_bounds__(256) k_slot_emit(const uint32_t *__restrict__ 
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const uint32_t i = (uint32_t)t + 256u * k;
-    v[k] = i < blockIdx.x ? c4[i] : make_uint4(0u, 0u, 0u, 0u);
+    v[k] = i < bid ? c4[i] : make_uint4(0u, 0u, 0u, 0u);
   }
-  const uint4 own = c4[blockIdx.x];
+  const uint4 own = c4[bid];
   const uint64_t *bin = bins + (size_t)(b0 + w) * bin_cap;
   const uint64_t first = (uint32_t)lane < bin_cap ? bin[lane] : 0ull;
   uint32_t part = 0;
@@ -1397,7 +1419,7 @@ __global__ void __launch_bounds__(256) k_slot_emit(const uint32_t *__restrict__ 
   __syncthreads();
   uint32_t base = s_red[0] + s_red[1] + s_red[2] + s_red[3];
   const uint32_t c0 = own.x, c1 = own.y, c2 = own.z, c3 = own.w;
-  if (blockIdx.x == gridDim.x - 1 && t == 0) {
+  if (bid == nblk - 1 && t == 0) {
     status[0] = base + c0 + c1 + c2 + c3;  // surfels emitted
     uint32_t *hm = host_mailbox(status);
     if (hm) {
@@ -1473,6 +1495,21 @@ __global__ void __launch_bounds__(256) k_slot_emit(const uint32_t *__restrict__ 
     store(r, on0, d0);
     store(r + 6, on1, d1);
   }
+}
+
+__global__ void __launch_bounds__(256) k_slot_emit(const uint32_t *__restrict__ counts, const uint64_t *__restrict__ bins, uint32_t bin_cap,
+                                                  const wc_surfel *__restrict__ slots, const wc_surfel_id *__restrict__ slot_ids,
+                                                  uint32_t *status, wc_surfel *out, wc_surfel_id *out_ids, uint64_t cap, uint32_t *next_ctrl,
+                                                  uint32_t next_words) {
+  const SlotEmitArgs E{counts, bins, bin_cap, slots, slot_ids, status, out, out_ids, cap, next_ctrl, next_words};
+  slot_emit_body(E, blockIdx.x, gridDim.x);
+}
+// K sweeps' time ordering in one launch: kBuckets / 4 workgroups per sweep
+__global__ void __launch_bounds__(256) k_slot_emit_b(const SlotEmitArgs *__restrict__ Es, int K) {
+  const uint32_t per = kBuckets / 4;
+  const uint32_t k = blockIdx.x / per;
+  if ((int)k >= K) return;
+  slot_emit_body(Es[k], blockIdx.x - k * per, per);
 }
 
 // ---- run-binned bucket sort of the points ---------------------------------------------------------------------------
@@ -1869,7 +1906,7 @@ int run_pipeline_fast(wc_ctx *ctx, const wc_points &pts, double t_lo, double t_h
   // (WC_FX_SPLIT=0 / 1 pins the choice: tests run both forms on the same clouds)
   {
     static const char *env = getenv("WC_FX_SPLIT");
-    ctx->ex.fx_split = env ? atoi(env) != 0 : !A.static_map;
+    ctx->ex.fx_split = ctx->ex.batch_defer || (env ? atoi(env) != 0 : !A.static_map);  // (a batch: K sweeps' parents in one launch)
   }
   if (ctx->ex.fx_split) {
     A.static_map = 0u;
@@ -1931,6 +1968,21 @@ int run_pipeline_fast(wc_ctx *ctx, const wc_points &pts, double t_lo, double t_h
     fprintf(stderr, " %s flags=%u roots=%u nodes2=%u slots=%u spill=%u\n", hipGetErrorString(e), w[1], r, q, sl, sp);
   };
   if (dbg) fprintf(stderr, "[fx] n=%llu tiles=%u mr_per=%u mq_per=%u tr=%u slots_per=%u bin_cap=%u\n", (unsigned long long)n, tiles, A.mr_per, A.mq_per, tr, A.slots_per, bin_cap);
+  if (ctx->ex.batch_defer) {  // wc_extract_surfels_batch_enqueue launches this sweep's kernels together with the other sweeps'
+    static_assert(sizeof(FxArgs) <= sizeof(ctx->ex.roots_args), "ctx.h: roots_args too small");
+    std::memcpy(ctx->ex.roots_args, &A, sizeof(A));
+    ctx->ex.total_slots = total_slots;
+    ctx->ex.bin_cap = bin_cap;
+    ctx->ex.fast_slots = true;
+    ctx->ex.tail = &fx_tail;
+    ctx->ex.d_out = d_out, ctx->ex.d_ids = d_ids, ctx->ex.cap = cap;
+    ctx->ex.layer2_done = P.max_layer >= 2 && ctx->ex.last_splits > 0;
+    // (the node kernels of a batch loop over their sweep's parents, eight per wavefront: a grid of n / 256 blocks per sweep - what
+    // a single sweep's static hand-out wants - is 39 k workgroups for ten sweeps, 34 k of which find nothing to do)
+    ctx->ex.fx_tiles = tiles, ctx->ex.fx_ngrid = std::max(64u, ngrid / 8u);
+    ctx->ex.deferred = true;
+    return WC_OK;
+  }
   k_fx_acc<1><<<tiles, kFxThreads, 0, st>>>(A);
   dbg_sync("k_fx_acc<1>");
   mark(2);
@@ -2349,6 +2401,105 @@ extern "C" int wc_extract_surfels(wc_ctx *ctx, const wc_points *pts, double t_lo
   wc_dev_guard dg_(ctx);
   WC_TRY(wc_extract_surfels_enqueue(ctx, pts, t_lo, t_hi, d_out, d_ids, cap));
   return wc_extract_surfels_finish(ctx, h_n_out);
+}
+
+// ---- K sweeps through ONE launch chain (include/wildcat_hip.h) ------------------------------------------------------------------
+// A sweep of a million points is three launches of 5 - 18 us whose first microseconds are launch head and whose duration is one
+// wavefront's chain of dependent steps: 488 node wavefronts on 1024 SIMDs.  K sweeps that are known together - a window replayed
+// from a log, the sweeps of several sensors - share the chain: every sweep keeps its own tables (a sub-context each: the
+// tables are zero at rest and cleaned behind the sweep, as for single sweeps), the kernels run once over all of them.
+extern "C" int wc_extract_surfels_batch_enqueue(wc_ctx *ctx, const wc_sweep_job *jobs, int K) {
+  wc_dev_guard dg_(ctx);
+  if (!ctx || !jobs || K < 1 || K > 64) return wc_fail(ctx, WC_ERR_ARG, "%s: null or out-of-range argument", __func__);
+  while ((int)ctx->batch_subs.size() < K) {
+    wc_ctx *sub = nullptr;
+    const int rc = wc_ctx_create(&ctx->P, ctx->device, &sub);
+    if (rc != WC_OK) return wc_fail(ctx, rc, "wc_extract_surfels_batch: no sub-context");
+    ctx->batch_subs.push_back(sub);
+  }
+  hipStream_t st = ctx->stream;
+  std::vector<FxArgs> args;
+  std::vector<SlotEmitArgs> emit;
+  std::vector<uint32_t> s_acc(1, 0u), s_nodes(1, 0u), s_g2(1, 0u), flags;
+  bool any_l2 = false, any_merge = false;
+  for (int k = 0; k < K; ++k) {
+    wc_ctx *sub = ctx->batch_subs[k];
+    if (sub->stream != st) WC_TRY(wc_ctx_set_stream(sub, st));
+    if (std::memcmp(&sub->P, &ctx->P, sizeof(wc_params)) != 0) WC_TRY(wc_ctx_set_params(sub, &ctx->P));
+    sub->ex.batch_defer = true;
+    sub->ex.deferred = false;
+    const int rc = wc_extract_surfels_enqueue(sub, &jobs[k].pts, jobs[k].t_lo, jobs[k].t_hi, jobs[k].d_out, jobs[k].d_ids, jobs[k].cap);
+    sub->ex.batch_defer = false;
+    if (rc != WC_OK) return wc_fail(ctx, rc, "wc_extract_surfels_batch (sweep %d): %s", k, wc_last_error(sub));
+    if (!sub->ex.deferred) continue;  // (empty, or a sweep the default path does not take: enqueued on its own, on the same stream)
+    FxArgs A;
+    std::memcpy(&A, sub->ex.roots_args, sizeof(A));
+    args.push_back(A);
+    const uint32_t g2 = std::min(std::min(256u * 8u, sub->ex.fx_ngrid), std::max(64u, sub->ex.last_splits));
+    s_acc.push_back(s_acc.back() + sub->ex.fx_tiles);
+    s_nodes.push_back(s_nodes.back() + sub->ex.fx_ngrid);
+    s_g2.push_back(s_g2.back() + g2);
+    const uint32_t f = (sub->ex.layer2_done ? 1u : 0u) | (sub->ex.fx_long_lists ? 2u : 0u);
+    flags.push_back(f);
+    any_l2 = any_l2 || (f & 1u);
+    any_merge = any_merge || (f & 2u);
+    uint32_t *next_ctrl = (uint32_t *)sub->b_fx[5].p + (size_t)(sub->ex.fx_parity ^ 1) * kCtrlWords;
+    emit.push_back(SlotEmitArgs{A.slot_counts, A.slot_bins, sub->ex.bin_cap, (const wc_surfel *)sub->b_slots.p, (const wc_surfel_id *)sub->b_slot_ids.p,
+                                A.status, sub->ex.d_out, sub->ex.d_ids, sub->ex.cap, next_ctrl, (uint32_t)kCtrlWords});
+  }
+  const int Kd = (int)args.size();
+  if (Kd == 0) return WC_OK;
+  // one upload: {FxArgs[Kd] | SlotEmitArgs[Kd] | three prefix tables | flags}
+  const size_t o_emit = (sizeof(FxArgs) * Kd + 15) & ~(size_t)15, o_tab = (o_emit + sizeof(SlotEmitArgs) * Kd + 15) & ~(size_t)15;
+  const size_t bytes = o_tab + (size_t)(3 * (Kd + 1) + Kd) * 4;
+  std::vector<unsigned char> host(bytes, 0);
+  std::memcpy(host.data(), args.data(), sizeof(FxArgs) * Kd);
+  std::memcpy(host.data() + o_emit, emit.data(), sizeof(SlotEmitArgs) * Kd);
+  uint32_t *tab = (uint32_t *)(host.data() + o_tab);
+  std::memcpy(tab, s_acc.data(), (Kd + 1) * 4);
+  std::memcpy(tab + (Kd + 1), s_nodes.data(), (Kd + 1) * 4);
+  std::memcpy(tab + 2 * (Kd + 1), s_g2.data(), (Kd + 1) * 4);
+  std::memcpy(tab + 3 * (Kd + 1), flags.data(), Kd * 4);
+  WC_TRY(wc_ensure(ctx, ctx->b_batch, bytes));
+  WC_HIP(ctx, hipMemcpyAsync(ctx->b_batch.p, host.data(), bytes, hipMemcpyHostToDevice, st));
+  WC_HIP(ctx, hipStreamSynchronize(st));  // (pageable staging: `host` dies with this scope; ~10 us once per K sweeps)
+  const unsigned char *d = (const unsigned char *)ctx->b_batch.p;
+  const uint32_t *dt = (const uint32_t *)(d + o_tab);
+  FxBatch B;
+  B.args = (const FxArgs *)d, B.K = Kd, B.flags = dt + 3 * (Kd + 1);
+  B.start = dt;
+  k_fx_acc_b<1><<<s_acc.back(), kFxThreads, 0, st>>>(B);
+  B.start = dt + (Kd + 1);
+  if (any_merge) k_fx_merge_b<1><<<s_nodes.back(), 128, 0, st>>>(B);
+  k_fx_walk_b<1><<<s_nodes.back(), 64, 0, st>>>(B);
+  k_fx_test_b<1><<<s_nodes.back(), 64, 0, st>>>(B);
+  if (any_l2) {
+    B.start = dt;
+    k_fx_acc_b<2><<<s_acc.back(), kFxThreads, 0, st>>>(B);
+    B.start = dt + 2 * (Kd + 1);
+    if (any_merge) k_fx_merge_b<2><<<s_g2.back(), 128, 0, st>>>(B);
+    k_fx_walk_b<2><<<s_g2.back(), 64, 0, st>>>(B);
+    k_fx_test_b<2><<<s_g2.back(), 64, 0, st>>>(B);
+  }
+  k_slot_emit_b<<<(unsigned)Kd * (kBuckets / 4), 256, 0, st>>>((const SlotEmitArgs *)(d + o_emit), Kd);
+  WC_HIP(ctx, hipGetLastError());
+  return WC_OK;
+}
+
+extern "C" int wc_extract_surfels_batch_finish(wc_ctx *ctx, uint64_t *h_n_out, int K) {
+  wc_dev_guard dg_(ctx);
+  if (!ctx || !h_n_out || K < 1 || K > (int)ctx->batch_subs.size()) return wc_fail(ctx, WC_ERR_ARG, "%s: null or out-of-range argument", __func__);
+  int first_rc = WC_OK;
+  for (int k = 0; k < K; ++k) {
+    wc_ctx *sub = ctx->batch_subs[k];
+    h_n_out[k] = 0;
+    if (!sub->ex.active) continue;
+    // (the sweep's own finish: waits for the shared stream, runs a layer-2 pass that turned out to be needed, repeats a sweep whose
+    // gates fell inside the noise band on the exact path - all on the sub-context, as for a single sweep)
+    const int rc = wc_extract_surfels_finish(sub, &h_n_out[k]);
+    if (rc != WC_OK && first_rc == WC_OK) first_rc = wc_fail(ctx, rc, "wc_extract_surfels_batch (sweep %d): %s", k, wc_last_error(sub));
+  }
+  return first_rc;
 }
 
 extern "C" int wc_extract_profile(wc_ctx *ctx, int enable) {

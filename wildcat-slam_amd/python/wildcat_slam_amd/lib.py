@@ -192,6 +192,26 @@ class Context:
         self._ck(self.lib.wc_extract_surfels_finish(self.h, C.byref(n)))
         return int(n.value)
 
+    def extract_batch_prepare(self, jobs):
+        """jobs: list of (desc, d_out, d_ids or None, cap, t_lo, t_hi) -> (enqueue(), finish() -> [n_surfels per sweep]): K sweeps
+        through one launch chain (wc_extract_surfels_batch_*)"""
+        K = len(jobs)
+        arr = (R.SweepJob * K)()
+        for k, (desc, d_out, d_ids, cap, t_lo, t_hi) in enumerate(jobs):
+            arr[k].pts, arr[k].t_lo, arr[k].t_hi = desc, t_lo, t_hi
+            arr[k].d_out, arr[k].d_ids, arr[k].cap = d_out.ptr, (d_ids.ptr if d_ids else 0), cap
+        counts = (C.c_uint64 * K)()
+        enq, fin, ck, h = self.lib.wc_extract_surfels_batch_enqueue, self.lib.wc_extract_surfels_batch_finish, self._ck, self.h
+
+        def enqueue():
+            ck(enq(h, arr, C.c_int(K)))
+
+        def finish():
+            ck(fin(h, counts, C.c_int(K)))
+            return [int(c) for c in counts]
+
+        return enqueue, finish
+
     def prepare_extract(self, desc, d_out, d_ids, cap, t_lo=1.0, t_hi=0.0):
         """the same enqueue / finish pair with the ctypes argument objects built once: a sweep takes ~80 us, building them
         anew for every call is several us of host turn-around.  -> (enqueue(), finish() -> n_surfels)"""

@@ -115,5 +115,11 @@ def points_from_aos(arr, base_ptr=None):
     return Points(base, base + 24, 48, 48, len(arr))
 
 
+class SweepJob(C.Structure):
+    """wc_sweep_job (include/wc_types.h): one sweep of wc_extract_surfels_batch_*"""
+
+    _fields_ = [("pts", Points), ("t_lo", C.c_double), ("t_hi", C.c_double), ("d_out", C.c_void_p), ("d_ids", C.c_void_p), ("cap", C.c_uint64)]
+
+
 def ptr(a):
     return a.ctypes.data_as(C.c_void_p)
