@@ -28,7 +28,7 @@ struct wc_ctx {
   // scratch buffers (device), grown on demand and kept for the lifetime of the ctx
   wc_buf b_ex_ctrl;  // the extraction's control block (status words, bucket / bin counters): never shared, cleared ahead of time
   wc_buf b_keys[2], b_vals[2], b_sorttmp, b_slots, b_slot_ids, b_slot_keys[2], b_slot_idx[2], b_cand, b_cand_meta,
-      b_status, b_misc[8], b_route[4], b_fx[10], b_match_stat, b_match_samp;
+      b_status, b_misc[8], b_route[4], b_fx[10], b_match_stat, b_match_samp, b_match_defer;
   bool match_nf[2] = {false, false};  // wc_match: normal half of a candidate first (per kind of call: other set / same set)
   // ... and what the two orders cost on this context's calls (device time of k_knn_gate per query, smoothed; 0 = not yet tried):
   // once both are known the faster one is used, and the other is tried again every 16th call

@@ -245,7 +245,11 @@ __global__ void __launch_bounds__(128, 4) k_knn_gate(const wc_surfel *q_surf, co
                                                  const uint32_t *skeys, const uint32_t *sorig, const double *tworld, uint32_t nt,
                                                  MatchParams M, uint32_t *gated, uint32_t *knn_idx, double *knn_d2,
                                                  const uint32_t *__restrict__ qorder, uint32_t q_begin, uint32_t q_end, uint32_t *gated_shard,
-                                                 double *kth_stat) {
+                                                 double *kth_stat, uint32_t budget, uint32_t *defer) {
+  // budget / defer: a query that has looked at more than `budget` candidates when a shell ends without its k-th distance being
+  // inside the searched cube gives up here and is put on the list defer[1..] (defer[0] = their number): k_knn_wave finishes it
+  // with a whole wavefront.  One lane walking the 10 - 60 k candidates of a query whose 10th neighbour is metres away in a
+  // room that holds 280 surfels per cubic metre WAS the kernel: 5 ms per 50 k queries, the other 63 lanes of its wavefront idle.
   // qorder: the queries in the order of their grid cell (same-set matching: the sorted target permutation).  Neighbouring
   // threads then scan the same cell ranges: their feature loads hit the same cache lines and their trip counts agree.
   __shared__ uint2 s_rng[2 * kRowChunk][128];  // per thread: the candidate ranges of a chunk of rows (only its own column)
@@ -283,7 +287,8 @@ __global__ void __launch_bounds__(128, 4) k_knn_gate(const wc_surfel *q_surf, co
   // the insertion code whenever ANY of its 64 lanes has one - measured with clocks around the call: ~1.8 k clocks each, ~800
   // times per wavefront, most of the kernel.  The k-th distance used by the first look may be stale by a few notes: more notes,
   // same result.
-  uint32_t bcnt = 0;
+  uint32_t bcnt = 0, scanned = 0;
+  bool deferred = false;
   auto drain = [&]() {
     for (uint32_t j = 0; __ballot(j < bcnt); ++j) {
       if (j < bcnt) {
@@ -306,8 +311,14 @@ __global__ void __launch_bounds__(128, 4) k_knn_gate(const wc_surfel *q_surf, co
 #endif
     // shell r of the cube of cells around the query: rows (dy, dz); full x-span on the faces |dy| = r or |dz| = r,
     // only the two end cells elsewhere
-    for (int dz = -r; dz <= r; ++dz)
+    for (int dz = -r; dz <= r && !deferred; ++dz)
       for (int dy0 = -r; dy0 <= r; dy0 += kRowChunk) {
+        // (the budget is looked at between chunks of rows, not only between shells: the second shell of a dense room holds
+        // ~11 k candidates, and a lane that had to finish it first made its whole wavefront wait)
+        if (defer && scanned > budget && r > 0) {
+          deferred = true;
+          break;
+        }
         // ---- the ranges of kRowChunk rows (two parts each off the faces), looked up TOGETHER: against a sparse target set
         // a query visits ~200 rows of ~4 candidates, and a dependent table lookup per row is a round trip to L2 per row
         uint32_t bb[2 * kRowChunk], ee[2 * kRowChunk];
@@ -358,6 +369,7 @@ __global__ void __launch_bounds__(128, 4) k_knn_gate(const wc_surfel *q_surf, co
 #ifdef WC_PROF_KNN
           pc_ += e - b, pr_ += (e > b);
 #endif
+          scanned += e - b;
           // Candidates in groups of four: ONE half of the six components of a group is requested together (one candidate per
           // trip of a load - test loop costs a full round trip to L2 each).  Which half is decided per CALL from the k-th
           // distances of the previous call on this context (NF): the centre part while the k-th distance is small against the
@@ -388,15 +400,31 @@ __global__ void __launch_bounds__(128, 4) k_knn_gate(const wc_surfel *q_surf, co
         }
       }
     drain();
+    if (deferred) break;
     // everything not yet scanned is at least `bound` away from the query (in 3-D, hence in 6-D)
     const double bound = r * M.h + in_cell;
     if (top.cnt == K && top.worst() < bound * bound) break;
+    if (defer && scanned > budget && r < rmax) {
+      deferred = true;
+      break;
+    }
+  }
+  {  // the deferred queries of this wavefront -> the list (one atomic per wavefront)
+    const unsigned long long dm = __ballot(deferred);
+    if (dm) {
+      const int lane = threadIdx.x & 63;
+      uint32_t base = 0;
+      if (lane == __ffsll((long long)dm) - 1) base = atomicAdd(&defer[0], (uint32_t)__popcll(dm));
+      base = (uint32_t)__shfl((int)base, __ffsll((long long)dm) - 1);
+      if (deferred) defer[1 + base + (uint32_t)__popcll(dm & ((1ull << lane) - 1ull))] = qi;
+    }
   }
 #ifdef WC_PROF_KNN
   atomicAdd(&g_knn_prof[0], pc_), atomicAdd(&g_knn_prof[1], pr_), atomicAdd(&g_knn_prof[2], ps_), atomicAdd(&g_knn_prof[3], 1ull);
 #endif
   if (kth_stat && (blockIdx.x & 15u) == 0u && q_begin + (blockIdx.x + 1u) * blockDim.x <= q_end) {  // (full workgroups only)  // a sample of the k-th distances (in cells^2): the next call's order of the halves
-    double v = top.cnt == K ? fmin(top.worst() / (M.h * M.h), 1e6) : 0.0, c1 = top.cnt == K ? 1.0 : 0.0;
+    const bool have = top.cnt == K && !deferred;
+    double v = have ? fmin(top.worst() / (M.h * M.h), 1e6) : 0.0, c1 = have ? 1.0 : 0.0;
     for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m), c1 += __shfl_xor(c1, m);
     if ((threadIdx.x & 63) == 0) {
       double *slot = kth_stat + ((blockIdx.x >> 4) & 15u) * 16u;  // 16 slots, 128 bytes apart
@@ -404,6 +432,7 @@ __global__ void __launch_bounds__(128, 4) k_knn_gate(const wc_surfel *q_surf, co
       atomicAdd(slot + 1, c1);
     }
   }
+  if (deferred) return;  // (k_knn_wave writes this query's lists)
   // Q10: FLANN leaves the tail of the result untouched (zero-initialised) when fewer than k targets exist
   uint32_t out = 0;
 #pragma unroll
@@ -428,6 +457,160 @@ __global__ void __launch_bounds__(128, 4) k_knn_gate(const wc_surfel *q_surf, co
       gated_shard[(size_t)(qi - q_begin) * K + out] = kNone;
     else
       gated[(size_t)out * nq + q] = kNone;
+  }
+}
+
+// The queries k_knn_gate gave up on (more than `budget` candidates looked at and still not done): ONE WAVEFRONT per query.  The
+// rows of a shell are looked up 64 at a time (lane = row: range + exact pruning bound), their candidates streamed 64 per load (lane =
+// candidate: 48 contiguous bytes each, the distance summed in flann::L2_Simple's order as everywhere), the k best kept in lanes
+// 0 .. K-1 in (distance, index) order - a strict total order, so the list that comes out is the one the per-lane search would
+// have found.  Persistent wavefronts over the list (its length is only known on the device).
+template <int K>
+__global__ void __launch_bounds__(256) k_knn_wave(const wc_surfel *q_surf, const wc_pose *q_pose, uint32_t nq, const double *sfeat, const uint32_t *skeys,
+                                                 const uint32_t *sorig, const double *tworld, uint32_t nt, MatchParams M, uint32_t *gated,
+                                                 uint32_t *knn_idx, double *knn_d2, const uint32_t *__restrict__ qorder, uint32_t q_begin,
+                                                 uint32_t *gated_shard, const uint32_t *defer) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwave = (gridDim.x * blockDim.x) >> 6;
+  const uint32_t nd = defer[0];
+  for (uint32_t w = wave; w < nd; w += nwave) {
+    const uint32_t qi = defer[1 + w];
+    const uint32_t q = qorder ? qorder[qi] : qi;
+    double f[6];
+    V3 cq, nq_w;
+    feature6(q_surf[q], q_pose[q], M.cs, M.as, f, cq, nq_w);
+    const double tq = q_surf[q].t;
+    const double gx = (f[0] - M.org[0]) / M.h, gy = (f[1] - M.org[1]) / M.h, gz = (f[2] - M.org[2]) / M.h;
+    const int cx = (int)floor(gx), cy = (int)floor(gy), cz = (int)floor(gz);
+    const double in_cell = fmin(fmin(fmin(gx - cx, cx + 1 - gx), fmin(gy - cy, cy + 1 - gy)), fmin(gz - cz, cz + 1 - gz)) * M.h;
+    const int rmax = max(max(max(cx, M.dim[0] - 1 - cx), max(cy, M.dim[1] - 1 - cy)), max(cz, M.dim[2] - 1 - cz));
+    // the list: lane j < K holds the j-th best (ld, li); empty = (1e300, ~0)
+    double ld = 1e300;
+    uint32_t li = 0xFFFFFFFFu;
+    int cnt = 0;  // (uniform)
+    auto worst = [&]() -> double {
+      const double dk = __shfl(ld, K - 1);
+      return cnt < K ? 1e300 : dk;
+    };
+    for (int r = 0; r <= rmax; ++r) {
+      const int side = 2 * r + 1, nrows = side * side;
+      for (int r0 = 0; r0 < nrows; r0 += 64) {
+        // lane = row (dy, dz) of the shell: its candidate ranges (two parts off the faces), pruned against the k-th distance
+        const double wq = worst() / (M.h * M.h);
+        uint32_t b0 = 0, e0 = 0, b1 = 0, e1 = 0;
+        const int ri = r0 + lane;
+        if (ri < nrows) {
+          const int dz = ri / side - r, dy = ri % side - r;
+          const int y = cy + dy, z = cz + dz;
+          if (y >= 0 && y < M.dim[1] && z >= 0 && z < M.dim[2]) {
+            const bool face = max(abs(dy), abs(dz)) == r;
+            const int nparts = (face || r == 0) ? 1 : 2;
+            const double dyd = dy > 0 ? (double)(cy + dy) - gy : (dy < 0 ? gy - (double)(cy + dy + 1) : 0.0);
+            const double dzd = dz > 0 ? (double)(cz + dz) - gz : (dz < 0 ? gz - (double)(cz + dz + 1) : 0.0);
+            const double rem = wq - (dyd * dyd + dzd * dzd);
+            const int xs = rem < 1e12 ? (int)sqrt(fmax(rem, 0.0)) + 2 : (1 << 20);
+            if (!(rem < -1e-9 * wq) && (face || r <= xs)) {
+              const size_t row = (size_t)M.dim[0] * ((size_t)y + (size_t)M.dim[1] * (size_t)z);
+              for (int part = 0; part < nparts; ++part) {
+                int x0 = face ? max(cx - r, cx - xs) : (part == 0 ? cx - r : cx + r);
+                int x1 = face ? min(cx + r, cx + xs) : x0;
+                x0 = max(x0, 0), x1 = min(x1, M.dim[0] - 1);
+                if (x0 > x1) continue;
+                uint32_t b, e;
+                if (M.cell_start) {
+                  b = M.cell_start[row + x0], e = M.cell_start[row + x1 + 1];
+                } else {
+                  const uint32_t base = ((uint32_t)y << 10) | ((uint32_t)z << 20);
+                  b = lower_bound_u32(skeys, nt, base | (uint32_t)x0), e = lower_bound_u32(skeys, nt, (base | (uint32_t)x1) + 1u);
+                }
+                if (part == 0)
+                  b0 = b, e0 = e;
+                else
+                  b1 = b, e1 = e;
+              }
+            }
+          }
+        }
+        // the rows with candidates, one after the other; 64 candidates per trip
+        unsigned long long live = __ballot(e0 > b0 || e1 > b1);
+        while (live) {
+          const int src = __ffsll((long long)live) - 1;
+          live &= live - 1ull;
+          for (int part = 0; part < 2; ++part) {
+            const uint32_t b = (uint32_t)__shfl((int)(part ? b1 : b0), src), e = (uint32_t)__shfl((int)(part ? e1 : e0), src);
+            for (uint32_t i0 = b; i0 < e; i0 += 64u) {
+              const uint32_t i = i0 + (uint32_t)lane;
+              double sd = 1e300;
+              uint32_t oid = 0xFFFFFFFFu;
+              const double wk0 = worst();  // (read with all lanes active: a shuffle from an inactive lane returns 0)
+              if (i < e) {
+                const double *p = sfeat + (size_t)i * 6;
+                double sacc = 0.0;
+#pragma unroll
+                for (int d = 0; d < 6; ++d) {
+                  const double df = f[d] - p[d];
+                  sacc += df * df;
+                }
+                sd = sacc;
+                if (!(sd > wk0)) oid = sorig[i];
+              }
+              // insert the lanes' candidates that can still enter, one at a time (the k-th distance shrinks as they go in)
+              unsigned long long pend = __ballot(oid != 0xFFFFFFFFu);
+              while (pend) {
+                const int c = __ffsll((long long)pend) - 1;
+                pend &= pend - 1ull;
+                const double cd = __shfl(sd, c);
+                const uint32_t ci = (uint32_t)__shfl((int)oid, c);
+                const double wk = __shfl(ld, K - 1);
+                const uint32_t wi = (uint32_t)__shfl((int)li, K - 1);
+                if (cnt == K && !(cd < wk || (cd == wk && ci < wi))) continue;
+                // position = number of list entries before (cd, ci); entries from there on move up one lane
+                const bool before = lane < K && (ld < cd || (ld == cd && li < ci));
+                const int pos = __popcll(__ballot(before));
+                const double upd = __shfl_up(ld, 1);
+                const uint32_t upi = (uint32_t)__shfl_up((int)li, 1);
+                if (lane < K && lane > pos) ld = upd, li = upi;
+                if (lane == pos) ld = cd, li = ci;
+                if (cnt < K) ++cnt;
+              }
+            }
+          }
+        }
+      }
+      const double bound = r * M.h + in_cell;
+      if (cnt == K && worst() < bound * bound) break;
+    }
+    // outputs: lane j < K = the j-th neighbour (Q10: index 0 beyond the number of targets), gates as in k_knn_gate
+    const uint32_t c = (lane < K && lane < cnt) ? li : 0u;
+    bool pass = false;
+    if (lane < K) {
+      if (knn_idx) {
+        knn_idx[(size_t)q * K + lane] = c;
+        knn_d2[(size_t)q * K + lane] = lane < cnt ? ld : 0.0;
+      }
+      const double *wv = tworld + (size_t)c * 7;
+      pass = !(fabs(wv[6] - tq) < M.time_min);
+      const V3 nc = mk3(wv[3], wv[4], wv[5]);
+      pass = pass && !(acos(dot(nq_w, nc)) > M.ang_max);
+      pass = pass && !(fabs(dot(nq_w, cq - mk3(wv[0], wv[1], wv[2]))) > M.dist_max);
+    }
+    const unsigned long long pm = __ballot(pass);
+    const int npass = __popcll(pm);
+    if (lane < K) {
+      const int o = __popcll(pm & ((1ull << lane) - 1ull));
+      if (pass) {
+        if (gated_shard)
+          gated_shard[(size_t)(qi - q_begin) * K + o] = c;
+        else
+          gated[(size_t)o * nq + q] = c;
+      }
+      if (lane >= npass) {
+        if (gated_shard)
+          gated_shard[(size_t)(qi - q_begin) * K + lane] = kNone;
+        else
+          gated[(size_t)lane * nq + q] = kNone;
+      }
+    }
   }
 }
 
@@ -566,7 +749,9 @@ static int match_impl(wc_ctx *ctx, const wc_surfel *d_q_surf, const wc_pose *d_q
   // quarter of that distance; on the facade's room stream the MEDIAN is 0.18 - 0.25 units but the tail reaches 2.8 - 5.7 (surfels
   // whose normal has no like within metres), and a query walks (k-th distance / h)^3 cells: cells of 2 x the median made the
   // search 5 x slower (25 - 40 ms), of 0.5 x the median 2000 x.  The tail, not the median, sets the cost of a search, so the
-  // density rule stays the default and the sampled rule an experiment behind WC_KNN_CELL=<factor>.
+  // density rule stays the default and the sampled rule an experiment behind WC_KNN_CELL=<factor>.  (Measured again with the heavy
+  // queries handed to k_knn_wave, and with table look-ups counted against the budget: finer cells still lose on the room stream -
+  // 2 - 12 ms against 1.7 - 2.3 - and counting look-ups sends half of a sparse fixed window's queries to the wavefront kernel.)
   if (sample) {
     // median over the samples of the smallest radius that holds k targets (strided counts scaled up); samples that never
     // reach k inside 22 units (fewer than k targets, or a target set far from the queries) vote for the largest radius
@@ -670,14 +855,26 @@ static int match_impl(wc_ctx *ctx, const wc_surfel *d_q_surf, const wc_pose *d_q
   WC_TRY(wc_ensure(ctx, ctx->b_match_stat, 16 * 16 * 8));
   double *kth_stat = (double *)ctx->b_match_stat.p;
   WC_HIP(ctx, hipMemsetAsync(kth_stat, 0, 16 * 16 * 8, st));
+  // queries that look at more than `budget` candidates without finishing are handed to k_knn_wave (WC_KNN_BUDGET: 0 = never)
+  static const char *budget_env = getenv("WC_KNN_BUDGET");
+  const uint32_t budget = budget_env ? (uint32_t)atoi(budget_env) : 4096u;
+  uint32_t *defer = nullptr;
+  if (budget && nq_mine) {
+    WC_TRY(wc_ensure(ctx, ctx->b_match_defer, ((size_t)nq_mine + 2) * 4));
+    defer = (uint32_t *)ctx->b_match_defer.p;
+    WC_HIP(ctx, hipMemsetAsync(defer, 0, 4, st));
+  }
 #define WC_KNN_LAUNCH(KK)                                                                                                        \
   if (nq_mine) {                                                                                                                 \
     if (nf)                                                                                                                      \
       k_knn_gate<KK, true><<<(nq_mine + 127) / 128, 128, 0, st>>>(d_q_surf, d_q_pose, nq, (const double *)b_sfeat.p, k1, v1, (const double *)b_world.p, \
-                                                            nt, M, (uint32_t *)b_gated.p, d_knn_idx, d_knn_d2, qorder, q_begin, q_end, gated_shard, kth_stat); \
+                                                            nt, M, (uint32_t *)b_gated.p, d_knn_idx, d_knn_d2, qorder, q_begin, q_end, gated_shard, kth_stat, budget, defer); \
     else                                                                                                                         \
       k_knn_gate<KK, false><<<(nq_mine + 127) / 128, 128, 0, st>>>(d_q_surf, d_q_pose, nq, (const double *)b_sfeat.p, k1, v1, (const double *)b_world.p, \
-                                                             nt, M, (uint32_t *)b_gated.p, d_knn_idx, d_knn_d2, qorder, q_begin, q_end, gated_shard, kth_stat); \
+                                                             nt, M, (uint32_t *)b_gated.p, d_knn_idx, d_knn_d2, qorder, q_begin, q_end, gated_shard, kth_stat, budget, defer); \
+    if (defer)                                                                                                                   \
+      k_knn_wave<KK><<<1024, 256, 0, st>>>(d_q_surf, d_q_pose, nq, (const double *)b_sfeat.p, k1, v1, (const double *)b_world.p, nt, M,       \
+                                          (uint32_t *)b_gated.p, d_knn_idx, d_knn_d2, qorder, q_begin, gated_shard, defer);                 \
   }
   switch (P.knn_k) {  // the reference's k = 10 gets its own instantiation (top-k in 30 registers)
     case 10: WC_KNN_LAUNCH(10); break;
