@@ -236,7 +236,7 @@ struct TopK {
 };
 
 constexpr int kKeep = 16;      // notes per lane (k_knn_gate)
-constexpr int kRowChunk = 4;  // rows of a shell whose candidate ranges are looked up together
+constexpr int kRowChunk = 4;  // rows of a shell whose candidate ranges are looked up together (8: spills, no gain)
 
 // exact k-NN + gates.  gated[j][q] (plane j of nq entries: the resolve rounds read plane 0 coalesced and rarely more) =
 // j-th neighbour of q passing the first three gates (kNone-terminated).
@@ -614,13 +614,21 @@ __global__ void __launch_bounds__(256) k_knn_wave(const wc_surfel *q_surf, const
   }
 }
 
-// the all-gathered, position-major gated lists of every rank -> the plane layout the resolve rounds read
-__global__ void __launch_bounds__(256) k_unpack_gated(const uint32_t *__restrict__ all, const uint32_t *__restrict__ qorder, uint32_t nq, int k,
-                                                     uint32_t *gated) {
+// The searches write a query's gated list where the query stands in the CELL order (position-major: 4 k contiguous bytes per
+// thread, coalesced); the resolve rounds read plane j of the lists by query index.  Round 2 wrote the planes straight from the
+// search, gated[j nq + q] with q = qorder[qi]: ten scattered 4-byte stores per query, 342 MB of write traffic for 40 MB of lists at
+// a million queries.  Now: ONE scattered plane (the inverse permutation) and a transposition whose reads are 4 k-byte runs and
+// whose writes are coalesced.
+__global__ void __launch_bounds__(256) k_inv_perm(const uint32_t *__restrict__ qorder, uint32_t nq, uint32_t *qpos) {
   const uint32_t qi = blockIdx.x * blockDim.x + threadIdx.x;
-  if (qi >= nq) return;
-  const uint32_t q = qorder ? qorder[qi] : qi;
-  for (int j = 0; j < k; ++j) gated[(size_t)j * nq + q] = all[(size_t)qi * k + j];
+  if (qi < nq) qpos[qorder ? qorder[qi] : qi] = qi;
+}
+__global__ void __launch_bounds__(256) k_gated_planes(const uint32_t *__restrict__ pos_major, const uint32_t *__restrict__ qpos, uint32_t nq, int k,
+                                                     uint32_t *gated) {
+  const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= nq) return;
+  const uint32_t *src = pos_major + (size_t)qpos[q] * k;
+  for (int j = 0; j < k; ++j) gated[(size_t)j * nq + q] = src[j];
 }
 
 // choice(q) = first gated candidate c that is not already paired with q from c's own turn (c < q and choice(c) == q).
@@ -822,14 +830,15 @@ static int match_impl(wc_ctx *ctx, const wc_surfel *d_q_surf, const wc_pose *d_q
   // (the predicate only depends on arguments every rank shares: a rank-dependent one would leave the others in the all-gather)
   const bool sharded = want_shard && ctx->have_comm && ctx->comm.world > 1 && ctx->comm.allgatherv && nq >= 4096;
   uint32_t q_begin = 0, q_end = nq;
-  uint32_t *gated_shard = nullptr;
   if (sharded) {
     const uint32_t w = (uint32_t)ctx->comm.world, r = (uint32_t)ctx->comm.rank;
     q_begin = (uint32_t)(((uint64_t)nq * r) / w), q_end = (uint32_t)(((uint64_t)nq * (r + 1)) / w);
-    WC_TRY(wc_ensure(ctx, ctx->b_route[2], (size_t)nq * P.knn_k * 4));                     // all ranks' lists, position-major
-    WC_TRY(wc_ensure(ctx, ctx->b_route[3], (size_t)(q_end - q_begin + 1) * P.knn_k * 4));  // this rank's share
-    gated_shard = (uint32_t *)ctx->b_route[3].p;
   }
+  // the searches' output: position-major lists (this rank's share [q_begin, q_end) of the positions when sharded); all ranks'
+  // lists - or simply this call's - then sit in b_route[2] and are transposed into the planes of b_gated
+  WC_TRY(wc_ensure(ctx, ctx->b_route[2], (size_t)nq * P.knn_k * 4));
+  WC_TRY(wc_ensure(ctx, ctx->b_route[3], (size_t)(q_end - q_begin + 1) * P.knn_k * 4));
+  uint32_t *gated_shard = sharded ? (uint32_t *)ctx->b_route[3].p : (uint32_t *)ctx->b_route[2].p;
   const uint32_t nq_mine = q_end - q_begin;
   // order of the two halves of a candidate (see k_knn_gate).  First guess: from the k-th distances of the previous call of this
   // kind on this context.  That rule is wrong for windows whose 6-D distances are dominated by the normals' noise (the facade's
@@ -905,7 +914,11 @@ static int match_impl(wc_ctx *ctx, const wc_surfel *d_q_surf, const wc_pose *d_q
     if (!ctx->comm.stream_ordered) WC_HIP(ctx, hipStreamSynchronize(st));
     if (ctx->comm.allgatherv(ctx->comm.user, gated_shard, (uint64_t)nq_mine * P.knn_k * 4, ctx->b_route[2].p, bytes.data()) != 0)
       return wc_fail(ctx, WC_ERR_HIP, "wc_match: all-gather of the gated neighbour lists failed");
-    k_unpack_gated<<<(nq + 255) / 256, 256, 0, st>>>((const uint32_t *)ctx->b_route[2].p, qorder, nq, P.knn_k, (uint32_t *)b_gated.p);
+  }
+  {
+    uint32_t *qpos = (uint32_t *)b_choice.p + nq;  // (choice[1]: free until the resolve rounds)
+    k_inv_perm<<<(nq + 255) / 256, 256, 0, st>>>(qorder, nq, qpos);
+    k_gated_planes<<<(nq + 255) / 256, 256, 0, st>>>((const uint32_t *)ctx->b_route[2].p, qpos, nq, P.knn_k, (uint32_t *)b_gated.p);
     WC_HIP(ctx, hipGetLastError());
   }
   // 4. resolve the order-dependent "pair already seen" rule by fixed-point iteration
