@@ -668,6 +668,16 @@ def bench_window(ctx, args, world, rank, dev, torch, dist, cpu=False):
                                         "panel steps) on the %d pose unknowns" % (6 * ns)},
         "build_ms": round(t_build * 1e3, 3), "match_s": round(t_match, 4), "match_surfels_per_s": round(2 * n_s / t_match, 1), "generate_s": round(t_gen, 2),
     }
+    # matcher roofline (48 B feature + 144 B surfel per query and per target, both searches of the window step)
+    b_match = 192 * (2 * n_s + n_s + len(w["fix_surf"]))
+    out["match_roofline"] = {"bound": "hbm", "achieved": round(b_match / t_match / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": round(b_match / t_match / 1e9 / HBM_PEAK_GBS, 5), "algorithmic_bytes": b_match,
+                             "note": "latency-bound gather work (exact 10-NN in 6-D on a 3-D grid), far from the byte roofline by construction: the "
+                                     "window's normals are random, the 10th neighbour lies 2 - 5.7 grid units away"}
+    try:  # the matcher on what a real scanner produces (never quoted without it): surfels on the surfaces of a room, many sweeps deep
+        out["match_room_stream"] = bench_match_room(ctx)
+    except Exception as e:
+        out["match_room_stream"] = {"error": repr(e)}
     if cpu:
         # CPU baseline of the LM step: the single-thread oracle (oracle/window.cc + oracle/match.cc) on a BOUNDED sample - the
         # same 20-sweep window geometry (same 127 sample states / 1524 unknowns, same IMU factors) with 1/20 of the surfels
@@ -707,6 +717,35 @@ def ring_allreduce_model_us(nbytes, world):
     return 2.0 * (world - 1) / world * nbytes / 153e9 * 1e6 + 2 * (world - 1) * 1.5  # + ~1.5 us per hop
 
 
+def bench_match_room(ctx):
+    """the sliding-window search (KnnSurfelMatcher, knn_surfel_matcher.cc:16-49) on the surfels of a ROOM seen by eight sweeps of a
+    spinning scanner (synth.raw_stream, the facade's test stream at 640 k points/s): surfels lie on surfaces, ~280 per cubic metre
+    where there are any; the 10th 6-D neighbour is 0.2 units away in the median and 3 - 6 units for the loneliest surfels"""
+    from wildcat_slam_amd import records as R, synth
+
+    msgs, _, _ = synth.raw_stream(4.0, pts_per_s=640_000, t_start=1000.0)
+    surf = []
+    for k in range(0, len(msgs) - 4, 5):
+        s, _ = ctx.extract_surfels(synth.concat_points(*msgs[k:k + 5]))
+        surf.append(s)
+    S = np.concatenate(surf)
+    P = np.zeros(len(S), R.POSE)
+    P["quat"][:, 0] = 1.0
+    n = len(S)
+    d_s, d_p, d_pairs = ctx.to_device(S), ctx.to_device(P), ctx.alloc(8 * n)
+    ts = []
+    for _ in range(6):
+        ctx.sync()
+        t0 = time.perf_counter()
+        m = ctx.match_device(d_s, d_p, n, d_s, d_p, n, True, d_pairs, n)
+        ts.append(time.perf_counter() - t0)
+    t = min(ts[1:])
+    b = 192 * 2 * n
+    return {"workload": "%d surfels of 8 room sweeps, matched against themselves" % n, "ms_per_search": round(t * 1e3, 4), "pairs": m,
+            "queries_per_s": round(n / t, 1), "ms_per_50k_queries": round(t * 1e3 * 50_000 / n, 4),
+            "roofline": {"bound": "hbm", "achieved": round(b / t / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(b / t / 1e9 / HBM_PEAK_GBS, 6)}}
+
+
 def bench_odometry_step(ctx, args, world, rank, dev, torch, dist, cpu=False):
     """north_star's headline workload, one FULL odometry step (LidarOdometry::AddLidarScan, lidar_odometry.cc:523-566) through the
     C-ABI on a 10-sweep window of 1 M-point sweeps (10 x C2): 9 sweeps are already in the window (extracted, posed; the two oldest
@@ -738,11 +777,12 @@ def bench_odometry_step(ctx, args, world, rank, dev, torch, dist, cpu=False):
     T = runs[reps // 2]  # the median repetition (a repetition that meets a host hiccup - one in a few dozen - is 2x the others)
     it = max(1, info["iters"])
     # algorithmic bytes of the step: extraction 20 B/pt + 144 B/surfel; pose update ~200 B/surfel R+W per call; matcher
-    # 48 B feature + 144 B surfel per query and target per call; assembly (136 / 96 / 128 B per factor) x 2 passes per LM iteration
+    # 48 B feature + 144 B surfel per query and target per call; assembly (136 / 96 / 128 B per factor) x ONE pass per LM iteration
+    # (+ the first linearisation): the candidate's cost comes from a linearisation at the candidate since round 3
     b_ext = 20 * n_pts + 144 * info["new_surfels"]
     b_pose = 2 * 200 * info["sld"]
     b_match = 192 * (2 * info["sld"] + info["sld"] + info["fix"])
-    b_asm = 2 * it * (136 * info["binary"] + 96 * info["unary"] + 128 * info["imu"])
+    b_asm = (it + 1) * (136 * info["binary"] + 96 * info["unary"] + 128 * info["imu"])
     total_b = b_ext + b_pose + b_match + b_asm
     out = {"workload": "10 x C2 window: %d-point newest sweep; sliding window %d surfels, fixed window %d; %d binary + %d unary + %d IMU factors; %d sample states"
                        % (n_pts, info["sld"], info["fix"], info["binary"], info["unary"], info["imu"], ns),
