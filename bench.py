@@ -668,6 +668,14 @@ def bench_window(ctx, args, world, rank, dev, torch, dist, cpu=False):
                                         "panel steps) on the %d pose unknowns" % (6 * ns)},
         "build_ms": round(t_build * 1e3, 3), "match_s": round(t_match, 4), "match_surfels_per_s": round(2 * n_s / t_match, 1), "generate_s": round(t_gen, 2),
     }
+    # the assembly's OTHER roof (the binding one): fp64 vector issue.  Flops per record by a fixed counting rule - the
+    # Gram matrix of the record's row [J r] (upper triangle: 325 / 91 multiply-adds for 24 / 12 unknowns + residual) plus ~450 / ~250
+    # for the evaluation (Exp and Jr from one sincos per side, the row right to left, Cauchy corrector); an fma = 2
+    flops = nb * (2 * 325 + 450) + nu * (2 * 91 + 250) + ni * 12 * (2 * 37 * 19 + 600)
+    out["assembly_flop_roofline"] = {"bound": "fp64 vector", "achieved": round(flops / (lin_ms * 1e-3) / 1e12, 3), "peak": 78.6, "unit": "TFLOP/s",
+                                     "frac": round(flops / (lin_ms * 1e-3) / 1e12 / 78.6, 5), "flops_per_binary_record": 2 * 325 + 450,
+                                     "flops_per_unary_record": 2 * 91 + 250, "counting_rule": "useful multiply-adds of the formulas, not issued instructions "
+                                     "(the kernel issues ~2 300 fp64 instructions per binary record, VALU busy 58 %)"}
     # matcher roofline (48 B feature + 144 B surfel per query and per target, both searches of the window step)
     b_match = 192 * (2 * n_s + n_s + len(w["fix_surf"]))
     out["match_roofline"] = {"bound": "hbm", "achieved": round(b_match / t_match / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
