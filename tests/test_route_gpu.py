@@ -169,6 +169,24 @@ def test_c5_cloud_routed_two_ranks(gpu):
         assert mi.tobytes() == i_ref.tobytes() and ms.tobytes() == s_ref.tobytes()
 
 
+def test_c5_cloud_routed_full_size_four_ranks(gpu):
+    """BASELINE config 5 at FULL size through the routed path: the 9 999 872-point cloud as four time-contiguous slices on four ranks
+    (threads + contexts on the one GPU; dist.ThreadComm stands in for RCCL), ONE all-to-all of 24-byte records by root voxel, every
+    rank extracts its voxels (above 2 M points per rank: the two-kernel node stage), wc_gather_surfels merges: every rank ends with
+    the unsharded call's 312 496 surfels, byte for byte."""
+    n_roots = 39_062
+    pts, _ = synth.g2_lattice(n_roots, m=32, seed=synth.SEED + 50)
+    s_ref, i_ref = gpu.extract_surfels(pts)
+    assert len(pts) == 9_999_872 and len(s_ref) == 8 * n_roots and gpu.extract_path_info()["fast"]
+    out = _run_ranks(4, pts)
+    assert all(o[0][3] for o in out)  # every rank on the default (integer-moment) path
+    share = [o[0][2] / len(pts) for o in out]
+    assert abs(sum(share) - 1.0) < 1e-12 and max(share) < 0.27  # every point owned once, balanced ownership
+    for r in range(4):
+        ms, mi = out[r][1]
+        assert mi.tobytes() == i_ref.tobytes() and ms.tobytes() == s_ref.tobytes()
+
+
 def test_in_library_rccl_communicator_world_of_one(gpu):
     """csrc/comm.hip on the one GPU of this box: librccl.so is dlopen()ed, ncclCommInitRank with one rank, and the sharded
     extraction + gather run their collectives (grouped ncclSend / ncclRecv to self on the ctx stream) through it - the result is
