@@ -47,7 +47,10 @@ using namespace wc;
 
 namespace {
 
-constexpr int kPiece = 256;   // records per piece (= threads per assembly workgroup)
+#ifndef WC_PIECE
+#define WC_PIECE 256
+#endif
+constexpr int kPiece = WC_PIECE;   // records per piece (= threads per assembly workgroup)
 constexpr int kNB = 32;       // Cholesky block size
 constexpr uint32_t kHeavySrc = 24;  // block pairs with more gather sources than this get the multi-group gather
 
@@ -463,7 +466,10 @@ __global__ void __launch_bounds__(1024) k_seg_heads(const uint32_t *keys, uint32
 
 // ---- assembly: one workgroup per piece ------------------------------------------------------------------------------
 // (tried: workgroups of 256 / 128 / 64 threads by the size of the piece - a third of C4's binary pieces holds <= 64 records.
-// No gain: phase A is bound by its fp64 arithmetic per WAVEFRONT, and a small piece already keeps only one wavefront busy.)
+// No gain: phase A is bound by its fp64 arithmetic per WAVEFRONT, and a small piece already keeps only one wavefront busy.
+// Round 3, -DWC_PIECE=128: pieces of <= 128 records, 128 threads and half the LDS each, six workgroups per CU instead of
+// three - 0.182 ms per linearisation at C4 against 0.178 with 256 (19 879 pieces against 12 299): not the pieces in flight
+// either.)
 // Phase A: thread k evaluates record k of the piece (residual + W-wide Jacobian row) into LDS (row k of V = [J r]).
 // Phase B: the Gram matrix V^T V ((W+1)^2, packed upper triangle; the corner (W,W) carries the piece's cost instead of
 //          sum r^2) in 4x4 register blocks: thread = (block of the upper block triangle, slice of the records); per
@@ -483,7 +489,7 @@ __global__ void __launch_bounds__(kPiece) k_lin_surfel(WinParams wp, const Piece
   constexpr int PB = 17;                     // doubles per partial block in LDS: 16 + 1 (a stride of 16 doubles puts every second lane on the same banks)
   constexpr int PSZ = NS * NBLK * PB;
   __shared__ __attribute__((aligned(16))) double sV[VSZ > PSZ ? VSZ : PSZ];  // V, later the per-slice partial blocks
-  __shared__ double sC[kPiece / 64];
+  __shared__ double sC[4];
   const Piece pc = pieces[blockIdx.x];
   const int tid = threadIdx.x;
 #ifdef WC_PROF_LIN
@@ -575,7 +581,7 @@ __global__ void __launch_bounds__(kPiece) k_lin_surfel(WinParams wp, const Piece
     const int j = i + (e - (i * T - i * (i - 1) / 2));
     double out = 0.0;
     if (i == W) {
-      out = (sC[0] + sC[1]) + (sC[2] + sC[3]);
+      out = kPiece == 256 ? (sC[0] + sC[1]) + (sC[2] + sC[3]) : kPiece == 128 ? sC[0] + sC[1] : sC[0];
     } else {
       const int ti = i >> 2, tj = j >> 2;
       const int q = ti * NB - ti * (ti - 1) / 2 + (tj - ti);  // index of block (ti, tj) in the ti <= tj enumeration
@@ -2350,18 +2356,12 @@ extern "C" int wc_window_solve(wc_ctx *ctx, double *h_x_inout, wc_solve_summary 
         double *X = nullptr;
         k_pcr_init<<<dim3(M, nch), 256, 0, st>>>(src, Dp[0], Ap[0], Rp[0], ldr, fail);
         for (int s = 1, lev = 0; lev < nlev; s *= 2, ++lev) {  // (ns >= 4: at least one level)
-          const bool first = false, last = lev == nlev - 1;
+          const bool last = lev == nlev - 1;
           const dim3 grid(M, nch);
-#define WC_PCR(F, L) k_pcr_level<F, L><<<grid, 256, 0, st>>>(s, M, src, Dp[cur], Ap[cur], Rp[cur], Dp[cur ^ 1], Ap[cur ^ 1], Rp[cur ^ 1], ldr, fail)
-          if (first && last)
-            WC_PCR(true, true);
-          else if (first)
-            WC_PCR(true, false);
-          else if (last)
-            WC_PCR(false, true);
+          if (last)
+            k_pcr_level<true><<<grid, 256, 0, st>>>(s, M, Dp[cur], Ap[cur], Rp[cur], Dp[cur ^ 1], Ap[cur ^ 1], Rp[cur ^ 1], ldr, fail);
           else
-            WC_PCR(false, false);
-#undef WC_PCR
+            k_pcr_level<false><<<grid, 256, 0, st>>>(s, M, Dp[cur], Ap[cur], Rp[cur], Dp[cur ^ 1], Ap[cur ^ 1], Rp[cur ^ 1], ldr, fail);
           cur ^= 1;
         }
         X = Rp[cur];  // the last level wrote X = T^-1 [C | bB] where the others write R'
