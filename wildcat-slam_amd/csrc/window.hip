@@ -1659,11 +1659,13 @@ __global__ void __launch_bounds__(1024) k_chol_back_gemv(const double *A, int ld
 // ---- host helpers ----------------------------------------------------------------------------------------------------
 int sort_u32(wc_ctx *ctx, wc_window_state *W, uint32_t *kin, uint32_t *kout, uint32_t *vin, uint32_t *vout, size_t n,
              unsigned end_bit) {
+  // (the Onesweep radix path at every size: rocPRIM's default is a merge sort of ~14 launches below 2^20 items - extract.hip's sort_pairs)
+  using cfg = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 0>;
   size_t tmp = 0;
-  WC_HIP(ctx, rocprim::radix_sort_pairs(nullptr, tmp, kin, kout, vin, vout, n, 0u, end_bit, ctx->stream));
+  WC_HIP(ctx, rocprim::radix_sort_pairs<cfg>(nullptr, tmp, kin, kout, vin, vout, n, 0u, end_bit, ctx->stream));
   WC_TRY(wc_ensure(ctx, ctx->b_sorttmp, tmp));
   tmp = ctx->b_sorttmp.cap;
-  WC_HIP(ctx, rocprim::radix_sort_pairs(ctx->b_sorttmp.p, tmp, kin, kout, vin, vout, n, 0u, end_bit, ctx->stream));
+  WC_HIP(ctx, rocprim::radix_sort_pairs<cfg>(ctx->b_sorttmp.p, tmp, kin, kout, vin, vout, n, 0u, end_bit, ctx->stream));
   return WC_OK;
 }
 
