@@ -44,6 +44,7 @@ struct wc_ctx {
   void *rccl = nullptr;  // the in-library RCCL communicator (comm.hip), if any
   // pinned host mailbox
   uint32_t *h_status = nullptr;  // [0] n_emitted, [1] flags, ...
+  unsigned long long mail_ticket = 0;  // last ticket handed to a k_post_reduce (window.hip: wait_mail)
   double *h_mail = nullptr;      // pinned: 64 doubles of mailbox (costs etc.) + 4096 doubles of staging (the window's unknowns)
   // pending extraction (enqueue/finish split)
   struct {

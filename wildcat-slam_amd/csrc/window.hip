@@ -2102,7 +2102,10 @@ inline double *lin_H(wc_window_state *W, bool other = false) { return (double *)
 inline double *lin_g(wc_window_state *W, bool other = false) { return lin_H(W, other) + (size_t)W->n * W->n; }
 inline double *lin_cost(wc_window_state *W, bool other = false) { return lin_g(W, other) + W->np; }
 
-__global__ void __launch_bounds__(1024) k_post_reduce(const double *g, const double *cost, int n, double *mail, int slot, double *host_mail = nullptr) {
+// ticket != 0: stored to host_mail[48] behind the mailbox (system-scope fence in between) - the host waits for it by reading
+// pinned memory instead of waiting for the stream (wait_mail)
+__global__ void __launch_bounds__(1024) k_post_reduce(const double *g, const double *cost, int n, double *mail, int slot, double *host_mail = nullptr,
+                                                     unsigned long long ticket = 0) {
   __shared__ double s[1024];
   const int tid = threadIdx.x;
   double mx = 0.0;
@@ -2118,6 +2121,10 @@ __global__ void __launch_bounds__(1024) k_post_reduce(const double *g, const dou
     mail[slot + 1] = s[0];
     if (host_mail) {  // the whole mailbox to pinned host memory (as k_sum_blocks does on the evaluation path)
       for (int i = 0; i < 40; ++i) host_mail[i] = (i == slot) ? cost[0] : (i == slot + 1 ? s[0] : mail[i]);
+      if (ticket) {
+        __threadfence_system();
+        __hip_atomic_store((unsigned long long *)(host_mail + 48), ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
     }
   }
 }
@@ -2142,7 +2149,7 @@ int do_allreduce(wc_ctx *ctx, wc_window_state *W, double *d_buf, size_t count) {
 
 // all kernels of one linearisation at x (device): partials -> H, g ; cost -> mail[slot], max|g| -> mail[slot+1]
 int enqueue_linearize(wc_ctx *ctx, wc_window_state *W, const double *d_x, int mail_slot, bool post = true, bool other = false,
-                      double *host_mail = nullptr) {
+                      double *host_mail = nullptr, unsigned long long ticket = 0) {
   hipStream_t st = ctx->stream;
   const Piece *pcs = (const Piece *)W->pieces.p;
   double *partial = (double *)W->partial.p;
@@ -2182,8 +2189,25 @@ int enqueue_linearize(wc_ctx *ctx, wc_window_state *W, const double *d_x, int ma
     k_expand_pairs<<<W->npairs + 1, 144, 0, st>>>(red, W->npairs, W->ns, W->np, lin_H(W, other), lin_g(W, other), (const uint32_t *)W->pair_off.p, W->red_H);
   }
   // (inside the LM loop the next lm_step forms cost / max |g| of this linearisation itself: post = false)
-  if (post) k_post_reduce<<<1, 1024, 0, st>>>(lin_g(W, other), lin_cost(W, other), W->n, (double *)W->mail.p, mail_slot, host_mail);
+  if (post) k_post_reduce<<<1, 1024, 0, st>>>(lin_g(W, other), lin_cost(W, other), W->n, (double *)W->mail.p, mail_slot, host_mail, ticket);
   WC_HIP(ctx, hipGetLastError());
+  return WC_OK;
+}
+
+// The host's wait for an iteration's mailbox: k_post_reduce stores a ticket to pinned memory behind the mailbox, the host reads
+// that word until it shows up - hipStreamSynchronize adds the end-of-kernel signal and the runtime's wake-up to every iteration
+// (~33 us between k_post_reduce's end and the next k_pcr_init's start in a kernel trace of the odometry step).  Falls back to the
+// stream wait after 50 ms (a faulted kernel never stores its ticket: the stream wait then reports the error).
+int wait_mail(wc_ctx *ctx, unsigned long long ticket) {
+  if (ticket) {
+    const volatile unsigned long long *w = (const volatile unsigned long long *)(ctx->h_mail + 48);
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t spin = 0;; ++spin) {
+      if (__atomic_load_n((const unsigned long long *)w, __ATOMIC_ACQUIRE) == ticket) return WC_OK;
+      if ((spin & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(50)) break;
+    }
+  }
+  WC_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return WC_OK;
 }
 
@@ -2314,6 +2338,7 @@ extern "C" int wc_window_solve(wc_ctx *ctx, double *h_x_inout, wc_solve_summary 
   // per iteration instead of two, -0.05 ms of 0.6 at C4), a rejected one has formed an H nobody uses (+0.1 ms).  Its cost and
   // max |g| arrive with the iteration's mailbox, so nothing is pending between iterations.  WC_LM_EVAL_PASS=1: round 2's flow.
   static const bool cand_lin = getenv("WC_LM_EVAL_PASS") == nullptr;
+  static const bool poll_mail = getenv("WC_LM_SYNC") == nullptr;  // (WC_LM_SYNC=1: wait for the stream instead of the ticket)
   double *h_mail_dev = nullptr, *h_stage_dev = nullptr;  // device addresses of the pinned mailbox and of its staging area
   {
     void *dp = nullptr;
@@ -2405,14 +2430,16 @@ extern "C" int wc_window_solve(wc_ctx *ctx, double *h_x_inout, wc_solve_summary 
           }
         }
       }
+      unsigned long long ticket = 0;
+      if (cand_lin && poll_mail && !multi_gpu(ctx, W) && h_mail_dev) ticket = ++ctx->mail_ticket;
       if (cand_lin)
-        WC_TRY(enqueue_linearize(ctx, W, xc, 5, /*post=*/true, /*other=*/true, multi_gpu(ctx, W) ? nullptr : h_mail_dev));  // mail[5] = cost, [6] = max |g| at the candidate
+        WC_TRY(enqueue_linearize(ctx, W, xc, 5, /*post=*/true, /*other=*/true, multi_gpu(ctx, W) ? nullptr : h_mail_dev, ticket));  // mail[5] = cost, [6] = max |g| at the candidate
       else
         WC_TRY(enqueue_evaluate(ctx, W, xc, nullptr, 5, h_mail_dev));
       WC_HIP(ctx, hipGetLastError());
       // (one GPU: k_sum_blocks has stored the mailbox to pinned host memory itself; with an all-reduce behind it, copy)
       if (multi_gpu(ctx, W) || !h_mail_dev) WC_HIP(ctx, hipMemcpyAsync(ctx->h_mail, mail, 40 * 8, hipMemcpyDeviceToHost, st));
-      WC_HIP(ctx, hipStreamSynchronize(st));
+      WC_TRY(wait_mail(ctx, ticket));
       if (lin_pending) {
         resolve_pending();
         if (gmax <= 1e-10) {  // GradientToleranceReached at the point this iteration started from
