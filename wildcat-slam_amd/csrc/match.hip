@@ -1010,6 +1010,10 @@ extern "C" int wc_match_pair_sharded(wc_ctx *ctx, const wc_surfel *d_sld_surf, c
   return wc_match_sharded(ctx, d_sld_surf, d_sld_pose, n_sld, d_fix_surf, d_fix_pose, n_fix, 0, d_pairs_fix, cap_fix, h_n_pairs_fix);
 }
 
+// (Round 3, tried: a rendezvous of the two searches behind their preparations, so that both k_knn_gate start together - in a kernel
+// trace the second search's small preparation launches wait for wavefront slots behind the first one's k_knn_gate, a one-workgroup
+// fill takes 357 us and its own k_knn_gate starts 630 us late.  Measured with the candidate order pinned, alternating on one box:
+// 2.80 - 2.90 ms with the rendezvous against 2.68 - 2.76 without: the staggered start is the better overlap.  Not kept.)
 // The two searches of an outer iteration side by side (see include/wildcat_hip.h).  wc_match is synchronous and talks to the
 // host between its launches (the fixed-point rounds of the pair rule), so the second search gets its own context AND its own
 // host thread; both only read the surfels.
