@@ -2153,6 +2153,9 @@ int enqueue_linearize(wc_ctx *ctx, wc_window_state *W, const double *d_x, int ma
   hipStream_t st = ctx->stream;
   const Piece *pcs = (const Piece *)W->pieces.p;
   double *partial = (double *)W->partial.p;
+  // (Round 3, tried: k_lin_imu - 14.5 us of dependent fp64 chains in a few hundred workgroups - on a stream of its own beside the
+  // surfel families, fork / join by events: 1 650 LM it/s against 1 790 at C4, odometry-step solve 2.58 against 2.39 ms - the two
+  // cross-stream waits cost more than the launch they hide.  One stream.)
   if (W->npiece_b)
     k_lin_surfel<24, false><<<W->npiece_b, kPiece, 0, st>>>(W->wp, pcs, (const double *)W->brec.p, (const uint32_t *)W->bkey.p, W->nb,
                                                           d_x, partial);
