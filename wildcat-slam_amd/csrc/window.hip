@@ -477,20 +477,26 @@ __global__ void __launch_bounds__(1024) k_seg_heads(const uint32_t *keys, uint32
 //          this phase LDS-bandwidth bound at ~190 us per linearisation; an fp64-MFMA variant is no faster (fp64 MFMA has
 //          the vector rate and a 25-wide Gram wastes 58 % of 32x32 tiles).  The slices are added in fixed order: no
 //          atomics, bitwise reproducible.
+// LDS of a surfel piece in doubles: V (later the per-slice partial blocks) + the wavefronts' cost sums
+template <int W>
+struct LinSurfelLds {
+  static constexpr int T = W + 1;
+  static constexpr int NB = (T + 3) / 4;            // 4-column blocks of V
+  static constexpr int NBLK = NB * (NB + 1) / 2;    // blocks (bi <= bj) of the Gram matrix
+  static constexpr int NS = kPiece / NBLK;          // record slices
+  static constexpr int TS = T + (T & 1);            // row stride in LDS: even, so that a row's 4-column blocks are 16-byte aligned (ds_read_b128)
+  static constexpr int VSZ = kPiece * TS + 4;       // + 4: the padded columns of the last block read past the last row
+  static constexpr int PB = 17;                     // doubles per partial block in LDS: 16 + 1 (a stride of 16 doubles puts every second lane on the same banks)
+  static constexpr int PSZ = NS * NBLK * PB;
+  static constexpr int VMAX = VSZ > PSZ ? VSZ : PSZ;
+  static constexpr int DOUBLES = VMAX + 4;
+};
 template <int W, bool UNARY>
-__global__ void __launch_bounds__(kPiece) k_lin_surfel(WinParams wp, const Piece *pieces, const double *rec, const uint32_t *keys,
-                                                      uint32_t nrec, const double *x, double *partial) {
-  constexpr int T = W + 1;
-  constexpr int NB = (T + 3) / 4;            // 4-column blocks of V
-  constexpr int NBLK = NB * (NB + 1) / 2;    // blocks (bi <= bj) of the Gram matrix
-  constexpr int NS = kPiece / NBLK;          // record slices
-  constexpr int TS = T + (T & 1);            // row stride in LDS: even, so that a row's 4-column blocks are 16-byte aligned (ds_read_b128)
-  constexpr int VSZ = kPiece * TS + 4;       // + 4: the padded columns of the last block read past the last row
-  constexpr int PB = 17;                     // doubles per partial block in LDS: 16 + 1 (a stride of 16 doubles puts every second lane on the same banks)
-  constexpr int PSZ = NS * NBLK * PB;
-  __shared__ __attribute__((aligned(16))) double sV[VSZ > PSZ ? VSZ : PSZ];  // V, later the per-slice partial blocks
-  __shared__ double sC[4];
-  const Piece pc = pieces[blockIdx.x];
+__device__ __forceinline__ void lin_surfel_body(const WinParams &wp, const Piece pc, const double *rec, uint32_t nrec, const double *x,
+                                                double *partial, double *smem /* 16-byte aligned, LinSurfelLds<W>::DOUBLES */) {
+  using L = LinSurfelLds<W>;
+  constexpr int T = L::T, NB = L::NB, NBLK = L::NBLK, NS = L::NS, TS = L::TS, PB = L::PB;
+  double *sV = smem, *sC = smem + L::VMAX;
   const int tid = threadIdx.x;
 #ifdef WC_PROF_LIN
   long long lt_[6];
@@ -598,6 +604,12 @@ __global__ void __launch_bounds__(kPiece) k_lin_surfel(WinParams wp, const Piece
            lt_[4] - lt_[0]);
 #endif
 }
+template <int W, bool UNARY>
+__global__ void __launch_bounds__(kPiece) k_lin_surfel(WinParams wp, const Piece *pieces, const double *rec, const uint32_t *keys,
+                                                      uint32_t nrec, const double *x, double *partial) {
+  __shared__ __attribute__((aligned(16))) double smem[LinSurfelLds<W>::DOUBLES];
+  lin_surfel_body<W, UNARY>(wp, pieces[blockIdx.x], rec, nrec, x, partial, smem);
+}
 
 using f64x4 = __attribute__((ext_vector_type(4))) double;
 
@@ -622,12 +634,11 @@ __constant__ const ImuGramOrder kImuGram{};
 
 // IMU factors of one sample interval: <= kImuMax factors x 12 residual rows, 36-wide Jacobian
 constexpr int kImuMax = 8;  // (16: 30 us at C4, 8: 24 us - one round of 252 workgroups, 4: 37 us - two rounds)
-__global__ void __launch_bounds__(256) k_lin_imu(WinParams wp, const Piece *pieces, const ImuRec *recs, const double *x,
-                                                const double *times, double *partial) {
+constexpr int kLinImuLds = kImuMax * 12 * 37 + kImuMax;  // doubles: the pieces' rows + the factors' costs
+__device__ __forceinline__ void lin_imu_body(const WinParams &wp, const Piece pc, const ImuRec *recs, const double *x, const double *times,
+                                             double *partial, double *smem /* kLinImuLds */) {
   constexpr int T = 37;
-  __shared__ double sV[kImuMax * 12 * T];
-  __shared__ double sC[kImuMax];
-  const Piece pc = pieces[blockIdx.x];
+  double *sV = smem, *sC = smem + kImuMax * 12 * T;
   const int tid = threadIdx.x;
   for (int e = tid; e < (int)pc.count * 12 * T; e += 256) sV[e] = 0.0;  // eval_imu stores the non-zero 3x3 groups only
   __syncthreads();
@@ -698,6 +709,35 @@ __global__ void __launch_bounds__(256) k_lin_imu(WinParams wp, const Piece *piec
     }
     partial[pc.part_off + tri_index((uint32_t)i, (uint32_t)j, (uint32_t)T)] = acc;
   }
+}
+__global__ void __launch_bounds__(256) k_lin_imu(WinParams wp, const Piece *pieces, const ImuRec *recs, const double *x,
+                                                const double *times, double *partial) {
+  __shared__ double smem[kLinImuLds];
+  lin_imu_body(wp, pieces[blockIdx.x], recs, x, times, partial, smem);
+}
+
+// ALL families of a linearisation in one launch (round 3): workgroups [0, n_imu) take the IMU pieces - dispatched first: a few
+// hundred workgroups of dependent fp64 chains, 14.5 us as a launch of their own whatever the window -, then the binary pieces,
+// then the unary ones.  The binary pieces' 53 KB of LDS already cap a CU at three workgroups, which is what the IMU body's 168
+// VGPRs allow: the fused kernel's occupancy is the binary kernel's.  Measured, alternating on one box: IMU inside the binary
+// launch 0.177 -> 0.166 - 0.172 ms per linearisation at C4 (1 775 -> 1 795 - 1 820 LM it/s), odometry-step solve 2.42 -> 2.30 ms;
+// the unary pieces inside too (at the binary pieces' LDS: three workgroups per CU instead of four, but no drain between the
+// families): solve 2.30 -> 2.25 ms, C4 unchanged.
+static_assert(kPiece == 256, "k_lin_imu's workgroups have 256 threads");
+template <bool WITH_UNARY>
+__global__ void __launch_bounds__(256, 3) k_lin_fused(WinParams wp, const Piece *pieces, uint32_t n_imu, uint32_t n_b, uint32_t n_u, const double *brec,
+                                                     uint32_t nb, const double *urec, uint32_t nu, const ImuRec *irec, const double *times,
+                                                     const double *x, double *partial) {
+  constexpr int SZ = LinSurfelLds<24>::DOUBLES > kLinImuLds ? LinSurfelLds<24>::DOUBLES : kLinImuLds;
+  static_assert(LinSurfelLds<12>::DOUBLES <= SZ, "the unary pieces fit the binary pieces' LDS");
+  __shared__ __attribute__((aligned(16))) double smem[SZ];
+  const uint32_t b = blockIdx.x;
+  if (b < n_imu)
+    lin_imu_body(wp, pieces[n_b + n_u + b], irec, x, times, partial, smem);
+  else if (!WITH_UNARY || b < n_imu + n_b)
+    lin_surfel_body<24, false>(wp, pieces[b - n_imu], brec, nb, x, partial, smem);
+  else
+    lin_surfel_body<12, true>(wp, pieces[b - n_imu], urec, nu, x, partial, smem);
 }
 
 // Gather of the piece partials into the dense normal equations, g and the cost: ONE launch with four roles by workgroup
@@ -2156,13 +2196,25 @@ int enqueue_linearize(wc_ctx *ctx, wc_window_state *W, const double *d_x, int ma
   // (Round 3, tried: k_lin_imu - 14.5 us of dependent fp64 chains in a few hundred workgroups - on a stream of its own beside the
   // surfel families, fork / join by events: 1 650 LM it/s against 1 790 at C4, odometry-step solve 2.58 against 2.39 ms - the two
   // cross-stream waits cost more than the launch they hide.  One stream.)
-  if (W->npiece_b)
+  static const bool imu_apart = getenv("WC_LIN_IMU_APART") != nullptr;  // (A/B: the IMU family as a launch of its own)
+  static const bool unary_in = getenv("WC_LIN_UNARY_APART") == nullptr;  // (A/B: the unary family as a launch of its own)
+  const bool fused = W->npiece_b && W->npiece_i && !imu_apart;
+  const bool fused_u = fused && unary_in && W->npiece_u;
+  if (fused_u)
+    k_lin_fused<true><<<W->npiece_i + W->npiece_b + W->npiece_u, 256, 0, st>>>(W->wp, pcs, W->npiece_i, W->npiece_b, W->npiece_u, (const double *)W->brec.p, W->nb,
+                                                                             (const double *)W->urec.p, W->nu, (const ImuRec *)W->irec.p,
+                                                                             (const double *)W->times_d.p, d_x, partial);
+  else if (fused)
+    k_lin_fused<false><<<W->npiece_i + W->npiece_b, 256, 0, st>>>(W->wp, pcs, W->npiece_i, W->npiece_b, W->npiece_u, (const double *)W->brec.p, W->nb,
+                                                                 (const double *)W->urec.p, W->nu, (const ImuRec *)W->irec.p, (const double *)W->times_d.p,
+                                                                 d_x, partial);
+  else if (W->npiece_b)
     k_lin_surfel<24, false><<<W->npiece_b, kPiece, 0, st>>>(W->wp, pcs, (const double *)W->brec.p, (const uint32_t *)W->bkey.p, W->nb,
                                                           d_x, partial);
-  if (W->npiece_u)
+  if (W->npiece_u && !fused_u)
     k_lin_surfel<12, true><<<W->npiece_u, kPiece, 0, st>>>(W->wp, pcs + W->npiece_b, (const double *)W->urec.p,
                                                          (const uint32_t *)W->ukey.p, W->nu, d_x, partial);
-  if (W->npiece_i)
+  if (W->npiece_i && !fused)
     k_lin_imu<<<W->npiece_i, 256, 0, st>>>(W->wp, pcs + W->npiece_b + W->npiece_u, (const ImuRec *)W->irec.p, d_x,
                                           (const double *)W->times_d.p, partial);
   GatherArgs ga;
