@@ -768,6 +768,12 @@ struct GatherArgs {
   int packed;  // H = the multi-GPU reduction buffer: block pairs in pair order at pair_off[pid] (144 doubles, or the 6 x 6 pose
                // corner of a pair more than two sample blocks apart); else the dense n x n matrix
   const uint32_t *pair_off;
+  // post != 0: the last of the ns + 1 workgroups that form g and the cost also forms max |g| and stores the mailbox (what
+  // k_post_reduce does as a launch of its own): `done` counts them, and is left at zero
+  int post, mail_slot;
+  uint32_t *done;
+  double *mail, *host_mail;
+  unsigned long long ticket;
 };
 
 // Sum of the sources s0, s0 + STRIDE, ... of one entry (u, v) of a block pair, in list order.  A source costs two dependent
@@ -814,6 +820,39 @@ __device__ __forceinline__ double gather_pair_sum(const Src *src, const double *
       if (ok[q]) acc += val[q];
   }
   return acc;
+}
+
+// k_post_reduce inside k_gather: called by every thread of the ns + 1 workgroups that wrote g / the cost (their stores were made
+// by wavefront 0).  The host's mailbox leaves while the block-pair workgroups of the launch are still summing.
+__device__ __forceinline__ void gather_post(const GatherArgs &a, double *sred) {
+  __shared__ uint32_t s_last;
+  const int tid = threadIdx.x;
+  if (tid < 64) __threadfence();
+  if (tid == 0) s_last = atomicAdd(a.done, 1u) == (uint32_t)a.ns ? 1u : 0u;
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  const int n = 12 * a.ns;
+  double mx = 0.0;
+  for (int i = tid; i < n; i += 144 * kGG) mx = fmax(mx, fabs(__hip_atomic_load(&a.g[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) mx = fmax(mx, __shfl_xor(mx, d, 64));
+  if ((tid & 63) == 0) sred[tid >> 6] = mx;
+  __syncthreads();
+  if (tid == 0) {
+    for (int w = 1; w < (144 * kGG + 63) / 64; ++w) mx = fmax(mx, sred[w]);
+    const double cost = __hip_atomic_load(&a.cost[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    a.mail[a.mail_slot] = cost;
+    a.mail[a.mail_slot + 1] = mx;
+    if (a.host_mail) {
+      for (int i = 0; i < 40; ++i) a.host_mail[i] = (i == a.mail_slot) ? cost : (i == a.mail_slot + 1 ? mx : a.mail[i]);
+      if (a.ticket) {
+        __threadfence_system();
+        __hip_atomic_store((unsigned long long *)(a.host_mail + 48), a.ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+    *a.done = 0u;
+  }
 }
 
 __global__ void __launch_bounds__(144 * kGG, 8) k_gather(GatherArgs a) {
@@ -957,12 +996,14 @@ __global__ void __launch_bounds__(144 * kGG, 8) k_gather(GatherArgs a) {
       sred[tid] = acc;
     }
     __syncthreads();
-    if (tid >= 12) return;
-    acc = 0.0;
-    for (int q = 0; q < NGg; ++q) acc += sred[q * 12 + u];
-    const int gi = I * 12 + u;
-    if (a.fix_first && gi >= 3 && gi < 6) acc = 0.0;
-    a.g[gi] = acc;
+    if (tid < 12) {
+      acc = 0.0;
+      for (int q = 0; q < NGg; ++q) acc += sred[q * 12 + u];
+      const int gi = I * 12 + u;
+      if (a.fix_first && gi >= 3 && gi < 6) acc = 0.0;
+      a.g[gi] = acc;
+    }
+    if (a.post) gather_post(a, sred);
     return;
   }
   {  // cost: deterministic sum of the cost slots of all partials
@@ -1008,6 +1049,7 @@ __global__ void __launch_bounds__(144 * kGG, 8) k_gather(GatherArgs a) {
       for (int q = 0; q < 16; ++q) t += sred[q * 63];
       a.cost[0] = t;
     }
+    if (a.post) gather_post(a, sred);
   }
 }
 
@@ -2057,6 +2099,7 @@ static int window_build_impl(wc_ctx *ctx, const wc_surfel *d_sld_surf, const wc_
   WC_TRY(wc_ensure(ctx, W->Lmat, (size_t)W->np * W->ld * 8));
   WC_TRY(wc_ensure(ctx, W->y, (size_t)W->np * 8));
   WC_TRY(wc_ensure(ctx, W->mail, 64 * 8));
+  WC_HIP(ctx, hipMemsetAsync((double *)W->mail.p + 60, 0, 8, ctx->stream));  // k_gather's count of finished g / cost workgroups
   const size_t ncb = (W->nb + 255) / 256 + (W->nu + 255) / 256 + (W->ni + 255) / 256 + 8;
   WC_TRY(wc_ensure(ctx, W->cost_part, ncb * 8));
   WC_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the uploads above read host vectors of this scope
@@ -2237,6 +2280,10 @@ int enqueue_linearize(wc_ctx *ctx, wc_window_state *W, const double *d_x, int ma
   ga.packed = packed ? 1 : 0;
   ga.nheavy = W->nheavy, ga.npairs = W->npairs, ga.npieces = W->npiece_b + W->npiece_u + W->npiece_i;
   ga.nb_pieces = W->npiece_b, ga.nu_pieces = W->npiece_u, ga.ns = W->ns, ga.fix_first = W->wp.fix_first;
+  // max |g| + the mailbox by the last of k_gather's g / cost workgroups (one GPU; behind an all-reduce k_post_reduce stays a launch)
+  static const bool post_apart = getenv("WC_LIN_POST_APART") != nullptr;
+  ga.post = (post && !packed && !post_apart) ? 1 : 0;
+  ga.mail_slot = mail_slot, ga.done = (uint32_t *)((double *)W->mail.p + 60), ga.mail = (double *)W->mail.p, ga.host_mail = host_mail, ga.ticket = ticket;
   k_gather<<<W->nheavy + (W->npairs + kGG * kLightSets - 1) / (kGG * kLightSets) + W->ns + 1, 144 * kGG, 0, st>>>(ga);
   WC_HIP(ctx, hipGetLastError());
   if (packed) {
@@ -2244,7 +2291,7 @@ int enqueue_linearize(wc_ctx *ctx, wc_window_state *W, const double *d_x, int ma
     k_expand_pairs<<<W->npairs + 1, 144, 0, st>>>(red, W->npairs, W->ns, W->np, lin_H(W, other), lin_g(W, other), (const uint32_t *)W->pair_off.p, W->red_H);
   }
   // (inside the LM loop the next lm_step forms cost / max |g| of this linearisation itself: post = false)
-  if (post) k_post_reduce<<<1, 1024, 0, st>>>(lin_g(W, other), lin_cost(W, other), W->n, (double *)W->mail.p, mail_slot, host_mail, ticket);
+  if (post && !ga.post) k_post_reduce<<<1, 1024, 0, st>>>(lin_g(W, other), lin_cost(W, other), W->n, (double *)W->mail.p, mail_slot, host_mail, ticket);
   WC_HIP(ctx, hipGetLastError());
   return WC_OK;
 }
