@@ -845,7 +845,7 @@ static int match_impl(wc_ctx *ctx, const wc_surfel *d_q_surf, const wc_pose *d_q
   // order of the two halves of a candidate (see k_knn_gate).  First guess: from the k-th distances of the previous call of this
   // kind on this context.  That rule is wrong for windows whose 6-D distances are dominated by the normals' noise (the facade's
   // room stream: the k-th neighbour lies within 1.5 cells, yet the normal half first is 1.6 x faster), so the device time of
-  // the search is measured and, once both orders have been tried, the faster one is used; the other is tried again every 16th
+  // the search is measured and, once both orders have been tried, the faster one is used; the other is tried again every 64th
   // call.  The lists do not depend on the order.
   const int kind = same_set ? 1 : 0;
   bool nf = ctx->match_nf[kind];
@@ -854,7 +854,7 @@ static int match_impl(wc_ctx *ctx, const wc_surfel *d_q_surf, const wc_pose *d_q
     const uint32_t call = ctx->match_calls[kind]++;
     if (t0 > 0.0 && t1 > 0.0) {
       nf = t1 < t0;
-      if ((call & 15u) == 15u) nf = !nf;
+      if ((call & 63u) == 63u) nf = !nf;
     } else if (call > 0 && (t0 > 0.0 || t1 > 0.0)) {
       nf = !(t1 > 0.0);  // the order not yet tried
     }
@@ -930,7 +930,16 @@ static int match_impl(wc_ctx *ctx, const wc_surfel *d_q_surf, const wc_pose *d_q
   int cur = 0;
   // rounds are issued eight at a time between host checks (a round past the fixed point changes nothing, so the extra ones
   // are harmless); round r of a batch reports into changed[r] and only the last word is read back
+  // The compaction (step 5) is enqueued right behind every batch, before the host knows whether the batch reached the fixed point: the
+  // rule - it did - then costs ONE host round trip for rounds + compaction instead of two (a batch that did not is followed by another
+  // one, and the compaction is redone on its result).
   bool converged = false;
+  double h_stat[16 * 16];
+  {
+    size_t tmp = 0;
+    WC_HIP(ctx, rocprim::exclusive_scan(nullptr, tmp, flags, offsets, 0u, (size_t)nq, rocprim::plus<uint32_t>(), st));
+    WC_TRY(wc_ensure(ctx, b_scan, tmp + 16));
+  }
   for (int batch = 0; batch < 250000 && !converged; ++batch) {
     const int rounds = same_set ? 8 : 1;
     WC_HIP(ctx, hipMemsetAsync(changed, 0, 32, st));
@@ -940,6 +949,17 @@ static int match_impl(wc_ctx *ctx, const wc_surfel *d_q_surf, const wc_pose *d_q
     }
     uint32_t hc8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     WC_HIP(ctx, hipMemcpyAsync(hc8, changed, 32, hipMemcpyDeviceToHost, st));
+    // 5. compact in query order
+    if (batch > 0) WC_HIP(ctx, hipMemsetAsync(status, 0, 8, st));  // (count + order flag of the previous, unconverged, attempt)
+    k_flags<<<(nq + 255) / 256, 256, 0, st>>>(choice[cur], nq, flags);
+    {
+      size_t tmp = b_scan.cap;
+      WC_HIP(ctx, rocprim::exclusive_scan(b_scan.p, tmp, flags, offsets, 0u, (size_t)nq, rocprim::plus<uint32_t>(), st));
+    }
+    k_emit_pairs<<<(nq + 255) / 256, 256, 0, st>>>(choice[cur], offsets, nq, d_q_surf, (const double *)b_world.p, same_set, d_pairs, cap, status);
+    WC_HIP(ctx, hipGetLastError());
+    if (batch == 0) WC_HIP(ctx, hipMemcpyAsync(h_stat, kth_stat, sizeof(h_stat), hipMemcpyDeviceToHost, st));
+    WC_HIP(ctx, hipMemcpyAsync(ctx->h_status, status, 8, hipMemcpyDeviceToHost, st));
     WC_HIP(ctx, hipStreamSynchronize(st));
     const uint32_t hc = hc8[rounds - 1];
     if (getenv("WC_MATCH_DEBUG"))
@@ -948,21 +968,6 @@ static int match_impl(wc_ctx *ctx, const wc_surfel *d_q_surf, const wc_pose *d_q
     converged = !hc || !same_set;
   }
   if (!converged) return wc_fail(ctx, WC_ERR_NUMERIC, "wc_match: the pair de-duplication did not reach its fixed point");
-  // 5. compact in query order
-  k_flags<<<(nq + 255) / 256, 256, 0, st>>>(choice[cur], nq, flags);
-  {
-    size_t tmp = 0;
-    WC_HIP(ctx, rocprim::exclusive_scan(nullptr, tmp, flags, offsets, 0u, (size_t)nq, rocprim::plus<uint32_t>(), st));
-    WC_TRY(wc_ensure(ctx, b_scan, tmp + 16));
-    tmp = b_scan.cap;
-    WC_HIP(ctx, rocprim::exclusive_scan(b_scan.p, tmp, flags, offsets, 0u, (size_t)nq, rocprim::plus<uint32_t>(), st));
-  }
-  k_emit_pairs<<<(nq + 255) / 256, 256, 0, st>>>(choice[cur], offsets, nq, d_q_surf, (const double *)b_world.p, same_set, d_pairs, cap, status);
-  WC_HIP(ctx, hipGetLastError());
-  double h_stat[16 * 16];
-  WC_HIP(ctx, hipMemcpyAsync(h_stat, kth_stat, sizeof(h_stat), hipMemcpyDeviceToHost, st));
-  WC_HIP(ctx, hipMemcpyAsync(ctx->h_status, status, 8, hipMemcpyDeviceToHost, st));
-  WC_HIP(ctx, hipStreamSynchronize(st));
   {
     double sum = 0.0, cnt = 0.0;
     for (int s = 0; s < 16; ++s) sum += h_stat[16 * s], cnt += h_stat[16 * s + 1];
