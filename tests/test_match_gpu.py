@@ -156,12 +156,15 @@ def test_queries_outside_the_target_box_and_pruned_shells(gpu, oracle):
     assert np.array_equal(pairs, oracle.match(q, qp, t, tp, False))
 
 
+@pytest.mark.parametrize("f32", ["0", "1"])
 @pytest.mark.parametrize("order", ["centre", "normal"])
-def test_both_orders_of_the_candidate_halves(gpu, oracle, order, monkeypatch):
+def test_both_orders_of_the_candidate_halves(gpu, oracle, order, f32, monkeypatch):
     """k_knn_gate tests one half of a candidate's six components before it loads the other; which half goes first is chosen
-    per call from the previous call's k-th distances (WC_KNN_ORDER pins it here).  Neighbour lists, distances (bit for bit)
-    and pairs must not depend on it: random normals (the normal half prunes), coherent normals (the centre half does)"""
+    per call from the previous call's k-th distances (WC_KNN_ORDER pins it here), and so is the precision of that first look
+    (WC_KNN_F32: single precision with a bound on its own rounding, or fp64).  Neighbour lists, distances (bit for bit) and
+    pairs must not depend on either: random normals (the normal half prunes), coherent normals (the centre half does)"""
     monkeypatch.setenv("WC_KNN_ORDER", order)
+    monkeypatch.setenv("WC_KNN_F32", f32)
     rng = np.random.default_rng(4711)
     t, tp = _random_surfels(rng, 6000, 12.0)
     q, qp = _random_surfels(rng, 3000, 14.0, t0=10.0)
@@ -171,6 +174,32 @@ def test_both_orders_of_the_candidate_halves(gpu, oracle, order, monkeypatch):
     assert np.array_equal(pairs, oracle.match(q, qp, t, tp, False))
     w = synth.surfel_window(4, 300, seed=21)
     assert np.array_equal(gpu.match(w["surf"], w["pose"], w["surf"], w["pose"], True), oracle.match(w["surf"], w["pose"], w["surf"], w["pose"], True))
+
+
+@pytest.mark.parametrize("order", ["centre", "normal"])
+def test_single_precision_first_look_is_conservative(gpu, oracle, order, monkeypatch):
+    """the fp32 first look of k_knn_gate (WC_KNN_F32=1) where single precision cannot tell the candidates apart: clusters of
+    surfels ~95 m from the origin whose members differ by micrometres in position and by 1e-7 in the normal (below the fp32
+    resolution of both halves of the feature), so that which ten are nearest is decided far below its rounding; lists, distances
+    and pairs must still be the oracle's, bit for bit"""
+    monkeypatch.setenv("WC_KNN_ORDER", order)
+    monkeypatch.setenv("WC_KNN_F32", "1")
+    rng = np.random.default_rng(99)
+    nc, m = 60, 40
+    centres = rng.uniform(-3, 3, size=(nc, 3)) + np.array([95.0, -95.0, 95.0])
+    nrm = rng.normal(size=(nc, 3))
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    s = np.zeros(nc * m, R.SURFEL)
+    s["center"] = np.repeat(centres, m, 0) + rng.integers(-50, 50, size=(nc * m, 3)) * 1e-6
+    n2 = np.repeat(nrm, m, 0) + rng.integers(-50, 50, size=(nc * m, 3)) * 1e-7
+    s["normal"] = n2 / np.linalg.norm(n2, axis=1, keepdims=True)
+    s["t"] = np.sort(rng.uniform(0, 5, size=nc * m))
+    p = np.zeros(nc * m, R.POSE)
+    p["quat"][:, 0] = 1.0
+    pairs, idx, d2 = gpu.match(s, p, s, p, True, want_knn=True)
+    ridx, rd2 = oracle.knn6(_feat(s), _feat(s), 10)
+    assert np.array_equal(idx.astype(np.int64), ridx.astype(np.int64)) and np.array_equal(d2, rd2)
+    assert np.array_equal(pairs, oracle.match(s, p, s, p, True))
 
 
 @pytest.mark.parametrize("k", [1, 3, 16])

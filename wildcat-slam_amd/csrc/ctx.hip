@@ -119,6 +119,7 @@ extern "C" void wc_ctx_destroy(wc_ctx *ctx) {
   if (ctx->b_match_samp.p) (void)hipFree(ctx->b_match_samp.p);
   if (ctx->b_batch.p) (void)hipFree(ctx->b_batch.p);
   if (ctx->b_match_defer.p) (void)hipFree(ctx->b_match_defer.p);
+  if (ctx->b_match_half.p) (void)hipFree(ctx->b_match_half.p);
   for (wc_ctx *sub : ctx->batch_subs) wc_ctx_destroy(sub);
   ctx->batch_subs.clear();
   for (wc_buf &b : ctx->b_fx)

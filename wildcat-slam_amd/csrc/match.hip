@@ -187,11 +187,17 @@ __global__ void __launch_bounds__(256) k_cell_table(const uint32_t *skeys, uint3
   for (; c0 <= c; ++c0) cell_first[c0] = i;
 }
 
-__global__ void __launch_bounds__(256) k_sorted_feat(const double *feat, const uint32_t *sorted_idx, uint32_t n, double *sfeat) {
+// shalf: the two halves of every sorted feature once more in single precision, 16 bytes each (centre part [0, n), normal part
+// [n, 2 n)): what k_knn_gate's first look at a candidate reads (see there)
+__global__ void __launch_bounds__(256) k_sorted_feat(const double *feat, const uint32_t *sorted_idx, uint32_t n, double *sfeat, float4 *shalf) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const uint32_t o = sorted_idx[i];
-  for (int d = 0; d < 6; ++d) sfeat[(size_t)i * 6 + d] = feat[(size_t)o * 6 + d];
+  double f[6];
+  for (int d = 0; d < 6; ++d) f[d] = feat[(size_t)o * 6 + d];
+  for (int d = 0; d < 6; ++d) sfeat[(size_t)i * 6 + d] = f[d];
+  shalf[i] = make_float4((float)f[0], (float)f[1], (float)f[2], 0.f);
+  shalf[(size_t)n + i] = make_float4((float)f[3], (float)f[4], (float)f[5], 0.f);
 }
 
 __device__ __forceinline__ uint32_t lower_bound_u32(const uint32_t *a, uint32_t n, uint32_t key) {
@@ -240,12 +246,20 @@ constexpr int kRowChunk = 4;  // rows of a shell whose candidate ranges are look
 
 // exact k-NN + gates.  gated[j][q] (plane j of nq entries: the resolve rounds read plane 0 coalesced and rarely more) =
 // j-th neighbour of q passing the first three gates (kNone-terminated).
-template <int K, bool NF>
+template <int K, bool NF, bool F32 = false>
 __global__ void __launch_bounds__(128, 4) k_knn_gate(const wc_surfel *q_surf, const wc_pose *q_pose, uint32_t nq, const double *sfeat,
                                                  const uint32_t *skeys, const uint32_t *sorig, const double *tworld, uint32_t nt,
                                                  MatchParams M, uint32_t *gated, uint32_t *knn_idx, double *knn_d2,
                                                  const uint32_t *__restrict__ qorder, uint32_t q_begin, uint32_t q_end, uint32_t *gated_shard,
-                                                 double *kth_stat, uint32_t budget, uint32_t *defer) {
+                                                 double *kth_stat, uint32_t budget, uint32_t *defer, const float4 *__restrict__ shalf) {
+  // F32 / shalf: the half of the sorted features the first look at a candidate tests (NF: the normal part), in SINGLE precision,
+  // 16 bytes per target.  The first look only has to be conservative - whoever passes it is summed exactly, in fp64, by drain()
+  // - so it compares the fp32 half-sum with the k-th distance plus a bound on its own rounding (thr32 below): one 16-byte load
+  // per candidate instead of 24 bytes in two, a third of the cache lines per row of candidates.  Same lists, bit for bit.
+  // Used for windows whose k-th neighbour is cells away (the call before this one on the context measured that: match_sparse):
+  // the odometry step's two searches 2.65 -> 2.52 ms, a C4 window's 472 -> 500 M surfels/s.  On the facade's room stream - k-th
+  // neighbour inside the query's own cells, long dense rows - the same first look is SLOWER (k_knn_gate 2.49 -> 2.67 ms normal
+  // half first, 2.94 -> 4.10 centre first, alternating on one box by rocprofv3), so the fp64 look stays there.
   // budget / defer: a query that has looked at more than `budget` candidates when a shell ends without its k-th distance being
   // inside the searched cube gives up here and is put on the list defer[1..] (defer[0] = their number): k_knn_wave finishes it
   // with a whole wavefront.  One lane walking the 10 - 60 k candidates of a query whose 10th neighbour is metres away in a
@@ -270,6 +284,21 @@ __global__ void __launch_bounds__(128, 4) k_knn_gate(const wc_surfel *q_surf, co
     top.d[i] = 1e300;
     top.id[i] = 0xFFFFFFFFu;
   }
+  // first look in fp32: a candidate that belongs to the list has |d_i| <= sqrt(w) in every component (w = the k-th distance), so
+  // its components are at most |q_i| + sqrt(w) in magnitude, the fp32 images of the two operands are off by <= 2^-24 of their
+  // magnitudes, each difference by <= delta = 2^-23 (2 qmax + sqrt(w)) including its own rounding, each square by
+  // 2 sqrt(w) delta + delta^2, and the three-term fp32 sum by a few 2^-24 of itself: thr32 bounds all of that from above.
+  // (the query's fp32 half and qmax are formed where they are used: three conversions per group of four candidates are cheaper
+  // than five more live registers in a kernel that sits at its 128)
+  // (sqrt(w) is bounded by (w + 1) / 2 instead of being taken: the bound is refreshed behind every drain, and a dense room drains
+  // every few candidates - with an fp64 square root there the first look cost more than it saved, 2.4 -> 2.8 ms per room search)
+  auto thr32_of = [&](double w) -> float {
+    if (!(w < 1e30)) return __builtin_inff();
+    const double qmax = fmax(fmax(fabs(f[NF ? 3 : 0]), fabs(f[NF ? 4 : 1])), fabs(f[NF ? 5 : 2]));
+    const double sw = 0.5 * (w + 1.0), delta = 1.1920928955078125e-7 * (2.0 * qmax + sw) * 1.01;
+    return __double2float_ru(w * (1.0 + 2e-6) + 3.0 * (2.0 * sw * delta + delta * delta) + 1e-30);
+  };
+  float thr32 = __builtin_inff();
   // query cell (unclamped, so that the distance bound stays valid for queries outside the target bbox)
   const double gx = (f[0] - M.org[0]) / M.h, gy = (f[1] - M.org[1]) / M.h, gz = (f[2] - M.org[2]) / M.h;
   const int cx = (int)floor(gx), cy = (int)floor(gy), cz = (int)floor(gz);
@@ -304,6 +333,7 @@ __global__ void __launch_bounds__(128, 4) k_knn_gate(const wc_surfel *q_surf, co
       }
     }
     bcnt = 0;
+    if (F32) thr32 = thr32_of(top.worst());
   };
   for (int r = 0; r <= rmax; ++r) {
 #ifdef WC_PROF_KNN
@@ -378,6 +408,32 @@ __global__ void __launch_bounds__(128, 4) k_knn_gate(const wc_surfel *q_surf, co
           // and the centre part of nearly every candidate lies below it).  A half that exceeds the k-th distance on its own
           // bounds the full sum from below in floating point too (adding non-negative terms is monotone).
           uint32_t i = b;
+          if (F32) {
+            for (; i + 4 <= e; i += 4) {
+              float4 v4[4];
+              const float4 *p4 = shalf + i;  // (one address, immediate offsets: i + u may wrap as far as the compiler knows)
+#pragma unroll
+              for (int u = 0; u < 4; ++u) v4[u] = p4[u];
+              float h4[4];
+              const float q0 = (float)f[NF ? 3 : 0], q1 = (float)f[NF ? 4 : 1], q2 = (float)f[NF ? 5 : 2];
+#pragma unroll
+              for (int u = 0; u < 4; ++u) {
+                const float d0 = q0 - v4[u].x, d1 = q1 - v4[u].y, d2 = q2 - v4[u].z;
+                h4[u] = d0 * d0 + d1 * d1 + d2 * d2;
+              }
+#pragma unroll
+              for (int u = 0; u < 4; ++u)
+                if (!(h4[u] > thr32)) s_keep[bcnt++][threadIdx.x] = i + u;
+              if (__ballot(bcnt >= (uint32_t)(kKeep - 4))) drain();
+            }
+            for (; i < e; ++i) {
+              const float4 v = shalf[i];
+              const float d0 = (float)f[NF ? 3 : 0] - v.x, d1 = (float)f[NF ? 4 : 1] - v.y, d2 = (float)f[NF ? 5 : 2] - v.z;
+              if (!(d0 * d0 + d1 * d1 + d2 * d2 > thr32)) s_keep[bcnt++][threadIdx.x] = i;
+              if (__ballot(bcnt >= (uint32_t)(kKeep - 4))) drain();
+            }
+            continue;
+          }
           for (; i + 4 <= e; i += 4) {
             const double *p = sfeat + (size_t)i * 6 + (NF ? 3 : 0);
             double h4[4];
@@ -699,6 +755,7 @@ static int match_impl(wc_ctx *ctx, const wc_surfel *d_q_surf, const wc_pose *d_q
   WC_TRY(wc_ensure(ctx, b_feat, (size_t)nt * 6 * 8));
   WC_TRY(wc_ensure(ctx, b_world, (size_t)nt * 7 * 8));
   WC_TRY(wc_ensure(ctx, b_sfeat, (size_t)nt * 6 * 8));
+  WC_TRY(wc_ensure(ctx, ctx->b_match_half, (size_t)nt * 2 * 16 + 16));
   WC_TRY(wc_ensure(ctx, b_gated, (size_t)nq * P.knn_k * 4));
   WC_TRY(wc_ensure(ctx, b_choice, (size_t)nq * 4 * 4));  // choice[2], flags, offsets
   WC_TRY(wc_ensure(ctx, ctx->b_keys[0], (size_t)std::max(nt, nq) * 4));
@@ -805,7 +862,7 @@ static int match_impl(wc_ctx *ctx, const wc_surfel *d_q_surf, const wc_pose *d_q
     tmp = ctx->b_sorttmp.cap;
     WC_HIP(ctx, rocprim::radix_sort_pairs(ctx->b_sorttmp.p, tmp, k0, k1, v0, v1, (size_t)nt, 0u, 30u, st));
   }
-  k_sorted_feat<<<(nt + 255) / 256, 256, 0, st>>>((const double *)b_feat.p, v1, nt, (double *)b_sfeat.p);
+  k_sorted_feat<<<(nt + 255) / 256, 256, 0, st>>>((const double *)b_feat.p, v1, nt, (double *)b_sfeat.p, (float4 *)ctx->b_match_half.p);
   const size_t ncell = (size_t)M.dim[0] * M.dim[1] * M.dim[2];
   M.cell_start = nullptr;
   if (ncell <= (1u << 24)) {  // dense [start, end) table (<= 128 MB); larger grids fall back to binary searches
@@ -860,6 +917,9 @@ static int match_impl(wc_ctx *ctx, const wc_surfel *d_q_surf, const wc_pose *d_q
     }
   }
   if (const char *o = getenv("WC_KNN_ORDER")) nf = o[0] == 'n';  // "normal" / "centre": tests pin each instantiation
+  // the single-precision first look (k_knn_gate<.., F32>): for windows whose k-th neighbour was cells away in the previous call
+  bool f32 = ctx->match_sparse[kind];
+  if (const char *o = getenv("WC_KNN_F32")) f32 = o[0] == '1';  // (tests pin each instantiation)
   for (hipEvent_t &e : ctx->ev_knn)
     if (!e) WC_HIP(ctx, hipEventCreate(&e));
   WC_HIP(ctx, hipEventRecord(ctx->ev_knn[0], st));
@@ -875,14 +935,19 @@ static int match_impl(wc_ctx *ctx, const wc_surfel *d_q_surf, const wc_pose *d_q
     defer = (uint32_t *)ctx->b_match_defer.p;
     WC_HIP(ctx, hipMemsetAsync(defer, 0, 4, st));
   }
+#define WC_KNN_ARGS                                                                                                              \
+  d_q_surf, d_q_pose, nq, (const double *)b_sfeat.p, k1, v1, (const double *)b_world.p, nt, M, (uint32_t *)b_gated.p, d_knn_idx, d_knn_d2, qorder, \
+      q_begin, q_end, gated_shard, kth_stat, budget, defer, (const float4 *)ctx->b_match_half.p + (nf ? (size_t)nt : 0)
 #define WC_KNN_LAUNCH(KK)                                                                                                        \
   if (nq_mine) {                                                                                                                 \
-    if (nf)                                                                                                                      \
-      k_knn_gate<KK, true><<<(nq_mine + 127) / 128, 128, 0, st>>>(d_q_surf, d_q_pose, nq, (const double *)b_sfeat.p, k1, v1, (const double *)b_world.p, \
-                                                            nt, M, (uint32_t *)b_gated.p, d_knn_idx, d_knn_d2, qorder, q_begin, q_end, gated_shard, kth_stat, budget, defer); \
+    if (KK == 10 && f32 && nf)                                                                                                   \
+      k_knn_gate<KK, true, (KK == 10)><<<(nq_mine + 127) / 128, 128, 0, st>>>(WC_KNN_ARGS);                                       \
+    else if (KK == 10 && f32)                                                                                                    \
+      k_knn_gate<KK, false, (KK == 10)><<<(nq_mine + 127) / 128, 128, 0, st>>>(WC_KNN_ARGS);                                      \
+    else if (nf)                                                                                                                 \
+      k_knn_gate<KK, true><<<(nq_mine + 127) / 128, 128, 0, st>>>(WC_KNN_ARGS);                                                   \
     else                                                                                                                         \
-      k_knn_gate<KK, false><<<(nq_mine + 127) / 128, 128, 0, st>>>(d_q_surf, d_q_pose, nq, (const double *)b_sfeat.p, k1, v1, (const double *)b_world.p, \
-                                                             nt, M, (uint32_t *)b_gated.p, d_knn_idx, d_knn_d2, qorder, q_begin, q_end, gated_shard, kth_stat, budget, defer); \
+      k_knn_gate<KK, false><<<(nq_mine + 127) / 128, 128, 0, st>>>(WC_KNN_ARGS);                                                  \
     if (defer)                                                                                                                   \
       k_knn_wave<KK><<<1024, 256, 0, st>>>(d_q_surf, d_q_pose, nq, (const double *)b_sfeat.p, k1, v1, (const double *)b_world.p, nt, M,       \
                                           (uint32_t *)b_gated.p, d_knn_idx, d_knn_d2, qorder, q_begin, gated_shard, defer);                 \
@@ -906,6 +971,7 @@ static int match_impl(wc_ctx *ctx, const wc_surfel *d_q_surf, const wc_pose *d_q
     default: WC_KNN_LAUNCH(16); break;
   }
 #undef WC_KNN_LAUNCH
+#undef WC_KNN_ARGS
   WC_HIP(ctx, hipGetLastError());
   WC_HIP(ctx, hipEventRecord(ctx->ev_knn[1], st));
   if (sharded) {
@@ -972,6 +1038,7 @@ static int match_impl(wc_ctx *ctx, const wc_surfel *d_q_surf, const wc_pose *d_q
     double sum = 0.0, cnt = 0.0;
     for (int s = 0; s < 16; ++s) sum += h_stat[16 * s], cnt += h_stat[16 * s + 1];
     if (cnt > 0.0) ctx->match_nf[same_set ? 1 : 0] = sum / cnt > 2.25;  // mean k-th distance beyond 1.5 cells: the centre half prunes little
+    if (cnt > 0.0) ctx->match_sparse[same_set ? 1 : 0] = sum / cnt > 2.25;
     float ms = 0.f;
     if (nq_mine >= 4096 && hipEventElapsedTime(&ms, ctx->ev_knn[0], ctx->ev_knn[1]) == hipSuccess && ms > 0.f) {
       double &t = ctx->match_ns_per_q[kind][nf ? 1 : 0];
