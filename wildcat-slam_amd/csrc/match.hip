@@ -407,13 +407,13 @@ __global__ void __launch_bounds__(128, 4) k_knn_gate(const wc_surfel *q_surf, co
           // normal part when it is not (normals that differ: 5 degrees are one unit, the 6-D k-th distance is several cells
           // and the centre part of nearly every candidate lies below it).  A half that exceeds the k-th distance on its own
           // bounds the full sum from below in floating point too (adding non-negative terms is monotone).
-          uint32_t i = b;
+          // (a range's last, partial group is ONE trip too - the lanes' clamped loads repeat the range's last candidate -, not
+          // one trip per candidate: against a sparse target set the rows hold ~5 candidates, and most trips were such leftovers)
           if (F32) {
-            for (; i + 4 <= e; i += 4) {
+            for (uint32_t i = b; i < e; i += 4) {
               float4 v4[4];
-              const float4 *p4 = shalf + i;  // (one address, immediate offsets: i + u may wrap as far as the compiler knows)
 #pragma unroll
-              for (int u = 0; u < 4; ++u) v4[u] = p4[u];
+              for (int u = 0; u < 4; ++u) v4[u] = shalf[min(i + (uint32_t)u, e - 1u)];
               float h4[4];
               const float q0 = (float)f[NF ? 3 : 0], q1 = (float)f[NF ? 4 : 1], q2 = (float)f[NF ? 5 : 2];
 #pragma unroll
@@ -423,34 +423,22 @@ __global__ void __launch_bounds__(128, 4) k_knn_gate(const wc_surfel *q_surf, co
               }
 #pragma unroll
               for (int u = 0; u < 4; ++u)
-                if (!(h4[u] > thr32)) s_keep[bcnt++][threadIdx.x] = i + u;
-              if (__ballot(bcnt >= (uint32_t)(kKeep - 4))) drain();
-            }
-            for (; i < e; ++i) {
-              const float4 v = shalf[i];
-              const float d0 = (float)f[NF ? 3 : 0] - v.x, d1 = (float)f[NF ? 4 : 1] - v.y, d2 = (float)f[NF ? 5 : 2] - v.z;
-              if (!(d0 * d0 + d1 * d1 + d2 * d2 > thr32)) s_keep[bcnt++][threadIdx.x] = i;
+                if (i + (uint32_t)u < e && !(h4[u] > thr32)) s_keep[bcnt++][threadIdx.x] = i + u;
               if (__ballot(bcnt >= (uint32_t)(kKeep - 4))) drain();
             }
             continue;
           }
-          for (; i + 4 <= e; i += 4) {
-            const double *p = sfeat + (size_t)i * 6 + (NF ? 3 : 0);
+          for (uint32_t i = b; i < e; i += 4) {
             double h4[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-              const double d0 = f[NF ? 3 : 0] - p[6 * u], d1 = f[NF ? 4 : 1] - p[6 * u + 1], d2 = f[NF ? 5 : 2] - p[6 * u + 2];
+              const double *p = sfeat + (size_t)min(i + (uint32_t)u, e - 1u) * 6 + (NF ? 3 : 0);
+              const double d0 = f[NF ? 3 : 0] - p[0], d1 = f[NF ? 4 : 1] - p[1], d2 = f[NF ? 5 : 2] - p[2];
               h4[u] = (0.0 + d0 * d0 + d1 * d1) + d2 * d2;
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u)
-              if (!(h4[u] > top.worst())) s_keep[bcnt++][threadIdx.x] = i + u;
-            if (__ballot(bcnt >= (uint32_t)(kKeep - 4))) drain();
-          }
-          for (; i < e; ++i) {
-            const double *p = sfeat + (size_t)i * 6 + (NF ? 3 : 0);
-            const double d0 = f[NF ? 3 : 0] - p[0], d1 = f[NF ? 4 : 1] - p[1], d2 = f[NF ? 5 : 2] - p[2];
-            if (!((0.0 + d0 * d0 + d1 * d1) + d2 * d2 > top.worst())) s_keep[bcnt++][threadIdx.x] = i;
+              if (i + (uint32_t)u < e && !(h4[u] > top.worst())) s_keep[bcnt++][threadIdx.x] = i + u;
             if (__ballot(bcnt >= (uint32_t)(kKeep - 4))) drain();
           }
         }
