@@ -407,6 +407,8 @@ __global__ void __launch_bounds__(128, 4) k_knn_gate(const wc_surfel *q_surf, co
           // normal part when it is not (normals that differ: 5 degrees are one unit, the 6-D k-th distance is several cells
           // and the centre part of nearly every candidate lies below it).  A half that exceeds the k-th distance on its own
           // bounds the full sum from below in floating point too (adding non-negative terms is monotone).
+          // (tried on top: the candidates of ALL ranges of a chunk as one stream, a trip filling up from the next non-empty range -
+          // 188 bytes of scratch and two more loops per trip: 2.45 -> 3.9 ms for the odometry step's searches.  Range by range.)
           // (a range's last, partial group is ONE trip too - the lanes' clamped loads repeat the range's last candidate -, not
           // one trip per candidate: against a sparse target set the rows hold ~5 candidates, and most trips were such leftovers)
           if (F32) {
