@@ -781,6 +781,8 @@ def bench_odometry_step(ctx, args, world, rank, dev, torch, dist, cpu=False):
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             T = dict(zip(sorted(T), [float(v) for v in tt.tolist()]))
         runs.append(T)
+    if os.environ.get("WC_BENCH_DEBUG"):
+        print("[bench] odometry step, match ms per repetition: " + " ".join("%.2f" % (t["match"] * 1e3) for t in runs), file=sys.stderr)
     runs.sort(key=lambda t: t["total"])
     T = runs[reps // 2]  # the median repetition (a repetition that meets a host hiccup - one in a few dozen - is 2x the others)
     it = max(1, info["iters"])

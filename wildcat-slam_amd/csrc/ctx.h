@@ -35,6 +35,7 @@ struct wc_ctx {
   // once both are known the faster one is used, and the other is tried again every 16th call
   double match_ns_per_q[2][2] = {{0.0, 0.0}, {0.0, 0.0}};  // [kind][normal first]
   uint32_t match_calls[2] = {0u, 0u};
+  uint32_t match_prev_n[2][2] = {{0u, 0u}, {0u, 0u}};  // queries / targets of the previous call of each kind (a new workload forgets the timings)
   double match_last_rk = 0.0;
   std::vector<wc_ctx *> batch_subs;  // sub-contexts of wc_extract_surfels_batch_* (own scratch, the parent's stream)
   wc_buf b_batch;  // median sampled k-th 6-D distance of the last wc_match call (scaled units): what set its cell size
@@ -91,6 +92,9 @@ struct wc_ctx {
   wc_window_state *win = nullptr;
   wc_ctx *aux = nullptr;  // helper context of wc_match_pair (second stream + scratch), owned by this ctx
   hipEvent_t ev_aux = nullptr;  // orders the helper's stream behind the ctx stream
+  hipEvent_t ev_pair[2] = {nullptr, nullptr};
+  struct wc_pair_gate *pair_gate = nullptr;  // wc_match_pair: the rendezvous of its two searches before their k_knn_gate (match.hip)
+  int pair_side = 0;
   // optional per-stage HIP events of the extraction pipeline (wc_extract_profile)
   bool ex_prof = false;
   int ex_prof_mode = 0;

@@ -15,6 +15,9 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <chrono>
+#include <condition_variable>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -24,6 +27,47 @@
 #include "dmath.h"
 
 using namespace wc;
+
+// wc_match_pair's two searches meet here before they launch k_knn_gate: each records an event behind its preparation (features,
+// sorts, cell table) and lets its stream wait for the other's (see wc_match_pair).
+struct wc_pair_gate {
+  std::mutex m;
+  std::condition_variable cv;
+  bool arrived[2] = {false, false}, left[2] = {false, false};
+  hipEvent_t ev[2] = {nullptr, nullptr};
+  // side s has enqueued its preparation: returns the other side's event to wait for (null: it never got here)
+  hipEvent_t meet(int s, hipStream_t st) {
+    if (hipEventRecord(ev[s], st) != hipSuccess) {
+      leave(s);
+      return nullptr;
+    }
+    std::unique_lock<std::mutex> lk(m);
+    arrived[s] = true;
+    cv.notify_all();
+    cv.wait_for(lk, std::chrono::milliseconds(200), [&] { return arrived[1 - s] || left[1 - s]; });
+    return arrived[1 - s] ? ev[1 - s] : nullptr;
+  }
+  void leave(int s) {  // the search of side s is over (or failed before it met the other)
+    std::lock_guard<std::mutex> lk(m);
+    left[s] = true;
+    cv.notify_all();
+  }
+  // side 0's k_knn_gate is enqueued first: both are ready at the same moment, the one dispatched first has all its wavefronts
+  // resident and the other fills the slots it leaves - that must be the LONGER search (the sliding window against itself, on
+  // the ctx stream): the other way round the step's two searches end 400 us later
+  bool launched0 = false;
+  void launched(int s) {
+    if (s != 0) return;
+    std::lock_guard<std::mutex> lk(m);
+    launched0 = true;
+    cv.notify_all();
+  }
+  void before_launch(int s) {
+    if (s != 1) return;
+    std::unique_lock<std::mutex> lk(m);
+    cv.wait_for(lk, std::chrono::milliseconds(200), [&] { return launched0 || left[0]; });
+  }
+};
 
 namespace {
 
@@ -895,6 +939,17 @@ static int match_impl(wc_ctx *ctx, const wc_surfel *d_q_surf, const wc_pose *d_q
   // the search is measured and, once both orders have been tried, the faster one is used; the other is tried again every 64th
   // call.  The lists do not depend on the order.
   const int kind = same_set ? 1 : 0;
+  {  // a different workload (twice / half the queries or targets of the previous call of this kind) starts without history: the
+     // per-query times of a 1 M-surfel window say nothing about a 250 k one, and with stale figures for the order NOT in use the
+     // choice took half a dozen calls to turn - bench.py's odometry step, measured behind its window section, 3.3 ms instead of 2.5
+    uint32_t *pn = ctx->match_prev_n[kind];
+    const auto far = [](uint32_t a, uint32_t b) { return a > 2u * b || 2u * a < b; };
+    if (pn[0] && (far(nq, pn[0]) || far(nt, pn[1]))) {
+      ctx->match_ns_per_q[kind][0] = ctx->match_ns_per_q[kind][1] = 0.0;
+      ctx->match_calls[kind] = 0;
+    }
+    pn[0] = nq, pn[1] = nt;
+  }
   bool nf = ctx->match_nf[kind];
   {
     const double t0 = ctx->match_ns_per_q[kind][0], t1 = ctx->match_ns_per_q[kind][1];
@@ -912,6 +967,13 @@ static int match_impl(wc_ctx *ctx, const wc_surfel *d_q_surf, const wc_pose *d_q
   if (const char *o = getenv("WC_KNN_F32")) f32 = o[0] == '1';  // (tests pin each instantiation)
   for (hipEvent_t &e : ctx->ev_knn)
     if (!e) WC_HIP(ctx, hipEventCreate(&e));
+  bool met = false;
+  if (ctx->pair_gate) {  // wc_match_pair: both searches start behind both preparations
+    if (hipEvent_t other = ctx->pair_gate->meet(ctx->pair_side, st)) {
+      WC_HIP(ctx, hipStreamWaitEvent(st, other, 0));
+      met = true;
+    }
+  }
   WC_HIP(ctx, hipEventRecord(ctx->ev_knn[0], st));
   WC_TRY(wc_ensure(ctx, ctx->b_match_stat, 16 * 16 * 8));
   double *kth_stat = (double *)ctx->b_match_stat.p;
@@ -942,6 +1004,7 @@ static int match_impl(wc_ctx *ctx, const wc_surfel *d_q_surf, const wc_pose *d_q
       k_knn_wave<KK><<<1024, 256, 0, st>>>(d_q_surf, d_q_pose, nq, (const double *)b_sfeat.p, k1, v1, (const double *)b_world.p, nt, M,       \
                                           (uint32_t *)b_gated.p, d_knn_idx, d_knn_d2, qorder, q_begin, gated_shard, defer);                 \
   }
+  if (met) ctx->pair_gate->before_launch(ctx->pair_side);
   switch (P.knn_k) {  // the reference's k = 10 gets its own instantiation (top-k in 30 registers)
     case 10: WC_KNN_LAUNCH(10); break;
     case 1: WC_KNN_LAUNCH(1); break;
@@ -962,6 +1025,7 @@ static int match_impl(wc_ctx *ctx, const wc_surfel *d_q_surf, const wc_pose *d_q
   }
 #undef WC_KNN_LAUNCH
 #undef WC_KNN_ARGS
+  if (ctx->pair_gate) ctx->pair_gate->launched(ctx->pair_side);
   WC_HIP(ctx, hipGetLastError());
   WC_HIP(ctx, hipEventRecord(ctx->ev_knn[1], st));
   if (sharded) {
@@ -1072,10 +1136,6 @@ extern "C" int wc_match_pair_sharded(wc_ctx *ctx, const wc_surfel *d_sld_surf, c
   return wc_match_sharded(ctx, d_sld_surf, d_sld_pose, n_sld, d_fix_surf, d_fix_pose, n_fix, 0, d_pairs_fix, cap_fix, h_n_pairs_fix);
 }
 
-// (Round 3, tried: a rendezvous of the two searches behind their preparations, so that both k_knn_gate start together - in a kernel
-// trace the second search's small preparation launches wait for wavefront slots behind the first one's k_knn_gate, a one-workgroup
-// fill takes 357 us and its own k_knn_gate starts 630 us late.  Measured with the candidate order pinned, alternating on one box:
-// 2.80 - 2.90 ms with the rendezvous against 2.68 - 2.76 without: the staggered start is the better overlap.  Not kept.)
 // The two searches of an outer iteration side by side (see include/wildcat_hip.h).  wc_match is synchronous and talks to the
 // host between its launches (the fixed-point rounds of the pair rule), so the second search gets its own context AND its own
 // host thread; both only read the surfels.
@@ -1090,6 +1150,7 @@ extern "C" int wc_match_pair(wc_ctx *ctx, const wc_surfel *d_sld_surf, const wc_
     return wc_match(ctx, d_sld_surf, d_sld_pose, n_sld, d_fix_surf, d_fix_pose, n_fix, 0, d_pairs_fix, cap_fix, h_n_pairs_fix, nullptr, nullptr);
   }
   wc_dev_guard dg_(ctx);
+  static const bool no_gate = getenv("WC_MATCH_PAIR_NOGATE") != nullptr;
   if (!ctx->aux) {
     const int rc = wc_ctx_create(&ctx->P, ctx->device, &ctx->aux);
     if (rc != WC_OK) return wc_fail(ctx, rc, "wc_match_pair: no helper context");
@@ -1101,6 +1162,20 @@ extern "C" int wc_match_pair(wc_ctx *ctx, const wc_surfel *d_sld_surf, const wc_
   WC_HIP(ctx, hipEventRecord(ctx->ev_aux, ctx->stream));
   WC_HIP(ctx, hipStreamWaitEvent(aux->stream, ctx->ev_aux, 0));
   int rc_fix = WC_OK, rc_sld = WC_OK;
+  // Rendezvous behind the preparations, then the ctx stream's k_knn_gate is enqueued first.  Without it the search that is ready first fills every wavefront slot of the
+  // chip and the other one's preparation - twenty small launches - waits for slots: how long depends on when the helper thread gets
+  // going (bench.py's odometry step behind its window section: the helper's k_sorted_feat 650 us, its k_knn_gate 1.25 ms late, the
+  // two searches 3.1 - 3.3 ms; on a fresh process 2.5).  With the helper's stream at the lowest priority its workgroups did not
+  // fill the slots the other search left but waited for its END (2.65 ms for a 1.2 ms kernel): equal priorities.
+  wc_pair_gate gate;
+  if (!no_gate) {
+    for (int s = 0; s < 2; ++s) {
+      if (!ctx->ev_pair[s]) WC_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_pair[s], hipEventDisableTiming));
+      gate.ev[s] = ctx->ev_pair[s];
+    }
+    ctx->pair_gate = aux->pair_gate = &gate;
+    ctx->pair_side = 0, aux->pair_side = 1;
+  }
   // no exception may cross the C boundary: a failed thread creation runs the second search on this thread, an allocation
   // failure inside a search becomes a status code
   auto guarded = [](int &rc, auto &&fn) {
@@ -1110,21 +1185,40 @@ extern "C" int wc_match_pair(wc_ctx *ctx, const wc_surfel *d_sld_surf, const wc_
       rc = WC_ERR_HIP;
     }
   };
-  auto search_fix = [&] { return wc_match(aux, d_sld_surf, d_sld_pose, n_sld, d_fix_surf, d_fix_pose, n_fix, 0, d_pairs_fix, cap_fix, h_n_pairs_fix, nullptr, nullptr); };
+  // which search runs where: the one on the ctx stream starts at once, the helper's a thread start later; the helper's stream has
+  // the lower priority (its workgroups fill the slots the other's leave)
+  static const bool swap = getenv("WC_MATCH_PAIR_SWAP") != nullptr;
+  wc_ctx *c_fix = swap ? ctx : aux, *c_sld = swap ? aux : ctx;
+  auto search_fix = [&] { return wc_match(c_fix, d_sld_surf, d_sld_pose, n_sld, d_fix_surf, d_fix_pose, n_fix, 0, d_pairs_fix, cap_fix, h_n_pairs_fix, nullptr, nullptr); };
+  auto search_sld = [&] { return wc_match(c_sld, d_sld_surf, d_sld_pose, n_sld, d_sld_surf, d_sld_pose, n_sld, 1, d_pairs_sld, cap_sld, h_n_pairs_sld, nullptr, nullptr); };
   std::thread helper;
   bool threaded = true;
   try {
-    helper = std::thread([&] { guarded(rc_fix, search_fix); });
+    helper = std::thread([&] {
+      if (swap)
+        guarded(rc_sld, search_sld);
+      else
+        guarded(rc_fix, search_fix);
+      gate.leave(1);
+    });
   } catch (...) {
     threaded = false;
+    gate.leave(1);  // (the second search runs behind the first one, on this thread: nobody to meet)
   }
-  guarded(rc_sld, [&] { return wc_match(ctx, d_sld_surf, d_sld_pose, n_sld, d_sld_surf, d_sld_pose, n_sld, 1, d_pairs_sld, cap_sld, h_n_pairs_sld, nullptr, nullptr); });
+  if (swap)
+    guarded(rc_fix, search_fix);
+  else
+    guarded(rc_sld, search_sld);
+  gate.leave(0);
   if (threaded)
     helper.join();
+  else if (swap)
+    guarded(rc_sld, search_sld);
   else
     guarded(rc_fix, search_fix);
-  if (rc_sld != WC_OK) return rc_sld;
-  if (rc_fix != WC_OK) return wc_fail(ctx, rc_fix, "wc_match_pair (fixed window): %s", wc_last_error(aux));
+  ctx->pair_gate = aux->pair_gate = nullptr;
+  if (rc_sld != WC_OK) return c_sld == ctx ? rc_sld : wc_fail(ctx, rc_sld, "wc_match_pair (sliding window): %s", wc_last_error(aux));
+  if (rc_fix != WC_OK) return c_fix == ctx ? rc_fix : wc_fail(ctx, rc_fix, "wc_match_pair (fixed window): %s", wc_last_error(aux));
   return WC_OK;
 }
 
