@@ -1,10 +1,13 @@
-"""Repetition-to-repetition spread of the odometry step's stages (one box): python profiles/dev/step_var.py [reps]"""
+"""Repetition-to-repetition spread of the odometry step's stages (one box): python profiles/dev/step_var.py [reps] [torch]"""
 import sys, os, time
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "..", "wildcat-slam_amd", "python"))
 import numpy as np
 from wildcat_slam_amd import lib, synth
 from wildcat_slam_amd.step import StepWindow
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+if len(sys.argv) > 2 and sys.argv[2] == "torch":  # (bench.py imports torch: does the runtime it initialises change the host waits?)
+    import torch
+    torch.cuda.init(); _x = torch.zeros(4, device="cuda:0"); torch.cuda.synchronize()
 ctx = lib.Context(0)
 w = synth.g2_scan_sequence(10, 3906, m=32, seed=synth.SEED + 21)
 sw = StepWindow(ctx, w, rank=0, world=1)

@@ -92,9 +92,6 @@ struct wc_ctx {
   wc_window_state *win = nullptr;
   wc_ctx *aux = nullptr;  // helper context of wc_match_pair (second stream + scratch), owned by this ctx
   hipEvent_t ev_aux = nullptr;  // orders the helper's stream behind the ctx stream
-  hipEvent_t ev_pair[2] = {nullptr, nullptr};
-  struct wc_pair_gate *pair_gate = nullptr;  // wc_match_pair: the rendezvous of its two searches before their k_knn_gate (match.hip)
-  int pair_side = 0;
   // optional per-stage HIP events of the extraction pipeline (wc_extract_profile)
   bool ex_prof = false;
   int ex_prof_mode = 0;

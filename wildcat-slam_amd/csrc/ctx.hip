@@ -101,8 +101,6 @@ extern "C" void wc_ctx_destroy(wc_ctx *ctx) {
     ctx->aux = nullptr;
   }
   if (ctx->ev_aux) (void)hipEventDestroy(ctx->ev_aux);
-  for (hipEvent_t e : ctx->ev_pair)
-    if (e) (void)hipEventDestroy(e);
   for (hipEvent_t e : ctx->ev_knn)
     if (e) (void)hipEventDestroy(e);
   (void)wc_comm_rccl_destroy(ctx);

@@ -16,8 +16,6 @@
 #include <cmath>
 #include <cstring>
 #include <chrono>
-#include <condition_variable>
-#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -27,47 +25,6 @@
 #include "dmath.h"
 
 using namespace wc;
-
-// wc_match_pair's two searches meet here before they launch k_knn_gate: each records an event behind its preparation (features,
-// sorts, cell table) and lets its stream wait for the other's (see wc_match_pair).
-struct wc_pair_gate {
-  std::mutex m;
-  std::condition_variable cv;
-  bool arrived[2] = {false, false}, left[2] = {false, false};
-  hipEvent_t ev[2] = {nullptr, nullptr};
-  // side s has enqueued its preparation: returns the other side's event to wait for (null: it never got here)
-  hipEvent_t meet(int s, hipStream_t st) {
-    if (hipEventRecord(ev[s], st) != hipSuccess) {
-      leave(s);
-      return nullptr;
-    }
-    std::unique_lock<std::mutex> lk(m);
-    arrived[s] = true;
-    cv.notify_all();
-    cv.wait_for(lk, std::chrono::milliseconds(200), [&] { return arrived[1 - s] || left[1 - s]; });
-    return arrived[1 - s] ? ev[1 - s] : nullptr;
-  }
-  void leave(int s) {  // the search of side s is over (or failed before it met the other)
-    std::lock_guard<std::mutex> lk(m);
-    left[s] = true;
-    cv.notify_all();
-  }
-  // side 0's k_knn_gate is enqueued first: both are ready at the same moment, the one dispatched first has all its wavefronts
-  // resident and the other fills the slots it leaves - that must be the LONGER search (the sliding window against itself, on
-  // the ctx stream): the other way round the step's two searches end 400 us later
-  bool launched0 = false;
-  void launched(int s) {
-    if (s != 0) return;
-    std::lock_guard<std::mutex> lk(m);
-    launched0 = true;
-    cv.notify_all();
-  }
-  void before_launch(int s) {
-    if (s != 1) return;
-    std::unique_lock<std::mutex> lk(m);
-    cv.wait_for(lk, std::chrono::milliseconds(200), [&] { return launched0 || left[0]; });
-  }
-};
 
 namespace {
 
@@ -777,6 +734,7 @@ static int match_impl(wc_ctx *ctx, const wc_surfel *d_q_surf, const wc_pose *d_q
                       const wc_pose *d_t_pose, uint64_t nt_, int same_set, wc_pair *d_pairs, uint64_t cap, uint64_t *h_n_pairs,
                       uint32_t *d_knn_idx, double *d_knn_d2, bool want_shard) {
   wc_dev_guard dg_(ctx);
+  const auto t_entry = std::chrono::steady_clock::now();
   if (!ctx || !h_n_pairs) return wc_fail(ctx, WC_ERR_ARG, "%s: null or out-of-range argument", __func__);
   *h_n_pairs = 0;
   if (nt_ == 0 || nq_ == 0) return WC_OK;  // knn_surfel_matcher.cc:18-20
@@ -952,13 +910,16 @@ static int match_impl(wc_ctx *ctx, const wc_surfel *d_q_surf, const wc_pose *d_q
   }
   bool nf = ctx->match_nf[kind];
   {
+    // calls 0 / 2 of a workload: the rule's order, calls 1 / 3: the other one; then the order whose BEST time is lower (the times are
+    // taken beside the other search of wc_match_pair: one sample per order, averaged, once left the slower order in use for good -
+    // its only sample of the faster one had waited for wavefront slots), the other one again every 64th call
     const double t0 = ctx->match_ns_per_q[kind][0], t1 = ctx->match_ns_per_q[kind][1];
     const uint32_t call = ctx->match_calls[kind]++;
-    if (t0 > 0.0 && t1 > 0.0) {
+    if (call < 4u)
+      nf = (call & 1u) ? !nf : nf;
+    else if (t0 > 0.0 && t1 > 0.0) {
       nf = t1 < t0;
       if ((call & 63u) == 63u) nf = !nf;
-    } else if (call > 0 && (t0 > 0.0 || t1 > 0.0)) {
-      nf = !(t1 > 0.0);  // the order not yet tried
     }
   }
   if (const char *o = getenv("WC_KNN_ORDER")) nf = o[0] == 'n';  // "normal" / "centre": tests pin each instantiation
@@ -967,13 +928,8 @@ static int match_impl(wc_ctx *ctx, const wc_surfel *d_q_surf, const wc_pose *d_q
   if (const char *o = getenv("WC_KNN_F32")) f32 = o[0] == '1';  // (tests pin each instantiation)
   for (hipEvent_t &e : ctx->ev_knn)
     if (!e) WC_HIP(ctx, hipEventCreate(&e));
-  bool met = false;
-  if (ctx->pair_gate) {  // wc_match_pair: both searches start behind both preparations
-    if (hipEvent_t other = ctx->pair_gate->meet(ctx->pair_side, st)) {
-      WC_HIP(ctx, hipStreamWaitEvent(st, other, 0));
-      met = true;
-    }
-  }
+  static const bool tdbg = getenv("WC_MATCH_TIMING") != nullptr;
+  const auto t_prep = std::chrono::steady_clock::now();
   WC_HIP(ctx, hipEventRecord(ctx->ev_knn[0], st));
   WC_TRY(wc_ensure(ctx, ctx->b_match_stat, 16 * 16 * 8));
   double *kth_stat = (double *)ctx->b_match_stat.p;
@@ -1004,7 +960,6 @@ static int match_impl(wc_ctx *ctx, const wc_surfel *d_q_surf, const wc_pose *d_q
       k_knn_wave<KK><<<1024, 256, 0, st>>>(d_q_surf, d_q_pose, nq, (const double *)b_sfeat.p, k1, v1, (const double *)b_world.p, nt, M,       \
                                           (uint32_t *)b_gated.p, d_knn_idx, d_knn_d2, qorder, q_begin, gated_shard, defer);                 \
   }
-  if (met) ctx->pair_gate->before_launch(ctx->pair_side);
   switch (P.knn_k) {  // the reference's k = 10 gets its own instantiation (top-k in 30 registers)
     case 10: WC_KNN_LAUNCH(10); break;
     case 1: WC_KNN_LAUNCH(1); break;
@@ -1025,7 +980,7 @@ static int match_impl(wc_ctx *ctx, const wc_surfel *d_q_surf, const wc_pose *d_q
   }
 #undef WC_KNN_LAUNCH
 #undef WC_KNN_ARGS
-  if (ctx->pair_gate) ctx->pair_gate->launched(ctx->pair_side);
+  const auto t_launched = std::chrono::steady_clock::now();
   WC_HIP(ctx, hipGetLastError());
   WC_HIP(ctx, hipEventRecord(ctx->ev_knn[1], st));
   if (sharded) {
@@ -1097,7 +1052,7 @@ static int match_impl(wc_ctx *ctx, const wc_surfel *d_q_surf, const wc_pose *d_q
     if (nq_mine >= 4096 && hipEventElapsedTime(&ms, ctx->ev_knn[0], ctx->ev_knn[1]) == hipSuccess && ms > 0.f) {
       double &t = ctx->match_ns_per_q[kind][nf ? 1 : 0];
       const double now = (double)ms * 1e6 / (double)nq_mine;
-      t = t > 0.0 ? 0.5 * (t + now) : now;
+      t = t > 0.0 ? fmin(now, 1.05 * t) : now;  // the best of the recent samples (an old best fades by 5 % per call)
     }
   }
 #ifdef WC_PROF_KNN
@@ -1109,6 +1064,14 @@ static int match_impl(wc_ctx *ctx, const wc_surfel *d_q_surf, const wc_pose *d_q
             (double)h[1] / h[3], (double)h[2] / h[3], M.h, M.dim[0], M.dim[1], M.dim[2]);
   }
 #endif
+  if (tdbg) {
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, ctx->ev_knn[0], ctx->ev_knn[1]);
+    auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+    const auto t_end = std::chrono::steady_clock::now();
+    fprintf(stderr, "[match] kind %d nq %u nt %u: host enqueue of the preparation %.0f us, rendezvous + launch %.0f us, launch -> done %.0f us (k_knn_gate + k_knn_wave by events %.0f us), nf %d f32 %d\n",
+            kind, nq, nt, us(t_entry, t_prep), us(t_prep, t_launched), us(t_launched, t_end), ms * 1e3, (int)nf, (int)f32);
+  }
   *h_n_pairs = ctx->h_status[0];
   if (ctx->h_status[1] & 2u) return wc_fail(ctx, WC_ERR_ORDER, "fixed-window surfel newer than its sliding-window match");
   if (ctx->h_status[0] > cap) return wc_fail(ctx, WC_ERR_CAPACITY, "pair capacity %llu < %u", (unsigned long long)cap, ctx->h_status[0]);
@@ -1150,7 +1113,6 @@ extern "C" int wc_match_pair(wc_ctx *ctx, const wc_surfel *d_sld_surf, const wc_
     return wc_match(ctx, d_sld_surf, d_sld_pose, n_sld, d_fix_surf, d_fix_pose, n_fix, 0, d_pairs_fix, cap_fix, h_n_pairs_fix, nullptr, nullptr);
   }
   wc_dev_guard dg_(ctx);
-  static const bool no_gate = getenv("WC_MATCH_PAIR_NOGATE") != nullptr;
   if (!ctx->aux) {
     const int rc = wc_ctx_create(&ctx->P, ctx->device, &ctx->aux);
     if (rc != WC_OK) return wc_fail(ctx, rc, "wc_match_pair: no helper context");
@@ -1162,20 +1124,10 @@ extern "C" int wc_match_pair(wc_ctx *ctx, const wc_surfel *d_sld_surf, const wc_
   WC_HIP(ctx, hipEventRecord(ctx->ev_aux, ctx->stream));
   WC_HIP(ctx, hipStreamWaitEvent(aux->stream, ctx->ev_aux, 0));
   int rc_fix = WC_OK, rc_sld = WC_OK;
-  // Rendezvous behind the preparations, then the ctx stream's k_knn_gate is enqueued first.  Without it the search that is ready first fills every wavefront slot of the
-  // chip and the other one's preparation - twenty small launches - waits for slots: how long depends on when the helper thread gets
-  // going (bench.py's odometry step behind its window section: the helper's k_sorted_feat 650 us, its k_knn_gate 1.25 ms late, the
-  // two searches 3.1 - 3.3 ms; on a fresh process 2.5).  With the helper's stream at the lowest priority its workgroups did not
-  // fill the slots the other search left but waited for its END (2.65 ms for a 1.2 ms kernel): equal priorities.
-  wc_pair_gate gate;
-  if (!no_gate) {
-    for (int s = 0; s < 2; ++s) {
-      if (!ctx->ev_pair[s]) WC_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_pair[s], hipEventDisableTiming));
-      gate.ev[s] = ctx->ev_pair[s];
-    }
-    ctx->pair_gate = aux->pair_gate = &gate;
-    ctx->pair_side = 0, aux->pair_side = 1;
-  }
+  // (Round 3, tried twice: a rendezvous of the two searches behind their preparations - both k_knn_gate ready together, the ctx
+  // stream's enqueued first, with and without a lower priority for the helper's stream.  2.50 - 2.76 ms for the odometry step's
+  // searches against 2.45 - 2.50 without, alternating on one box: the search that is ready first had better start.  What had made
+  // single runs take 3.1 - 3.4 ms was the ORDER of the candidate halves chosen from one noisy timing sample - see match_impl.)
   // no exception may cross the C boundary: a failed thread creation runs the second search on this thread, an allocation
   // failure inside a search becomes a status code
   auto guarded = [](int &rc, auto &&fn) {
@@ -1185,8 +1137,7 @@ extern "C" int wc_match_pair(wc_ctx *ctx, const wc_surfel *d_sld_surf, const wc_
       rc = WC_ERR_HIP;
     }
   };
-  // which search runs where: the one on the ctx stream starts at once, the helper's a thread start later; the helper's stream has
-  // the lower priority (its workgroups fill the slots the other's leave)
+  // which search runs where: the one on the ctx stream starts at once, the helper's a thread start later (WC_MATCH_PAIR_SWAP: A/B)
   static const bool swap = getenv("WC_MATCH_PAIR_SWAP") != nullptr;
   wc_ctx *c_fix = swap ? ctx : aux, *c_sld = swap ? aux : ctx;
   auto search_fix = [&] { return wc_match(c_fix, d_sld_surf, d_sld_pose, n_sld, d_fix_surf, d_fix_pose, n_fix, 0, d_pairs_fix, cap_fix, h_n_pairs_fix, nullptr, nullptr); };
@@ -1199,24 +1150,20 @@ extern "C" int wc_match_pair(wc_ctx *ctx, const wc_surfel *d_sld_surf, const wc_
         guarded(rc_sld, search_sld);
       else
         guarded(rc_fix, search_fix);
-      gate.leave(1);
     });
   } catch (...) {
     threaded = false;
-    gate.leave(1);  // (the second search runs behind the first one, on this thread: nobody to meet)
   }
   if (swap)
     guarded(rc_fix, search_fix);
   else
     guarded(rc_sld, search_sld);
-  gate.leave(0);
   if (threaded)
     helper.join();
   else if (swap)
     guarded(rc_sld, search_sld);
   else
     guarded(rc_fix, search_fix);
-  ctx->pair_gate = aux->pair_gate = nullptr;
   if (rc_sld != WC_OK) return c_sld == ctx ? rc_sld : wc_fail(ctx, rc_sld, "wc_match_pair (sliding window): %s", wc_last_error(aux));
   if (rc_fix != WC_OK) return c_fix == ctx ? rc_fix : wc_fail(ctx, rc_fix, "wc_match_pair (fixed window): %s", wc_last_error(aux));
   return WC_OK;
