@@ -842,8 +842,8 @@ static int match_impl(wc_ctx *ctx, const wc_surfel *d_q_surf, const wc_pose *d_q
     M.dim[d] = std::min(1024, (int)std::floor((hi[d] - lo[d]) / M.h) + 1);
   }
   // 2. sort targets by cell (x fastest).  (rocPRIM's default - a merge sort below 2^20 items; the Onesweep radix path that
-  // window.hip / extract.hip force makes no difference to a search: 2.73 / 2.81 against 2.75 / 2.80 ms for the odometry step's two
-  // searches, alternating on one box - runs on different boxes differ by more, 2.6 - 3.4 ms)
+  // window.hip / extract.hip force is SLOWER here: 2.54 against 2.41 ms for the odometry step's two searches, three alternations of
+  // 20 repetitions on one box - its look-back passes run beside the other search's k_knn_gate)
   uint32_t *k0 = (uint32_t *)ctx->b_keys[0].p, *k1 = (uint32_t *)ctx->b_keys[1].p;
   uint32_t *v0 = (uint32_t *)ctx->b_vals[0].p, *v1 = (uint32_t *)ctx->b_vals[1].p;
   k_cell_keys<<<(nt + 255) / 256, 256, 0, st>>>((const double *)b_feat.p, nt, M, k0, v0);
