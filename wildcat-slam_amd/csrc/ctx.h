@@ -92,6 +92,8 @@ struct wc_ctx {
   wc_window_state *win = nullptr;
   wc_ctx *aux = nullptr;  // helper context of wc_match_pair (second stream + scratch), owned by this ctx
   hipEvent_t ev_aux = nullptr;  // orders the helper's stream behind the ctx stream
+  void *pair_worker = nullptr;  // wc_match_pair's helper thread (match.hip: wc_pair_worker), freed through pair_worker_free
+  void (*pair_worker_free)(void *) = nullptr;
   // optional per-stage HIP events of the extraction pipeline (wc_extract_profile)
   bool ex_prof = false;
   int ex_prof_mode = 0;

@@ -96,6 +96,8 @@ extern "C" void wc_ctx_destroy(wc_ctx *ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->pair_worker && ctx->pair_worker_free) ctx->pair_worker_free(ctx->pair_worker);  // (joins the helper thread first)
+  ctx->pair_worker = nullptr;
   if (ctx->aux) {
     wc_ctx_destroy(ctx->aux);
     ctx->aux = nullptr;

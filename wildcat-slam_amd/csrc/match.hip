@@ -16,6 +16,9 @@
 #include <cmath>
 #include <cstring>
 #include <chrono>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -25,6 +28,48 @@
 #include "dmath.h"
 
 using namespace wc;
+
+// wc_match_pair's helper thread, kept between calls (a thread per call cost its creation - 60 to 100 us before the second
+// search's first launch - on every odometry step).  Owned by the ctx through ctx->pair_worker / pair_worker_free.
+struct wc_pair_worker {
+  std::thread th;
+  std::mutex m;
+  std::condition_variable cv;
+  std::function<void()> job;
+  bool has = false, done = true, quit = false;
+  wc_pair_worker() {
+    th = std::thread([this] {
+      std::unique_lock<std::mutex> lk(m);
+      for (;;) {
+        cv.wait(lk, [&] { return has || quit; });
+        if (quit) return;
+        has = false;
+        lk.unlock();
+        job();  // (never throws: wc_match_pair wraps the search)
+        lk.lock();
+        done = true;
+        cv.notify_all();
+      }
+    });
+  }
+  void start(std::function<void()> fn) {
+    std::lock_guard<std::mutex> lk(m);
+    job = std::move(fn), has = true, done = false;
+    cv.notify_all();
+  }
+  void wait() {
+    std::unique_lock<std::mutex> lk(m);
+    cv.wait(lk, [&] { return done; });
+  }
+  ~wc_pair_worker() {
+    {
+      std::lock_guard<std::mutex> lk(m);
+      quit = true;
+      cv.notify_all();
+    }
+    if (th.joinable()) th.join();
+  }
+};
 
 namespace {
 
@@ -1142,24 +1187,36 @@ extern "C" int wc_match_pair(wc_ctx *ctx, const wc_surfel *d_sld_surf, const wc_
   wc_ctx *c_fix = swap ? ctx : aux, *c_sld = swap ? aux : ctx;
   auto search_fix = [&] { return wc_match(c_fix, d_sld_surf, d_sld_pose, n_sld, d_fix_surf, d_fix_pose, n_fix, 0, d_pairs_fix, cap_fix, h_n_pairs_fix, nullptr, nullptr); };
   auto search_sld = [&] { return wc_match(c_sld, d_sld_surf, d_sld_pose, n_sld, d_sld_surf, d_sld_pose, n_sld, 1, d_pairs_sld, cap_sld, h_n_pairs_sld, nullptr, nullptr); };
-  std::thread helper;
   bool threaded = true;
-  try {
-    helper = std::thread([&] {
-      if (swap)
-        guarded(rc_sld, search_sld);
-      else
-        guarded(rc_fix, search_fix);
-    });
-  } catch (...) {
-    threaded = false;
+  wc_pair_worker *worker = (wc_pair_worker *)ctx->pair_worker;
+  if (!worker) {
+    try {
+      worker = new wc_pair_worker();
+      ctx->pair_worker = worker;
+      ctx->pair_worker_free = [](void *p) { delete (wc_pair_worker *)p; };
+    } catch (...) {
+      worker = nullptr;
+      threaded = false;
+    }
+  }
+  if (threaded) {
+    try {
+      worker->start([&] {
+        if (swap)
+          guarded(rc_sld, search_sld);
+        else
+          guarded(rc_fix, search_fix);
+      });
+    } catch (...) {
+      threaded = false;
+    }
   }
   if (swap)
     guarded(rc_fix, search_fix);
   else
     guarded(rc_sld, search_sld);
   if (threaded)
-    helper.join();
+    worker->wait();
   else if (swap)
     guarded(rc_sld, search_sld);
   else
