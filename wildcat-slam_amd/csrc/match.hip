@@ -840,11 +840,20 @@ static int match_impl(wc_ctx *ctx, const wc_surfel *d_q_surf, const wc_pose *d_q
     if (!std::isfinite(lo[d]) || !std::isfinite(hi[d])) return wc_fail(ctx, WC_ERR_ARG, "non-finite surfel centre");
     ext = std::max(ext, hi[d] - lo[d]);
   }
-  // cell size: about 4 targets per occupied-volume cell, at most one scaled unit (= 1 m), at least extent / 1000
+  // cell size: about 4 targets per occupied-volume cell, at least extent / 1000, at most one scaled unit (= 1 m) when a set is
+  // matched against itself and two when it is matched against another set.  (The fixed window holds a fifth of the sliding window's
+  // surfels - one or two re-observations per query -, so the k-th neighbour of a query is 5 - 8 units away and the density rule asks
+  // for cells of 1.3 - 1.9 units; capped at one, a query walked 178 rows of ~5 candidates.  Odometry step, both searches, 20
+  // repetitions each on one box: cap 1 / 1 -> 2.39 ms, other set 1.5 / 2 / 3 -> 2.08 / 2.06 / 2.07 ms; C4 window 543 -> 587 M
+  // surfels/s.  For the same-set search the cap stays: 0.8 / 1.0 / 1.2 -> 2.01 / 2.07 / 2.05, but 1.202 - the density rule's own
+  // figure there, which cuts the 0.4 m patch lattice of the synthetic windows unevenly - 2.51.)  WC_KNN_HCAP_SAME / _OTHER: A/B.
   double vol = 1.0;
   for (int d = 0; d < 3; ++d) vol *= std::max(hi[d] - lo[d], 0.05);
-  const double h_vol = std::min(1.0, std::cbrt(4.0 * vol / (double)nt));
+  const char *hcap_env = getenv(same_set ? "WC_KNN_HCAP_SAME" : "WC_KNN_HCAP_OTHER");
+  const double h_cap = hcap_env ? atof(hcap_env) : (same_set ? 1.0 : 2.0), h_raw = std::cbrt(4.0 * vol / (double)nt);
+  const double h_vol = std::min(h_cap, h_raw);
   M.h = h_vol;
+  if (getenv("WC_MATCH_DEBUG")) fprintf(stderr, "[match] nq %u nt %u same %d: density rule %.3f, capped %.3f\n", nq, nt, same_set, h_raw, h_vol);
   // Round 3 tried to take the cell size from THIS call's data: kSampleQ queries measure their k-th 6-D distance
   // (k_kth_sample) and the grid gets cells of a multiple of the median.  Measured (profiles/dev/time_match.py, time_facade.py;
   // DESIGN 3.3): the bench windows (random normals, k-th distance 2 - 5.7 units) are fastest with the density rule's cells of a
