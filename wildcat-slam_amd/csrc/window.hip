@@ -1913,6 +1913,9 @@ static int window_build_impl(wc_ctx *ctx, const wc_surfel *d_sld_surf, const wc_
     }
     WC_TRY(wc_ensure(ctx, W->heads, std::max<size_t>(((size_t)W->nb + W->nu) * 8, 16)));
   }
+  // (Round 3, measured with WC_WIN_DEBUG: of the odometry step's 0.40 ms build the host waits ~110 us for the binary family's chain
+  // - keys, three sort passes of 16 workgroups each, records, segment heads: ~240 us of small launches - and computes for ~65 us;
+  // the unary family on a stream of its own took 20 us off, uploads out of pinned memory nothing: one stream, pageable vectors.)
   FamilyJob job_b, job_u;
   WC_TRY(build_family(ctx, W, false, d_sld_surf, d_sld_pose, d_sld_surf, d_sld_pose, d_pairs_sld, W->nb, W->brec, W->bkey,
                       W->borig, job_b));
