@@ -2298,6 +2298,11 @@ extern "C" int wc_extract_surfels_finish(wc_ctx *ctx, uint64_t *h_n_out) {
   ctx->ex.active = false;
   if (h_n_out) *h_n_out = 0;
   if (ctx->ex.pts.n == 0) return WC_OK;
+  // (Round 3, tried: a completion ticket stored to the pinned mailbox by k_slot_emit's last workgroup, so that this wait reads host
+  // memory instead of waiting for the stream - as the LM loop does with k_post_reduce's single workgroup.  "Last of 1 024
+  // workgroups" needs a count with a device-scope release in front of every workgroup's increment, and on this chip - one L2 per
+  // XCD - that fence writes the XCD's L2 back: 43 -> 70 us per sweep with a two-stage count, 130 us with one counter.  Without the
+  // fences a copy on another stream could read the surfels before they have left L2.  The stream wait stays.)
   auto wait = [&]() -> int {  // stream done; fold the mailbox flag words (raise_flag) into h_status[1]
     WC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     for (int i = 0; i < 7; ++i)
