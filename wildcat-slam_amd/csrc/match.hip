@@ -288,12 +288,13 @@ struct TopK {
 };
 
 constexpr int kKeep = 16;      // notes per lane (k_knn_gate)
+constexpr int kKnnThreads = 64;  // k_knn_gate's workgroup: one wavefront (64 / 128 / 256 threads: 2.00 / 2.03 / 2.13 ms for the odometry step's searches)
 constexpr int kRowChunk = 4;  // rows of a shell whose candidate ranges are looked up together (8: spills, no gain)
 
 // exact k-NN + gates.  gated[j][q] (plane j of nq entries: the resolve rounds read plane 0 coalesced and rarely more) =
 // j-th neighbour of q passing the first three gates (kNone-terminated).
 template <int K, bool NF, bool F32 = false>
-__global__ void __launch_bounds__(128, 4) k_knn_gate(const wc_surfel *q_surf, const wc_pose *q_pose, uint32_t nq, const double *sfeat,
+__global__ void __launch_bounds__(kKnnThreads, 4) k_knn_gate(const wc_surfel *q_surf, const wc_pose *q_pose, uint32_t nq, const double *sfeat,
                                                  const uint32_t *skeys, const uint32_t *sorig, const double *tworld, uint32_t nt,
                                                  MatchParams M, uint32_t *gated, uint32_t *knn_idx, double *knn_d2,
                                                  const uint32_t *__restrict__ qorder, uint32_t q_begin, uint32_t q_end, uint32_t *gated_shard,
@@ -312,8 +313,8 @@ __global__ void __launch_bounds__(128, 4) k_knn_gate(const wc_surfel *q_surf, co
   // room that holds 280 surfels per cubic metre WAS the kernel: 5 ms per 50 k queries, the other 63 lanes of its wavefront idle.
   // qorder: the queries in the order of their grid cell (same-set matching: the sorted target permutation).  Neighbouring
   // threads then scan the same cell ranges: their feature loads hit the same cache lines and their trip counts agree.
-  __shared__ uint2 s_rng[2 * kRowChunk][128];  // per thread: the candidate ranges of a chunk of rows (only its own column)
-  __shared__ uint32_t s_keep[kKeep][128];      // per thread: candidates noted for the next drain
+  __shared__ uint2 s_rng[2 * kRowChunk][kKnnThreads];  // per thread: the candidate ranges of a chunk of rows (only its own column)
+  __shared__ uint32_t s_keep[kKeep][kKnnThreads];      // per thread: candidates noted for the next drain
   // query-sharded call (several GPUs): this rank takes the positions [q_begin, q_end) of the cell order and writes its gated
   // lists position-major into gated_shard (K words per position) - contiguous, so that ONE all-gather assembles all ranks'
   const uint32_t qi = q_begin + blockIdx.x * blockDim.x + threadIdx.x;
@@ -1003,13 +1004,13 @@ static int match_impl(wc_ctx *ctx, const wc_surfel *d_q_surf, const wc_pose *d_q
 #define WC_KNN_LAUNCH(KK)                                                                                                        \
   if (nq_mine) {                                                                                                                 \
     if (KK == 10 && f32 && nf)                                                                                                   \
-      k_knn_gate<KK, true, (KK == 10)><<<(nq_mine + 127) / 128, 128, 0, st>>>(WC_KNN_ARGS);                                       \
+      k_knn_gate<KK, true, (KK == 10)><<<(nq_mine + kKnnThreads - 1) / kKnnThreads, kKnnThreads, 0, st>>>(WC_KNN_ARGS);                                       \
     else if (KK == 10 && f32)                                                                                                    \
-      k_knn_gate<KK, false, (KK == 10)><<<(nq_mine + 127) / 128, 128, 0, st>>>(WC_KNN_ARGS);                                      \
+      k_knn_gate<KK, false, (KK == 10)><<<(nq_mine + kKnnThreads - 1) / kKnnThreads, kKnnThreads, 0, st>>>(WC_KNN_ARGS);                                      \
     else if (nf)                                                                                                                 \
-      k_knn_gate<KK, true><<<(nq_mine + 127) / 128, 128, 0, st>>>(WC_KNN_ARGS);                                                   \
+      k_knn_gate<KK, true><<<(nq_mine + kKnnThreads - 1) / kKnnThreads, kKnnThreads, 0, st>>>(WC_KNN_ARGS);                                                   \
     else                                                                                                                         \
-      k_knn_gate<KK, false><<<(nq_mine + 127) / 128, 128, 0, st>>>(WC_KNN_ARGS);                                                  \
+      k_knn_gate<KK, false><<<(nq_mine + kKnnThreads - 1) / kKnnThreads, kKnnThreads, 0, st>>>(WC_KNN_ARGS);                                                  \
     if (defer)                                                                                                                   \
       k_knn_wave<KK><<<1024, 256, 0, st>>>(d_q_surf, d_q_pose, nq, (const double *)b_sfeat.p, k1, v1, (const double *)b_world.p, nt, M,       \
                                           (uint32_t *)b_gated.p, d_knn_idx, d_knn_d2, qorder, q_begin, gated_shard, defer);                 \
