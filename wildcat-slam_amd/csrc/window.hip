@@ -1908,8 +1908,11 @@ static int window_build_impl(wc_ctx *ctx, const wc_surfel *d_sld_surf, const wc_
     if (W->h_pin_cap < need) {
       if (W->h_pin) (void)hipHostFree(W->h_pin);
       W->h_pin = nullptr, W->h_pin_cap = 0;
-      WC_HIP(ctx, hipHostMalloc(&W->h_pin, need));
-      W->h_pin_cap = need;
+      // (sized for the largest window wc_window_build accepts, once: a pinned allocation is 0.3 - 0.5 ms, and a window that gains
+      // sample states from sweep to sweep - the facade's first seconds - asked for a larger one on every call)
+      const size_t half_max = 64 + ((size_t)340 * 340 + 1) * 8, want = std::max(need, 2 * ((half_max + 127) / 128 * 128));
+      WC_HIP(ctx, hipHostMalloc(&W->h_pin, want));
+      W->h_pin_cap = want;
     }
     WC_TRY(wc_ensure(ctx, W->heads, std::max<size_t>(((size_t)W->nb + W->nu) * 8, 16)));
   }
