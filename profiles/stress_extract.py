@@ -1,5 +1,6 @@
 """Ad-hoc stress of the extraction against the CPU oracle on larger and odder sweeps than the unit tests use (run on the GPU
-box: python profiles/stress_extract.py).  Every case must be bit-identical."""
+box: python profiles/stress_extract.py), in the EXACT arithmetic (wc_params.exact_sums = 1: every sum in the reference's order; the
+default integer-moment path has profiles/stress_fast.py).  Every case must be bit-identical."""
 import os
 import sys
 
@@ -14,6 +15,7 @@ import pyoracle  # noqa: E402
 from wildcat_slam_amd import lib, synth  # noqa: E402
 
 ctx = lib.Context(0)
+ctx.set_exact_sums(True)
 rng = np.random.default_rng(2024)
 
 
