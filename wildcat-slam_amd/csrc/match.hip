@@ -899,6 +899,9 @@ static int match_impl(wc_ctx *ctx, const wc_surfel *d_q_surf, const wc_pose *d_q
   // 2. sort targets by cell (x fastest).  (rocPRIM's default - a merge sort below 2^20 items; the Onesweep radix path that
   // window.hip / extract.hip force is SLOWER here: 2.54 against 2.41 ms for the odometry step's two searches, three alternations of
   // 20 repetitions on one box - its look-back passes run beside the other search's k_knn_gate)
+  // (Also tried: a counting sort through the dense cell table - atomic counts, a scan over the cells, an atomic scatter: three launches.
+  // 2.00 against 2.03 ms, and the order inside a cell is whatever the atomics make it: the ranks of a query-sharded search, which
+  // shard the POSITIONS of the cell order, then disagree about who searches what.  The stable key sort stays.)
   uint32_t *k0 = (uint32_t *)ctx->b_keys[0].p, *k1 = (uint32_t *)ctx->b_keys[1].p;
   uint32_t *v0 = (uint32_t *)ctx->b_vals[0].p, *v1 = (uint32_t *)ctx->b_vals[1].p;
   k_cell_keys<<<(nt + 255) / 256, 256, 0, st>>>((const double *)b_feat.p, nt, M, k0, v0);
