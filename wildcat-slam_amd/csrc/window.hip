@@ -477,6 +477,26 @@ __global__ void __launch_bounds__(1024) k_seg_heads(const uint32_t *keys, uint32
 //          this phase LDS-bandwidth bound at ~190 us per linearisation; an fp64-MFMA variant is no faster (fp64 MFMA has
 //          the vector rate and a 25-wide Gram wastes 58 % of 32x32 tiles).  The slices are added in fixed order: no
 //          atomics, bitwise reproducible.
+// where entry e of a piece's packed upper triangle sits in a slice's partial blocks (offset in doubles; 0xFFFF: the corner, which
+// carries the piece's cost): a table instead of the closed-form inversion of e -> (i, j) - a square root, two correction steps and
+// the block arithmetic per entry, in the tail every piece pays
+template <int W>
+struct LinTailTable {
+  static constexpr int T = W + 1, NB = (T + 3) / 4, PB = 17, NOUT = T * (T + 1) / 2;
+  uint16_t off[NOUT];
+  constexpr LinTailTable() : off() {
+    int e = 0;
+    for (int i = 0; i < T; ++i)
+      for (int j = i; j < T; ++j, ++e) {
+        const int ti = i >> 2, tj = j >> 2;
+        const int q = ti * NB - ti * (ti - 1) / 2 + (tj - ti);
+        off[e] = (i == W) ? (uint16_t)0xFFFF : (uint16_t)(q * PB + (i & 3) * 4 + (j & 3));
+      }
+  }
+};
+__constant__ const LinTailTable<24> kLinTail24{};
+__constant__ const LinTailTable<12> kLinTail12{};
+
 // LDS of a surfel piece in doubles: V (later the per-slice partial blocks) + the wavefronts' cost sums
 template <int W>
 struct LinSurfelLds {
@@ -578,20 +598,15 @@ __device__ __forceinline__ void lin_surfel_body(const WinParams &wp, const Piece
   }
   __syncthreads();
   constexpr int NOUT = T * (T + 1) / 2;
+  static_assert(W == 24 || W == 12, "tail tables exist for the binary and the unary family");
+  const uint16_t *tail_off = W == 24 ? kLinTail24.off : kLinTail12.off;
   for (int e = tid; e < NOUT; e += kPiece) {
-    // row of the packed upper triangle: e = i T - i (i - 1) / 2 + (j - i); closed form + one correction step each way
-    int i = (int)(((float)(2 * T + 1) - sqrtf((float)((2 * T + 1) * (2 * T + 1) - 8 * e))) * 0.5f);
-    i = min(max(i, 0), T - 1);
-    if (i * T - i * (i - 1) / 2 > e) --i;
-    if ((i + 1) * T - (i + 1) * i / 2 <= e) ++i;
-    const int j = i + (e - (i * T - i * (i - 1) / 2));
+    const int off = tail_off[e];
     double out = 0.0;
-    if (i == W) {
+    if (off == 0xFFFF) {
       out = kPiece == 256 ? (sC[0] + sC[1]) + (sC[2] + sC[3]) : kPiece == 128 ? sC[0] + sC[1] : sC[0];
     } else {
-      const int ti = i >> 2, tj = j >> 2;
-      const int q = ti * NB - ti * (ti - 1) / 2 + (tj - ti);  // index of block (ti, tj) in the ti <= tj enumeration
-      const int off = q * PB + (i & 3) * 4 + (j & 3);
+#pragma unroll
       for (int sl = 0; sl < NS; ++sl) out += sV[sl * NBLK * PB + off];
     }
     partial[pc.part_off + e] = out;
