@@ -133,9 +133,9 @@ def _feat(s):
     return np.concatenate([s["center"] / 1.0, s["normal"] / (5.0 * np.pi / 180.0)], 1)
 
 
-def test_sparse_wide_extent_uses_binary_search_fallback(gpu, oracle):
-    """3 000 surfels in a 600 m cube: 600^3 one-unit cells do not fit the dense cell table (<= 2^24 cells), the kernel
-    falls back to binary searches on the sorted cell keys, and a query needs many shells; k-NN table and pairs exact"""
+def test_sparse_wide_extent(gpu, oracle):
+    """3 000 surfels in a 600 m cube: the 10th neighbour of a query is tens of metres away (rounds 1-3: the grid's binary-search
+    fallback; now simply a tree whose boxes are large); k-NN table and pairs exact"""
     rng = np.random.default_rng(77)
     s, p = _random_surfels(rng, 3000, 600.0)
     pairs, idx, d2 = gpu.match(s, p, s, p, True, want_knn=True)
@@ -144,9 +144,8 @@ def test_sparse_wide_extent_uses_binary_search_fallback(gpu, oracle):
     assert np.array_equal(pairs, oracle.match(s, p, s, p, True))
 
 
-def test_queries_outside_the_target_box_and_pruned_shells(gpu, oracle):
-    """targets in a 20 m cube, queries in a 60 m cube around it (most of them outside the grid: unclamped query cells,
-    row / cell pruning against the k-th distance with the query far from every cell)"""
+def test_queries_outside_the_target_box(gpu, oracle):
+    """targets in a 20 m cube, queries in a 60 m cube around it (most of them outside every box of the tree)"""
     rng = np.random.default_rng(78)
     t, tp = _random_surfels(rng, 2500, 20.0)
     q, qp = _random_surfels(rng, 800, 60.0, t0=10.0)
@@ -156,15 +155,9 @@ def test_queries_outside_the_target_box_and_pruned_shells(gpu, oracle):
     assert np.array_equal(pairs, oracle.match(q, qp, t, tp, False))
 
 
-@pytest.mark.parametrize("f32", ["0", "1"])
-@pytest.mark.parametrize("order", ["centre", "normal"])
-def test_both_orders_of_the_candidate_halves(gpu, oracle, order, f32, monkeypatch):
-    """k_knn_gate tests one half of a candidate's six components before it loads the other; which half goes first is chosen
-    per call from the previous call's k-th distances (WC_KNN_ORDER pins it here), and so is the precision of that first look
-    (WC_KNN_F32: single precision with a bound on its own rounding, or fp64).  Neighbour lists, distances (bit for bit) and
-    pairs must not depend on either: random normals (the normal half prunes), coherent normals (the centre half does)"""
-    monkeypatch.setenv("WC_KNN_ORDER", order)
-    monkeypatch.setenv("WC_KNN_F32", f32)
+def test_random_and_coherent_normals(gpu, oracle):
+    """random normals (the normal half of the metric prunes) and coherent ones (the centre half does): neighbour lists, distances
+    (bit for bit) and pairs against the oracle"""
     rng = np.random.default_rng(4711)
     t, tp = _random_surfels(rng, 6000, 12.0)
     q, qp = _random_surfels(rng, 3000, 14.0, t0=10.0)
@@ -176,14 +169,11 @@ def test_both_orders_of_the_candidate_halves(gpu, oracle, order, f32, monkeypatc
     assert np.array_equal(gpu.match(w["surf"], w["pose"], w["surf"], w["pose"], True), oracle.match(w["surf"], w["pose"], w["surf"], w["pose"], True))
 
 
-@pytest.mark.parametrize("order", ["centre", "normal"])
-def test_single_precision_first_look_is_conservative(gpu, oracle, order, monkeypatch):
-    """the fp32 first look of k_knn_gate (WC_KNN_F32=1) where single precision cannot tell the candidates apart: clusters of
+def test_single_precision_first_look_is_conservative(gpu, oracle):
+    """the fp32 first look of k_knn_tree (boxes and points) where single precision cannot tell the candidates apart: clusters of
     surfels ~95 m from the origin whose members differ by micrometres in position and by 1e-7 in the normal (below the fp32
-    resolution of both halves of the feature), so that which ten are nearest is decided far below its rounding; lists, distances
-    and pairs must still be the oracle's, bit for bit"""
-    monkeypatch.setenv("WC_KNN_ORDER", order)
-    monkeypatch.setenv("WC_KNN_F32", "1")
+    resolution of the features), so that which ten are nearest is decided far below its rounding; lists, distances and pairs
+    must still be the oracle's, bit for bit"""
     rng = np.random.default_rng(99)
     nc, m = 60, 40
     centres = rng.uniform(-3, 3, size=(nc, 3)) + np.array([95.0, -95.0, 95.0])
@@ -200,6 +190,65 @@ def test_single_precision_first_look_is_conservative(gpu, oracle, order, monkeyp
     ridx, rd2 = oracle.knn6(_feat(s), _feat(s), 10)
     assert np.array_equal(idx.astype(np.int64), ridx.astype(np.int64)) and np.array_equal(d2, rd2)
     assert np.array_equal(pairs, oracle.match(s, p, s, p, True))
+
+
+@pytest.mark.parametrize("nt", [1, 9, 10, 11, 600, 1024, 1025, 2100, 5000, 33000, 70000])
+def test_tree_shapes(gpu, oracle, nt):
+    """every shape of the index (match_tree.inc): a single leaf, one bucket, one sample stage (> 1 024 targets), two (> 32 k);
+    other-set queries (located, sorted by leaf) and same-set ones; k-NN tables bit-exact against the oracle's kd-tree"""
+    rng = np.random.default_rng(1000 + nt)
+    ext = max(2.0, (nt / 20.0) ** (1 / 3))
+    t, tp = _random_surfels(rng, nt, ext)
+    q, qp = _random_surfels(rng, 700, 1.2 * ext, t0=10.0)
+    _, idx, d2 = gpu.match(q, qp, t, tp, False, want_knn=True)
+    ridx, rd2 = oracle.knn6(_feat(t), _feat(q), 10)
+    assert np.array_equal(idx.astype(np.int64), ridx.astype(np.int64)) and np.array_equal(d2, rd2)
+    _, idx, d2 = gpu.match(t, tp, t, tp, True, want_knn=True)
+    ridx, rd2 = oracle.knn6(_feat(t), _feat(t), 10)
+    assert np.array_equal(idx.astype(np.int64), ridx.astype(np.int64)) and np.array_equal(d2, rd2)
+
+
+def test_coincident_features_overflow_a_bucket(gpu, oracle):
+    """5 000 surfels with the SAME centre and normal next to 3 000 ordinary ones: every split plane of the coincident ones is the
+    same value, they all land in one bucket that does not fit a workgroup's LDS (k_kd_bottom's in-place path), and all their
+    distances tie - the lists are decided by the target index alone (FLANN's order of equal distances is the oracle's)"""
+    rng = np.random.default_rng(5)
+    s, p = _random_surfels(rng, 8000, 6.0)
+    s["center"][1000:6000] = s["center"][1000]
+    s["normal"][1000:6000] = s["normal"][1000]
+    pairs, idx, d2 = gpu.match(s, p, s, p, True, want_knn=True)
+    ridx, rd2 = oracle.knn6(_feat(s), _feat(s), 10)
+    assert np.array_equal(d2, rd2)
+    far = np.ones(len(s), bool)
+    far[1000:6000] = False  # (among 5 000 equal distances the reference's choice is its tree's visiting order: compare the others)
+    assert np.array_equal(idx[far].astype(np.int64), ridx[far].astype(np.int64))
+    assert (d2[~far] == 0).all() and ((idx[~far] >= 1000) & (idx[~far] < 6000)).all()
+    # ties by index: the ten smallest indices of the coincident block
+    assert np.array_equal(idx[~far], np.tile(np.arange(1000, 1010), (5000, 1)))
+
+
+def test_tree_is_reproducible_and_three_stage(gpu):
+    """4.2 M targets: three sample stages (13 top levels), 256 other-set queries against numpy brute force; a second context
+    returns the same table (the build is deterministic: ties by index, canonical order inside a bucket)"""
+    from wildcat_slam_amd import lib
+
+    rng = np.random.default_rng(31)
+    nt = 4_200_000
+    t, tp = _random_surfels(rng, nt, 120.0)
+    q, qp = _random_surfels(rng, 256, 100.0, t0=10.0)
+    _, idx, d2 = gpu.match(q, qp, t, tp, False, want_knn=True)
+    ft, fq = _feat(t), _feat(q)
+    for i in range(0, 256, 16):
+        dd = np.zeros(nt)
+        for d in range(6):  # flann::L2_Simple's order
+            df = fq[i, d] - ft[:, d]
+            dd += df * df
+        o = np.lexsort((np.arange(nt), dd))[:10]
+        assert np.array_equal(idx[i].astype(np.int64), o) and np.array_equal(d2[i], dd[o])
+    c2 = lib.Context(0)
+    _, idx2, d22 = c2.match(q, qp, t, tp, False, want_knn=True)
+    c2.close()
+    assert np.array_equal(idx, idx2) and np.array_equal(d2, d22)
 
 
 @pytest.mark.parametrize("k", [1, 3, 16])

@@ -28,18 +28,13 @@ struct wc_ctx {
   // scratch buffers (device), grown on demand and kept for the lifetime of the ctx
   wc_buf b_ex_ctrl;  // the extraction's control block (status words, bucket / bin counters): never shared, cleared ahead of time
   wc_buf b_keys[2], b_vals[2], b_sorttmp, b_slots, b_slot_ids, b_slot_keys[2], b_slot_idx[2], b_cand, b_cand_meta,
-      b_status, b_misc[8], b_route[4], b_fx[10], b_match_stat, b_match_samp, b_match_defer;
-  bool match_sparse[2] = {false, false};  // wc_match: the previous call's mean k-th distance was beyond 1.5 cells (single-precision first look)
-  bool match_nf[2] = {false, false};  // wc_match: normal half of a candidate first (per kind of call: other set / same set)
-  // ... and what the two orders cost on this context's calls (device time of k_knn_gate per query, smoothed; 0 = not yet tried):
-  // once both are known the faster one is used, and the other is tried again every 16th call
-  double match_ns_per_q[2][2] = {{0.0, 0.0}, {0.0, 0.0}};  // [kind][normal first]
-  uint32_t match_calls[2] = {0u, 0u};
-  uint32_t match_prev_n[2][2] = {{0u, 0u}, {0u, 0u}};  // queries / targets of the previous call of each kind (a new workload forgets the timings)
-  double match_last_rk = 0.0;
+      b_status, b_misc[8], b_route[4], b_fx[10], b_match_stat;
+  // wc_match: what the last search's traversal touched (sampled, see k_knn_tree): wide nodes, leaves, points, exact distances, queries
+  double match_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  wc_buf b_kd[10];  // match_tree.inc: planes (dim, value), bucket ids, padded counters, starts x 2, index lists x 2, box heap, leaf ranges
   std::vector<wc_ctx *> batch_subs;  // sub-contexts of wc_extract_surfels_batch_* (own scratch, the parent's stream)
-  wc_buf b_batch;  // median sampled k-th 6-D distance of the last wc_match call (scaled units): what set its cell size
-  wc_buf b_match_half;  // match.hip: the sorted features' halves in single precision (k_knn_gate's first look)
+  wc_buf b_batch;
+  wc_buf b_match_half;  // match.hip: the sorted features in single precision, 32 bytes per target (the first look of k_knn_tree)
   hipEvent_t ev_knn[2] = {nullptr, nullptr};
   // multi-GPU: the job's communicator (wc_ctx_set_comm / wc_comm_rccl_init)
   wc_comm comm{};

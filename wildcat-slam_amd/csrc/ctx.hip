@@ -118,9 +118,9 @@ extern "C" void wc_ctx_destroy(wc_ctx *ctx) {
   for (wc_buf &b : ctx->b_route)
     if (b.p) (void)hipFree(b.p);
   if (ctx->b_match_stat.p) (void)hipFree(ctx->b_match_stat.p);
-  if (ctx->b_match_samp.p) (void)hipFree(ctx->b_match_samp.p);
   if (ctx->b_batch.p) (void)hipFree(ctx->b_batch.p);
-  if (ctx->b_match_defer.p) (void)hipFree(ctx->b_match_defer.p);
+  for (wc_buf &b : ctx->b_kd)
+    if (b.p) (void)hipFree(b.p);
   if (ctx->b_match_half.p) (void)hipFree(ctx->b_match_half.p);
   for (wc_ctx *sub : ctx->batch_subs) wc_ctx_destroy(sub);
   ctx->batch_subs.clear();
