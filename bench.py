@@ -166,6 +166,19 @@ def main():
     ap.add_argument("--in-flight", type=int, default=3, help="sweeps in flight (contexts) of the extra pipelined measurement")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` as typed: become the launcher - one rank per GPU through torch.distributed.run (rendezvous on
+        # 127.0.0.1: the container's hostname may not resolve); rank 0 of the children prints the JSON line
+        import socket
+
+        sk = socket.socket()
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+        sk.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % args.gpus, "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        os.execvp(cmd[0], cmd)
+
     # stdout carries exactly ONE line, the JSON result: everything libraries print (RCCL greets with a version banner on
     # stdout when its first communicator comes up) goes to stderr
     real_stdout = os.fdopen(os.dup(1), "w")
@@ -182,7 +195,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     force_dist = os.environ.get("WC_BENCH_FORCE_DIST") == "1"  # exercise the RCCL plumbing on one GPU (world size 1)
     if args.gpus > 1 or world > 1 or force_dist:
-        assert world == args.gpus, f"launch with torch.distributed.run --nproc-per-node {args.gpus}"
+        assert world == args.gpus, f"launched with WORLD_SIZE={world} but --gpus {args.gpus}"
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     else:
@@ -386,11 +399,21 @@ def main():
                 result["window"] = bench_window(ctx, args, world, rank, dev, torch, dist, cpu=cpu)
             except Exception as e:  # the headline line must survive a failure of the extra section
                 result["window"] = {"error": repr(e)}
+            w_ = result["window"]
+            if "lm_iters_per_s" in w_:  # BASELINE.json names "GN iters/sec on 1M-surfel window" first: beside the extraction value
+                result["lm_iters_per_s"] = w_["lm_iters_per_s"]
+                result["lm_roofline"] = w_["lm_roofline"]
+                result["assembly_roofline"] = w_["assembly_roofline"]
         if not args.no_extras:
             try:
                 result["odometry_step"] = bench_odometry_step(ctx, args, world, rank, dev, torch, dist, cpu=cpu)
             except Exception as e:
                 result["odometry_step"] = {"error": repr(e)}
+            if world == 1:  # (the facade is one object on one GPU, as the reference's node holds it)
+                try:
+                    result["facade_stream"] = bench_facade_stream(local_rank, cpu)
+                except Exception as e:
+                    result["facade_stream"] = {"error": repr(e)}
 
     if world == 1:
         extras()
@@ -620,6 +643,11 @@ def bench_window(ctx, args, world, rank, dev, torch, dist, cpu=False):
         n_b, n_u = ctx.match_pair_device(d_surf, d_pose, n_s, d_fs, d_fp, len(w["fix_surf"]), d_pairs, n_s, d_pf, n_s, sharded=world > 1)
         t_runs.append(time.perf_counter() - t0)
     t_match = sorted(t_runs)[2]
+    # what a query of the fixed-window search touches (the 3-D grid looked at ~860 candidates per query)
+    ctx.match_device(d_surf, d_pose, n_s, d_fs, d_fp, len(w["fix_surf"]), False, d_pf, n_s)
+    st_fix = ctx.match_stats()
+    ctx.match_device(d_surf, d_pose, n_s, d_surf, d_pose, n_s, True, d_pairs, n_s)
+    st_sld = ctx.match_stats()
     # N > 1: wc_window_build_sharded - every rank passes the same replicated lists, the library takes this rank's contiguous share of
     # the correspondences and of the IMU triples; every linearisation then ends in ONE all-reduce through the ctx's communicator
     build_args = (d_surf, d_pose, d_pairs, n_b, w["imu"], w["sample_times"], w["grav"], False, d_fs, d_fp, d_pf, n_u)
@@ -672,6 +700,9 @@ def bench_window(ctx, args, world, rank, dev, torch, dist, cpu=False):
                         "linear_solve": "bias unknowns eliminated by parallel cyclic reduction (12 x 12 super-blocks), dense blocked Cholesky (fp64 MFMA "
                                         "panel steps) on the %d pose unknowns" % (6 * ns)},
         "build_ms": round(t_build * 1e3, 3), "match_s": round(t_match, 4), "match_surfels_per_s": round(2 * n_s / t_match, 1), "generate_s": round(t_gen, 2),
+        "match_walk_per_query": {"fixed_window": {k_: round(v_, 1) for k_, v_ in st_fix.items()}, "sliding_window": {k_: round(v_, 1) for k_, v_ in st_sld.items()},
+                                 "index": "6-D kd-tree with bounding boxes over [centre, normal / 5 deg] (csrc/match_tree.inc); points_per_query = targets given the "
+                                          "fp32 first look, exact_per_query = fp64 distances"},
     }
     # the assembly's OTHER roof (the binding one): fp64 vector issue.  Flops per record by a fixed counting rule - the
     # Gram matrix of the record's row [J r] (upper triangle: 325 / 91 multiply-adds for 24 / 12 unknowns + residual) plus ~450 / ~250
@@ -685,39 +716,45 @@ def bench_window(ctx, args, world, rank, dev, torch, dist, cpu=False):
     b_match = 192 * (2 * n_s + n_s + len(w["fix_surf"]))
     out["match_roofline"] = {"bound": "hbm", "achieved": round(b_match / t_match / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": round(b_match / t_match / 1e9 / HBM_PEAK_GBS, 5), "algorithmic_bytes": b_match,
-                             "note": "latency-bound gather work (exact 10-NN in 6-D on a 3-D grid), far from the byte roofline by construction: the "
-                                     "window's normals are random, the 10th neighbour lies 2 - 5.7 grid units away"}
+                             "note": "latency-bound gather work (exact 10-NN in 6-D through a kd-tree), far from the byte roofline by construction: the "
+                                     "window's normals are random, the 10th neighbour lies 2 - 5.7 units away"}
     try:  # the matcher on what a real scanner produces (never quoted without it): surfels on the surfaces of a room, many sweeps deep
         out["match_room_stream"] = bench_match_room(ctx)
     except Exception as e:
         out["match_room_stream"] = {"error": repr(e)}
     if cpu:
-        # CPU baseline of the LM step: the single-thread oracle (oracle/window.cc + oracle/match.cc) on a BOUNDED sample - the
-        # same 20-sweep window geometry (same 127 sample states / 1524 unknowns, same IMU factors) with 1/20 of the surfels
+        # CPU baseline of the LM step: the single-thread oracle (oracle/window.cc + oracle/match.cc) on the SAME window (BASELINE.md
+        # section 3: identical synthetic inputs): both matches, the problem construction and two LM iterations at full size (~20 - 30 s
+        # of one core; --cpu-seconds below 5 keeps round 3's 1/20-size sample)
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import pyoracle  # test infrastructure, used here ONLY as the timed CPU baseline
 
-        frac = 20
-        ws = synth.surfel_window(args.window_scans, max(1, args.window_patches // frac), seed=synth.SEED + 7,
-                                 fixed_patches=max(1, args.window_patches // frac))
+        frac = 1 if args.cpu_seconds >= 5.0 else 20
+        ws = w if frac == 1 else synth.surfel_window(args.window_scans, max(1, args.window_patches // frac), seed=synth.SEED + 7,
+                                                     fixed_patches=max(1, args.window_patches // frac))
         prm = pyoracle.default_params()
+        if frac == 1:
+            prm.max_iterations = 2
         with pinned_core() as pc:
             t1 = time.perf_counter()
             pb = pyoracle.match(ws["surf"], ws["pose"], ws["surf"], ws["pose"], True, prm)
             pu = pyoracle.match(ws["surf"], ws["pose"], ws["fix_surf"], ws["fix_pose"], False, prm)
             t_cm = time.perf_counter() - t1
+            t1 = time.perf_counter()
             Wc = pyoracle.Window(ws["sample_times"], ws["grav"], False, prm)
             Wc.add_binary(ws["surf"], ws["pose"], pb)
             Wc.add_unary(ws["fix_surf"], ws["fix_pose"], ws["surf"], ws["pose"], pu)
             Wc.add_imu(ws["imu"])
+            t_cb = time.perf_counter() - t1
             t1 = time.perf_counter()
             _, sc, _ = Wc.solve(np.zeros(12 * len(ws["sample_times"])))
             t_cs = time.perf_counter() - t1
         out["cpu_baseline"] = {
-            "value": round(max(1, sc.iterations) / t_cs, 3), "unit": "LM iterations/s", "cores": 1, "kind": "port", "pinned_core": pc.core, "cpu": cpu_info()["model"],
-            "sample": "same window geometry with 1/%d of the surfels (%d surfels, %d + %d surfel factors, %d unknowns): %d LM iterations in %.1f s; "
-                      "matcher %.0f surfels/s" % (frac, len(ws["surf"]), len(pb), len(pu), 12 * len(ws["sample_times"]), sc.iterations, t_cs,
-                                                   2 * len(ws["surf"]) / t_cm)}
+            "value": round(max(1, sc.iterations) / t_cs, 4), "unit": "LM iterations/s", "cores": 1, "kind": "port", "pinned_core": pc.core, "cpu": cpu_info()["model"],
+            "matcher_surfels_per_s": round(2 * len(ws["surf"]) / t_cm, 1), "build_s": round(t_cb, 2),
+            "sample": ("the SAME window at full size" if frac == 1 else "same window geometry with 1/%d of the surfels" % frac)
+                      + " (%d surfels, %d + %d surfel factors, %d unknowns): %d LM iterations in %.1f s; both matches %.1f s"
+                      % (len(ws["surf"]), len(pb), len(pu), 12 * len(ws["sample_times"]), sc.iterations, t_cs, t_cm)}
     return out
 
 
@@ -808,6 +845,12 @@ def bench_odometry_step(ctx, args, world, rank, dev, torch, dist, cpu=False):
                         "frac": round(total_b / T["total"] / 1e9 / HBM_PEAK_GBS, 5),
                         "algorithmic_bytes": {"extract": b_ext, "pose_update": b_pose, "match": b_match, "assembly_all_iterations": b_asm}},
            "timing": "wall clock around each C-ABI call (every call is synchronous on return), the median of %d repetitions from the same window state" % reps}
+    try:  # the fixed-window search alone on this context, for its walk statistics
+        n_fix_, n_sld_ = sw.n_fix, info["sld"]
+        ctx.match_device(_Ptr(sw.d_surf.ptr + 144 * n_fix_), _Ptr(sw.d_pose.ptr + 56 * n_fix_), n_sld_, sw.d_surf, sw.d_pose, n_fix_, False, sw.d_pu, sw.cap_all)
+        out["match_walk_per_query_fixed_window"] = {k_: round(v_, 1) for k_, v_ in ctx.match_stats().items()}
+    except Exception as e:
+        out["match_walk_per_query_fixed_window"] = {"error": repr(e)}
     if world > 1:
         out["scaling"] = "strong"
         out["n_gpus"] = world
@@ -819,8 +862,9 @@ def bench_odometry_step(ctx, args, world, rank, dev, torch, dist, cpu=False):
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import pyoracle  # test infrastructure, used here ONLY as the timed CPU baseline
 
-        # bounded sample: the same step with 1/10 of the roots per sweep (same 10-sweep geometry, same sample states and IMU factors)
-        ws = synth.g2_scan_sequence(K, max(8, roots // 10), m=32, seed=synth.SEED + 21)
+        # the SAME step at full size (~15 s of one core); --cpu-seconds below 5: 1/10 of the roots per sweep
+        full = args.cpu_seconds >= 5.0
+        ws = w if full else synth.g2_scan_sequence(K, max(8, roots // 10), m=32, seed=synth.SEED + 21)
         with pinned_core() as pc:
             surf = []
             for s in ws["scans"][:-1]:
@@ -847,8 +891,62 @@ def bench_odometry_step(ctx, args, world, rank, dev, torch, dist, cpu=False):
             pyoracle.update_surfel_poses(ws["imu"], sl_s, sl_p, np.ones(len(sl_s), np.uint8))
             t_cpu = time.perf_counter() - t0
         out["cpu_baseline"] = {"value": round(1.0 / t_cpu, 4), "unit": "steps/s", "cores": 1, "kind": "port", "pinned_core": pc.core, "cpu": cpu_info()["model"],
-                               "sample": "the same step at 1/10 scale (%d-point sweeps, %d sliding + %d fixed surfels, %d + %d surfel factors, %d LM iterations): %.2f s "
-                                         "of single-thread oracle" % (len(ws["scans"][-1]), len(sl_s), n_fx, len(pb), len(pu), sc.iterations, t_cpu)}
+                               "sample": "the same step %s (%d-point sweeps, %d sliding + %d fixed surfels, %d + %d surfel factors, %d LM iterations): %.2f s "
+                                         "of single-thread oracle" % ("at FULL size" if full else "at 1/10 scale", len(ws["scans"][-1]), len(sl_s), n_fx, len(pb), len(pu),
+                                                                      sc.iterations, t_cpu)}
+    return out
+
+
+def bench_facade_stream(local_rank, cpu):
+    """the drop-in class itself: LidarOdometry::AddLidarScan (lidar_odometry.cc:487-605) through libwildcat_odometry.so
+    (host/lidar_odometry.cc, INTEGRATION.md route A) on the synthetic room stream of tests/test_facade_gpu.py - 4 s of a 32-beam
+    scanner at 640 k points/s, messages of 0.1 s, 200 Hz IMU: ms per completed sweep (median behind the first two) with the
+    facade's own stage split; beside it the orchestrated CPU oracle (oracle/odometry.cc) on the same messages"""
+    from wildcat_slam_amd import lib, synth
+
+    msgs, imu, _ = synth.raw_stream(4.0, pts_per_s=640_000, gyro_bias=(0.0, 0.0, 0.02), t_start=1000.0)
+
+    def drive(odo, stage=None):
+        k, times, before = 0, [], 0
+        for m in msgs:
+            if len(m) == 0:
+                continue
+            t_end = m["time"][-1]
+            while k < len(imu["t"]) and imu["t"][k] <= t_end + 0.02:
+                odo.add_imu(imu["t"][k], imu["acc"][k], imu["gyr"][k])
+                k += 1
+            t0 = time.perf_counter()
+            odo.add_scan(m)
+            dt = time.perf_counter() - t0
+            if odo.sweeps() > before:
+                before = odo.sweeps()
+                times.append((dt, stage() if stage else None, dict(odo.stats())))
+        return times
+
+    odo = lib.Odometry(local_rank)
+    times = drive(odo, odo.stage_ms)
+    fast, exact = odo.extract_paths()
+    odo.close()
+    tail = times[2:]
+    ts = np.array([t for t, _, _ in tail])
+    med = {k_: round(float(np.median([st[k_] for _, st, _ in tail])), 4) for k_ in tail[0][1]}
+    out = {"workload": "room stream, %d completed sweeps of ~%d points; sliding window %d .. %d surfels, fixed window up to %d" % (
+               len(times), int(np.mean([len(m) for m in msgs])) * 5, int(min(s_["sld_surfels"] for _, _, s_ in tail)), int(max(s_["sld_surfels"] for _, _, s_ in tail)),
+               int(max(s_["fix_surfels"] for _, _, s_ in tail))),
+           "ms_per_sweep_median": round(float(np.median(ts)) * 1e3, 4), "ms_per_sweep_max": round(float(ts.max()) * 1e3, 4),
+           "stage_ms_median": med, "sweeps_on_the_default_extraction_path": fast, "sweeps_on_the_exact_path": exact,
+           "timing": "wall clock around LidarOdometry::AddLidarScan for the message that completes a sweep; stages by the facade's own clock"}
+    if cpu:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import pyoracle  # test infrastructure, used here ONLY as the timed CPU baseline
+
+        with pinned_core() as pc:
+            oo = pyoracle.Odometry()
+            ot = drive(oo)
+            oo.close()
+        otail = np.array([t for t, _, _ in ot[2:]])
+        out["cpu_baseline"] = {"value": round(float(np.median(otail)) * 1e3, 3), "unit": "ms per sweep (median)", "cores": 1, "kind": "port", "pinned_core": pc.core,
+                               "sample": "the same %d sweeps through the orchestrated oracle: %.1f s" % (len(ot), float(sum(t for t, _, _ in ot)))}
     return out
 
 

@@ -192,9 +192,15 @@ int wc_match(wc_ctx *ctx, const wc_surfel *d_q_surf, const wc_pose *d_q_pose, ui
              const wc_pose *d_t_pose, uint64_t nt, int same_set, wc_pair *d_pairs, uint64_t cap, uint64_t *h_n_pairs,
              uint32_t *d_knn_idx, double *d_knn_d2);
 
+/* What the walk of the last wc_match on this context touched (the index is a 6-D kd-tree with bounding boxes, csrc/match_tree.inc),
+ * from a sample of its wavefronts: h_out[0 .. 3] = wide nodes opened, leaves scanned, points given the fp32 first look, exact
+ * fp64 distances - sums over h_out[4] sampled queries; h_out[5] = depth of the tree, h_out[6] = levels above the buckets,
+ * h_out[7] = targets.  Measurement only (bench.py's candidates-per-query figure). */
+int wc_match_stats(wc_ctx *ctx, double h_out[8]);
+
 /* Multi-GPU form of wc_match (the queries are independent, knn_surfel_matcher.cc:22-48): a COLLECTIVE of the ctx's
  * communicator - every rank calls it with the same replicated arguments; each searches a contiguous share of the queries (in
- * grid-cell order) and ONE all-gather of the gated neighbour lists (4 k bytes per query) gives every rank the whole table, on
+ * tree-leaf order) and ONE all-gather of the gated neighbour lists (4 k bytes per query) gives every rank the whole table, on
  * which the order-dependent de-duplication (cc:35-38) runs replicated: every rank ends with the unsharded call's pairs, byte for
  * byte.  wc_match itself is never a collective, whatever is installed on the ctx.  Without a communicator (or a world of one) this
  * is wc_match. */
@@ -210,8 +216,9 @@ int wc_match_pair_sharded(wc_ctx *ctx, const wc_surfel *d_sld_surf, const wc_pos
  *   wc_match(ctx, sld, sld_pose, n_sld, sld, sld_pose, n_sld, 1, d_pairs_sld, ...) followed by
  *   wc_match(ctx, sld, sld_pose, n_sld, fix, fix_pose, n_fix, 0, d_pairs_fix, ...),
  * but the fixed-window search runs on a helper context of its own (own stream and scratch, created on first use, ordered
- * behind the work already enqueued on the ctx stream): one search is a single round of wavefronts whose durations differ by
- * 3x, so the wavefronts of the other fill the slots the early finishers leave.  Never a collective (wc_match_pair_sharded is). */
+ * behind the work already enqueued on the ctx stream): the builds of the two trees are chains of small launches and a search is a
+ * single round of wavefronts of unequal length, so each fills the slots the other leaves.  Never a collective
+ * (wc_match_pair_sharded is). */
 int wc_match_pair(wc_ctx *ctx, const wc_surfel *d_sld_surf, const wc_pose *d_sld_pose, uint64_t n_sld,
                   const wc_surfel *d_fix_surf, const wc_pose *d_fix_pose, uint64_t n_fix, wc_pair *d_pairs_sld, uint64_t cap_sld,
                   uint64_t *h_n_pairs_sld, wc_pair *d_pairs_fix, uint64_t cap_fix, uint64_t *h_n_pairs_fix);

@@ -439,6 +439,12 @@ extern "C" int wc_match(wc_ctx *ctx, const wc_surfel *d_q_surf, const wc_pose *d
   return match_impl(ctx, d_q_surf, d_q_pose, nq, d_t_surf, d_t_pose, nt, same_set, d_pairs, cap, h_n_pairs, d_knn_idx, d_knn_d2, false);
 }
 
+extern "C" int wc_match_stats(wc_ctx *ctx, double h_out[8]) {
+  if (!ctx || !h_out) return wc_fail(ctx, WC_ERR_ARG, "%s: null argument", __func__);
+  for (int j = 0; j < 8; ++j) h_out[j] = ctx->match_stats[j];
+  return WC_OK;
+}
+
 extern "C" int wc_match_sharded(wc_ctx *ctx, const wc_surfel *d_q_surf, const wc_pose *d_q_pose, uint64_t nq, const wc_surfel *d_t_surf,
                                 const wc_pose *d_t_pose, uint64_t nt, int same_set, wc_pair *d_pairs, uint64_t cap, uint64_t *h_n_pairs) {
   return match_impl(ctx, d_q_surf, d_q_pose, nq, d_t_surf, d_t_pose, nt, same_set, d_pairs, cap, h_n_pairs, nullptr, nullptr, true);

@@ -488,12 +488,13 @@ void LidarOdometry::AddLidarScan(const pcl::PointCloud<hilti_ros::Point>::Ptr &m
   double sweep_endtime = point_times_.front() + config_.sweep_duration;
   if (point_times_.back() < sweep_endtime || imu_buff_.empty() || imu_buff_.back().timestamp < sweep_endtime) return;
 
-  // (WC_ODOM_DEBUG=1: wall time of the stages of a completed sweep on stderr)
+  // wall time of the stages of a completed sweep (last_stage_ms(); WC_ODOM_DEBUG=1 also prints them on stderr)
   static const bool dbg_t = getenv("WC_ODOM_DEBUG") != nullptr;
   auto t_prev = std::chrono::steady_clock::now();
-  double t_stage[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  double (&t_stage)[8] = last_stage_ms_;
+  for (double &v : t_stage) v = 0.0;
+  last_lm_iterations_ = 0;
   auto lap = [&](int i) {
-    if (!dbg_t) return;
     const auto now = std::chrono::steady_clock::now();
     t_stage[i] += std::chrono::duration<double, std::milli>(now - t_prev).count();
     t_prev = now;
@@ -569,6 +570,7 @@ void LidarOdometry::AddLidarScan(const pcl::PointCloud<hilti_ros::Point>::Ptr &m
       LogResiduals(x, "[before solve] ");
     }
     WC_CALL(wc_window_solve(ctx_, x.data(), &last_summary_, nullptr));
+    last_lm_iterations_ += (int)last_summary_.iterations;
     lap(4);
     for (size_t i = 0; i < samples_.size(); ++i) std::memcpy(samples_[i].cor, &x[12 * i], 96);
     // state update (:564-566)

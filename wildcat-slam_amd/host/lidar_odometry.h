@@ -52,6 +52,9 @@ class LidarOdometry {
   // timestamps of the fixed window in its own order (newest first, like the reference's deque after push_front, Q11)
   const std::deque<double> &fixed_window_times() const { return fix_times_; }
   const wc_solve_summary &last_solve() const { return last_summary_; }
+  // wall time [ms] of the last completed sweep's stages: predict + undistort, extract + poses, match, build, solve, update, shrink
+  const double *last_stage_ms() const { return last_stage_ms_; }
+  int last_lm_iterations() const { return last_lm_iterations_; }
   uint64_t last_correspondences(int which) const { return last_corr_[which]; }
   // sweeps whose extraction was completed by the default (integer-moment) path / by the reference-order path (configured, or
   // fallen back to because a gate lay inside the reference's own rounding noise)
@@ -132,5 +135,7 @@ class LidarOdometry {
   void *d_res_ = nullptr;
   size_t cap_res_ = 0;
   wc_solve_summary last_summary_{};
+  double last_stage_ms_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int last_lm_iterations_ = 0;  // over the sweep's outer iterations
   uint64_t last_corr_[2] = {0, 0};
 };

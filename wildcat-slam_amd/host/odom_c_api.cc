@@ -57,6 +57,14 @@ void wc_odom_stats(void *h, double *stats) {
   stats[7] = o->last_solve().termination;
 }
 
+// wall time [ms] of the last completed sweep's stages (predict + undistort, extract + poses, match, build, solve, update, shrink)
+// and, in out[7], the LM iterations of its outer iterations together
+void wc_odom_stage_ms(void *h, double out[8]) {
+  const LidarOdometry *o = (const LidarOdometry *)h;
+  for (int i = 0; i < 7; ++i) out[i] = o->last_stage_ms()[i];
+  out[7] = (double)o->last_lm_iterations();
+}
+
 // out[2] = sweeps extracted by the default (integer-moment) arithmetic, sweeps extracted in the reference's summation order
 void wc_odom_extract_paths(void *h, int out[2]) {
   out[0] = ((LidarOdometry *)h)->sweeps_fast_path();

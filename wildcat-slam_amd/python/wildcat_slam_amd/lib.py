@@ -492,6 +492,14 @@ class Context:
                                    C.byref(n), C.c_void_p(d_knn_idx.ptr if d_knn_idx else 0), C.c_void_p(d_knn_d2.ptr if d_knn_d2 else 0)))
         return int(n.value)
 
+    def match_stats(self):
+        """what the last wc_match on this context touched, per sampled query (wc_match_stats)"""
+        out = (C.c_double * 8)()
+        self._ck(self.lib.wc_match_stats(self.h, out))
+        n = max(out[4], 1.0)
+        return {"nodes_per_query": out[0] / n, "leaves_per_query": out[1] / n, "points_per_query": out[2] / n, "exact_per_query": out[3] / n,
+                "sampled_queries": int(out[4]), "tree_depth": int(out[5]), "top_levels": int(out[6]), "targets": int(out[7])}
+
     def match_pair_device(self, d_sld_surf, d_sld_pose, n_sld, d_fix_surf, d_fix_pose, n_fix, d_pairs_sld, cap_sld, d_pairs_fix, cap_fix, sharded=False):
         """both searches of an outer iteration side by side (wc_match_pair; sharded: wc_match_pair_sharded, a collective)
         -> (n_pairs_sld, n_pairs_fix)"""
@@ -544,6 +552,15 @@ class Odometry:
     def add_scan(self, points):
         assert points.dtype == R.POINT
         self.lib.wc_odom_add_scan(self.h, R.ptr(points), C.c_uint64(len(points)))
+
+    def stage_ms(self):
+        """wall time [ms] of the last completed sweep's stages + its LM iterations (host/lidar_odometry.cc)"""
+        out = (C.c_double * 8)()
+        self.lib.wc_odom_stage_ms(self.h, out)
+        names = ("predict_undistort", "extract_poses", "match", "build", "solve", "update", "shrink")
+        d = dict(zip(names, [float(v) for v in out[:7]]))
+        d["lm_iterations"] = int(out[7])
+        return d
 
     def extract_paths(self):
         """(sweeps extracted by the default integer-moment path, sweeps extracted in the reference's summation order)"""
