@@ -75,7 +75,7 @@ def check_fast_and_exact(gpu, oracle, pts, params=None, expect_fast=None, **kw):
         else:
             if expect_fast:
                 assert path["fast"], path
-            info = check_surfels(s_gpu, id_gpu, s_ref, id_ref, tol=1e-6, t_tol=1e-4) if len(s_ref) else dict(n=0)
+            info = check_surfels(s_gpu, id_gpu, s_ref, id_ref, tol=1e-6, t_tol=1e-5) if len(s_ref) else dict(n=0)
             info["fast_path"] = path["fast"]
         out["exact" if exact else "fast"] = info
     return out, st

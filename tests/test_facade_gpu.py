@@ -206,6 +206,11 @@ def test_facade_free_running_drift_report(gpu, oracle, exact_sums):
         # face, or a gate within it of its threshold, on the other side - reported, and bounded, not a parity failure)
         d_surf = abs(sa["sld_surfels"] - sb["sld_surfels"]) + abs(sa["fix_surfels"] - sb["fix_surfels"])
         per_sweep.append((k, float("%.2g" % _state_diff(a, b)), int(d_surf)))
+        if k <= 7:
+            # the parity gate of the free-running pair: through sweep 7 the chain carries nothing but rounding - same
+            # surfels, same LM iterations, same termination, states within 1e-7 (measured: <= 9e-9); in sweep 8 one of the sweep's
+            # solves ends on the other side of Ceres' function tolerance in the two runs (3.4e-5)
+            assert d_surf == 0 and sa["lm_iters"] == sb["lm_iters"] and sa["termination"] == sb["termination"] and per_sweep[-1][1] <= 1e-7, per_sweep
         assert per_sweep[-1][1] <= (1e-6 * 2 ** min(k, 8) if d_surf == 0 and all(p[2] == 0 for p in per_sweep) else 1e-3) and d_surf <= 8, per_sweep
 
     _feed(odo, ref, msgs, imu, on_sweep)

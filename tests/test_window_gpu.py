@@ -269,11 +269,12 @@ def test_sharded_solve_through_the_ctx_communicator(gpu, oracle):
         c.close()
 
 
-def test_c3_window_size_independent_properties(gpu):
-    """BASELINE config C3 (5-scan window, 200 k surfels) at full size, where the oracle would take minutes: properties that
-    hold at any size.  Correspondences from the GPU matcher; the normal equations are symmetric with a positive diagonal,
-    bitwise reproducible, the gradient of the gauge-fixed position block is zero, the LM run decreases the cost and ends at a
-    point where the gradient is much smaller than at the start; every pair is (older, newer)."""
+def test_c3_window_full_size(gpu, oracle):
+    """BASELINE config C3 (5-scan window, 200 k surfels) at full size.  Correspondences from the GPU matcher; the normal equations
+    are symmetric with a positive diagonal, bitwise reproducible, the gradient of the gauge-fixed position block is zero, the LM
+    run decreases the cost and ends at a point where the gradient is much smaller than at the start; every pair is (older,
+    newer); and BY VALUE against the oracle's linearisation of the same 200 k + 20 k factors (a second or two of one core): H
+    block by block, g, cost, every loss-corrected residual, at x = 0 and at a random point."""
     w = synth.surfel_window(5, 40_000, seed=31, fixed_patches=20_000)
     n_s = len(w["surf"])
     d_surf, d_pose = gpu.to_device(w["surf"]), gpu.to_device(w["pose"])
@@ -302,6 +303,24 @@ def test_c3_window_size_independent_properties(gpu):
     _, g_end, c_end = gpu.window_linearize(x)
     assert abs(c_end - s.final_cost) <= 1e-9 * c_end
     assert np.abs(g_end).max() < 1e-2 * np.abs(g).max()
+    # by value (lidar_odometry.cc:254-317 -> cost_functor.h through oracle/window.cc)
+    pf = d_pf.download(R.PAIR, n_u)
+    Wref = oracle.Window(w["sample_times"], w["grav"], True)
+    Wref.add_binary(w["surf"], w["pose"], pairs)
+    Wref.add_unary(w["fix_surf"], w["fix_pose"], w["surf"], w["pose"], pf)
+    Wref.add_imu(w["imu"])
+    x1 = 2e-3 * np.random.default_rng(23).normal(size=12 * ns)
+    for xv, (Hg, gg, cg) in ((x0, (H, g, c0)), (x1, gpu.window_linearize(x1))):
+        Hr, gr, cr = Wref.linearize(xv)
+        assert abs(cg - cr) <= 1e-10 * cr
+        assert np.abs(Hg - Hr).max() <= 1e-9 * np.abs(Hr).max() and np.abs(gg - gr).max() <= 1e-9 * np.abs(gr).max()
+        Hb = np.abs(Hg - Hr).reshape(ns, 12, ns, 12).max(axis=(1, 3))
+        Hs = np.abs(Hr).reshape(ns, 12, ns, 12).max(axis=(1, 3))
+        assert np.all(Hb <= 1e-8 * np.maximum(Hs, 1e-300) + 1e-12 * np.abs(Hr).max())
+        assert np.array_equal(Hs == 0, np.abs(Hg).reshape(ns, 12, ns, 12).max(axis=(1, 3)) == 0)  # same block sparsity
+    cr1, res_ref = Wref.evaluate(x1, want_residuals=True)
+    c1, res1 = gpu.window_evaluate(x1, want_residuals=True)
+    assert abs(c1 - cr1) <= 1e-10 * cr1 and np.abs(res1 - res_ref).max() <= 1e-9 * np.abs(res_ref).max()
 
 
 def test_c4_window_full_size_properties(gpu, oracle):
