@@ -71,6 +71,7 @@ def test_facade_residual_log(gpu):
         assert head in log
         blk = log[log.index(head):]
         assert "dist: Count: %d  Min: " % int(st["binary"]) in blk.split("\n")[0]
+        assert float(blk[len(head):].split(",")[0]) > 0
         for kind in ("gyro", "acc", "gyro_bias", "acc_bias"):
             assert when + "Imu residuals with type " + kind + ", cost: " in log
     assert "Fixed Window" not in log  # (no fixed window yet: PrintSurfelResiduals returns on an empty block list, :57-59)

@@ -58,7 +58,7 @@ def test_pointcloud2_of_a_hesai_driver_layout(host):
     for f in ("x", "y", "z", "intensity"):
         assert np.array_equal(pts[f], a[f])
     assert np.array_equal(pts["time"], a["timestamp"]) and np.array_equal(pts["ring"], a["ring"])
-    assert np.all(pts.view(np.uint8).reshape(n, 48)[:, 12:16].view(np.float32) == 1.0)  # PCL_ADD_POINT4D: data[3] = 1
+    assert np.all(pts.view(np.uint8).reshape(n, 48)[:, 12:16].view(np.float32) == 0.0)  # value-initialised points: the padding word stays 0
     # organised cloud with padded rows: row_step > width * point_step
     rows = np.zeros((2, 50 * 34 + 6), np.uint8)
     rows[0, : 50 * 34] = np.frombuffer(a[:50].tobytes(), np.uint8)
@@ -80,6 +80,11 @@ def test_pointcloud2_fields_pcl_would_not_match(host):
     assert not pts["time"].any() and not pts["ring"].any() and not pts["intensity"].any()
     assert _to_points(host, fields, n, 1, 20, d.tobytes(), big=True)[0] == -1
     assert _to_points(host, fields, n, 1, 20, d.tobytes()[:-4])[0] == -1  # payload shorter than its description
+    # two fields of one name: PCL's mapping takes the first
+    d["y"] = 3.0
+    twice = [("x", 0, FLOAT32, 1), ("x", 4, FLOAT32, 1), ("z", 8, FLOAT32, 1)]
+    m, pts = _to_points(host, twice, n, 1, 20, d.tobytes())
+    assert m == 2 and np.array_equal(pts["x"], np.arange(n, dtype=np.float32))
 
 
 def test_points_to_pointcloud2_layout_and_round_trip(host):

@@ -2435,7 +2435,15 @@ extern "C" int wc_extract_surfels_batch_enqueue(wc_ctx *ctx, const wc_sweep_job 
     sub->ex.deferred = false;
     const int rc = wc_extract_surfels_enqueue(sub, &jobs[k].pts, jobs[k].t_lo, jobs[k].t_hi, jobs[k].d_out, jobs[k].d_ids, jobs[k].cap);
     sub->ex.batch_defer = false;
-    if (rc != WC_OK) return wc_fail(ctx, rc, "wc_extract_surfels_batch (sweep %d): %s", k, wc_last_error(sub));
+    if (rc != WC_OK) {
+      // the sub-contexts prepared so far (tables and control blocks set up, their kernels never launched) are withdrawn: their
+      // tables are cleared before the next use and a later finish() has nothing to wait for
+      for (int j = 0; j <= k; ++j) {
+        wc_ctx *pj = ctx->batch_subs[j];
+        if (pj->ex.deferred || j == k) pj->ex.fx_dirty = true, pj->ex.active = false, pj->ex.deferred = false;
+      }
+      return wc_fail(ctx, rc, "wc_extract_surfels_batch (sweep %d): %s", k, wc_last_error(sub));
+    }
     if (!sub->ex.deferred) continue;  // (empty, or a sweep the default path does not take: enqueued on its own, on the same stream)
     FxArgs A;
     std::memcpy(&A, sub->ex.roots_args, sizeof(A));

@@ -2168,10 +2168,22 @@ extern "C" int wc_window_build_sharded(wc_ctx *ctx, const wc_surfel *d_sld_surf,
   share(n_pairs_fix, lo_u, n_u);
   const uint64_t n_fac = (h_imu && n_imu >= 3) ? n_imu - 2 : 0;
   share(n_fac, lo_i, n_i);
-  WC_TRY(window_build_impl(ctx, d_sld_surf, d_sld_pose, d_pairs_sld ? d_pairs_sld + lo_b : nullptr, n_b, d_fix_surf, d_fix_pose,
-                           d_pairs_fix ? d_pairs_fix + lo_u : nullptr, n_u, n_i ? h_imu + lo_i : nullptr, n_i ? n_i + 2 : 0, h_sample_times, ns_,
-                           h_grav, fix_first_pos, true));
+  const int rc_local = window_build_impl(ctx, d_sld_surf, d_sld_pose, d_pairs_sld ? d_pairs_sld + lo_b : nullptr, n_b, d_fix_surf, d_fix_pose,
+                                         d_pairs_fix ? d_pairs_fix + lo_u : nullptr, n_u, n_i ? h_imu + lo_i : nullptr, n_i ? n_i + 2 : 0,
+                                         h_sample_times, ns_, h_grav, fix_first_pos, true);
   wc_dev_guard dg_(ctx);
+  if (rc_local != WC_OK) {
+    // A rank whose local build failed (bad argument, out of memory, too few sample states) still takes part in the share check,
+    // with a poisoned share: the others then fail the check instead of waiting in the collective for a rank that has left
+    // (ADVICE r3).  The message of the local failure is kept.
+    const std::string why = ctx->err;
+    const double poison[4] = {std::nan(""), std::nan(""), std::nan(""), std::nan("")};
+    if (wc_ensure(ctx, ctx->b_status, 64 * 4) == WC_OK && hipMemcpyAsync(ctx->b_status.p, poison, sizeof(poison), hipMemcpyHostToDevice, ctx->stream) == hipSuccess &&
+        hipStreamSynchronize(ctx->stream) == hipSuccess)
+      (void)ctx->comm.allreduce_f64(ctx->comm.user, (double *)ctx->b_status.p, 4);
+    ctx->err = why;
+    return rc_local;
+  }
   wc_window_state *W = ctx->win;
   // the whole problem's IMU factor count, from the replicated states (the selection rule of BuildImuResiduals, cc:324-329)
   uint64_t ni_all = 0;

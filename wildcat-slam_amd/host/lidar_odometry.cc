@@ -318,7 +318,10 @@ void LidarOdometry::PredictImuStatesAndSampleStates(double end_time) {
 
 // PrintSurfelResiduals x 2 + PrintImuResiduals (:56-94) on the problem wc_window_build holds: ONE wc_window_evaluate (the
 // reference's three problem.Evaluate calls, each on one family's blocks, apply_loss_function = true) gives the loss-corrected
-// residuals in the reference's block order - binary, unary, 12 per IMU factor; a family's cost is half its squared norm.  The
+// residuals in the reference's block order - binary, unary, 12 per IMU factor.  The cost the reference prints is problem.Evaluate's
+// 0.5 * sum rho(s): for the IMU family (TrivialLoss) half the squared norm; for the surfel families (CauchyLoss(0.4), cc:273,311)
+// the corrected residual is r' = sqrt(rho'(s)) r with rho(s) = b log(1 + s / b), b = 0.16, so s = r'^2 / (1 - r'^2 / b) is
+// recovered and rho summed - half the squared norm of r' would understate it (0.08 against 0.111 at s = b).  The
 // text goes to last_residual_log() (and to stderr with WC_ODOM_DEBUG): the reference's LOG(INFO) lines, glog prefix aside.
 void LidarOdometry::LogResiduals(const std::vector<double> &x, const char *when) {
   uint64_t cnt[4] = {0, 0, 0, 0};
@@ -335,11 +338,18 @@ void LidarOdometry::LogResiduals(const std::vector<double> &x, const char *when)
   std::vector<double> r(nres);
   WC_CALL(wc_d2h(ctx_, r.data(), d_res_, nres * sizeof(double)));
   char buf[96];
+  wc_params P;
+  ParamsFromConfig(config_, &P);
+  const double cb = P.cauchy_a * P.cauchy_a;
   auto surfel = [&](size_t first, size_t n, const char *window_type) {
     if (n == 0) return;  // (:57-59)
     Histogram hist;
     double c = 0;
-    for (size_t i = first; i < first + n; ++i) hist.Add(r[i]), c += r[i] * r[i];
+    for (size_t i = first; i < first + n; ++i) {
+      hist.Add(r[i]);
+      const double q = r[i] * r[i], s = q / (1.0 - q / cb);  // (r'^2 = s / (1 + s / b) < b)
+      c += cb * std::log1p(s / cb);
+    }
     std::snprintf(buf, sizeof(buf), " Surfel residuals, cost: %g, dist: ", 0.5 * c);
     residual_log_ += std::string(when) + window_type + buf + hist.ToString(10) + "\n";
   };

@@ -58,7 +58,9 @@ inline const Registered *registered_fields() {
 
 // pcl::fromROSMsg for hilti_ros::Point: a registered field is filled from the message field of the SAME name, datatype and
 // count 1 (pcl::FieldMatches); a field the message lacks keeps the value of a default-constructed point (PCL warns "Failed to
-// find match for field" and goes on: zero here, w = 1 as PCL_ADD_POINT4D's constructor sets it).  Returns the number of
+// find match for field" and goes on: zero here - hilti_ros::Point is a plain struct without a constructor, common.h:13-19, and
+// pcl::fromROSMsg value-initialises the points, so the padding word data[3] stays 0 too); of two fields with one name the
+// FIRST is taken, as PCL's mapping does.  Returns the number of
 // registered fields that found their match (6 = complete); out gets width * height points.  A big-endian payload, which PCL
 // refuses as well, returns -1.
 inline int PointsFromCloud2(const PointCloud2 &msg, std::vector<hilti_ros::Point> &out) {
@@ -73,7 +75,10 @@ inline int PointsFromCloud2(const PointCloud2 &msg, std::vector<hilti_ros::Point
   for (int f = 0; f < 6; ++f) {
     const PointField *src = nullptr;
     for (const PointField &pf : msg.fields)
-      if (pf.name == reg[f].name && pf.datatype == reg[f].datatype && (pf.count == 1 || pf.count == 0)) src = &pf;
+      if (pf.name == reg[f].name && pf.datatype == reg[f].datatype && (pf.count == 1 || pf.count == 0)) {
+        src = &pf;
+        break;
+      }
     if (!src) continue;
     ++matched;
     for (uint32_t r = 0; r < msg.height; ++r)
@@ -83,8 +88,6 @@ inline int PointsFromCloud2(const PointCloud2 &msg, std::vector<hilti_ros::Point
         std::memcpy((char *)&out[(size_t)r * msg.width + c] + reg[f].offset, &msg.data[at], reg[f].size);
       }
   }
-  const float one = 1.0f;
-  for (hilti_ros::Point &p : out) std::memcpy((char *)&p + 12, &one, 4);  // data[3] = 1.0f (PCL_ADD_POINT4D's constructor)
   return matched;
 }
 
