@@ -56,3 +56,45 @@ def test_n_rank_odometry_step_equals_the_one_rank_step(gpu, world):
         assert abs(info["cost"][1] - info1["cost"][1]) <= 1e-9 * info1["cost"][1]
     for c in ctxs:
         c.close()
+
+
+def test_two_processes_on_one_gpu_run_the_n_rank_step(gpu, tmp_path):
+    """process-level plumbing of the multi-GPU step: TWO PROCESSES, each with its own context on GPU 0 and a
+    torch.distributed (gloo) communicator - rendezvous on 127.0.0.1, no shared Python state, the collectives through the ctx's
+    callbacks (dist.StagedTorchComm) - run wildcat_slam_amd/step.py's 2-rank step; both end bitwise equal, with the counts,
+    iterations and termination of the 1-rank step and its corrections within 1e-6."""
+    import os
+    import socket
+    import subprocess
+    import sys
+
+    scans, roots = 6, 400
+    w = synth.g2_scan_sequence(scans, roots, m=32, seed=synth.SEED + 5)
+    _, info1, x1 = StepWindow(gpu, w).step()
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    out = str(tmp_path / "step")
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_step_worker.py")
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, worker, out, str(scans), str(roots)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    logs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=600)
+        except subprocess.TimeoutExpired:  # pragma: no cover
+            for q in procs:
+                q.kill()
+            raise
+        logs.append(o.decode(errors="replace")[-2000:])
+    assert all(p.returncode == 0 for p in procs), logs
+    res = [np.load(out + ".rank%d.npz" % r) for r in range(2)]
+    assert np.array_equal(res[0]["x"], res[1]["x"]), "ranks diverged"
+    for r in range(2):
+        for key in ("new_surfels", "sld", "fix", "binary", "unary", "iters", "term"):
+            assert int(res[r][key]) == info1[key], (r, key, res[r][key], info1[key])
+        assert int(res[r]["allreduce_bytes"]) == 8 * wdist.packed_count(len(w["sample_times"]))
+        assert np.abs(res[r]["x"] - x1).max() <= 1e-6 * max(np.abs(x1).max(), 1e-12)

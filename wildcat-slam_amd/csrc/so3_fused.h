@@ -12,6 +12,33 @@ __device__ __forceinline__ double rsqrt_nr(double a) {
   return fma(h, fma(-a * inv, inv, 1.0), inv);  // inv + inv/2 (1 - a inv^2)
 }
 
+// sin and cos of a half angle.  The corrections the window solves for are milliradians: when every active lane's |h| is below
+// 0.5 the two Taylor polynomials (to h^15 / h^16: truncation below 1e-19) take the place of the library's sincos - ~20
+// fused multiply-adds instead of ~150 instructions of argument reduction, polynomial selection and sign handling, in a kernel
+// whose phase A is bound by fp64 instruction issue.  One wave-uniform branch; larger angles take the library call.
+__device__ __forceinline__ void sincos_half(double h, double *s, double *c) {
+  if (__all(fabs(h) < 0.5)) {
+    const double z = h * h;
+    double ps = fma(z, -1.0 / 1307674368000.0, 1.0 / 6227020800.0);
+    ps = fma(z, ps, -1.0 / 39916800.0);
+    ps = fma(z, ps, 1.0 / 362880.0);
+    ps = fma(z, ps, -1.0 / 5040.0);
+    ps = fma(z, ps, 1.0 / 120.0);
+    ps = fma(z, ps, -1.0 / 6.0);
+    *s = fma(h * z, ps, h);
+    double pc = fma(z, 1.0 / 20922789888000.0, -1.0 / 87178291200.0);
+    pc = fma(z, pc, 1.0 / 479001600.0);
+    pc = fma(z, pc, -1.0 / 3628800.0);
+    pc = fma(z, pc, 1.0 / 40320.0);
+    pc = fma(z, pc, -1.0 / 720.0);
+    pc = fma(z, pc, 1.0 / 24.0);
+    pc = fma(z, pc, -0.5);
+    *c = fma(z, pc, 1.0);
+  } else {
+    sincos(h, s, c);
+  }
+}
+
 // The IMU factor evaluates Exp of the same two rotation vectors five times, Jr of them three times and Jr^-1 of two
 // logarithms (cost_functor.h:286-321, :446-448): twenty fp64 sin / cos calls and three atan2 in ONE thread's dependent
 // chain (44 k clocks per factor, `-DWC_PROF`-style clocks).  Here: Exp and Jr of a vector from one sincos of the half angle
@@ -31,7 +58,7 @@ __device__ __forceinline__ ExpJr exp_jr(V3 r) {
   }
   const double ith = rsqrt_nr(th2), th = th2 * ith;
   double sh, ch;
-  sincos(0.5 * th, &sh, &ch);
+  sincos_half(0.5 * th, &sh, &ch);
   const double imag = sh * ith;
   o.E = {ch, imag * r.x, imag * r.y, imag * r.z};
   const double s2 = (sh + sh) * ith, s = s2 * ch, omc = s2 * sh;  // sin th / th, (1 - cos th) / th

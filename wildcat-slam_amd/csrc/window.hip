@@ -76,7 +76,7 @@ struct GSrc {
 };
 
 struct WinParams {
-  double sigma0_sq, cauchy_b, w_gyr, w_acc, w_bg, w_ba, dt, grav[3];
+  double sigma0_sq, cauchy_b, inv_cauchy_b, w_gyr, w_acc, w_bg, w_ba, dt, grav[3];
   int quirks, ns, fix_first;
 };
 
@@ -157,7 +157,7 @@ __device__ __forceinline__ void surfel_side(const double *xl, const double *xr, 
     ith = rsqrt_nr(th2);
     const double th = th2 * ith;
     double sh, ch;
-    sincos(0.5 * th, &sh, &ch);
+    sincos_half(0.5 * th, &sh, &ch);
     const double imag = sh * ith;
     qw = ch, qu = imag * r;
     const double s2 = (sh + sh) * ith;
@@ -178,10 +178,11 @@ __device__ __forceinline__ void surfel_side(const double *xl, const double *xr, 
 }
 
 // ceres::CauchyLoss(a): rho(s) = b log(1 + s/b), b = a^2; returns rho, sets sqrt(rho') (Corrector with rho'' < 0)
-__device__ __forceinline__ double cauchy(double b, double s, double &sqrt_rho1) {
-  const double sum = 1 + s * (1 / b);
-  const double inv = 1 / sum;
-  sqrt_rho1 = sqrt(fmax(DBL_MIN, inv));
+// (1 / b comes with the parameters and sqrt(1 / sum) is ONE reciprocal square root with a Newton step: the division, the
+// reciprocal and the square root of the literal form were ~70 fp64 instructions per record)
+__device__ __forceinline__ double cauchy(double b, double inv_b, double s, double &sqrt_rho1) {
+  const double sum = fma(s, inv_b, 1.0);
+  sqrt_rho1 = fmax(1.4916681462400413e-154 /* sqrt(DBL_MIN) */, rsqrt_nr(sum));
   return b * log(sum);
 }
 
@@ -203,7 +204,7 @@ __device__ __forceinline__ void eval_binary(const WinParams &wp, const double *r
   surfel_side(x + 12 * sp2l, x + 12 * (sp2l + 1), f2, a2, wn, +1.0, s2, j2, v != nullptr);
   double r = w * dotf(n, (s1 + dp) - s2);  // cost_functor.h:140
   double sc;
-  cost = 0.5 * cauchy(wp.cauchy_b, r * r, sc);
+  cost = 0.5 * cauchy(wp.cauchy_b, wp.inv_cauchy_b, r * r, sc);
   r_out = r * sc;
   if (!v) return;
   const int mode = (sp2l > sp1l + 1) ? 0 : (sp2l == sp1l + 1 ? 1 : 2);
@@ -211,18 +212,20 @@ __device__ __forceinline__ void eval_binary(const WinParams &wp, const double *r
   // in slots 0 / 1, side 2 in 2 / 3 (mode 0), 1 / 2 (mode 1) or 0 / 1 (mode 2).  Written with static indices and selects:
   // indexing v[] with the slot number puts the whole row into scratch memory (208 B per lane).
   const double w1l = sc * (1 - f1), w1r = sc * f1, w2l = sc * (1 - f2), w2r = sc * f2;  // corrector folded in
+  // The reference's dispatch (DispatchPtr, cost_functor.h:216-229, with the later write winning: Q1) as a BLEND: every entry of
+  // the row is j1 * A + j2 * B with weights that depend on the mode alone (zero where a side does not reach a slot; x + 0 = x,
+  // so the values are those of the assignments).  As nested selects per entry the dispatch was ~200 v_cndmask per record; as
+  // branches per mode the row went to scratch memory.
+  const bool q = wp.quirks != 0;
+  const double A0 = (mode == 2 && q) ? 0.0 : w1l, B0 = mode == 2 ? w2l : 0.0;
+  const double A1 = (mode != 0 && q) ? 0.0 : w1r, B1 = mode == 0 ? 0.0 : (mode == 1 ? w2l : w2r);
+  const double B2 = mode == 0 ? w2l : (mode == 1 ? w2r : 0.0), B3 = mode == 0 ? w2r : 0.0;
 #pragma unroll
   for (int c = 0; c < 6; ++c) {
-    const double a1 = j1[c] * w1l, b1 = j1[c] * w1r, a2v = j2[c] * w2l, b2v = j2[c] * w2r;
-    if (wp.quirks) {  // four plain assignments, later write wins (Q1)
-      v[c] = (mode == 2) ? a2v : a1;
-      v[6 + c] = (mode == 2) ? b2v : (mode == 1 ? a2v : b1);
-    } else {
-      v[c] = a1 + ((mode == 2) ? a2v : 0.0);
-      v[6 + c] = b1 + ((mode == 2) ? b2v : (mode == 1 ? a2v : 0.0));
-    }
-    v[12 + c] = (mode == 0) ? a2v : (mode == 1 ? b2v : 0.0);
-    v[18 + c] = (mode == 0) ? b2v : 0.0;
+    v[c] = fma(j2[c], B0, j1[c] * A0);
+    v[6 + c] = fma(j2[c], B1, j1[c] * A1);
+    v[12 + c] = j2[c] * B2;
+    v[18 + c] = j2[c] * B3;
   }
 }
 
@@ -240,7 +243,7 @@ __device__ __forceinline__ void eval_unary(const WinParams &wp, const double *re
   surfel_side(x + 12 * sp2l, x + 12 * (sp2l + 1), f2, a2, wn, +1.0, s2, j2, v != nullptr);
   double r = w * dotf(n, d - s2);  // cost_functor.h:39
   double sc;
-  cost = 0.5 * cauchy(wp.cauchy_b, r * r, sc);
+  cost = 0.5 * cauchy(wp.cauchy_b, wp.inv_cauchy_b, r * r, sc);
   r_out = r * sc;
   if (!v) return;
   const double wl = sc * (1 - f2), wr = sc * f2;
@@ -1895,6 +1898,7 @@ static int window_build_impl(wc_ctx *ctx, const wc_surfel *d_sld_surf, const wc_
   WinParams &wp = W->wp;
   wp.sigma0_sq = P.surfel_sigma0 * P.surfel_sigma0;
   wp.cauchy_b = P.cauchy_a * P.cauchy_a;
+  wp.inv_cauchy_b = 1.0 / wp.cauchy_b;
   wp.w_gyr = P.w_gyr, wp.w_acc = P.w_acc, wp.w_bg = P.w_bg, wp.w_ba = P.w_ba, wp.dt = P.imu_dt;
   for (int i = 0; i < 3; ++i) wp.grav[i] = h_grav[i];
   wp.quirks = P.reference_quirks;

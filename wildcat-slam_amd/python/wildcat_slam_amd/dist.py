@@ -192,6 +192,47 @@ class TorchComm:
         self._done()
 
 
+class StagedTorchComm:
+    """the three collectives through torch.distributed on HOST copies of the device buffers (wc_d2h / wc_h2d of the context that
+    owns them): lets several PROCESSES share one GPU under the gloo backend - RCCL refuses two ranks on one device - so that the
+    process-level plumbing of the N-rank step (one context per process, no shared Python state, rendezvous through
+    torch.distributed) can be tested on a one-GPU box (tests/test_step_gpu.py)"""
+
+    def __init__(self, torch, dist, ctx):
+        import ctypes
+
+        self.torch, self.dist, self.ctx, self.C = torch, dist, ctx, ctypes
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+
+    def _down(self, ptr, n):
+        a = np.empty(max(int(n), 1), np.uint8)
+        if n:
+            self.ctx._ck(self.ctx.lib.wc_d2h(self.ctx.h, self.C.c_void_p(a.ctypes.data), self.C.c_void_p(int(ptr)), self.C.c_size_t(int(n))))
+        return self.torch.from_numpy(a[: int(n)])
+
+    def _up(self, ptr, t):
+        a = np.ascontiguousarray(t.numpy())
+        if a.nbytes:
+            self.ctx._ck(self.ctx.lib.wc_h2d(self.ctx.h, self.C.c_void_p(int(ptr)), self.C.c_void_p(a.ctypes.data), self.C.c_size_t(a.nbytes)))
+
+    def allreduce(self, ptr, count):
+        t = self._down(ptr, 8 * count).view(self.torch.float64)
+        self.dist.all_reduce(t)
+        self._up(ptr, t.view(self.torch.uint8))
+
+    def alltoallv(self, send_ptr, send_bytes, recv_ptr, recv_bytes):
+        s = self._down(send_ptr, int(sum(send_bytes)))
+        r = self.torch.empty(int(sum(recv_bytes)), dtype=self.torch.uint8)
+        self.dist.all_to_all_single(r, s, [int(b) for b in recv_bytes], [int(b) for b in send_bytes])
+        self._up(recv_ptr, r)
+
+    def allgatherv(self, send_ptr, send_bytes, recv_ptr, recv_bytes):
+        s = self._down(send_ptr, int(send_bytes)).repeat(self.world)
+        r = self.torch.empty(int(sum(recv_bytes)), dtype=self.torch.uint8)
+        self.dist.all_to_all_single(r, s, [int(b) for b in recv_bytes], [int(send_bytes)] * self.world)
+        self._up(recv_ptr, r)
+
+
 def route_partition_host(points, keys_xyz, world):
     """host restatement of wc_route_partition (CPU / gloo test): stable partition of a POINT array by the owner of each
     point's root voxel -> list of `world` arrays, time order preserved inside each"""
