@@ -190,7 +190,7 @@ static KdPlan kd_plan(uint32_t nt) {
   const double avg = (double)nt / (double)(1u << p.T);
   p.Bd = std::max(0, std::min(kKdBdMax, (int)std::ceil(std::log2(std::max(avg / leaf, 1.0)))));
   p.D = p.T + p.Bd;
-  p.first = p.D % 3 ? p.D % 3 : 3;
+  p.first = p.D % kW ? p.D % kW : kW;
   for (int rem = p.T; rem > 0;) {  // top stages of at most kKdStageMax levels, as even as possible
     const int nst = (rem + kKdStageMax - 1) / kKdStageMax, ts = (rem + nst - 1) / nst;
     p.stages[p.nstage++] = ts;
@@ -319,14 +319,14 @@ static int match_impl(wc_ctx *ctx, const wc_surfel *d_q_surf, const wc_pose *d_q
   const uint32_t nq_mine = q_end - q_begin;
   for (hipEvent_t &e : ctx->ev_knn)
     if (!e) WC_HIP(ctx, hipEventCreate(&e));
-  // pending nodes of a walk: the children of the root's step, then 7 more per further step above the leaves
-  const int wide_steps = plan.D > 0 ? 1 + (plan.D - plan.first) / 3 : 0, stack_cap = std::max(1, (1 << plan.first) + 7 * std::max(0, wide_steps - 2));
+  // pending nodes of a walk: the children of the root's step, then 2^kW - 1 more per further step above the leaves
+  const int wide_steps = plan.D > 0 ? 1 + (plan.D - plan.first) / kW : 0, stack_cap = std::max(1, (1 << plan.first) + (kNch - 1) * std::max(0, wide_steps - 2));
   static const bool tdbg = getenv("WC_MATCH_TIMING") != nullptr;
   const auto t_prep = std::chrono::steady_clock::now();
   if (tdbg) WC_HIP(ctx, hipEventRecord(ctx->ev_knn[0], st));
 #define WC_KNN_LAUNCH(KK)                                                                                                                            \
   if (nq_mine)                                                                                                                                       \
-    k_knn_tree<KK><<<(nq_mine + 63) / 64, 64, (size_t)(9 + stack_cap) * 64 * 4, st>>>(d_q_surf, d_q_pose, nq, tree, (const double *)b_world.p, nt, M, (uint32_t *)b_gated.p, d_knn_idx, \
+    k_knn_tree<KK><<<(nq_mine + 63) / 64, 64, (size_t)(kNch + 1 + stack_cap) * 64 * 4, st>>>(d_q_surf, d_q_pose, nq, tree, (const double *)b_world.p, nt, M, (uint32_t *)b_gated.p, d_knn_idx, \
                                                        d_knn_d2, qorder, q_begin, q_end, gated_shard, stats, status, stack_cap);
   switch (P.knn_k) {  // the reference's k = 10 gets its own instantiation (top-k in 30 registers)
     case 10: WC_KNN_LAUNCH(10); break;
