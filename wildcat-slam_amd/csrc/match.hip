@@ -485,10 +485,12 @@ extern "C" int wc_match_pair(wc_ctx *ctx, const wc_surfel *d_sld_surf, const wc_
   WC_HIP(ctx, hipEventRecord(ctx->ev_aux, ctx->stream));
   WC_HIP(ctx, hipStreamWaitEvent(aux->stream, ctx->ev_aux, 0));
   int rc_fix = WC_OK, rc_sld = WC_OK;
-  // (Round 3, tried twice: a rendezvous of the two searches behind their preparations - both k_knn_gate ready together, the ctx
-  // stream's enqueued first, with and without a lower priority for the helper's stream.  2.50 - 2.76 ms for the odometry step's
-  // searches against 2.45 - 2.50 without, alternating on one box: the search that is ready first had better start.  What had made
-  // single runs take 3.1 - 3.4 ms was the ORDER of the candidate halves chosen from one noisy timing sample - see match_impl.)
+  // (A rendezvous of the two searches in front of their walk kernels was tried in round 3 - grid kernels: 2.50 - 2.76 ms against
+  // 2.45 - 2.50 - and again in round 4 with the tree: a kernel trace showed the fixed-window search's locate + radix passes waiting
+  // for wavefront slots behind the other search's k_knn_tree - one Onesweep pass of 250 k keys took 446 us - and its walk starting
+  // when the other was nearly over; with the first walk held back until the second preparation is through both walks start together
+  // at 0.39 ms, last 1.31 / 1.47 ms instead of 1.02 / 1.03, and the pair ends at the same 2.04 ms: the walks are bound by
+  // wavefront-slot time (3 906 wavefronts each for 4 096 slots), not by when they start.  Not kept.)
   // no exception may cross the C boundary: a failed thread creation runs the second search on this thread, an allocation
   // failure inside a search becomes a status code
   auto guarded = [](int &rc, auto &&fn) {
