@@ -282,10 +282,12 @@ def test_query_sharded_match_equals_unsharded(gpu):
     from wildcat_slam_amd import dist as wdist
     from wildcat_slam_amd import lib
 
-    w = synth.surfel_window(4, 3000, seed=11, fixed_patches=1500)
+    # (48 000 / 40 000 targets: trees with TWO sample stages - the later stage samples out of the scattered index list, and every
+    # rank has to come to the same tree whatever order its atomics left that list in)
+    w = synth.surfel_window(4, 12000, seed=11, fixed_patches=40000)
     ref_b = gpu.match(w["surf"], w["pose"], w["surf"], w["pose"], True)
     ref_u = gpu.match(w["surf"], w["pose"], w["fix_surf"], w["fix_pose"], False)
-    assert len(ref_b) > 5000 and len(ref_u) > 1000
+    assert len(ref_b) > 20000 and len(ref_u) > 10000
     world = 2
     ctxs = [lib.Context(0) for _ in range(world)]
     shared = wdist.ThreadComm.shared(world)
