@@ -149,7 +149,7 @@ def test_facade_each_sweep_against_the_oracle_resynchronised(gpu, oracle, exact_
     odo.set_exact_sums(exact_sums)
     odo.set_quirks(quirks)
     ref.set_quirks(quirks)
-    per_sweep, last = [], {}
+    per_sweep, last, pair_diff = [], {}, []
 
     def on_sweep(k):
         a, b = odo.samples(), ref.samples()
@@ -158,13 +158,16 @@ def test_facade_each_sweep_against_the_oracle_resynchronised(gpu, oracle, exact_
         for key in ("sld_surfels", "fix_surfels", "lm_iters", "termination"):
             assert sa[key] == sb[key], (k, key, sa[key], sb[key])
         for key in ("binary", "unary"):
-            # exact sums: the oracle's surfels in the oracle's order -> the same correspondences.  Default arithmetic: surfel
-            # stamps are the correctly rounded means (<= 2e-6 s from the reference's running sums), so surfels closer in time
-            # than that may swap places and the matcher's order-dependent de-duplication (knn_surfel_matcher.cc:35-38) may
-            # keep a different one of two mutual pairs: the count is the same, give or take a handful
-            assert sa[key] == sb[key] if exact_sums else abs(sa[key] - sb[key]) <= 2 + 0.002 * sb[key], (k, key, sa[key], sb[key])
+            # exact sums: the oracle's surfels in the oracle's order -> the same correspondences.  Default arithmetic: surfel stamps
+            # are the correctly rounded means (<= 2e-6 s from the reference's running sums), so two surfels closer in time than that
+            # may swap places - which cannot change a pair: a surfel and any of its candidates are >= 0.06 s apart (the time gate,
+            # knn_surfel_matcher.cc:26), so the order of a surfel and its candidates, all the de-duplication (cc:35-38) looks at, is
+            # the same in both runs.  What can differ is a gate within 2e-6 s / 3e-10 of its threshold: measured 0 in all 17 sweeps
+            # with and without the quirks; two are allowed.
+            assert sa[key] == sb[key] if exact_sums else abs(sa[key] - sb[key]) <= 2, (k, key, sa[key], sb[key])
         d = _state_diff(a, b)
         per_sweep.append((k, float("%.2g" % d)))
+        pair_diff.append((int(sa["binary"] - sb["binary"]), int(sa["unary"] - sb["unary"])))
         assert d <= 1e-6, per_sweep
         assert abs(sa["cost1"] - sb["cost1"]) <= 1e-5 * max(1.0, abs(sb["cost1"]))
         ft, rt = odo.fixed_times(), ref.window_times(True)
@@ -177,7 +180,7 @@ def test_facade_each_sweep_against_the_oracle_resynchronised(gpu, oracle, exact_
     _feed(odo, ref, msgs, imu, on_sweep)
     fast, exact = odo.extract_paths()
     print("arithmetic", "exact" if exact_sums else "default", "quirks", quirks, "sweeps on the fast / exact path", fast, exact,
-          "per-sweep worst sample-state difference", per_sweep)
+          "per-sweep worst sample-state difference", per_sweep, "correspondence-count differences (binary, unary) per sweep", pair_diff)
     # the arithmetic asked for is the one that ran (a default-arithmetic sweep may fall back when a gate lies in the noise band)
     assert fast + exact == len(per_sweep) and (fast == 0 if exact_sums else fast >= 0.8 * len(per_sweep))
     assert len(per_sweep) >= 15 and last["fix_surfels"] > 1000 and last["unary"] > 1000
