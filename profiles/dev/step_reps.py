@@ -1,4 +1,4 @@
-"""Per repetition of the odometry step in a kernel trace: when the two k_knn_gate start / end relative to the first k_features, and
+"""Per repetition of the odometry step in a kernel trace: when the two k_knn_tree start / end relative to the first k_features, and
 when the build's k_pair_keys starts.  python profiles/dev/step_reps.py <b_kernel_trace.csv>"""
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
@@ -9,7 +9,7 @@ for r in rows:
     g = int(r['Grid_Size_X'])
     s, e = int(r['Start_Timestamp']) / 1000, int(r['End_Timestamp']) / 1000
     if 'k_features' in n and g == 250112: ev.append(('feat', s, e, r['Queue_Id']))
-    elif 'k_knn_gate' in n and g == 249984: ev.append(('knn', s, e, r['Queue_Id']))
+    elif 'k_knn_tree' in n and g == 249984: ev.append(('knn', s, e, r['Queue_Id']))
     elif 'k_pair_keys' in n and g in (249600, 249344): ev.append(('keys', s, e, r['Queue_Id']))
     elif 'k_sorted_feat' in n and g == 62720: ev.append(('sfeat62k', s, e, r['Queue_Id']))
 i = 0
