@@ -324,8 +324,14 @@ static int match_impl(wc_ctx *ctx, const wc_surfel *d_q_surf, const wc_pose *d_q
   static const bool tdbg = getenv("WC_MATCH_TIMING") != nullptr;
   const auto t_prep = std::chrono::steady_clock::now();
   if (tdbg) WC_HIP(ctx, hipEventRecord(ctx->ev_knn[0], st));
+  // few queries: eight lanes per query (match_tree.inc: k_knn_tree_group) - the rule only depends on the number of queries
+  const bool group_walk = nq_mine < 131072u;
+  const int first3 = plan.D % 3 ? plan.D % 3 : 3;
 #define WC_KNN_LAUNCH(KK)                                                                                                                            \
-  if (nq_mine)                                                                                                                                       \
+  if (nq_mine && group_walk)                                                                                                                         \
+    k_knn_tree_group<KK><<<(nq_mine + 31) / 32, 256, 0, st>>>(d_q_surf, d_q_pose, nq, tree, first3, (const double *)b_world.p, nt, M, (uint32_t *)b_gated.p, \
+                                                              d_knn_idx, d_knn_d2, qorder, q_begin, q_end, gated_shard, stats, status);              \
+  else if (nq_mine)                                                                                                                                  \
     k_knn_tree<KK><<<(nq_mine + 63) / 64, 64, (size_t)(kNch + 1 + stack_cap) * 64 * 4, st>>>(d_q_surf, d_q_pose, nq, tree, (const double *)b_world.p, nt, M, (uint32_t *)b_gated.p, d_knn_idx, \
                                                        d_knn_d2, qorder, q_begin, q_end, gated_shard, stats, status, stack_cap);
   switch (P.knn_k) {  // the reference's k = 10 gets its own instantiation (top-k in 30 registers)
