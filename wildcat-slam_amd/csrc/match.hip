@@ -324,8 +324,13 @@ static int match_impl(wc_ctx *ctx, const wc_surfel *d_q_surf, const wc_pose *d_q
   static const bool tdbg = getenv("WC_MATCH_TIMING") != nullptr;
   const auto t_prep = std::chrono::steady_clock::now();
   if (tdbg) WC_HIP(ctx, hipEventRecord(ctx->ev_knn[0], st));
-  // few queries: eight lanes per query (match_tree.inc: k_knn_tree_group) - the rule only depends on the number of queries
-  const bool group_walk = nq_mine < 131072u;
+  // Which walk: eight lanes per query (match_tree.inc: k_knn_tree_group; every round trip coalesced, ~500 instructions per item) while the
+  // search is short of wavefronts, one lane per query (k_knn_tree) when it is not.  The two searches of a step-like window at 16 k / 64 k /
+  // 128 k / 250 k / 500 k queries, lane-per-query against group walk: same-set 0.59 / 0.77 / 0.88 / 1.18 / 2.08 against 0.35 / 0.54 /
+  // 0.71 / 1.08 / 2.01 ms, fixed-window 0.62 / 0.96 / 1.12 / 1.35 / 2.27 against 0.41 / 0.62 / 0.91 / 1.45 / 2.57 ms
+  // (profiles/dev/time_match_sizes.py).  The rule depends on the call's sizes and kind alone - no timing, no history.
+  static const int group_env = getenv("WC_KNN_GROUP") ? atoi(getenv("WC_KNN_GROUP")) : -1;  // (experiments: 0 / 1 pins the walk; read once)
+  const bool group_walk = group_env >= 0 ? group_env != 0 : (nq_mine < 200000u || (same_set && nq_mine < 600000u));
   const int first3 = plan.D % 3 ? plan.D % 3 : 3;
 #define WC_KNN_LAUNCH(KK)                                                                                                                            \
   if (nq_mine && group_walk)                                                                                                                         \
