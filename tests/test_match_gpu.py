@@ -340,3 +340,17 @@ def test_match_pair_equals_the_two_searches_and_the_oracle(gpu, oracle, serial, 
         assert np.array_equal(got_b, one_b) and np.array_equal(got_u, one_u)
         assert np.array_equal(got_b, ref_b) and np.array_equal(got_u, ref_u)
     assert len(ref_b) > 1000 and len(ref_u) > 500
+
+
+@pytest.mark.parametrize("group", ["0", "1"], ids=["lane-per-query", "eight-lanes-per-query"])
+def test_both_walks_every_k(gpu, group):
+    """the matcher picks its walk by the call's sizes (below 200 k queries: eight lanes per query); WC_KNN_GROUP pins it, read once per
+    process - so tests/_match_walk_worker.py runs in a process of its own under each setting: every instantiated k, both kinds of
+    search, trees of one leaf ... two sample stages, against the oracle"""
+    import os
+    import subprocess
+    import sys
+
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_match_walk_worker.py")
+    r = subprocess.run([sys.executable, worker], env=dict(os.environ, WC_KNN_GROUP=group), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    assert r.returncode == 0 and ("walk %s ok" % group) in r.stdout.decode(), r.stdout.decode()[-3000:]
