@@ -203,7 +203,9 @@ int wc_match_stats(wc_ctx *ctx, double h_out[8]);
  * tree-leaf order) and ONE all-gather of the gated neighbour lists (4 k bytes per query) gives every rank the whole table, on
  * which the order-dependent de-duplication (cc:35-38) runs replicated: every rank ends with the unsharded call's pairs, byte for
  * byte.  wc_match itself is never a collective, whatever is installed on the ctx.  Without a communicator (or a world of one) this
- * is wc_match. */
+ * is wc_match.  A rank that fails locally BEFORE the all-gather (an allocation, a HIP error) returns its error without entering it:
+ * treat a non-zero return of any rank as fatal for the job (wc_window_build_sharded, whose local part can fail on its arguments,
+ * joins its share check with a poisoned share instead). */
 int wc_match_sharded(wc_ctx *ctx, const wc_surfel *d_q_surf, const wc_pose *d_q_pose, uint64_t nq, const wc_surfel *d_t_surf,
                      const wc_pose *d_t_pose, uint64_t nt, int same_set, wc_pair *d_pairs, uint64_t cap, uint64_t *h_n_pairs);
 /* both searches of an outer iteration as collectives (one after the other: their all-gathers share the ctx stream) */
