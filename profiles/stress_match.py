@@ -13,7 +13,7 @@ import pyoracle  # noqa: E402
 from wildcat_slam_amd import lib, synth  # noqa: E402
 
 ctx = lib.Context(0)
-for scans, patches, fixed, seed in ((20, 2500, 2500, 7), (10, 8000, 20000, 8), (5, 20000, 3000, 9)):
+for scans, patches, fixed, seed in ((20, 2500, 2500, 7), (10, 8000, 20000, 8), (5, 20000, 3000, 9), (8, 31248, 62496, 10), (10, 70000, 30000, 11)):  # (the last two: the lane-per-query walk)
     w = synth.surfel_window(scans, patches, seed=seed, fixed_patches=fixed)
     t0 = time.perf_counter()
     ref_s = pyoracle.match(w["surf"], w["pose"], w["surf"], w["pose"], True)
