@@ -1,5 +1,6 @@
 """Ad-hoc stress of the matcher against the CPU oracle's kd-tree on windows larger than the unit tests use (run on the GPU
-box: python profiles/stress_match.py).  k-NN tables and pair lists must be identical."""
+box: python profiles/stress_match.py; the matcher takes the eight-lanes-per-query walk at these sizes, WC_KNN_GROUP=0 python
+profiles/stress_match.py runs the same windows through the lane-per-query walk).  k-NN tables and pair lists must be identical."""
 import os
 import sys
 import time
@@ -13,7 +14,7 @@ import pyoracle  # noqa: E402
 from wildcat_slam_amd import lib, synth  # noqa: E402
 
 ctx = lib.Context(0)
-for scans, patches, fixed, seed in ((20, 2500, 2500, 7), (10, 8000, 20000, 8), (5, 20000, 3000, 9), (8, 31248, 62496, 10), (10, 70000, 30000, 11)):  # (the last two: the lane-per-query walk)
+for scans, patches, fixed, seed in ((20, 2500, 2500, 7), (10, 8000, 20000, 8), (5, 20000, 3000, 9), (8, 31248, 62496, 10), (10, 70000, 30000, 11)):
     w = synth.surfel_window(scans, patches, seed=seed, fixed_patches=fixed)
     t0 = time.perf_counter()
     ref_s = pyoracle.match(w["surf"], w["pose"], w["surf"], w["pose"], True)

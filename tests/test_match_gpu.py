@@ -344,7 +344,7 @@ def test_match_pair_equals_the_two_searches_and_the_oracle(gpu, oracle, serial, 
 
 @pytest.mark.parametrize("group", ["0", "1"], ids=["lane-per-query", "eight-lanes-per-query"])
 def test_both_walks_every_k(gpu, group):
-    """the matcher picks its walk by the call's sizes (below 200 k queries: eight lanes per query); WC_KNN_GROUP pins it, read once per
+    """the matcher picks its walk by the call's sizes (below 750 k queries: eight lanes per query); WC_KNN_GROUP pins it, read once per
     process - so tests/_match_walk_worker.py runs in a process of its own under each setting: every instantiated k, both kinds of
     search, trees of one leaf ... two sample stages, against the oracle"""
     import os

@@ -287,7 +287,11 @@ static int match_impl(wc_ctx *ctx, const wc_surfel *d_q_surf, const wc_pose *d_q
   // nodes: same-set queries through the sorted target permutation, queries of another set (sliding window against fixed window)
   // by the leaf they would be looked for in first (in time order their walks are unrelated and the loads diverge)
   const uint32_t *qorder = tree.sorig;
-  if (!same_set) {
+  // (below ~40 k queries the two passes - locate, radix sort: ~70 us - cost more than the walks gain from them: 16 k queries against 4 k
+  // targets 0.38 -> 0.31 ms in query order, 64 k the same, 250 k 1.23 -> 1.36; the rule depends on the call's sizes alone)
+  const bool sort_queries = !same_set && nq >= 40000u;
+  if (!same_set && !sort_queries) qorder = nullptr;
+  if (sort_queries) {
     uint32_t *k0 = (uint32_t *)ctx->b_keys[0].p, *v0 = (uint32_t *)ctx->b_vals[0].p;
     uint32_t *qk = (uint32_t *)b_choice.p + 2 * (size_t)nq, *qo = (uint32_t *)b_choice.p + 3 * (size_t)nq;  // (flags / offsets: free until step 5)
     k_tree_locate<<<(nq + 255) / 256, 256, 0, st>>>(d_q_surf, d_q_pose, nq, tree, M.cs, M.as, k0, v0);
@@ -324,13 +328,14 @@ static int match_impl(wc_ctx *ctx, const wc_surfel *d_q_surf, const wc_pose *d_q
   static const bool tdbg = getenv("WC_MATCH_TIMING") != nullptr;
   const auto t_prep = std::chrono::steady_clock::now();
   if (tdbg) WC_HIP(ctx, hipEventRecord(ctx->ev_knn[0], st));
-  // Which walk: eight lanes per query (match_tree.inc: k_knn_tree_group; every round trip coalesced, ~500 instructions per item) while the
-  // search is short of wavefronts, one lane per query (k_knn_tree) when it is not.  The two searches of a step-like window at 16 k / 64 k /
-  // 128 k / 250 k / 500 k queries, lane-per-query against group walk: same-set 0.59 / 0.77 / 0.88 / 1.18 / 2.08 against 0.35 / 0.54 /
-  // 0.71 / 1.08 / 2.01 ms, fixed-window 0.62 / 0.96 / 1.12 / 1.35 / 2.27 against 0.41 / 0.62 / 0.91 / 1.45 / 2.57 ms
-  // (profiles/dev/time_match_sizes.py).  The rule depends on the call's sizes and kind alone - no timing, no history.
+  // Which walk: eight lanes per query (match_tree.inc: k_knn_tree_group; every round trip coalesced, eight independent walks per
+  // wavefront, VALU-bound at ~87 % busy) or one lane per query (k_knn_tree).  The two searches of a step-like window at 16 k / 64 k /
+  // 128 k / 250 k / 500 k queries, lane-per-query against group walk: same-set 0.59 / 0.77 / 0.88 / 1.18 / 2.09 against 0.33 / 0.48 /
+  // 0.62 / 0.94 / 1.77 ms, fixed-window 0.62 / 0.96 / 1.13 / 1.35 / 2.28 against 0.31 / 0.54 / 0.80 / 1.23 / 2.15 ms; at a million
+  // queries (C4) 2.06 against 2.02 and 3.50 against 3.96 (profiles/dev/time_match_sizes.py, time_match.py).  The rule depends on the
+  // call's sizes and kind alone - no timing, no history.
   static const int group_env = getenv("WC_KNN_GROUP") ? atoi(getenv("WC_KNN_GROUP")) : -1;  // (experiments: 0 / 1 pins the walk; read once)
-  const bool group_walk = group_env >= 0 ? group_env != 0 : (nq_mine < 200000u || (same_set && nq_mine < 600000u));
+  const bool group_walk = group_env >= 0 ? group_env != 0 : (nq_mine < 750000u || (same_set && nq_mine < 1500000u));
   const int first3 = plan.D % 3 ? plan.D % 3 : 3;
 #define WC_KNN_LAUNCH(KK)                                                                                                                            \
   if (nq_mine && group_walk)                                                                                                                         \
