@@ -2110,19 +2110,22 @@ static int window_build_impl(wc_ctx *ctx, const wc_surfel *d_sld_surf, const wc_
   WC_TRY(upload(ctx, W->gsrc, gsrc));
   WC_TRY(upload(ctx, W->gsrc_begin, gsrc_begin));
 
-  const size_t n = W->n;
+  // (the buffers whose size goes with the SQUARE of the sample states are allocated for at least 96 of them - the reference's default
+  // window has 82 -: a window that gains ten sample states per sweep, the facade's first seconds, otherwise re-allocates four of them on
+  // most calls, 0.1 - 0.7 ms of hipFree / hipMalloc each time; 4 x 10.6 MB)
+  const size_t n = W->n, n_al = std::max<size_t>(n, 12 * 96), np_al = ((n_al + 1 + kNB - 1) / kNB) * kNB;
   WC_TRY(wc_ensure(ctx, W->partial, std::max<size_t>((size_t)off * 8, 64)));
-  WC_TRY(wc_ensure(ctx, W->x, n * 8));
-  WC_TRY(wc_ensure(ctx, W->xc, n * 8));
-  WC_TRY(wc_ensure(ctx, W->lin, (n * n + (size_t)W->np + 2) * 8));
-  WC_TRY(wc_ensure(ctx, W->lin_alt, (n * n + (size_t)W->np + 2) * 8));
+  WC_TRY(wc_ensure(ctx, W->x, n_al * 8));
+  WC_TRY(wc_ensure(ctx, W->xc, n_al * 8));
+  WC_TRY(wc_ensure(ctx, W->lin, (n_al * n_al + np_al + 2) * 8));
+  WC_TRY(wc_ensure(ctx, W->lin_alt, (n_al * n_al + np_al + 2) * 8));
   W->lin_sel = 0;
-  WC_TRY(wc_ensure(ctx, W->Linv, (size_t)W->np * kNB * 8));
-  WC_TRY(wc_ensure(ctx, W->scale, n * 8));
-  WC_TRY(wc_ensure(ctx, W->diag, n * 8));
-  WC_TRY(wc_ensure(ctx, W->A, (size_t)W->np * W->ld * 8));
-  WC_TRY(wc_ensure(ctx, W->Lmat, (size_t)W->np * W->ld * 8));
-  WC_TRY(wc_ensure(ctx, W->y, (size_t)W->np * 8));
+  WC_TRY(wc_ensure(ctx, W->Linv, np_al * kNB * 8));
+  WC_TRY(wc_ensure(ctx, W->scale, n_al * 8));
+  WC_TRY(wc_ensure(ctx, W->diag, n_al * 8));
+  WC_TRY(wc_ensure(ctx, W->A, np_al * np_al * 8));
+  WC_TRY(wc_ensure(ctx, W->Lmat, np_al * np_al * 8));
+  WC_TRY(wc_ensure(ctx, W->y, np_al * 8));
   WC_TRY(wc_ensure(ctx, W->mail, 64 * 8));
   WC_HIP(ctx, hipMemsetAsync((double *)W->mail.p + 60, 0, 8, ctx->stream));  // k_gather's count of finished g / cost workgroups
   const size_t ncb = (W->nb + 255) / 256 + (W->nu + 255) / 256 + (W->ni + 255) / 256 + 8;
@@ -2446,13 +2449,13 @@ extern "C" int wc_window_solve(wc_ctx *ctx, double *h_x_inout, wc_solve_summary 
   static const bool lm_dense = getenv("WC_LM_DENSE") != nullptr;
   const bool use_schur = !lm_dense && W->ns >= 4;  // (two super-blocks at least: the reduction has a level)
   if (use_schur) {
-    const int npz = 6 * W->ns, M = (W->ns + 1) / 2, ldr = ((npz + 1 + 63) / 64) * 64;
+    const int ns_al = std::max(W->ns, 96), M_al = (ns_al + 1) / 2, ldr_al = ((6 * ns_al + 1 + 63) / 64) * 64;  // (as in wc_window_build: no re-allocation while a window grows)
     for (int b = 0; b < 2; ++b) {
-      WC_TRY(wc_ensure(ctx, W->pcr_D[b], (size_t)M * 144 * 8));
-      WC_TRY(wc_ensure(ctx, W->pcr_A[b], (size_t)M * 144 * 8));
-      WC_TRY(wc_ensure(ctx, W->pcr_R[b], (size_t)M * kSB * ldr * 8));
+      WC_TRY(wc_ensure(ctx, W->pcr_D[b], (size_t)M_al * 144 * 8));
+      WC_TRY(wc_ensure(ctx, W->pcr_A[b], (size_t)M_al * 144 * 8));
+      WC_TRY(wc_ensure(ctx, W->pcr_R[b], (size_t)M_al * kSB * ldr_al * 8));
     }
-    WC_TRY(wc_ensure(ctx, W->yred, (size_t)(npz + kNB + 64) * 8));
+    WC_TRY(wc_ensure(ctx, W->yred, (size_t)(6 * ns_al + kNB + 64) * 8));
   }
 
   WC_HIP(ctx, hipMemcpyAsync(x, cur.data(), (size_t)n * 8, hipMemcpyHostToDevice, st));
