@@ -233,16 +233,30 @@ def main():
     if use_dist:
         # the library's own RCCL communicator (csrc/comm.hip): collectives on the ctx stream, no host synchronisation; rank 0's
         # unique id travels through torch.distributed, which is plumbing here
-        try:
-            ids = [lib.rccl_unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(ids, src=0)
-            ctx.comm_rccl_init(rank, world, ids[0])
+        # (every step of the choice is agreed on by all ranks: a rank that fell back alone would leave the others in a collective)
+        ids, err = [None], None
+        if rank == 0:
+            try:
+                ids = [lib.rccl_unique_id()]
+            except Exception as e:  # librccl.so not loadable
+                err = e
+        dist.broadcast_object_list(ids, src=0)
+        ok = 0
+        if ids[0] is not None:
+            try:
+                ctx.comm_rccl_init(rank, world, ids[0])
+                ok = 1
+            except Exception as e:
+                err = e
+        agreed = torch.tensor([ok], dtype=torch.int32, device=dev)
+        dist.all_reduce(agreed, op=dist.ReduceOp.MIN)
+        if int(agreed.item()) == 1:
             comm_kind = "in-library RCCL (ncclAllReduce / grouped ncclSend+ncclRecv on the ctx stream)"
-        except Exception as e:
+        else:
             from wildcat_slam_amd import dist as wdist
 
             ctx.set_comm(wdist.TorchComm(torch, dist, dev))
-            comm_kind = "torch.distributed callbacks (in-library RCCL unavailable: %r)" % (e,)
+            comm_kind = "torch.distributed callbacks (in-library RCCL unavailable on some rank: %r)" % (err,)
     base = d_pts.data_ptr()
     desc = R.Points(base, base + 24, 48, 48, n_pts)
     t_lo, t_hi = float(pts["time"][0]), float(pts["time"][-1])
