@@ -1661,6 +1661,9 @@ __device__ __forceinline__ void lm_step(const double *x, const double *y, const 
   }
 }
 
+// (Round 4, tried: chunks of 16 block rows - two (column, quarter) items per thread -, so that the odometry step's 12 block rows
+// and the facade's 9 - 11 are ONE launch instead of chunk + gemv + chunk, and C4's 24 are 16 + 8: correct, and no faster - 1 807 against
+// 1 858 LM it/s at C4, the step's solve 2.29 against 2.25 ms: a step inside the wide chunk lasts as much longer as the launches saved.)
 constexpr int kBackChunk = 8;
 __global__ void __launch_bounds__(1024) k_chol_back_chunk(const double *A, int ld, int n, const double *Linv, const double *zsrc,
                                                          double *y, int lo_blk, int hi_blk, StepArgs S) {
