@@ -715,8 +715,9 @@ def bench_window(ctx, args, world, rank, dev, torch, dist, cpu=False):
                                         "panel steps) on the %d pose unknowns" % (6 * ns)},
         "build_ms": round(t_build * 1e3, 3), "match_s": round(t_match, 4), "match_surfels_per_s": round(2 * n_s / t_match, 1), "generate_s": round(t_gen, 2),
         "match_walk_per_query": {"fixed_window": {k_: round(v_, 1) for k_, v_ in st_fix.items()}, "sliding_window": {k_: round(v_, 1) for k_, v_ in st_sld.items()},
-                                 "index": "6-D kd-tree with bounding boxes over [centre, normal / 5 deg] (csrc/match_tree.inc); points_per_query = targets given the "
-                                          "fp32 first look, exact_per_query = fp64 distances"},
+                                 "index": "6-D kd-tree with bounding boxes over [centre, normal / 5 deg] (csrc/match_tree.inc); points_per_query = targets looked at, "
+                                          "exact_per_query = fp64 distances (the lane-per-query walk, from 750 k queries on, takes a fp32 first look and sums the "
+                                          "survivors; the eight-lanes-per-query walk sums every point of a visited leaf); nodes = node ITEMS (4 / 8 child boxes each)"},
     }
     # the assembly's OTHER roof (the binding one): fp64 vector issue.  Flops per record by a fixed counting rule - the
     # Gram matrix of the record's row [J r] (upper triangle: 325 / 91 multiply-adds for 24 / 12 unknowns + residual) plus ~450 / ~250
