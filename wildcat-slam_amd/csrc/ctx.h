@@ -28,7 +28,7 @@ struct wc_ctx {
   // scratch buffers (device), grown on demand and kept for the lifetime of the ctx
   wc_buf b_ex_ctrl;  // the extraction's control block (status words, bucket / bin counters): never shared, cleared ahead of time
   wc_buf b_keys[2], b_vals[2], b_sorttmp, b_slots, b_slot_ids, b_slot_keys[2], b_slot_idx[2], b_cand, b_cand_meta,
-      b_status, b_misc[8], b_route[4], b_fx[10], b_match_stat;
+      b_status, b_misc[8], b_route[4], b_fx[10];
   // wc_match: what the last search's traversal touched (sampled, see k_knn_tree): wide nodes, leaves, points, exact distances, queries
   double match_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   wc_buf b_kd[10];  // match_tree.inc: planes (dim, value), bucket ids, padded counters, starts x 2, index lists x 2, box heap, leaf ranges
@@ -41,7 +41,7 @@ struct wc_ctx {
   bool have_comm = false;
   void *rccl = nullptr;  // the in-library RCCL communicator (comm.hip), if any
   // pinned host mailbox
-  uint32_t *h_status = nullptr;  // [0] n_emitted, [1] flags, ...
+  uint32_t *h_status = nullptr;  // pinned, 128 words: [0] n_emitted, [1] flags, ... ; [64..95]: the matcher's read-backs (round words, walk statistics)
   unsigned long long mail_ticket = 0;  // last ticket handed to a k_post_reduce (window.hip: wait_mail)
   double *h_mail = nullptr;      // pinned: 64 doubles of mailbox (costs etc.) + 4096 doubles of staging (the window's unknowns)
   // pending extraction (enqueue/finish split)

@@ -78,7 +78,7 @@ extern "C" int wc_ctx_create(const wc_params *params, int device, wc_ctx **out) 
   } restore{prev_dev};
   if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess ||
-      hipHostMalloc((void **)&ctx->h_status, 64 * sizeof(uint32_t)) != hipSuccess ||
+      hipHostMalloc((void **)&ctx->h_status, 128 * sizeof(uint32_t)) != hipSuccess ||
       hipHostMalloc((void **)&ctx->h_mail, (64 + 4096) * sizeof(double)) != hipSuccess) {
     delete ctx;
     return WC_ERR_HIP;
@@ -117,7 +117,6 @@ extern "C" void wc_ctx_destroy(wc_ctx *ctx) {
     if (b.p) (void)hipFree(b.p);
   for (wc_buf &b : ctx->b_route)
     if (b.p) (void)hipFree(b.p);
-  if (ctx->b_match_stat.p) (void)hipFree(ctx->b_match_stat.p);
   if (ctx->b_batch.p) (void)hipFree(ctx->b_batch.p);
   for (wc_buf &b : ctx->b_kd)
     if (b.p) (void)hipFree(b.p);

@@ -130,7 +130,8 @@ __global__ void __launch_bounds__(256) k_gated_planes(const uint32_t *__restrict
 // choice(q) = first gated candidate c that is not already paired with q from c's own turn (c < q and choice(c) == q).
 // "Something changed" is reported with ONE plain store per workgroup (idempotent: every writer stores 1): an atomicOr per
 // wavefront was 15 600 atomics on one word in the first round of a 1 M-query match - 83 us per round for 72 MB of traffic.
-__global__ void __launch_bounds__(256) k_resolve(const uint32_t *gated, uint32_t nq, int k, int same_set, const uint32_t *choice_in,
+// first != 0: the round that starts from "nobody has chosen" - choice_in is not read (no memset of it in front of the rounds).
+__global__ void __launch_bounds__(256) k_resolve(const uint32_t *gated, uint32_t nq, int k, int same_set, int first, const uint32_t *choice_in,
                                                 uint32_t *choice_out, uint32_t *changed) {
   __shared__ uint32_t s_changed;
   if (threadIdx.x == 0) s_changed = 0u;
@@ -141,21 +142,20 @@ __global__ void __launch_bounds__(256) k_resolve(const uint32_t *gated, uint32_t
     for (int j = 0; j < k; ++j) {
       const uint32_t c = gated[(size_t)j * nq + q];
       if (c == kNone) break;
-      if (same_set && c < q && choice_in[c] == q) continue;  // {c, q} is already in surfel_pairs (cc:35-38)
+      if (same_set && !first && c < q && choice_in[c] == q) continue;  // {c, q} is already in surfel_pairs (cc:35-38)
       pick = c;
       break;
     }
     choice_out[q] = pick;
-    if (pick != choice_in[q]) s_changed = 1u;
+    if (pick != (first ? kNone : choice_in[q])) s_changed = 1u;
   }
   __syncthreads();
   if (threadIdx.x == 0 && s_changed) *changed = 1u;
 }
 
-__global__ void __launch_bounds__(256) k_flags(const uint32_t *choice, uint32_t nq, uint32_t *flags) {
-  const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
-  if (q < nq) flags[q] = choice[q] != kNone ? 1u : 0u;
-}
+struct ChoiceFlag {  // 1 where a query has chosen a partner: the scan of the compaction reads the choices through it (no pass, no array of flags)
+  __host__ __device__ uint32_t operator()(uint32_t c) const { return c != kNone ? 1u : 0u; }
+};
 
 __global__ void __launch_bounds__(256) k_emit_pairs(const uint32_t *choice, const uint32_t *offsets, uint32_t nq, const wc_surfel *q_surf,
                                                    const double *tworld, int same_set, wc_pair *pairs, uint64_t cap, uint32_t *status) {
@@ -224,9 +224,8 @@ static int kd_build(wc_ctx *ctx, const double *d_feat, uint32_t nt, const KdPlan
   uint32_t *idx_prev = nullptr;
   int tcum = 0;
   for (int s = 0; s < pl.nstage; ++s) {
-    k_kd_top<<<1u << tcum, kKdTopNT, 0, st>>>(d_feat, idx_prev, starts_prev, nt, tcum, pl.stages[s], plane_dim, plane_val);
+    k_kd_top<<<1u << tcum, kKdTopNT, 0, st>>>(d_feat, idx_prev, starts_prev, nt, tcum, pl.stages[s], plane_dim, plane_val, count);  // (also clears the stage's counters)
     tcum += pl.stages[s];
-    WC_HIP(ctx, hipMemsetAsync(count, 0, ((size_t)1 << tcum) * kKdPad * 4, st));
     k_kd_route<<<(nt + 1023) / 1024, 1024, 0, st>>>(d_feat, nt, tcum, plane_dim, plane_val, bucket, count);
     k_kd_scan<<<1, 1024, 0, st>>>(count, 1u << tcum, starts[s & 1]);
     k_kd_scatter<<<(nt + 1023) / 1024, 1024, 0, st>>>(bucket, nt, tcum, count, idx[s & 1]);
@@ -267,14 +266,14 @@ static int match_impl(wc_ctx *ctx, const wc_surfel *d_q_surf, const wc_pose *d_q
   WC_TRY(wc_ensure(ctx, ctx->b_vals[0], (size_t)nq * 4));
   WC_TRY(wc_ensure(ctx, b_aux, 256));
   WC_TRY(wc_ensure(ctx, ctx->b_status, 64 * 4));
-  WC_TRY(wc_ensure(ctx, ctx->b_match_stat, 8 * 8));
+  // ONE control block - [0] pairs, [1] flags, [32..39] "round r changed something", [40..55] the walk's sampled counts (8 x u64) -:
+  // one memset in front of the call's first kernel, one copy to pinned memory behind its last
   uint32_t *status = (uint32_t *)ctx->b_status.p;
-  uint32_t *changed = (uint32_t *)((char *)b_aux.p + 64);
-  unsigned long long *stats = (unsigned long long *)ctx->b_match_stat.p;
+  uint32_t *changed = status + 32;
+  unsigned long long *stats = (unsigned long long *)(status + 40);
 
   // 1. features of the targets, 2. their tree - no host round trip: the tree's shape only depends on nt
   WC_HIP(ctx, hipMemsetAsync(status, 0, 64 * 4, st));
-  WC_HIP(ctx, hipMemsetAsync(stats, 0, 8 * 8, st));
   k_features<<<(nt + 255) / 256, 256, 0, st>>>(d_t_surf, d_t_pose, nt, P.center_scale, P.angular_scale, (double *)b_feat.p, (double *)b_world.p, status);
   const KdPlan plan = kd_plan(nt);
   KdTree tree;
@@ -319,7 +318,10 @@ static int match_impl(wc_ctx *ctx, const wc_surfel *d_q_surf, const wc_pose *d_q
   // lists - or simply this call's - then sit in b_route[2] and are transposed into the planes of b_gated
   WC_TRY(wc_ensure(ctx, ctx->b_route[2], (size_t)nq * P.knn_k * 4));
   WC_TRY(wc_ensure(ctx, ctx->b_route[3], (size_t)(q_end - q_begin + 1) * P.knn_k * 4));
-  uint32_t *gated_shard = sharded ? (uint32_t *)ctx->b_route[3].p : (uint32_t *)ctx->b_route[2].p;
+  // (a search of few queries writes the planes of b_gated straight from the walk - ten scattered 4-byte stores per query, what the
+  // transposition below exists to avoid at a million queries, are nothing at 100 k, and two launches of the call's tail go)
+  const bool direct_planes = !sharded && nq < 131072u;
+  uint32_t *gated_shard = sharded ? (uint32_t *)ctx->b_route[3].p : (direct_planes ? nullptr : (uint32_t *)ctx->b_route[2].p);
   const uint32_t nq_mine = q_end - q_begin;
   for (hipEvent_t &e : ctx->ev_knn)
     if (!e) WC_HIP(ctx, hipEventCreate(&e));
@@ -375,7 +377,7 @@ static int match_impl(wc_ctx *ctx, const wc_surfel *d_q_surf, const wc_pose *d_q
     if (ctx->comm.allgatherv(ctx->comm.user, gated_shard, (uint64_t)nq_mine * P.knn_k * 4, ctx->b_route[2].p, bytes.data()) != 0)
       return wc_fail(ctx, WC_ERR_HIP, "wc_match: all-gather of the gated neighbour lists failed");
   }
-  {
+  if (!direct_planes) {
     uint32_t *qpos = (uint32_t *)b_choice.p + nq;  // (choice[1]: free until the resolve rounds)
     k_inv_perm<<<(nq + 255) / 256, 256, 0, st>>>(qorder, nq, qpos);
     k_gated_planes<<<(nq + 255) / 256, 256, 0, st>>>((const uint32_t *)ctx->b_route[2].p, qpos, nq, P.knn_k, (uint32_t *)b_gated.p);
@@ -383,8 +385,7 @@ static int match_impl(wc_ctx *ctx, const wc_surfel *d_q_surf, const wc_pose *d_q
   }
   // 4. resolve the order-dependent "pair already seen" rule by fixed-point iteration
   uint32_t *choice[2] = {(uint32_t *)b_choice.p, (uint32_t *)b_choice.p + nq};
-  uint32_t *flags = (uint32_t *)b_choice.p + 2 * (size_t)nq, *offsets = (uint32_t *)b_choice.p + 3 * (size_t)nq;
-  WC_HIP(ctx, hipMemsetAsync(choice[0], 0xFF, (size_t)nq * 4, st));
+  uint32_t *offsets = (uint32_t *)b_choice.p + 3 * (size_t)nq;
   int cur = 0;
   // rounds are issued eight at a time between host checks (a round past the fixed point changes nothing, so the extra ones
   // are harmless); round r of a batch reports into changed[r] and only the last word is read back
@@ -392,33 +393,36 @@ static int match_impl(wc_ctx *ctx, const wc_surfel *d_q_surf, const wc_pose *d_q
   // rule - it did - then costs ONE host round trip for rounds + compaction instead of two (a batch that did not is followed by another
   // one, and the compaction is redone on its result).
   bool converged = false;
-  unsigned long long h_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  // (the control block comes back in ONE copy, into PINNED memory - words 64.. of h_status -: into a stack array a copy is staged by the
+  // runtime and the call returns when it is through; the launches behind it were enqueued 15 - 20 us late, a kernel trace showed)
+  volatile uint32_t *h_ctl = ctx->h_status + 64;
+  volatile uint32_t *hc8 = h_ctl + 32;
+  volatile unsigned long long *h_stats = (volatile unsigned long long *)(h_ctl + 40);
   static const bool match_dbg = getenv("WC_MATCH_DEBUG") != nullptr;
   {
     size_t tmp = 0;
-    WC_HIP(ctx, rocprim::exclusive_scan(nullptr, tmp, flags, offsets, 0u, (size_t)nq, rocprim::plus<uint32_t>(), st));
+    WC_HIP(ctx, rocprim::exclusive_scan(nullptr, tmp, rocprim::make_transform_iterator((const uint32_t *)choice[0], ChoiceFlag{}), offsets, 0u, (size_t)nq,
+                                        rocprim::plus<uint32_t>(), st));
     WC_TRY(wc_ensure(ctx, b_scan, tmp + 16));
   }
   for (int batch = 0; batch < 250000 && !converged; ++batch) {
     const int rounds = same_set ? 8 : 1;
-    WC_HIP(ctx, hipMemsetAsync(changed, 0, 32, st));
+    if (batch > 0) WC_HIP(ctx, hipMemsetAsync(changed, 0, 32, st));  // (batch 0: cleared with the control block)
     for (int r = 0; r < rounds; ++r) {
-      k_resolve<<<(nq + 255) / 256, 256, 0, st>>>((const uint32_t *)b_gated.p, nq, P.knn_k, same_set, choice[cur], choice[cur ^ 1], changed + r);
+      k_resolve<<<(nq + 255) / 256, 256, 0, st>>>((const uint32_t *)b_gated.p, nq, P.knn_k, same_set, batch == 0 && r == 0 ? 1 : 0, choice[cur],
+                                                  choice[cur ^ 1], changed + r);
       cur ^= 1;
     }
-    uint32_t hc8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    WC_HIP(ctx, hipMemcpyAsync(hc8, changed, 32, hipMemcpyDeviceToHost, st));
     // 5. compact in query order
     if (batch > 0) WC_HIP(ctx, hipMemsetAsync(status, 0, 4, st));  // (the count of the previous, unconverged, attempt)
-    k_flags<<<(nq + 255) / 256, 256, 0, st>>>(choice[cur], nq, flags);
     {
       size_t tmp = b_scan.cap;
-      WC_HIP(ctx, rocprim::exclusive_scan(b_scan.p, tmp, flags, offsets, 0u, (size_t)nq, rocprim::plus<uint32_t>(), st));
+      WC_HIP(ctx, rocprim::exclusive_scan(b_scan.p, tmp, rocprim::make_transform_iterator((const uint32_t *)choice[cur], ChoiceFlag{}), offsets, 0u, (size_t)nq,
+                                          rocprim::plus<uint32_t>(), st));
     }
     k_emit_pairs<<<(nq + 255) / 256, 256, 0, st>>>(choice[cur], offsets, nq, d_q_surf, (const double *)b_world.p, same_set, d_pairs, cap, status);
     WC_HIP(ctx, hipGetLastError());
-    if (batch == 0) WC_HIP(ctx, hipMemcpyAsync(h_stats, stats, sizeof(h_stats), hipMemcpyDeviceToHost, st));
-    WC_HIP(ctx, hipMemcpyAsync(ctx->h_status, status, 8, hipMemcpyDeviceToHost, st));
+    WC_HIP(ctx, hipMemcpyAsync((void *)h_ctl, status, 56 * 4, hipMemcpyDeviceToHost, st));
     WC_HIP(ctx, hipStreamSynchronize(st));
     const uint32_t hc = hc8[rounds - 1];
     if (match_dbg)
@@ -441,11 +445,12 @@ static int match_impl(wc_ctx *ctx, const wc_surfel *d_q_surf, const wc_pose *d_q
     fprintf(stderr, "[match] same %d nq %u nt %u: host enqueue of the build %.0f us, launch %.0f us, launch -> done %.0f us (k_knn_tree by events %.0f us)\n",
             same_set, nq, nt, us(t_entry, t_prep), us(t_prep, t_launched), us(t_launched, t_end), ms * 1e3);
   }
-  *h_n_pairs = ctx->h_status[0];
-  if (ctx->h_status[1] & 4u) return wc_fail(ctx, WC_ERR_ARG, "non-finite surfel centre or normal");
-  if (ctx->h_status[1] & 8u) return wc_fail(ctx, WC_ERR_NUMERIC, "wc_match: traversal stack overflow (internal)");
-  if (ctx->h_status[1] & 2u) return wc_fail(ctx, WC_ERR_ORDER, "fixed-window surfel newer than its sliding-window match");
-  if (ctx->h_status[0] > cap) return wc_fail(ctx, WC_ERR_CAPACITY, "pair capacity %llu < %u", (unsigned long long)cap, ctx->h_status[0]);
+  const uint32_t n_found = h_ctl[0], fl = h_ctl[1];
+  *h_n_pairs = n_found;
+  if (fl & 4u) return wc_fail(ctx, WC_ERR_ARG, "non-finite surfel centre or normal");
+  if (fl & 8u) return wc_fail(ctx, WC_ERR_NUMERIC, "wc_match: traversal stack overflow (internal)");
+  if (fl & 2u) return wc_fail(ctx, WC_ERR_ORDER, "fixed-window surfel newer than its sliding-window match");
+  if (n_found > cap) return wc_fail(ctx, WC_ERR_CAPACITY, "pair capacity %llu < %u", (unsigned long long)cap, n_found);
   return WC_OK;
 }
 
