@@ -137,9 +137,11 @@ inline int wc_ensure(wc_ctx *ctx, wc_buf &b, size_t bytes) {
     b.p = nullptr;
     b.cap = 0;
   }
-  // (half as much again: a window that grows by a sweep per call - the facade's first seconds - re-allocated several buffers on EVERY
-  // call with an eighth of slack, 0.6 - 1.3 ms of hipFree / hipMalloc per sweep; 288 GB of HBM make the slack free)
-  size_t want = bytes + bytes / 2 + 256;
+  // (slack: a window that grows by a sweep per call - the facade's first seconds - re-allocated several buffers on EVERY call with an
+  // eighth of slack, and still ~14 of a context's ~70 per sweep with half - 0.5 - 1 ms of hipStreamSynchronize / hipFree / hipMalloc;
+  // now no buffer is smaller than 4 MB, one below 64 MB doubles, a larger one grows by half: 288 GB of HBM make the slack free)
+  size_t want = bytes < ((size_t)64 << 20) ? 2 * bytes : bytes + bytes / 2;
+  if (want < ((size_t)4 << 20)) want = (size_t)4 << 20;
   WC_HIP(ctx, hipMalloc(&b.p, want));
   b.cap = want;
   return WC_OK;
