@@ -43,6 +43,9 @@ struct wc_ctx {
   // pinned host mailbox
   uint32_t *h_status = nullptr;  // pinned, 128 words: [0] n_emitted, [1] flags, ... ; [64..95]: the matcher's read-backs (round words, walk statistics)
   unsigned long long mail_ticket = 0;  // last ticket handed to a k_post_reduce (window.hip: wait_mail)
+  wc_buf b_stage;                 // wc_d2h_strided: the packed elements on the device
+  void *h_stage = nullptr;        // ... and their pinned landing place
+  size_t h_stage_cap = 0;
   double *h_mail = nullptr;      // pinned: 64 doubles of mailbox (costs etc.) + 4096 doubles of staging (the window's unknowns)
   // pending extraction (enqueue/finish split)
   struct {

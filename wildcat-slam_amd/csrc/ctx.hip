@@ -127,6 +127,8 @@ extern "C" void wc_ctx_destroy(wc_ctx *ctx) {
     if (b.p) (void)hipFree(b.p);
   if (ctx->h_status) (void)hipHostFree(ctx->h_status);
   if (ctx->h_mail) (void)hipHostFree(ctx->h_mail);
+  if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
+  if (ctx->b_stage.p) (void)hipFree(ctx->b_stage.p);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
   for (hipEvent_t e : ctx->ex_ev)
@@ -193,11 +195,36 @@ extern "C" int wc_d2d(wc_ctx *ctx, void *d_dst, const void *d_src, size_t bytes)
   return WC_OK;
 }
 // one field out of every record of an array (e.g. the timestamps of fresh surfels): n elements of elem_bytes, src_stride apart
+__global__ void __launch_bounds__(256) k_pack_strided(const uint32_t *src, uint32_t ew, uint32_t sw, uint64_t words, uint32_t *dst) {
+  const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (w < words) dst[w] = src[(w / ew) * sw + (w % ew)];
+}
 extern "C" int wc_d2h_strided(wc_ctx *ctx, void *h_dst, const void *d_src, size_t elem_bytes, size_t src_stride, size_t n) {
   wc_dev_guard dg_(ctx);
   if (!ctx || (n && (!h_dst || !d_src)) || elem_bytes == 0 || src_stride < elem_bytes)
     return wc_fail(ctx, WC_ERR_ARG, "%s: null or out-of-range argument", __func__);
   if (!n) return WC_OK;
+  // word-sized elements (the facade's read-back of the new surfels' stamps, 8 of 144 bytes each): packed by a kernel, ONE contiguous
+  // copy into pinned memory, a host memcpy - a 2-D copy into pageable memory took ~80 us for 7 000 elements
+  if (elem_bytes % 4 == 0 && src_stride % 4 == 0 && ((uintptr_t)d_src % 4) == 0 && n * elem_bytes <= ((size_t)64 << 20)) {
+    const size_t bytes = n * elem_bytes;
+    WC_TRY(wc_ensure(ctx, ctx->b_stage, bytes));
+    if (ctx->h_stage_cap < bytes) {
+      if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
+      ctx->h_stage = nullptr, ctx->h_stage_cap = 0;
+      const size_t want = std::max<size_t>(2 * bytes, (size_t)1 << 20);
+      WC_HIP(ctx, hipHostMalloc(&ctx->h_stage, want));
+      ctx->h_stage_cap = want;
+    }
+    const uint32_t ew = (uint32_t)(elem_bytes / 4), sw = (uint32_t)(src_stride / 4);
+    const uint64_t words = (uint64_t)n * ew;
+    k_pack_strided<<<(unsigned)((words + 255) / 256), 256, 0, ctx->stream>>>((const uint32_t *)d_src, ew, sw, words, (uint32_t *)ctx->b_stage.p);
+    WC_HIP(ctx, hipGetLastError());
+    WC_HIP(ctx, hipMemcpyAsync(ctx->h_stage, ctx->b_stage.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    WC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    std::memcpy(h_dst, ctx->h_stage, bytes);
+    return WC_OK;
+  }
   WC_HIP(ctx, hipMemcpy2DAsync(h_dst, elem_bytes, d_src, src_stride, elem_bytes, n, hipMemcpyDeviceToHost, ctx->stream));
   WC_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return WC_OK;

@@ -108,6 +108,8 @@ struct wc_window_state {
   // pinned staging of the two families' segment heads + status words, and the events that say a family's copy has landed
   void *h_pin = nullptr;
   size_t h_pin_cap = 0;
+  void *h_up = nullptr;  // pinned staging of wc_window_build's uploads (pieces, source lists, IMU records)
+  size_t h_up_cap = 0;
   hipEvent_t fam_done[2] = {nullptr, nullptr};
   bool built = false;
 };
@@ -1825,6 +1827,7 @@ void wc_window_free(wc_ctx *ctx) {
   for (wc_buf *b : all)
     if (b->p) (void)hipFree(b->p);
   if (W->h_pin) (void)hipHostFree(W->h_pin);
+  if (W->h_up) (void)hipHostFree(W->h_up);
   for (hipEvent_t e : W->fam_done)
     if (e) (void)hipEventDestroy(e);
   delete W;
@@ -2106,12 +2109,39 @@ static int window_build_impl(wc_ctx *ctx, const wc_surfel *d_sld_surf, const wc_
             gsrc.size(), pieces.size());
   }
   auto t_c = tnow();
-  WC_TRY(upload(ctx, W->heavy, heavy));
-  WC_TRY(upload(ctx, W->pieces, pieces));
-  WC_TRY(upload(ctx, W->src, src));
-  WC_TRY(upload(ctx, W->src_begin, src_begin));
-  WC_TRY(upload(ctx, W->gsrc, gsrc));
-  WC_TRY(upload(ctx, W->gsrc_begin, gsrc_begin));
+  {
+    // the lists that exist only now go through ONE pinned staging buffer and are enqueued from there: a copy out of a pageable vector is
+    // staged by the runtime and returns when it is through - 10 - 35 us each, back to back ~0.1 ms of a small window's build (kernel
+    // trace of the facade: build 0.42 -> 0.23 ms).  The IMU records and the pair offsets, known early, still leave as plain copies
+    // while the host waits for the families' segment heads anyway.
+    struct Up {
+      wc_buf *b;
+      const void *h;
+      size_t bytes;
+    };
+    const Up ups[] = {{&W->heavy, heavy.data(), heavy.size() * 4},                      {&W->pieces, pieces.data(), pieces.size() * sizeof(Piece)},
+                      {&W->src, src.data(), src.size() * sizeof(Src)},                  {&W->src_begin, src_begin.data(), src_begin.size() * 4},
+                      {&W->gsrc, gsrc.data(), gsrc.size() * sizeof(GSrc)},              {&W->gsrc_begin, gsrc_begin.data(), gsrc_begin.size() * 4}};
+    size_t total = 0;
+    for (const Up &u : ups) total += (u.bytes + 255) / 256 * 256;
+    if (W->h_up_cap < total) {
+      WC_HIP(ctx, hipStreamSynchronize(ctx->stream));  // (copies of an earlier build out of the old buffer)
+      if (W->h_up) (void)hipHostFree(W->h_up);
+      W->h_up = nullptr, W->h_up_cap = 0;
+      const size_t want = std::max<size_t>(2 * total, (size_t)4 << 20);
+      WC_HIP(ctx, hipHostMalloc(&W->h_up, want));
+      W->h_up_cap = want;
+    }
+    size_t o = 0;
+    for (const Up &u : ups) {
+      WC_TRY(wc_ensure(ctx, *u.b, std::max<size_t>(u.bytes, 16)));
+      if (u.bytes) {
+        std::memcpy((char *)W->h_up + o, u.h, u.bytes);
+        WC_HIP(ctx, hipMemcpyAsync(u.b->p, (char *)W->h_up + o, u.bytes, hipMemcpyHostToDevice, ctx->stream));
+      }
+      o += (u.bytes + 255) / 256 * 256;
+    }
+  }
 
   // (the buffers whose size goes with the SQUARE of the sample states are allocated for at least 96 of them - the reference's default
   // window has 82 -: a window that gains ten sample states per sweep, the facade's first seconds, otherwise re-allocates four of them on
