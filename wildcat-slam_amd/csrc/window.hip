@@ -481,7 +481,11 @@ __global__ void __launch_bounds__(1024) k_seg_heads(const uint32_t *keys, uint32
 //          record it reads 8 values and does 16 products.  One thread per output entry (2 LDS reads per product) made
 //          this phase LDS-bandwidth bound at ~190 us per linearisation; an fp64-MFMA variant is no faster (fp64 MFMA has
 //          the vector rate and a 25-wide Gram wastes 58 % of 32x32 tiles).  The slices are added in fixed order: no
-//          atomics, bitwise reproducible.
+//          atomics, bitwise reproducible.  Round 4 built the matrix-core form again, in 16 x 16 tiles (v_mfma_f64_16x16x4: one
+//          double per lane and operand, a quarter of the LDS traffic; a wavefront takes every fourth group of four records, two sets
+//          of accumulators, operands requested a step ahead): correct (all parity tests), and the same 0.160 ms per linearisation in
+//          an A/B on one box - 48 matrix instructions of 64 clocks per wavefront are the 8.5 k clocks the register blocks took, three
+//          tiles for 325 of their 768 entries.
 // where entry e of a piece's packed upper triangle sits in a slice's partial blocks (offset in doubles; 0xFFFF: the corner, which
 // carries the piece's cost): a table instead of the closed-form inversion of e -> (i, j) - a square root, two correction steps and
 // the block arithmetic per entry, in the tail every piece pays
