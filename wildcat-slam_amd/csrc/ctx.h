@@ -145,6 +145,8 @@ inline int wc_ensure(wc_ctx *ctx, wc_buf &b, size_t bytes) {
   // now no buffer is smaller than 4 MB, one below 64 MB doubles, a larger one grows by half: 288 GB of HBM make the slack free)
   size_t want = bytes < ((size_t)64 << 20) ? 2 * bytes : bytes + bytes / 2;
   if (want < ((size_t)4 << 20)) want = (size_t)4 << 20;
+  static const bool alloc_dbg = getenv("WC_ALLOC_DEBUG") != nullptr;  // (read once per process)
+  if (alloc_dbg) fprintf(stderr, "[alloc] %zu bytes wanted -> %zu\n", bytes, want);
   WC_HIP(ctx, hipMalloc(&b.p, want));
   b.cap = want;
   return WC_OK;
