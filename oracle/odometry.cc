@@ -110,6 +110,7 @@ struct wco_odom {
   int error = 0;  // a CHECK of the reference would have fired (code = source line of the restatement)
   wc_solve_summary last_summary{};
   uint64_t last_corr[2] = {0, 0};
+  std::vector<double> pair_stamps[2];  // (first, second) surfel stamps of the last sweep's correspondences (test read-out)
   uint64_t last_new_surfels = 0;
 };
 
@@ -331,6 +332,14 @@ extern "C" void wco_odom_add_scan(wco_odom *o, const void *points48, uint64_t n)
     if (!fs.empty())
       ORACLE_CHECK(o, wco_match(&o->P, ss.data(), sp.data(), ss.size(), fs.data(), fp.data(), fs.size(), 0, pu.data(), pu.size(), &nu) == 0);
     o->last_corr[0] = nb, o->last_corr[1] = nu;
+    for (int which = 0; which < 2; ++which) {
+      o->pair_stamps[which].clear();
+      const std::vector<wc_pair> &pr = which ? pu : pb;
+      for (uint64_t i = 0; i < (which ? nu : nb); ++i) {
+        o->pair_stamps[which].push_back(which ? fs[(size_t)pr[i].first].t : ss[(size_t)pr[i].first].t);
+        o->pair_stamps[which].push_back(ss[(size_t)pr[i].second].t);
+      }
+    }
     // 5. the problem + solve (cc:541-562)
     std::vector<double> ts, x;
     for (const Sample &s : o->samples) {
@@ -407,6 +416,11 @@ extern "C" void wco_odom_stats(const wco_odom *o, double *stats) {
   stats[7] = o->last_summary.termination;
   stats[8] = (double)o->last_new_surfels;
   stats[9] = (double)o->imu_states.size();
+}
+extern "C" uint64_t wco_odom_pair_stamps(const wco_odom *o, int which, double *out, uint64_t cap) {
+  const std::vector<double> &v = o->pair_stamps[which ? 1 : 0];
+  for (uint64_t i = 0; i < v.size() && i < cap; ++i) out[i] = v[i];
+  return v.size();
 }
 // timestamps of the fixed window in its deque order (newest first, Q11) and of the sliding window
 extern "C" uint64_t wco_odom_window_times(const wco_odom *o, int fixed, double *out, uint64_t cap) {

@@ -285,6 +285,14 @@ class Odometry:
         lib().wco_odom_stats(self._h, R.ptr(s))
         return dict(zip(("sld_surfels", "fix_surfels", "binary", "unary", "lm_iters", "cost0", "cost1", "termination", "new_surfels", "imu_states"), s.tolist()))
 
+    def pair_stamps(self, which):
+        """(first, second) surfel timestamps of the last sweep's correspondences (0: sliding, 1: fixed window) -> float64[n, 2]"""
+        lib().wco_odom_pair_stamps.restype = C.c_uint64
+        n = int(lib().wco_odom_pair_stamps(self._h, C.c_int(which), None, C.c_uint64(0)))
+        out = np.zeros(max(n, 2))
+        lib().wco_odom_pair_stamps(self._h, C.c_int(which), R.ptr(out), C.c_uint64(n))
+        return out[:n].reshape(-1, 2)
+
     def window_times(self, fixed):
         n = int(lib().wco_odom_window_times(self._h, C.c_int(1 if fixed else 0), None, C.c_uint64(0)))
         out = np.zeros(max(n, 1))

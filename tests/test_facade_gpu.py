@@ -128,6 +128,41 @@ def _feed(odo, ref, msgs, imu, on_sweep):
             on_sweep(ref.sweeps())
 
 
+def _pair_set_difference(a, b, tol=1e-5):
+    """pairs of one run that have no partner in the other, matched on their two surfel TIMESTAMPS within tol (surfel indices mean
+    nothing across arithmetics: the default path's stamps are the correctly rounded means, <= 2e-6 s from the reference's running
+    sums, and two surfels closer than that swap places).  a, b: float64[n, 2] -> (only in a, only in b)"""
+    a, b = a[np.lexsort((a[:, 1], a[:, 0]))], b[np.lexsort((b[:, 1], b[:, 0]))]
+    if len(a) == len(b) and (len(a) == 0 or np.abs(a - b).max() <= tol):
+        return 0, 0  # the rule: same pairs in the same order
+    # the exception (two first surfels within 2e-6 s of each other sort differently, or a pair is missing): match by buckets
+    import collections
+
+    w = max(4 * tol, 1e-9)
+    left = collections.defaultdict(list)
+    for t0, t1 in b:
+        left[(int(t0 // w), int(t1 // w))].append((t0, t1))
+    only_a = 0
+    for t0, t1 in a:
+        k0, k1 = int(t0 // w), int(t1 // w)
+        hit = False
+        for d0 in (-1, 0, 1):
+            for d1 in (-1, 0, 1):
+                lst = left.get((k0 + d0, k1 + d1))
+                if lst:
+                    for i, (u0, u1) in enumerate(lst):
+                        if abs(u0 - t0) <= tol and abs(u1 - t1) <= tol:
+                            lst.pop(i)
+                            hit = True
+                            break
+                if hit:
+                    break
+            if hit:
+                break
+        only_a += 0 if hit else 1
+    return only_a, sum(len(v) for v in left.values())
+
+
 def _state_diff(a, b):
     return max(np.abs(a[:, 1:4] - b[:, 1:4]).max(), np.abs(a[:, 4:8] - b[:, 4:8]).max(), np.abs(a[:, 8:14] - b[:, 8:14]).max())
 
@@ -149,7 +184,8 @@ def test_facade_each_sweep_against_the_oracle_resynchronised(gpu, oracle, exact_
     odo.set_exact_sums(exact_sums)
     odo.set_quirks(quirks)
     ref.set_quirks(quirks)
-    per_sweep, last, pair_diff = [], {}, []
+    odo.set_keep_pair_stamps(True)
+    per_sweep, last, pair_diff, pair_sets = [], {}, [], []
 
     def on_sweep(k):
         a, b = odo.samples(), ref.samples()
@@ -165,6 +201,13 @@ def test_facade_each_sweep_against_the_oracle_resynchronised(gpu, oracle, exact_
             # the same in both runs.  What can differ is a gate within 2e-6 s / 3e-10 of its threshold: measured 0 in all 17 sweeps
             # with and without the quirks; two are allowed.
             assert sa[key] == sb[key] if exact_sums else abs(sa[key] - sb[key]) <= 2, (k, key, sa[key], sb[key])
+        # ... and the pair SETS themselves (equal counts do not show equal pairs): every correspondence of the
+        # facade has its partner in the oracle's list - the same two surfels, identified by their timestamps - and vice versa, up
+        # to the two threshold cases allowed above
+        for which in (0, 1):
+            only_f, only_o = _pair_set_difference(odo.pair_stamps(which), ref.pair_stamps(which), 0.0 if exact_sums else 1e-5)
+            pair_sets.append((k, which, only_f, only_o))
+            assert only_f + only_o <= (0 if exact_sums else 4), (k, which, only_f, only_o)
         d = _state_diff(a, b)
         per_sweep.append((k, float("%.2g" % d)))
         pair_diff.append((int(sa["binary"] - sb["binary"]), int(sa["unary"] - sb["unary"])))
@@ -180,7 +223,8 @@ def test_facade_each_sweep_against_the_oracle_resynchronised(gpu, oracle, exact_
     _feed(odo, ref, msgs, imu, on_sweep)
     fast, exact = odo.extract_paths()
     print("arithmetic", "exact" if exact_sums else "default", "quirks", quirks, "sweeps on the fast / exact path", fast, exact,
-          "per-sweep worst sample-state difference", per_sweep, "correspondence-count differences (binary, unary) per sweep", pair_diff)
+          "per-sweep worst sample-state difference", per_sweep, "correspondence-count differences (binary, unary) per sweep", pair_diff,
+          "correspondences without a partner in the other run (sweep, family, facade only, oracle only), non-zero entries", [p for p in pair_sets if p[2] or p[3]])
     # the arithmetic asked for is the one that ran (a default-arithmetic sweep may fall back when a gate lies in the noise band)
     assert fast + exact == len(per_sweep) and (fast == 0 if exact_sums else fast >= 0.8 * len(per_sweep))
     assert len(per_sweep) >= 15 and last["fix_surfels"] > 1000 and last["unary"] > 1000

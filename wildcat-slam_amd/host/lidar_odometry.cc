@@ -563,6 +563,21 @@ void LidarOdometry::AddLidarScan(const pcl::PointCloud<hilti_ros::Point>::Ptr &m
     WC_CALL(wc_match_pair(ctx_, d_surf_ + sld_begin_, d_pose_ + sld_begin_, n_sld, d_fix_surf_ + fix_start_, d_fix_pose_ + fix_start_, n_fix,
                           d_pairs_sld_, cap_surfels_, &n_b, d_pairs_fix_, cap_surfels_, &n_u));
     last_corr_[0] = n_b, last_corr_[1] = n_u;
+    if (keep_pair_stamps_) {  // (test hook: outside the stage clocks' interest, a few strided read-backs)
+      std::vector<double> ts_sld(n_sld), ts_fix(n_fix);
+      if (n_sld) WC_CALL(wc_d2h_strided(ctx_, ts_sld.data(), d_surf_ + sld_begin_, 8, sizeof(wc_surfel), n_sld));
+      if (n_fix) WC_CALL(wc_d2h_strided(ctx_, ts_fix.data(), d_fix_surf_ + fix_start_, 8, sizeof(wc_surfel), n_fix));
+      for (int which = 0; which < 2; ++which) {
+        const uint64_t n = which ? n_u : n_b;
+        std::vector<wc_pair> pr(n);
+        if (n) WC_CALL(wc_d2h(ctx_, pr.data(), which ? d_pairs_fix_ : d_pairs_sld_, n * sizeof(wc_pair)));
+        pair_stamps_[which].clear();
+        for (const wc_pair &q : pr) {
+          pair_stamps_[which].push_back(which ? ts_fix[(size_t)q.first] : ts_sld[(size_t)q.first]);  // (fixed window: first = its surfel)
+          pair_stamps_[which].push_back(ts_sld[(size_t)q.second]);
+        }
+      }
+    }
     lap(2);
     // 5. solve poses in windows (:541-562)
     std::vector<double> ts, x;

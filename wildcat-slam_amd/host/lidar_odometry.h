@@ -56,6 +56,10 @@ class LidarOdometry {
   const double *last_stage_ms() const { return last_stage_ms_; }
   int last_lm_iterations() const { return last_lm_iterations_; }
   uint64_t last_correspondences(int which) const { return last_corr_[which]; }
+  // test hook: keep, for the last completed sweep's last outer iteration, the two surfel timestamps of every correspondence
+  // (which = 0: sliding window, 1: fixed window) - what a comparison with another run can match pairs on when surfel ORDER differs
+  void set_keep_pair_stamps(bool on) { keep_pair_stamps_ = on; }
+  const std::vector<double> &last_pair_stamps(int which) const { return pair_stamps_[which]; }
   // sweeps whose extraction was completed by the default (integer-moment) path / by the reference-order path (configured, or
   // fallen back to because a gate lay inside the reference's own rounding noise)
   int sweeps_fast_path() const { return sweeps_fast_; }
@@ -138,4 +142,6 @@ class LidarOdometry {
   double last_stage_ms_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   int last_lm_iterations_ = 0;  // over the sweep's outer iterations
   uint64_t last_corr_[2] = {0, 0};
+  bool keep_pair_stamps_ = false;
+  std::vector<double> pair_stamps_[2];  // (first, second) stamps, pair after pair
 };

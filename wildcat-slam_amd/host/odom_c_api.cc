@@ -77,6 +77,13 @@ uint64_t wc_odom_fixed_times(void *h, double *out, uint64_t cap) {
   for (uint64_t i = 0; i < t.size() && i < cap; ++i) out[i] = t[i];
   return t.size();
 }
+// test hook: the surfel timestamps (first, second) of the last sweep's correspondences; which = 0 sliding, 1 fixed window
+void wc_odom_set_keep_pair_stamps(void *h, int on) { ((LidarOdometry *)h)->set_keep_pair_stamps(on != 0); }
+uint64_t wc_odom_pair_stamps(void *h, int which, double *out, uint64_t cap) {
+  const std::vector<double> &v = ((LidarOdometry *)h)->last_pair_stamps(which ? 1 : 0);
+  for (uint64_t i = 0; i < v.size() && i < cap; ++i) out[i] = v[i];
+  return v.size();
+}
 // both setters re-derive the device context's parameters (Q1 / Q3 Jacobians, extraction arithmetic), not only the host flags
 void wc_odom_set_quirks(void *h, int on) {
   ((LidarOdometry *)h)->config().reference_quirks = on != 0;

@@ -621,6 +621,17 @@ class Odometry:
             self.lib.wc_odom_sample(self.h, C.c_uint64(i), R.ptr(out[i]))
         return out
 
+    def set_keep_pair_stamps(self, on):
+        self.lib.wc_odom_set_keep_pair_stamps(self.h, C.c_int(1 if on else 0))
+
+    def pair_stamps(self, which):
+        """test hook: (first, second) surfel timestamps of the last sweep's correspondences (0: sliding, 1: fixed window) -> float64[n, 2]"""
+        self.lib.wc_odom_pair_stamps.restype = C.c_uint64
+        n = int(self.lib.wc_odom_pair_stamps(self.h, C.c_int(which), None, C.c_uint64(0)))
+        out = np.zeros(max(n, 2))
+        self.lib.wc_odom_pair_stamps(self.h, C.c_int(which), R.ptr(out), C.c_uint64(n))
+        return out[:n].reshape(-1, 2)
+
     def fixed_times(self):
         self.lib.wc_odom_fixed_times.restype = C.c_uint64
         n = int(self.lib.wc_odom_fixed_times(self.h, None, C.c_uint64(0)))
