@@ -256,7 +256,7 @@ static int match_impl(wc_ctx *ctx, const wc_surfel *d_q_surf, const wc_pose *d_q
   const uint32_t nq = (uint32_t)nq_, nt = (uint32_t)nt_;
   const wc_params &P = ctx->P;
   hipStream_t st = ctx->stream;
-  wc_buf &b_feat = ctx->b_misc[1], &b_world = ctx->b_misc[2], &b_gated = ctx->b_misc[4], &b_choice = ctx->b_misc[5], &b_aux = ctx->b_misc[6],
+  wc_buf &b_feat = ctx->b_misc[1], &b_world = ctx->b_misc[2], &b_gated = ctx->b_misc[4], &b_choice = ctx->b_misc[5],
          &b_scan = ctx->b_misc[7];
   WC_TRY(wc_ensure(ctx, b_feat, (size_t)nt * 6 * 8));
   WC_TRY(wc_ensure(ctx, b_world, (size_t)nt * 7 * 8));
@@ -264,7 +264,6 @@ static int match_impl(wc_ctx *ctx, const wc_surfel *d_q_surf, const wc_pose *d_q
   WC_TRY(wc_ensure(ctx, b_choice, (size_t)nq * 4 * 4));  // choice[2], flags, offsets
   WC_TRY(wc_ensure(ctx, ctx->b_keys[0], (size_t)nq * 4));
   WC_TRY(wc_ensure(ctx, ctx->b_vals[0], (size_t)nq * 4));
-  WC_TRY(wc_ensure(ctx, b_aux, 256));
   WC_TRY(wc_ensure(ctx, ctx->b_status, 64 * 4));
   // ONE control block - [0] pairs, [1] flags, [32..39] "round r changed something", [40..55] the walk's sampled counts (8 x u64) -:
   // one memset in front of the call's first kernel, one copy to pinned memory behind its last
