@@ -110,7 +110,7 @@ struct wc_window_state {
   size_t h_pin_cap = 0;
   void *h_up = nullptr;  // pinned staging of wc_window_build's uploads (pieces, source lists, IMU records)
   size_t h_up_cap = 0;
-  hipEvent_t fam_done[2] = {nullptr, nullptr};
+  hipEvent_t fam_done[2] = {nullptr, nullptr};  // [0]: segment heads in pinned memory; [1]: the build's last upload has left its staging buffer
   bool built = false;
 };
 
@@ -372,22 +372,39 @@ __device__ __forceinline__ int upper_bound_times(const double *times, int ns, do
   return lo;
 }
 
-// sort keys of the correspondences: (sp1l, sp2l) from std::upper_bound on the sample timestamps (cc:258-268,:303-307)
-__global__ void __launch_bounds__(256) k_pair_keys(const wc_surfel *s1, const wc_surfel *s2, const wc_pair *pairs, uint32_t n,
-                                                  const double *times, int ns, int unary, uint32_t *keys, uint32_t *vals,
+// One family of surfel correspondences as the record kernels see it (binary: both surfels of the sliding window; unary: s1 / p1 the
+// fixed window).  Both families go through ONE chain of launches - keys, sort, records, segment heads - since round 4's last
+// part: two chains of ~120 us of small launches each were most of wc_window_build's 0.40 ms in the odometry step.
+struct FamArgs {
+  const wc_surfel *s1, *s2;
+  const wc_pose *p1, *p2;
+  const wc_pair *pairs;
+  uint32_t n;
+  double *rec;
+  uint32_t *key_out, *orig_out;
+};
+
+// sort keys of the correspondences: (sp1l, sp2l) from std::upper_bound on the sample timestamps (cc:258-268,:303-307).  Binary
+// keys sp1l * ns + sp2l < ns^2, unary keys ns^2 + sp2l: the sorted array holds the binary family first, each family in the order
+// a sort of its own would give (the radix sort is stable, vals ascend).  A flagged record takes its family's key 0.
+__global__ void __launch_bounds__(256) k_pair_keys(FamArgs B, FamArgs U, const double *times, int ns, uint32_t *keys, uint32_t *vals,
                                                   uint32_t *status) {
   const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= n) return;
-  const double t1 = s1[pairs[k].first].t, t2 = s2[pairs[k].second].t;
+  if (k >= B.n + U.n) return;
+  const bool unary = k >= B.n;
+  const uint32_t kl = unary ? k - B.n : k;
+  const wc_pair pr = unary ? U.pairs[kl] : B.pairs[kl];
+  const double t1 = (unary ? U.s1 : B.s1)[pr.first].t, t2 = (unary ? U.s2 : B.s2)[pr.second].t;
   if (!(t1 < t2)) atomicOr(&status[1], 2u);  // CHECK_LT (cc:256,:301)
   const int i2 = upper_bound_times(times, ns, t2);
   int i1 = 1;
   if (!unary) i1 = upper_bound_times(times, ns, t1);
+  const uint32_t base = unary ? (uint32_t)ns * (uint32_t)ns : 0u;
   if (i2 == 0 || i2 == ns || i1 == 0 || i1 == ns) {
     atomicOr(&status[1], 1u);
-    keys[k] = 0;
+    keys[k] = base;
   } else {
-    keys[k] = unary ? (uint32_t)(i2 - 1) : ((uint32_t)(i1 - 1) * (uint32_t)ns + (uint32_t)(i2 - 1));
+    keys[k] = base + (unary ? (uint32_t)(i2 - 1) : ((uint32_t)(i1 - 1) * (uint32_t)ns + (uint32_t)(i2 - 1)));
   }
   vals[k] = k;
 }
@@ -404,25 +421,27 @@ __device__ __forceinline__ void surfel_world(const wc_surfel &s, const wc_pose &
 }
 
 // packed records in sorted order; ctor arithmetic of both surfel factors (cost_functor.h:21-25, :109-113)
-__global__ void __launch_bounds__(256) k_build_records(const wc_surfel *s1, const wc_pose *p1, const wc_surfel *s2,
-                                                      const wc_pose *p2, const wc_pair *pairs, const uint32_t *sorted_idx,
-                                                      const uint32_t *sorted_keys, uint32_t n, const double *times, int ns,
-                                                      int unary, double sigma0_sq, double *rec, uint32_t *key_out,
-                                                      uint32_t *orig_out) {
-  const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= n) return;
-  const uint32_t o = sorted_idx[k];
-  const wc_surfel A = s1[pairs[o].first], Bs = s2[pairs[o].second];
+__global__ void __launch_bounds__(256) k_build_records(FamArgs B, FamArgs U, const uint32_t *sorted_idx, const uint32_t *sorted_keys,
+                                                      const double *times, int ns, double sigma0_sq) {
+  const uint32_t kg = blockIdx.x * blockDim.x + threadIdx.x;
+  if (kg >= B.n + U.n) return;
+  const bool unary = kg >= B.n;  // (every binary key sorts in front of every unary key)
+  const FamArgs F = unary ? U : B;
+  const uint32_t k = unary ? kg - B.n : kg;
+  const uint32_t o = sorted_idx[kg] - (unary ? B.n : 0u);
+  const wc_pair pr = F.pairs[o];
+  const wc_surfel A = F.s1[pr.first], Bs = F.s2[pr.second];
   V3 a1, pos1, a2, pos2;
   M3 c1, c2;
-  surfel_world(A, p1[pairs[o].first], a1, pos1, c1);
-  surfel_world(Bs, p2[pairs[o].second], a2, pos2, c2);
+  surfel_world(A, F.p1[pr.first], a1, pos1, c1);
+  surfel_world(Bs, F.p2[pr.second], a2, pos2, c2);
   double ev[3];
   M3 V;
   eig3_sym(c1 + c2, ev, V);
   const double w = 1 / sqrt(sigma0_sq + ev[0]);
-  const uint32_t key = sorted_keys[k];
-  const size_t N = n;
+  const uint32_t key = sorted_keys[kg] - (unary ? (uint32_t)ns * (uint32_t)ns : 0u);
+  const size_t N = F.n;
+  double *rec = F.rec;
   rec[0 * N + k] = V.m[0][0], rec[1 * N + k] = V.m[1][0], rec[2 * N + k] = V.m[2][0];
   rec[3 * N + k] = w;
   if (!unary) {
@@ -433,16 +452,16 @@ __global__ void __launch_bounds__(256) k_build_records(const wc_surfel *s1, cons
     rec[10 * N + k] = dp.x, rec[11 * N + k] = dp.y, rec[12 * N + k] = dp.z;
     rec[13 * N + k] = (A.t - times[sp1l]) / (times[sp1l + 1] - times[sp1l]);
     rec[14 * N + k] = (Bs.t - times[sp2l]) / (times[sp2l + 1] - times[sp2l]);
-    key_out[k] = (uint32_t)sp1l | ((uint32_t)sp2l << 16);
+    F.key_out[k] = (uint32_t)sp1l | ((uint32_t)sp2l << 16);
   } else {
     const int sp2l = (int)key;
     rec[4 * N + k] = a2.x, rec[5 * N + k] = a2.y, rec[6 * N + k] = a2.z;
     const V3 d = (a1 + pos1) - pos2;  // c1_world - p2
     rec[7 * N + k] = d.x, rec[8 * N + k] = d.y, rec[9 * N + k] = d.z;
     rec[10 * N + k] = (Bs.t - times[sp2l]) / (times[sp2l + 1] - times[sp2l]);
-    key_out[k] = (uint32_t)sp2l;
+    F.key_out[k] = (uint32_t)sp2l;
   }
-  orig_out[k] = o;
+  F.orig_out[k] = o;
 }
 
 // segment heads of a sorted key array (unordered append; the host sorts the few thousand entries).  One append per
@@ -1486,7 +1505,7 @@ __device__ __forceinline__ void chol_lead(const double *A, int ld, int k, int nb
   }
 }
 
-__global__ void __launch_bounds__(256) k_chol_step(double *A, int ld, int k, int nblk, double *Lmat, double *Linv, int *fail) {
+__global__ void __launch_bounds__(256) k_chol_step(double *A, int ld, int k, int nblk, double *Lmat, double *Linv, int *fail, int n_real) {
   __shared__ double sA[64][kNB + 1];
   __shared__ double sLi[64][kNB + 1];
   __shared__ double sLj[64][kNB + 1];
@@ -1499,6 +1518,10 @@ __global__ void __launch_bounds__(256) k_chol_step(double *A, int ld, int k, int
   // tiles x (tiles + 1) grid whose upper half returned at once had up to 600 workgroups for 277 real ones: with more than
   // 256 of them the dispatcher put a tile onto the lead's CU and the lead took 9 us instead of 7 - the first 17 steps.)
   if (blockIdx.x == 0) {
+    // (a next diagonal block that holds only the augmented row and padding - the unknowns fill whole blocks, e.g. 64 sample states -
+    // is never used: the back substitution stops in front of it, z's last columns come from this launch's tile.  No lead, no
+    // 5 us factor in the last step's chain.)
+    if ((k + 1) * kNB >= n_real) return;
     chol_lead(A, ld, k, nblk, Lmat, Linv, fail, sA, sX, sLi, sLj);
     return;
   }
@@ -1790,20 +1813,20 @@ struct Seg {
   uint32_t start, count, key;
 };
 
-// One family's segment search in flight: head detection and the copy of (status words, head slots) into pinned memory are
-// enqueued by build_family; collect_family waits for the family's event and orders the heads on the host.  Both families
-// are enqueued before the first wait (one idle gap of the device per build instead of two; the host picks the IMU factors
-// in the meantime).
+// The segment search of both families in flight: head detection and the copy of (status words, head slots) into pinned memory are
+// enqueued by build_families; collect_families waits for the event and orders the heads on the host (the host picks the IMU
+// factors in the meantime).
 struct FamilyJob {
-  uint32_t n = 0, cap = 0;
+  uint32_t nb = 0, nu = 0, cap = 0;
+  int ns = 0;
   const uint32_t *h_st = nullptr;
   const std::pair<uint32_t, uint32_t> *h_heads = nullptr;
   hipEvent_t done = nullptr;
 };
 
-int collect_family(wc_ctx *ctx, const FamilyJob &J, std::vector<Seg> &segs) {
-  segs.clear();
-  if (J.n == 0) return WC_OK;
+int collect_families(wc_ctx *ctx, const FamilyJob &J, std::vector<Seg> &segs_b, std::vector<Seg> &segs_u) {
+  segs_b.clear(), segs_u.clear();
+  if (J.nb + J.nu == 0) return WC_OK;
   WC_HIP(ctx, hipEventSynchronize(J.done));
   const uint32_t *st = J.h_st;
   if (st[1] & 2u) return wc_fail(ctx, WC_ERR_ORDER, "correspondence is not (older, newer)");
@@ -1812,9 +1835,16 @@ int collect_family(wc_ctx *ctx, const FamilyJob &J, std::vector<Seg> &segs) {
   if (nh > J.cap) return wc_fail(ctx, WC_ERR_RANGE, "more key segments (%u) than distinct keys (%u)", nh, J.cap);
   std::vector<std::pair<uint32_t, uint32_t>> heads(J.h_heads, J.h_heads + nh);
   std::sort(heads.begin(), heads.end());
+  const uint32_t ns = (uint32_t)J.ns, ubase = ns * ns;
   for (uint32_t i = 0; i < nh; ++i) {
-    const uint32_t end = (i + 1 < nh) ? heads[i + 1].first : J.n;
-    segs.push_back({heads[i].first, end - heads[i].first, heads[i].second});
+    const uint32_t pos = heads[i].first, sk = heads[i].second;
+    const bool unary = pos >= J.nb;  // (a key of the other family at the boundary is a head of its own: no segment straddles it)
+    const uint32_t fam_end = unary ? J.nb + J.nu : J.nb;
+    const uint32_t end = (i + 1 < nh && heads[i + 1].first < fam_end) ? heads[i + 1].first : fam_end;
+    if (unary)
+      segs_u.push_back({pos - J.nb, end - pos, sk - ubase});
+    else
+      segs_b.push_back({pos, end - pos, (sk / ns) | ((sk % ns) << 16)});
   }
   return WC_OK;
 }
@@ -1840,47 +1870,49 @@ void wc_window_free(wc_ctx *ctx) {
 
 namespace {
 
-// enqueue one family of surfel records (binary or unary): keys -> sort -> packed records -> segment heads -> copy to the
-// family's half of the pinned staging area
-int build_family(wc_ctx *ctx, wc_window_state *W, bool unary, const wc_surfel *s1, const wc_pose *p1, const wc_surfel *s2,
-                 const wc_pose *p2, const wc_pair *pairs, uint32_t n, wc_buf &rec, wc_buf &key, wc_buf &orig, FamilyJob &J) {
+// enqueue the surfel records of both families (binary, unary): keys -> sort -> packed records -> segment heads -> copy to the
+// pinned staging area.  ONE chain for both (FamArgs): the sorted order holds the binary family first.
+int build_families(wc_ctx *ctx, wc_window_state *W, const FamArgs &B0, const FamArgs &U0, FamilyJob &J) {
   J = FamilyJob{};
+  const uint32_t nb = B0.n, nu = U0.n, n = nb + nu;
   if (n == 0) return WC_OK;
-  const int fam = unary ? 1 : 0;
-  const int nf = unary ? 11 : 15;
-  const uint64_t maxkey = unary ? (uint64_t)W->ns : (uint64_t)W->ns * W->ns;
-  const uint32_t cap = (uint32_t)std::min<uint64_t>(n, maxkey + 1);  // as many head slots as there can be distinct keys
+  const uint64_t ns = (uint64_t)W->ns, maxkey = ns * ns + ns;
+  const uint32_t cap = (uint32_t)(std::min<uint64_t>(nb, ns * ns + 1) + std::min<uint64_t>(nu, ns + 1));  // as many head slots as there can be distinct keys
   WC_TRY(wc_ensure(ctx, W->keys_tmp[0], (size_t)n * 4));
   WC_TRY(wc_ensure(ctx, W->keys_tmp[1], (size_t)n * 4));
   WC_TRY(wc_ensure(ctx, W->vals_tmp[0], (size_t)n * 4));
   WC_TRY(wc_ensure(ctx, W->vals_tmp[1], (size_t)n * 4));
-  WC_TRY(wc_ensure(ctx, rec, (size_t)n * nf * 8));
-  WC_TRY(wc_ensure(ctx, key, (size_t)n * 4));
-  WC_TRY(wc_ensure(ctx, orig, (size_t)n * 4));
+  WC_TRY(wc_ensure(ctx, W->brec, std::max<size_t>((size_t)nb * 15 * 8, 16)));
+  WC_TRY(wc_ensure(ctx, W->bkey, std::max<size_t>((size_t)nb * 4, 16)));
+  WC_TRY(wc_ensure(ctx, W->borig, std::max<size_t>((size_t)nb * 4, 16)));
+  WC_TRY(wc_ensure(ctx, W->urec, std::max<size_t>((size_t)nu * 11 * 8, 16)));
+  WC_TRY(wc_ensure(ctx, W->ukey, std::max<size_t>((size_t)nu * 4, 16)));
+  WC_TRY(wc_ensure(ctx, W->uorig, std::max<size_t>((size_t)nu * 4, 16)));
   WC_TRY(wc_ensure(ctx, W->status, 64 * 4));
-  if (!W->fam_done[fam]) WC_HIP(ctx, hipEventCreateWithFlags(&W->fam_done[fam], hipEventDisableTiming));
-  uint32_t *d_st = (uint32_t *)W->status.p + 16 * fam;  // (k_pair_keys: word 1 = flags, k_seg_heads: word 2 = heads)
+  if (!W->fam_done[0]) WC_HIP(ctx, hipEventCreateWithFlags(&W->fam_done[0], hipEventDisableTiming));
+  FamArgs B = B0, U = U0;
+  B.rec = (double *)W->brec.p, B.key_out = (uint32_t *)W->bkey.p, B.orig_out = (uint32_t *)W->borig.p;
+  U.rec = (double *)W->urec.p, U.key_out = (uint32_t *)W->ukey.p, U.orig_out = (uint32_t *)W->uorig.p;
+  uint32_t *d_st = (uint32_t *)W->status.p;  // (k_pair_keys: word 1 = flags, k_seg_heads: word 2 = heads)
   WC_HIP(ctx, hipMemsetAsync(d_st, 0, 16 * 4, ctx->stream));
   const unsigned grid = (n + 255) / 256;
-  k_pair_keys<<<grid, 256, 0, ctx->stream>>>(s1, s2, pairs, n, (const double *)W->times_d.p, W->ns, unary ? 1 : 0,
-                                            (uint32_t *)W->keys_tmp[0].p, (uint32_t *)W->vals_tmp[0].p, d_st);
-  // (k_pair_keys' flags are read back with the segment heads: a flagged record gets key 0, so everything downstream is safe)
+  k_pair_keys<<<grid, 256, 0, ctx->stream>>>(B, U, (const double *)W->times_d.p, W->ns, (uint32_t *)W->keys_tmp[0].p, (uint32_t *)W->vals_tmp[0].p, d_st);
+  // (k_pair_keys' flags are read back with the segment heads: a flagged record gets its family's key 0, so everything downstream is safe)
   unsigned bits = 1;
   while ((1ull << bits) < maxkey + 1) ++bits;
   WC_TRY(sort_u32(ctx, W, (uint32_t *)W->keys_tmp[0].p, (uint32_t *)W->keys_tmp[1].p, (uint32_t *)W->vals_tmp[0].p,
                   (uint32_t *)W->vals_tmp[1].p, n, bits));
-  k_build_records<<<grid, 256, 0, ctx->stream>>>(s1, p1, s2, p2, pairs, (const uint32_t *)W->vals_tmp[1].p,
-                                                (const uint32_t *)W->keys_tmp[1].p, n, (const double *)W->times_d.p, W->ns,
-                                                unary ? 1 : 0, W->wp.sigma0_sq, (double *)rec.p, (uint32_t *)key.p, (uint32_t *)orig.p);
-  // heads of family 0 / 1 in the two halves of W->heads (n_b and n_u entries at most)
-  uint32_t *d_heads = (uint32_t *)W->heads.p + (unary ? 2 * (size_t)W->nb : 0);
-  k_seg_heads<<<(n + 1023) / 1024, 1024, 0, ctx->stream>>>((const uint32_t *)key.p, n, d_heads, d_st);
+  k_build_records<<<grid, 256, 0, ctx->stream>>>(B, U, (const uint32_t *)W->vals_tmp[1].p, (const uint32_t *)W->keys_tmp[1].p,
+                                                (const double *)W->times_d.p, W->ns, W->wp.sigma0_sq);
+  // heads of the SORT keys (position in the sorted order, key): the host tells the families apart by position
+  uint32_t *d_heads = (uint32_t *)W->heads.p;
+  k_seg_heads<<<(n + 1023) / 1024, 1024, 0, ctx->stream>>>((const uint32_t *)W->keys_tmp[1].p, n, d_heads, d_st);
   WC_HIP(ctx, hipGetLastError());
-  char *h = (char *)W->h_pin + (size_t)fam * (W->h_pin_cap / 2);
+  char *h = (char *)W->h_pin;
   WC_HIP(ctx, hipMemcpyAsync(h, d_st, 16, hipMemcpyDeviceToHost, ctx->stream));
   WC_HIP(ctx, hipMemcpyAsync(h + 64, d_heads, (size_t)cap * 8, hipMemcpyDeviceToHost, ctx->stream));
-  WC_HIP(ctx, hipEventRecord(W->fam_done[fam], ctx->stream));
-  J.n = n, J.cap = cap, J.h_st = (const uint32_t *)h, J.h_heads = (const std::pair<uint32_t, uint32_t> *)(h + 64), J.done = W->fam_done[fam];
+  WC_HIP(ctx, hipEventRecord(W->fam_done[0], ctx->stream));
+  J.nb = nb, J.nu = nu, J.cap = cap, J.ns = W->ns, J.h_st = (const uint32_t *)h, J.h_heads = (const std::pair<uint32_t, uint32_t> *)(h + 64), J.done = W->fam_done[0];
   return WC_OK;
 }
 
@@ -1920,11 +1952,11 @@ static int window_build_impl(wc_ctx *ctx, const wc_surfel *d_sld_surf, const wc_
   std::vector<Src> src;
   std::vector<GSrc> gsrc;
   std::vector<uint32_t> src_begin, gsrc_begin, heavy, pair_off;
-  struct SyncGuard {
-    hipStream_t s;
-    ~SyncGuard() { (void)hipStreamSynchronize(s); }
-  } guard{ctx->stream};
-  WC_TRY(upload(ctx, W->times_d, W->times));
+  // Nothing enqueued below reads a vector of this scope: what the host builds leaves through the pinned staging buffers (h_up), so the
+  // call returns with its last copies still in flight (the solve is enqueued behind them on the same stream; the closing
+  // hipStreamSynchronize of rounds 1 - 3 was 30 - 40 us of every build).  The next build waits for fam_done[1] before it writes staging.
+  if (W->fam_done[1]) WC_HIP(ctx, hipEventSynchronize(W->fam_done[1]));
+  WC_TRY(upload(ctx, W->times_d, W->times));  // (W->times outlives the copy)
 
   std::vector<Seg> segs_b, segs_u;
   W->nb = (uint32_t)n_pairs_sld;
@@ -1948,11 +1980,12 @@ static int window_build_impl(wc_ctx *ctx, const wc_surfel *d_sld_surf, const wc_
   // (Round 3, measured with WC_WIN_DEBUG: of the odometry step's 0.40 ms build the host waits ~110 us for the binary family's chain
   // - keys, three sort passes of 16 workgroups each, records, segment heads: ~240 us of small launches - and computes for ~65 us;
   // the unary family on a stream of its own took 20 us off, uploads out of pinned memory nothing: one stream, pageable vectors.)
-  FamilyJob job_b, job_u;
-  WC_TRY(build_family(ctx, W, false, d_sld_surf, d_sld_pose, d_sld_surf, d_sld_pose, d_pairs_sld, W->nb, W->brec, W->bkey,
-                      W->borig, job_b));
-  WC_TRY(build_family(ctx, W, true, d_fix_surf, d_fix_pose, d_sld_surf, d_sld_pose, d_pairs_fix, W->nu, W->urec, W->ukey,
-                      W->uorig, job_u));
+  FamilyJob job;
+  {
+    const FamArgs fb{d_sld_surf, d_sld_surf, d_sld_pose, d_sld_pose, d_pairs_sld, W->nb, nullptr, nullptr, nullptr};
+    const FamArgs fu{d_fix_surf, d_sld_surf, d_fix_pose, d_sld_pose, d_pairs_fix, W->nu, nullptr, nullptr, nullptr};
+    WC_TRY(build_families(ctx, W, fb, fu, job));
+  }
 
   // IMU factors (BuildImuResiduals, lidar_odometry.cc:319-363), selected on the host: a few thousand records
   std::vector<Seg> segs_i;
@@ -1974,7 +2007,6 @@ static int window_build_impl(wc_ctx *ctx, const wc_surfel *d_sld_surf, const wc_
     }
   }
   W->ni = (uint32_t)irecs.size();
-  WC_TRY(upload(ctx, W->irec, irecs));
 
   auto t_b = tnow();
   // pieces + the CSR source lists of the gather
@@ -1998,9 +2030,7 @@ static int window_build_impl(wc_ctx *ctx, const wc_surfel *d_sld_surf, const wc_
     for (size_t i = first; i < pieces.size(); ++i) out[pos[kPiece - pieces[i].count]++] = pieces[i];
     std::copy(out.begin(), out.end(), pieces.begin() + first);
   };
-  // the binary family's pieces are cut, ordered and counted into the source lists while the device still works on the
-  // unary family's records
-  WC_TRY(collect_family(ctx, job_b, segs_b));
+  WC_TRY(collect_families(ctx, job, segs_b, segs_u));
   cut(segs_b, 25, true);
   W->npiece_b = (uint32_t)pieces.size();
   by_size(0);
@@ -2021,7 +2051,6 @@ static int window_build_impl(wc_ctx *ctx, const wc_surfel *d_sld_surf, const wc_
       for (int q = p; q < nblk; ++q) src_begin[pair_id(blk[p], blk[q]) + 1]++;
     }
   }
-  WC_TRY(collect_family(ctx, job_u, segs_u));
   cut(segs_u, 13, true);
   W->npiece_u = (uint32_t)pieces.size() - W->npiece_b;
   by_size(W->npiece_b);
@@ -2102,7 +2131,6 @@ static int window_build_impl(wc_ctx *ctx, const wc_surfel *d_sld_surf, const wc_
     pair_off[npairs] = o;
     W->red_H = o;
   }
-  WC_TRY(upload(ctx, W->pair_off, pair_off));
   for (uint32_t i = 0; i < npairs; ++i)
     if (src_begin[i + 1] - src_begin[i] > kHeavySrc) heavy.push_back(i);
   W->nheavy = (uint32_t)heavy.size();
@@ -2116,14 +2144,14 @@ static int window_build_impl(wc_ctx *ctx, const wc_surfel *d_sld_surf, const wc_
   {
     // the lists that exist only now go through ONE pinned staging buffer and are enqueued from there: a copy out of a pageable vector is
     // staged by the runtime and returns when it is through - 10 - 35 us each, back to back ~0.1 ms of a small window's build (kernel
-    // trace of the facade: build 0.42 -> 0.23 ms).  The IMU records and the pair offsets, known early, still leave as plain copies
-    // while the host waits for the families' segment heads anyway.
+    // trace of the facade: build 0.42 -> 0.23 ms).
     struct Up {
       wc_buf *b;
       const void *h;
       size_t bytes;
     };
-    const Up ups[] = {{&W->heavy, heavy.data(), heavy.size() * 4},                      {&W->pieces, pieces.data(), pieces.size() * sizeof(Piece)},
+    const Up ups[] = {{&W->irec, irecs.data(), irecs.size() * sizeof(ImuRec)},          {&W->pair_off, pair_off.data(), pair_off.size() * 4},
+                      {&W->heavy, heavy.data(), heavy.size() * 4},                      {&W->pieces, pieces.data(), pieces.size() * sizeof(Piece)},
                       {&W->src, src.data(), src.size() * sizeof(Src)},                  {&W->src_begin, src_begin.data(), src_begin.size() * 4},
                       {&W->gsrc, gsrc.data(), gsrc.size() * sizeof(GSrc)},              {&W->gsrc_begin, gsrc_begin.data(), gsrc_begin.size() * 4}};
     size_t total = 0;
@@ -2167,7 +2195,8 @@ static int window_build_impl(wc_ctx *ctx, const wc_surfel *d_sld_surf, const wc_
   WC_HIP(ctx, hipMemsetAsync((double *)W->mail.p + 60, 0, 8, ctx->stream));  // k_gather's count of finished g / cost workgroups
   const size_t ncb = (W->nb + 255) / 256 + (W->nu + 255) / 256 + (W->ni + 255) / 256 + 8;
   WC_TRY(wc_ensure(ctx, W->cost_part, ncb * 8));
-  WC_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the uploads above read host vectors of this scope
+  if (!W->fam_done[1]) WC_HIP(ctx, hipEventCreateWithFlags(&W->fam_done[1], hipEventDisableTiming));
+  WC_HIP(ctx, hipEventRecord(W->fam_done[1], ctx->stream));
   if (tdbg) {
     auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
     fprintf(stderr, "[win] build: families + imu %.0f us, pieces + source lists (host) %.0f us, uploads + sync %.0f us\n", us(t_a, t_b), us(t_b, t_c), us(t_c, tnow()));
@@ -2495,10 +2524,28 @@ extern "C" int wc_window_solve(wc_ctx *ctx, double *h_x_inout, wc_solve_summary 
     WC_TRY(wc_ensure(ctx, W->yred, (size_t)(6 * ns_al + kNB + 64) * 8));
   }
 
+  static const bool poll_mail = getenv("WC_LM_SYNC") == nullptr;  // (WC_LM_SYNC=1: wait for the stream instead of the ticket)
+  double *h_mail_dev = nullptr, *h_stage_dev = nullptr;  // device addresses of the pinned mailbox and of its staging area
+  {
+    void *dp = nullptr;
+    if (hipHostGetDevicePointer(&dp, ctx->h_mail, 0) != hipSuccess || !dp) return wc_fail(ctx, WC_ERR_HIP, "pinned mailbox is not device-mapped");
+    h_mail_dev = (double *)dp;
+    h_stage_dev = h_mail_dev + 64;
+  }
   WC_HIP(ctx, hipMemcpyAsync(x, cur.data(), (size_t)n * 8, hipMemcpyHostToDevice, st));
-  WC_TRY(enqueue_linearize(ctx, W, x, 0));
-  k_scale_init<<<(n + 255) / 256, 256, 0, st>>>(H, n, scale);
-  WC_TRY(read_mail(ctx, W, 2));
+  if (poll_mail && !multi_gpu(ctx, W)) {
+    // the first linearisation's cost / max |g| through the pinned mailbox and its ticket, like every later one (the stream
+    // wait of rounds 1 - 3 added the end-of-kernel signal and the runtime's wake-up, ~20 us per solve; k_scale_init runs behind it)
+    const unsigned long long ticket = ++ctx->mail_ticket;
+    WC_TRY(enqueue_linearize(ctx, W, x, 0, /*post=*/true, /*other=*/false, h_mail_dev, ticket));
+    k_scale_init<<<(n + 255) / 256, 256, 0, st>>>(H, n, scale);
+    WC_HIP(ctx, hipGetLastError());
+    WC_TRY(wait_mail(ctx, ticket));
+  } else {
+    WC_TRY(enqueue_linearize(ctx, W, x, 0));
+    k_scale_init<<<(n + 255) / 256, 256, 0, st>>>(H, n, scale);
+    WC_TRY(read_mail(ctx, W, 2));
+  }
   summary->n_linearizations = 1;
   double cost = ctx->h_mail[0], gmax = ctx->h_mail[1];
   summary->initial_cost = cost;
@@ -2517,14 +2564,6 @@ extern "C" int wc_window_solve(wc_ctx *ctx, double *h_x_inout, wc_solve_summary 
   // per iteration instead of two, -0.05 ms of 0.6 at C4), a rejected one has formed an H nobody uses (+0.1 ms).  Its cost and
   // max |g| arrive with the iteration's mailbox, so nothing is pending between iterations.  WC_LM_EVAL_PASS=1: round 2's flow.
   static const bool cand_lin = getenv("WC_LM_EVAL_PASS") == nullptr;
-  static const bool poll_mail = getenv("WC_LM_SYNC") == nullptr;  // (WC_LM_SYNC=1: wait for the stream instead of the ticket)
-  double *h_mail_dev = nullptr, *h_stage_dev = nullptr;  // device addresses of the pinned mailbox and of its staging area
-  {
-    void *dp = nullptr;
-    if (hipHostGetDevicePointer(&dp, ctx->h_mail, 0) != hipSuccess || !dp) return wc_fail(ctx, WC_ERR_HIP, "pinned mailbox is not device-mapped");
-    h_mail_dev = (double *)dp;
-    h_stage_dev = h_mail_dev + 64;
-  }
   auto resolve_pending = [&]() {
     cost = ctx->h_mail[0];
     gmax = ctx->h_mail[1];
@@ -2574,7 +2613,7 @@ extern "C" int wc_window_solve(wc_ctx *ctx, double *h_x_inout, wc_solve_summary 
         k_schur_form<<<dim3((np2 + 255) / 256, 1 + ns + (np2 - npz)), 256, 0, st>>>(H, g, scale, X, n, ns, ldr, np2, ld2, radius, A, diag, Lmat, (double *)W->Linv.p, fail);
         for (int k = 0; k + 1 < nblk2; ++k) {
           const int tiles = ((nblk2 - k - 1) * kNB + 63) / 64;
-          k_chol_step<<<1 + tiles * (tiles + 1) / 2, 256, 0, st>>>(A, ld2, k, nblk2, Lmat, (double *)W->Linv.p, fail);
+          k_chol_step<<<1 + tiles * (tiles + 1) / 2, 256, 0, st>>>(A, ld2, k, nblk2, Lmat, (double *)W->Linv.p, fail, npz);
         }
         const StepArgs sa{x, scale, g, diag, lin_cost(W), xc, mail, h_stage_dev, 0};
         const double *zsrc = Lmat + (size_t)npz * ld2;
@@ -2595,7 +2634,7 @@ extern "C" int wc_window_solve(wc_ctx *ctx, double *h_x_inout, wc_solve_summary 
         }
         for (int k = 0; k + 1 < nblk; ++k) {
           const int tiles = ((nblk - k - 1) * kNB + 63) / 64;
-          k_chol_step<<<1 + tiles * (tiles + 1) / 2, 256, 0, st>>>(A, ld, k, nblk, Lmat, (double *)W->Linv.p, fail);
+          k_chol_step<<<1 + tiles * (tiles + 1) / 2, 256, 0, st>>>(A, ld, k, nblk, Lmat, (double *)W->Linv.p, fail, n);
         }
         {  // back substitution, chunk by chunk from the last block row
           const double *zsrc = Lmat + (size_t)n * ld;
