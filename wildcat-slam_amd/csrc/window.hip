@@ -110,6 +110,7 @@ struct wc_window_state {
   size_t h_pin_cap = 0;
   void *h_up = nullptr;  // pinned staging of wc_window_build's uploads (pieces, source lists, IMU records)
   size_t h_up_cap = 0;
+  bool status_clear = false;  // W->status is zero at rest
   hipEvent_t fam_done[2] = {nullptr, nullptr};  // [0]: segment heads in pinned memory; [1]: the build's last upload has left its staging buffer
   bool built = false;
 };
@@ -865,36 +866,42 @@ __device__ __forceinline__ double gather_pair_sum(const Src *src, const double *
   return acc;
 }
 
-// k_post_reduce inside k_gather: called by every thread of the ns + 1 workgroups that wrote g / the cost (their stores were made
-// by wavefront 0).  The host's mailbox leaves while the block-pair workgroups of the launch are still summing.
-__device__ __forceinline__ void gather_post(const GatherArgs &a, double *sred) {
+// k_post_reduce inside k_gather: called by every thread of the ns + 1 workgroups that wrote g / the cost; local_max (thread 0) =
+// max |g| over the entries this workgroup wrote (0 for the cost workgroup).  The host's mailbox leaves while the block-pair
+// workgroups of the launch are still summing.  No fence and no second look at g: a workgroup publishes its maximum with an atomic
+// maximum on the bits of the (non-negative) double - mail[61], zero at rest - and the cost workgroup stores the cost atomically,
+// both at agent scope and acknowledged (vmcnt) before the workgroup is counted; the workgroup that counts last reads the two words
+// back atomically.  (Rounds 3 - 4: a __threadfence() in every workgroup, another in the last one, which then read all of g again -
+// two L2 write-backs of ~3.5 us each and a round of loads at the end of every linearisation.)
+__device__ __forceinline__ void gather_post(const GatherArgs &a, double local_max) {
   __shared__ uint32_t s_last;
   const int tid = threadIdx.x;
-  if (tid < 64) __threadfence();
-  if (tid == 0) s_last = atomicAdd(a.done, 1u) == (uint32_t)a.ns ? 1u : 0u;
-  __syncthreads();
-  if (!s_last) return;
-  __threadfence();
-  const int n = 12 * a.ns;
-  double mx = 0.0;
-  for (int i = tid; i < n; i += 144 * kGG) mx = fmax(mx, fabs(__hip_atomic_load(&a.g[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) mx = fmax(mx, __shfl_xor(mx, d, 64));
-  if ((tid & 63) == 0) sred[tid >> 6] = mx;
-  __syncthreads();
+  unsigned long long *gm = (unsigned long long *)(a.mail + 61);
   if (tid == 0) {
-    for (int w = 1; w < (144 * kGG + 63) / 64; ++w) mx = fmax(mx, sred[w]);
-    const double cost = __hip_atomic_load(&a.cost[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (local_max > 0.0)  // (a NaN entry is skipped, as fmax did)
+      (void)__hip_atomic_fetch_max(gm, (unsigned long long)__double_as_longlong(local_max), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    s_last = atomicAdd(a.done, 1u) == (uint32_t)a.ns ? 1u : 0u;
+  }
+  __syncthreads();
+  if (!s_last || tid >= 64) return;
+  const double mx = __longlong_as_double((long long)__hip_atomic_load(gm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  const double cost = __hip_atomic_load(&a.cost[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (a.host_mail && tid < 40) a.host_mail[tid] = (tid == a.mail_slot) ? cost : (tid == a.mail_slot + 1 ? mx : a.mail[tid]);
+  if (tid == 0) {
     a.mail[a.mail_slot] = cost;
     a.mail[a.mail_slot + 1] = mx;
-    if (a.host_mail) {
-      for (int i = 0; i < 40; ++i) a.host_mail[i] = (i == a.mail_slot) ? cost : (i == a.mail_slot + 1 ? mx : a.mail[i]);
-      if (a.ticket) {
-        __threadfence_system();
-        __hip_atomic_store((unsigned long long *)(a.host_mail + 48), a.ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-      }
+  }
+  if (a.host_mail && a.ticket) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the wavefront's 40 stores to the pinned mailbox
+    if (tid == 0) {
+      __threadfence_system();
+      __hip_atomic_store((unsigned long long *)(a.host_mail + 48), a.ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+  }
+  if (tid == 0) {
     *a.done = 0u;
+    __hip_atomic_store(gm, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -1046,7 +1053,15 @@ __global__ void __launch_bounds__(144 * kGG, 8) k_gather(GatherArgs a) {
       if (a.fix_first && gi >= 3 && gi < 6) acc = 0.0;
       a.g[gi] = acc;
     }
-    if (a.post) gather_post(a, sred);
+    if (a.post) {
+      double mx = tid < 12 ? fabs(acc) : 0.0;  // (lanes 0 .. 11 of wavefront 0 hold the block's entries)
+      if (!(mx == mx)) mx = 0.0;
+      if (tid < 64) {
+#pragma unroll
+        for (int d = 8; d >= 1; d >>= 1) mx = fmax(mx, __shfl_xor(mx, d, 64));
+      }
+      gather_post(a, mx);
+    }
     return;
   }
   {  // cost: deterministic sum of the cost slots of all partials
@@ -1090,9 +1105,9 @@ __global__ void __launch_bounds__(144 * kGG, 8) k_gather(GatherArgs a) {
     if (tid == 0) {
       double t = 0.0;
       for (int q = 0; q < 16; ++q) t += sred[q * 63];
-      a.cost[0] = t;
+      __hip_atomic_store(&a.cost[0], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (gather_post: read back by the workgroup that counts last)
     }
-    if (a.post) gather_post(a, sred);
+    if (a.post) gather_post(a, 0.0);
   }
 }
 
@@ -1894,7 +1909,10 @@ int build_families(wc_ctx *ctx, wc_window_state *W, const FamArgs &B0, const Fam
   B.rec = (double *)W->brec.p, B.key_out = (uint32_t *)W->bkey.p, B.orig_out = (uint32_t *)W->borig.p;
   U.rec = (double *)W->urec.p, U.key_out = (uint32_t *)W->ukey.p, U.orig_out = (uint32_t *)W->uorig.p;
   uint32_t *d_st = (uint32_t *)W->status.p;  // (k_pair_keys: word 1 = flags, k_seg_heads: word 2 = heads)
-  WC_HIP(ctx, hipMemsetAsync(d_st, 0, 16 * 4, ctx->stream));
+  if (!W->status_clear) {  // zero at rest: cleared behind the read-back of every build (a memset in front of the chain was ~6 us of it)
+    WC_HIP(ctx, hipMemsetAsync(d_st, 0, 16 * 4, ctx->stream));
+  }
+  W->status_clear = false;  // (until the memset behind the read-back is enqueued: a failure in between leaves it dirty)
   const unsigned grid = (n + 255) / 256;
   k_pair_keys<<<grid, 256, 0, ctx->stream>>>(B, U, (const double *)W->times_d.p, W->ns, (uint32_t *)W->keys_tmp[0].p, (uint32_t *)W->vals_tmp[0].p, d_st);
   // (k_pair_keys' flags are read back with the segment heads: a flagged record gets its family's key 0, so everything downstream is safe)
@@ -1902,9 +1920,8 @@ int build_families(wc_ctx *ctx, wc_window_state *W, const FamArgs &B0, const Fam
   while ((1ull << bits) < maxkey + 1) ++bits;
   WC_TRY(sort_u32(ctx, W, (uint32_t *)W->keys_tmp[0].p, (uint32_t *)W->keys_tmp[1].p, (uint32_t *)W->vals_tmp[0].p,
                   (uint32_t *)W->vals_tmp[1].p, n, bits));
-  k_build_records<<<grid, 256, 0, ctx->stream>>>(B, U, (const uint32_t *)W->vals_tmp[1].p, (const uint32_t *)W->keys_tmp[1].p,
-                                                (const double *)W->times_d.p, W->ns, W->wp.sigma0_sq);
-  // heads of the SORT keys (position in the sorted order, key): the host tells the families apart by position
+  // heads of the SORT keys (position in the sorted order, key): the host tells the families apart by position.  The heads leave
+  // BEFORE the records are formed: the host cuts pieces and builds the gather's lists (~65 us) while k_build_records runs.
   uint32_t *d_heads = (uint32_t *)W->heads.p;
   k_seg_heads<<<(n + 1023) / 1024, 1024, 0, ctx->stream>>>((const uint32_t *)W->keys_tmp[1].p, n, d_heads, d_st);
   WC_HIP(ctx, hipGetLastError());
@@ -1912,6 +1929,11 @@ int build_families(wc_ctx *ctx, wc_window_state *W, const FamArgs &B0, const Fam
   WC_HIP(ctx, hipMemcpyAsync(h, d_st, 16, hipMemcpyDeviceToHost, ctx->stream));
   WC_HIP(ctx, hipMemcpyAsync(h + 64, d_heads, (size_t)cap * 8, hipMemcpyDeviceToHost, ctx->stream));
   WC_HIP(ctx, hipEventRecord(W->fam_done[0], ctx->stream));
+  WC_HIP(ctx, hipMemsetAsync(d_st, 0, 16 * 4, ctx->stream));
+  W->status_clear = true;
+  k_build_records<<<grid, 256, 0, ctx->stream>>>(B, U, (const uint32_t *)W->vals_tmp[1].p, (const uint32_t *)W->keys_tmp[1].p,
+                                                (const double *)W->times_d.p, W->ns, W->wp.sigma0_sq);
+  WC_HIP(ctx, hipGetLastError());
   J.nb = nb, J.nu = nu, J.cap = cap, J.ns = W->ns, J.h_st = (const uint32_t *)h, J.h_heads = (const std::pair<uint32_t, uint32_t> *)(h + 64), J.done = W->fam_done[0];
   return WC_OK;
 }
@@ -2192,7 +2214,7 @@ static int window_build_impl(wc_ctx *ctx, const wc_surfel *d_sld_surf, const wc_
   WC_TRY(wc_ensure(ctx, W->Lmat, np_al * np_al * 8));
   WC_TRY(wc_ensure(ctx, W->y, np_al * 8));
   WC_TRY(wc_ensure(ctx, W->mail, 64 * 8));
-  WC_HIP(ctx, hipMemsetAsync((double *)W->mail.p + 60, 0, 8, ctx->stream));  // k_gather's count of finished g / cost workgroups
+  WC_HIP(ctx, hipMemsetAsync((double *)W->mail.p + 60, 0, 16, ctx->stream));  // k_gather's count of finished g / cost workgroups, their maximum of |g|
   const size_t ncb = (W->nb + 255) / 256 + (W->nu + 255) / 256 + (W->ni + 255) / 256 + 8;
   WC_TRY(wc_ensure(ctx, W->cost_part, ncb * 8));
   if (!W->fam_done[1]) WC_HIP(ctx, hipEventCreateWithFlags(&W->fam_done[1], hipEventDisableTiming));
