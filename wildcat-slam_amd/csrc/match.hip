@@ -231,9 +231,23 @@ static int kd_build(wc_ctx *ctx, const double *d_feat, uint32_t nt, const KdPlan
     k_kd_scatter<<<(nt + 1023) / 1024, 1024, 0, st>>>(bucket, nt, tcum, count, idx[s & 1]);
     starts_prev = starts[s & 1], idx_prev = idx[s & 1];
   }
+  static const bool kd_dbg = getenv("WC_MATCH_DEBUG") != nullptr;
+  if (kd_dbg && starts_prev) {  // (debug only: a stream wait and a read-back) sizes of the buckets the bottom levels are built on
+    std::vector<uint32_t> h((size_t)nbk + 1);
+    if (hipStreamSynchronize(st) == hipSuccess && hipMemcpy(h.data(), starts_prev, h.size() * 4, hipMemcpyDeviceToHost) == hipSuccess) {
+      uint32_t mx = 0, n512 = 0, n1024 = 0, n2048 = 0;
+      for (size_t b = 0; b < nbk; ++b) {
+        const uint32_t c = h[b + 1] - h[b];
+        mx = std::max(mx, c), n512 += c > 512u, n1024 += c > 1024u, n2048 += c > 2048u;
+      }
+      fprintf(stderr, "[match] kd buckets: %zu of %.0f points on average, largest %u; above 512 / 1024 / 2048 points: %u / %u / %u\n", nbk, (double)nt / (double)nbk, mx, n512, n1024, n2048);
+    }
+  }
   const KdOut out{(float4 *)B[8].p, (uint32_t *)B[9].p, (float4 *)ctx->b_match_half.p, (double *)ctx->b_misc[3].p, (uint32_t *)ctx->b_vals[1].p};
-  k_kd_bottom<1024><<<1u << pl.T, kKdBotNT, 0, st>>>(d_feat, idx_prev, starts_prev, nt, pl.T, pl.Bd, out);
+  // (the launch for the few larger buckets first: its workgroups need 108 KB of LDS each, and behind the other launch it can find the
+  // chip filled by another stream's walk - as an EMPTY launch it then waited 490 us for slots)
   if (pl.T > 0) k_kd_bottom<2048><<<1u << pl.T, kKdBotNT, 0, st>>>(d_feat, idx_prev, starts_prev, nt, pl.T, pl.Bd, out);  // (T = 0: one bucket of <= 1024)
+  k_kd_bottom<1024><<<1u << pl.T, kKdBotNT, 0, st>>>(d_feat, idx_prev, starts_prev, nt, pl.T, pl.Bd, out);
   if (pl.T > 0) k_kd_top_boxes<<<1, 1024, 0, st>>>((float4 *)B[8].p, pl.T);
   WC_HIP(ctx, hipGetLastError());
   tree.box = (const float4 *)B[8].p, tree.leaf_begin = (const uint32_t *)B[9].p, tree.pts32 = (const float4 *)ctx->b_match_half.p;
@@ -497,6 +511,19 @@ extern "C" int wc_match_pair(wc_ctx *ctx, const wc_surfel *d_sld_surf, const wc_
   if (!ctx->aux) {
     const int rc = wc_ctx_create(&ctx->P, ctx->device, &ctx->aux);
     if (rc != WC_OK) return wc_fail(ctx, rc, "wc_match_pair: no helper context");
+    // The helper's stream gets the device's highest priority: its search is prepared (tree, locate, radix passes - small launches)
+    // while the other search's walk fills the chip, and those launches wait for slots behind the walk's workgroups.  What a kernel
+    // trace of the odometry step shows with it: launches of 256- and 512-thread workgroups get through (k_kd_bottom 77 us next to the
+    // other tree's 127), a launch of 1 024-thread workgroups does not - a CU whose slots are refilled four wavefronts at a time never
+    // has sixteen free (one Onesweep pass: 500 us with or without priority).  Measured together with the order of the two
+    // k_kd_bottom launches (kd_build): the step's two searches 1.82 -> 1.76 - 1.79 ms.
+    int pr_lo = 0, pr_hi = 0;
+    hipStream_t hs = nullptr;
+    if (hipDeviceGetStreamPriorityRange(&pr_lo, &pr_hi) == hipSuccess && pr_hi < pr_lo &&
+        hipStreamCreateWithPriority(&hs, hipStreamNonBlocking, pr_hi) == hipSuccess) {
+      (void)hipStreamDestroy(ctx->aux->own_stream);
+      ctx->aux->own_stream = hs, ctx->aux->stream = hs;
+    }
   }
   wc_ctx *aux = ctx->aux;
   WC_TRY(wc_ctx_set_params(aux, &ctx->P));
