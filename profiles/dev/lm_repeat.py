@@ -3,6 +3,7 @@
 python profiles/dev/lm_repeat.py [reps]"""
 import sys, os
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "..", "wildcat-slam_amd", "python"))
+import zlib
 import numpy as np
 from wildcat_slam_amd import lib, synth
 from wildcat_slam_amd.step import StepWindow
@@ -17,5 +18,5 @@ for name, w in (("step", synth.g2_scan_sequence(10, 3906, m=32, seed=synth.SEED 
         if info["iters"] != info0["iters"] or info["cost"] != info0["cost"] or not np.array_equal(x, x0):
             bad += 1
             print(name, "repetition", r, "differs:", info["iters"], info["cost"], float(np.abs(x - x0).max()))
-    print(name, "iters", info0["iters"], "cost", info0["cost"], "reps", reps, "differing", bad)
+    print(name, "iters", info0["iters"], "cost", info0["cost"], "reps", reps, "differing", bad, "crc32 of x %08x" % zlib.crc32(x0.tobytes()))
 print("LM_REPEAT_OK" if bad == 0 else "LM_REPEAT_BAD")
