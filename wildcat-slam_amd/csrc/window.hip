@@ -108,7 +108,8 @@ struct wc_window_state {
   // pinned staging of the two families' segment heads + status words, and the events that say a family's copy has landed
   void *h_pin = nullptr;
   size_t h_pin_cap = 0;
-  void *h_up = nullptr;  // pinned staging of wc_window_build's uploads (pieces, source lists, IMU records)
+  wc_buf lists;          // device arena of the lists the host builds (irec, pair_off, heavy, pieces, src, src_begin, gsrc, gsrc_begin are views into it)
+  void *h_up = nullptr;  // pinned staging of that arena
   size_t h_up_cap = 0;
   bool status_clear = false;  // W->status is zero at rest
   hipEvent_t fam_done[2] = {nullptr, nullptr};  // [0]: segment heads in pinned memory; [1]: the build's last upload has left its staging buffer
@@ -1869,9 +1870,9 @@ int collect_families(wc_ctx *ctx, const FamilyJob &J, std::vector<Seg> &segs_b, 
 void wc_window_free(wc_ctx *ctx) {
   wc_window_state *W = ctx->win;
   if (!W) return;
-  wc_buf *all[] = {&W->times_d, &W->brec, &W->bkey, &W->borig, &W->urec, &W->ukey, &W->uorig, &W->irec, &W->pieces, &W->partial,
-                   &W->src, &W->src_begin, &W->gsrc, &W->gsrc_begin, &W->x, &W->xc, &W->lin, &W->lin_alt, &W->Linv, &W->heavy, &W->Lmat, &W->reduce, &W->scale, &W->diag, &W->A, &W->y,
-                   &W->mail, &W->cost_part, &W->keys_tmp[0], &W->keys_tmp[1], &W->vals_tmp[0], &W->vals_tmp[1], &W->heads, &W->status, &W->pair_off,
+  wc_buf *all[] = {&W->times_d, &W->brec, &W->bkey, &W->borig, &W->urec, &W->ukey, &W->uorig, &W->lists, &W->partial,
+                   &W->x, &W->xc, &W->lin, &W->lin_alt, &W->Linv, &W->Lmat, &W->reduce, &W->scale, &W->diag, &W->A, &W->y,
+                   &W->mail, &W->cost_part, &W->keys_tmp[0], &W->keys_tmp[1], &W->vals_tmp[0], &W->vals_tmp[1], &W->heads, &W->status,
                    &W->pcr_D[0], &W->pcr_D[1], &W->pcr_A[0], &W->pcr_A[1], &W->pcr_R[0], &W->pcr_R[1], &W->yred};
   for (wc_buf *b : all)
     if (b->p) (void)hipFree(b->p);
@@ -1971,8 +1972,6 @@ static int window_build_impl(wc_ctx *ctx, const wc_surfel *d_sld_surf, const wc_
   // host arrays the asynchronous uploads below read; the guard (destroyed first) waits for the stream on every way out
   std::vector<ImuRec> irecs;
   std::vector<Piece> pieces;
-  std::vector<Src> src;
-  std::vector<GSrc> gsrc;
   std::vector<uint32_t> src_begin, gsrc_begin, heavy, pair_off;
   // Nothing enqueued below reads a vector of this scope: what the host builds leaves through the pinned staging buffers (h_up), so the
   // call returns with its last copies still in flight (the solve is enqueued behind them on the same stream; the closing
@@ -2127,21 +2126,6 @@ static int window_build_impl(wc_ctx *ctx, const wc_surfel *d_sld_surf, const wc_
   }
   for (uint32_t i = 0; i < npairs; ++i) src_begin[i + 1] += src_begin[i];
   for (int i = 0; i < ns; ++i) gsrc_begin[i + 1] += gsrc_begin[i];
-  src.resize(src_begin[npairs]);
-  gsrc.resize(gsrc_begin[ns]);
-  {
-    std::vector<uint32_t> cur(src_begin.begin(), src_begin.end() - 1), gcur(gsrc_begin.begin(), gsrc_begin.end() - 1);
-    for (size_t pi = 0; pi < pieces.size(); ++pi) {
-      int blk[4];
-      uint8_t w, T;
-      const int nblk = blocks_of(pi, blk, w, T);
-      const uint32_t po = pieces[pi].part_off;
-      for (int p = 0; p < nblk; ++p) {
-        gsrc[gcur[blk[p]]++] = {po, (uint8_t)p, w, T, 0};
-        for (int q = p; q < nblk; ++q) src[cur[pair_id(blk[p], blk[q])]++] = {po, (uint8_t)p, (uint8_t)q, w, T};
-      }
-    }
-  }
   pair_off.assign(npairs + 1, 0);
   {
     uint32_t o = 0, pid = 0;
@@ -2156,46 +2140,61 @@ static int window_build_impl(wc_ctx *ctx, const wc_surfel *d_sld_surf, const wc_
   for (uint32_t i = 0; i < npairs; ++i)
     if (src_begin[i + 1] - src_begin[i] > kHeavySrc) heavy.push_back(i);
   W->nheavy = (uint32_t)heavy.size();
+  // Every list the host builds lives in ONE device arena and leaves in ONE copy out of ONE pinned staging buffer, in which the two
+  // large ones (the gather's source lists, ~0.5 MB in the odometry step) are written in place.  (Rounds 3 - 4: eight buffers, eight
+  // copies - out of pageable vectors at first: the runtime stages such a copy and returns when it is through, 10 - 35 us each -,
+  // then out of a staging buffer the vectors were copied into; a kernel trace of the odometry step showed the device idle for
+  // ~190 us between k_build_records and the solve's first kernel while the host copied and enqueued.)
+  const size_t n_src = src_begin[npairs], n_gsrc = gsrc_begin[ns];
+  struct Part {
+    wc_buf *b;
+    const void *h;  // nullptr: written in place below
+    size_t bytes, off;
+  };
+  Part parts[] = {{&W->irec, irecs.data(), irecs.size() * sizeof(ImuRec), 0}, {&W->pair_off, pair_off.data(), pair_off.size() * 4, 0},
+                  {&W->heavy, heavy.data(), heavy.size() * 4, 0},             {&W->pieces, pieces.data(), pieces.size() * sizeof(Piece), 0},
+                  {&W->src, nullptr, n_src * sizeof(Src), 0},                 {&W->src_begin, src_begin.data(), src_begin.size() * 4, 0},
+                  {&W->gsrc, nullptr, n_gsrc * sizeof(GSrc), 0},              {&W->gsrc_begin, gsrc_begin.data(), gsrc_begin.size() * 4, 0}};
+  size_t total = 0;
+  for (Part &pt : parts) {
+    pt.off = total;
+    total += (std::max<size_t>(pt.bytes, 16) + 255) / 256 * 256;
+  }
+  if (W->h_up_cap < total) {
+    WC_HIP(ctx, hipStreamSynchronize(ctx->stream));  // (copies of an earlier build out of the old buffer)
+    if (W->h_up) (void)hipHostFree(W->h_up);
+    W->h_up = nullptr, W->h_up_cap = 0;
+    const size_t want = std::max<size_t>(2 * total, (size_t)4 << 20);
+    WC_HIP(ctx, hipHostMalloc(&W->h_up, want));
+    W->h_up_cap = want;
+  }
+  WC_TRY(wc_ensure(ctx, W->lists, total));
+  for (Part &pt : parts) {  // the lists' buffers are views into the arena (not freed on their own)
+    pt.b->p = (char *)W->lists.p + pt.off, pt.b->cap = pt.bytes;
+    if (pt.h && pt.bytes) std::memcpy((char *)W->h_up + pt.off, pt.h, pt.bytes);
+  }
+  {  // CSR source lists, second pass (fill): sources of a pair / block in piece order, straight into the staging buffer
+    Src *src = (Src *)((char *)W->h_up + parts[4].off);
+    GSrc *gsrc = (GSrc *)((char *)W->h_up + parts[6].off);
+    std::vector<uint32_t> cur(src_begin.begin(), src_begin.end() - 1), gcur(gsrc_begin.begin(), gsrc_begin.end() - 1);
+    for (size_t pi = 0; pi < pieces.size(); ++pi) {
+      int blk[4];
+      uint8_t w, T;
+      const int nblk = blocks_of(pi, blk, w, T);
+      const uint32_t po = pieces[pi].part_off;
+      for (int p = 0; p < nblk; ++p) {
+        gsrc[gcur[blk[p]]++] = {po, (uint8_t)p, w, T, 0};
+        for (int q = p; q < nblk; ++q) src[cur[pair_id(blk[p], blk[q])]++] = {po, (uint8_t)p, (uint8_t)q, w, T};
+      }
+    }
+  }
   if (getenv("WC_DEBUG_GATHER")) {
     uint32_t mx = 0;
     for (uint32_t i = 0; i < npairs; ++i) mx = std::max(mx, src_begin[i + 1] - src_begin[i]);
-    fprintf(stderr, "gather: %u pairs, %u heavy, %zu sources (max %u per pair), %zu g-sources, %zu pieces\n", npairs, W->nheavy, src.size(), mx,
-            gsrc.size(), pieces.size());
+    fprintf(stderr, "gather: %u pairs, %u heavy, %zu sources (max %u per pair), %zu g-sources, %zu pieces\n", npairs, W->nheavy, n_src, mx, n_gsrc, pieces.size());
   }
   auto t_c = tnow();
-  {
-    // the lists that exist only now go through ONE pinned staging buffer and are enqueued from there: a copy out of a pageable vector is
-    // staged by the runtime and returns when it is through - 10 - 35 us each, back to back ~0.1 ms of a small window's build (kernel
-    // trace of the facade: build 0.42 -> 0.23 ms).
-    struct Up {
-      wc_buf *b;
-      const void *h;
-      size_t bytes;
-    };
-    const Up ups[] = {{&W->irec, irecs.data(), irecs.size() * sizeof(ImuRec)},          {&W->pair_off, pair_off.data(), pair_off.size() * 4},
-                      {&W->heavy, heavy.data(), heavy.size() * 4},                      {&W->pieces, pieces.data(), pieces.size() * sizeof(Piece)},
-                      {&W->src, src.data(), src.size() * sizeof(Src)},                  {&W->src_begin, src_begin.data(), src_begin.size() * 4},
-                      {&W->gsrc, gsrc.data(), gsrc.size() * sizeof(GSrc)},              {&W->gsrc_begin, gsrc_begin.data(), gsrc_begin.size() * 4}};
-    size_t total = 0;
-    for (const Up &u : ups) total += (u.bytes + 255) / 256 * 256;
-    if (W->h_up_cap < total) {
-      WC_HIP(ctx, hipStreamSynchronize(ctx->stream));  // (copies of an earlier build out of the old buffer)
-      if (W->h_up) (void)hipHostFree(W->h_up);
-      W->h_up = nullptr, W->h_up_cap = 0;
-      const size_t want = std::max<size_t>(2 * total, (size_t)4 << 20);
-      WC_HIP(ctx, hipHostMalloc(&W->h_up, want));
-      W->h_up_cap = want;
-    }
-    size_t o = 0;
-    for (const Up &u : ups) {
-      WC_TRY(wc_ensure(ctx, *u.b, std::max<size_t>(u.bytes, 16)));
-      if (u.bytes) {
-        std::memcpy((char *)W->h_up + o, u.h, u.bytes);
-        WC_HIP(ctx, hipMemcpyAsync(u.b->p, (char *)W->h_up + o, u.bytes, hipMemcpyHostToDevice, ctx->stream));
-      }
-      o += (u.bytes + 255) / 256 * 256;
-    }
-  }
+  WC_HIP(ctx, hipMemcpyAsync(W->lists.p, W->h_up, total, hipMemcpyHostToDevice, ctx->stream));
 
   // (the buffers whose size goes with the SQUARE of the sample states are allocated for at least 96 of them - the reference's default
   // window has 82 -: a window that gains ten sample states per sweep, the facade's first seconds, otherwise re-allocates four of them on
