@@ -1840,7 +1840,8 @@ int fx_ensure_zero(wc_ctx *ctx, wc_buf &b, size_t bytes) {
 
 bool fx_applicable(const wc_ctx *ctx, uint64_t n, double t_lo, double t_hi) {
   const wc_params &P = ctx->P;
-  if (P.exact_sums || getenv("WC_EXACT_SUMS")) return false;
+  static const bool env_exact = getenv("WC_EXACT_SUMS") != nullptr;  // (debug knobs are read once per process)
+  if (P.exact_sums || env_exact) return false;
   if (n < 64 || !(P.voxel_size > 0.0f) || P.voxel_size >= 0.99f) return false;  // |p - centre| 2^32 must fit an int32
   if (!(P.cluster_gap > 1e-6) || !(t_hi > t_lo)) return false;
   if ((t_hi - t_lo) / (P.cluster_gap * 0.999) >= 1048000.0) return false;
@@ -1862,7 +1863,8 @@ int run_pipeline_fast(wc_ctx *ctx, const wc_points &pts, double t_lo, double t_h
   E.gap = P.cluster_gap, E.cluster_min = P.cluster_min_points;
   E.t_lo_bits = ordered_bits_host(t_lo);
   E.t_span_bits = ordered_bits_host(t_hi) - E.t_lo_bits;
-  E.dbg = getenv("WC_DEBUG_SKIP") ? atoi(getenv("WC_DEBUG_SKIP")) : 0;
+  static const int env_skip = getenv("WC_DEBUG_SKIP") ? atoi(getenv("WC_DEBUG_SKIP")) : 0;
+  E.dbg = env_skip;
   unsigned tbits = 1;
   while (tbits < 64 && (E.t_span_bits >> tbits)) ++tbits;
   A.pts = pts;
@@ -1955,7 +1957,7 @@ int run_pipeline_fast(wc_ctx *ctx, const wc_points &pts, double t_lo, double t_h
   };
   mark(0);
   mark(1);
-  const bool dbg = getenv("WC_FX_DEBUG") != nullptr;
+  static const bool dbg = getenv("WC_FX_DEBUG") != nullptr;
   auto dbg_sync = [&](const char *what) {
     if (!dbg) return;
     fprintf(stderr, "[fx] %s ...", what);
@@ -2035,7 +2037,8 @@ int fx_tail(wc_ctx *ctx, bool layer2) {
                                            (const wc_surfel_id *)ctx->b_slot_ids.p, A.status, ctx->ex.d_out, ctx->ex.d_ids, ctx->ex.cap, next_ctrl,
                                            kCtrlWords);
   mark(5);
-  if (getenv("WC_FX_DEBUG")) fprintf(stderr, "[fx] k_slot_emit (layer2=%d) ... %s\n", (int)layer2, hipGetErrorString(hipStreamSynchronize(st)));
+  static const bool fx_dbg = getenv("WC_FX_DEBUG") != nullptr;
+  if (fx_dbg) fprintf(stderr, "[fx] k_slot_emit (layer2=%d) ... %s\n", (int)layer2, hipGetErrorString(hipStreamSynchronize(st)));
   WC_HIP(ctx, hipGetLastError());
   return WC_OK;
 }
@@ -2105,7 +2108,8 @@ int run_pipeline(wc_ctx *ctx, const wc_points &pts, double t_lo, double t_hi, wc
   E.gap = P.cluster_gap;
   E.cluster_min = P.cluster_min_points;
   E.t_lo_bits = ordered_bits_host(t_lo);
-  E.dbg = getenv("WC_DEBUG_SKIP") ? atoi(getenv("WC_DEBUG_SKIP")) : 0;
+  static const int env_skip = getenv("WC_DEBUG_SKIP") ? atoi(getenv("WC_DEBUG_SKIP")) : 0;
+  E.dbg = env_skip;
   const uint64_t span = ordered_bits_host(t_hi) - E.t_lo_bits;
   E.t_span_bits = span;
   unsigned tbits = 1;
@@ -2276,7 +2280,8 @@ extern "C" int wc_extract_surfels_enqueue(wc_ctx *ctx, const wc_points *pts, dou
   ctx->ex.t_hi = t_hi;
   // after a bin overflow of the run-binned point sort (very many points in few voxels, or points in no spatial order)
   // the next calls go to the radix-sort path directly; the fast path is tried again every 16th call
-  ctx->ex.general = ctx->ex.general_calls > 0 || getenv("WC_NO_BUCKET_SORT") != nullptr;
+  static const bool env_general = getenv("WC_NO_BUCKET_SORT") != nullptr;
+  ctx->ex.general = ctx->ex.general_calls > 0 || env_general;
   if (ctx->ex.general_calls > 0) --ctx->ex.general_calls;
   ctx->ex.order_general = false;
   ctx->ex.fx_active = fx_applicable(ctx, pts->n, t_lo, t_hi);

@@ -1982,7 +1982,8 @@ static int window_build_impl(wc_ctx *ctx, const wc_surfel *d_sld_surf, const wc_
   std::vector<Seg> segs_b, segs_u;
   W->nb = (uint32_t)n_pairs_sld;
   W->nu = (uint32_t)n_pairs_fix;
-  const bool tdbg = getenv("WC_WIN_DEBUG") != nullptr;
+  static const bool tdbg = getenv("WC_WIN_DEBUG") != nullptr;  // (debug knobs: read once per process, never on a later call)
+  static const bool gdbg = getenv("WC_DEBUG_GATHER") != nullptr;
   auto tnow = [] { return std::chrono::steady_clock::now(); };
   auto t_a = tnow();
   {  // staging for both families' (status, heads); heads of both in one device buffer
@@ -2078,7 +2079,7 @@ static int window_build_impl(wc_ctx *ctx, const wc_surfel *d_sld_surf, const wc_
   cut(segs_i, 37, false);
   W->npiece_i = (uint32_t)pieces.size() - W->npiece_b - W->npiece_u;
   W->npart_doubles = off;
-  if (getenv("WC_WIN_DEBUG")) {  // piece sizes per family
+  if (tdbg) {  // piece sizes per family
     uint32_t hist[3][6] = {{0}};
     for (size_t i = 0; i < pieces.size(); ++i) {
       const int fam = i < W->npiece_b ? 0 : (i < W->npiece_b + W->npiece_u ? 1 : 2);
@@ -2188,7 +2189,7 @@ static int window_build_impl(wc_ctx *ctx, const wc_surfel *d_sld_surf, const wc_
       }
     }
   }
-  if (getenv("WC_DEBUG_GATHER")) {
+  if (gdbg) {
     uint32_t mx = 0;
     for (uint32_t i = 0; i < npairs; ++i) mx = std::max(mx, src_begin[i + 1] - src_begin[i]);
     fprintf(stderr, "gather: %u pairs, %u heavy, %zu sources (max %u per pair), %zu g-sources, %zu pieces\n", npairs, W->nheavy, n_src, mx, n_gsrc, pieces.size());
