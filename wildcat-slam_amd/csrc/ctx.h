@@ -142,9 +142,11 @@ inline int wc_ensure(wc_ctx *ctx, wc_buf &b, size_t bytes) {
   }
   // (slack: a window that grows by a sweep per call - the facade's first seconds - re-allocated several buffers on EVERY call with an
   // eighth of slack, and still ~14 of a context's ~70 per sweep with half - 0.5 - 1 ms of hipStreamSynchronize / hipFree / hipMalloc;
-  // now no buffer is smaller than 4 MB, one below 64 MB doubles, a larger one grows by half: 288 GB of HBM make the slack free)
+  // now no buffer is smaller than 16 MB, one below 64 MB doubles, a larger one grows by half: 288 GB of HBM make the slack free.
+  // The floor was 4 MB until the end of round 4: the facade's window (55 k surfels: 6.6 MB of binary records) crossed it, and the
+  // re-allocations showed as sweeps of 6 - 8 ms among sweeps of 4.7 - a hipFree is a device synchronisation, a hipMalloc ~ms.)
   size_t want = bytes < ((size_t)64 << 20) ? 2 * bytes : bytes + bytes / 2;
-  if (want < ((size_t)4 << 20)) want = (size_t)4 << 20;
+  if (want < ((size_t)16 << 20)) want = (size_t)16 << 20;
   static const bool alloc_dbg = getenv("WC_ALLOC_DEBUG") != nullptr;  // (read once per process)
   if (alloc_dbg) fprintf(stderr, "[alloc] %zu bytes wanted -> %zu\n", bytes, want);
   WC_HIP(ctx, hipMalloc(&b.p, want));

@@ -116,6 +116,7 @@ bool LidarOdometry::ImportState(const double *samples23, size_t ns, const wc_imu
     std::memcpy(s.pos, p + 20, 24);
   }
   for (size_t i = 0; i < n_imu; ++i) imu_states_[i] = imu[i];
+  TouchImu();
   UpdateSurfelPosesOnDevice();
   return true;
 }
@@ -258,6 +259,7 @@ bool LidarOdometry::SyncHeadingMsgs() {
 // PredictImuStatesAndSampleStates (:365-455)
 void LidarOdometry::PredictImuStatesAndSampleStates(double end_time) {
   WC_CHECK(imu_buff_.size() >= 2);
+  TouchImu();
   const double dt = 1 / config_.imu_rate;
   if (!init_sld_win_) {
     for (int i = 0; i < 2; ++i) {
@@ -412,9 +414,20 @@ void LidarOdometry::UploadImuStates() {
     void *p = nullptr;
     WC_CALL(wc_dev_alloc(ctx_, cap_imu_ * sizeof(wc_imu_state), &p));
     d_imu_ = (wc_imu_state *)p;
+    imu_dev_stale_ = true;
   }
-  std::vector<wc_imu_state> flat(imu_states_.begin(), imu_states_.end());
+  if (!imu_dev_stale_) return;
+  const std::vector<wc_imu_state> &flat = FlatImu();
   WC_CALL(wc_h2d(ctx_, d_imu_, flat.data(), n_imu * sizeof(wc_imu_state)));
+  imu_dev_stale_ = false;
+}
+
+const std::vector<wc_imu_state> &LidarOdometry::FlatImu() {
+  if (imu_flat_stale_) {
+    imu_flat_.assign(imu_states_.begin(), imu_states_.end());
+    imu_flat_stale_ = false;
+  }
+  return imu_flat_;
 }
 
 void LidarOdometry::UpdateSurfelPosesOnDevice() {  // UpdateSurfelPoses (:160-170) over the sliding window
@@ -426,6 +439,7 @@ void LidarOdometry::UpdateSurfelPosesOnDevice() {  // UpdateSurfelPoses (:160-17
 
 // UpdateImuPoses (:187-215) with the CubicBSplineSampleCorrector (:22-54)
 void LidarOdometry::UpdateImuPoses() {
+  TouchImu();
   std::vector<double> ts;
   std::vector<V3> rc, pc;
   for (const Sample &s : samples_) {
@@ -471,6 +485,7 @@ void LidarOdometry::ShrinkToFit() {
   if (samples_.empty() || samples_.back().timestamp - samples_.front().timestamp <= config_.sliding_window_duration) return;
   while (samples_.back().timestamp - samples_.front().timestamp > config_.sliding_window_duration) samples_.pop_front();
   while (imu_states_.front().t < samples_.front().timestamp) imu_states_.pop_front();
+  TouchImu();
   size_t k = 0;
   while (k < surfel_times_.size() && surfel_times_[k] < imu_states_.front().t) ++k;
   if (k) {
@@ -513,7 +528,9 @@ void LidarOdometry::AddLidarScan(const pcl::PointCloud<hilti_ros::Point>::Ptr &m
   PredictImuStatesAndSampleStates(sweep_endtime);
   sweep_endtime = samples_.back().timestamp;
   size_t n_sweep = 0;  // BuildSweep (:134-141): the leading points with time < sweep_endtime
-  while (n_sweep < point_times_.size() && point_times_[n_sweep] < sweep_endtime) ++n_sweep;
+  // (the stamps ascend - the CHECK of :491 holds on the device, AppendScanOnDevice -, so the first one that is not earlier is found by
+  // bisection; counted one by one through the deque, 300 k stamps were 0.25 ms of every completed sweep)
+  n_sweep = (size_t)(std::lower_bound(point_times_.begin(), point_times_.end(), sweep_endtime) - point_times_.begin());
   WC_CHECK(n_sweep > 0);
   const double sweep_t0 = point_times_.front(), sweep_t1 = point_times_[n_sweep - 1];
 
@@ -531,7 +548,6 @@ void LidarOdometry::AddLidarScan(const pcl::PointCloud<hilti_ros::Point>::Ptr &m
   WC_CALL(wc_undistort_sweep_packed(ctx_, (const char *)d_pts_[pts_cur_] + pts_begin_ * sizeof(hilti_ros::Point), n_sweep, d_imu_, imu_states_.size(),
                                     (float *)d_sweep_xyz_, (double *)d_sweep_t_));
   const void *d_raw_sweep = (const char *)d_pts_[pts_cur_] + pts_begin_ * sizeof(hilti_ros::Point);  // (stays where it is until the next scan arrives)
-  DropBufferedPoints(n_sweep);
   lap(0);
 
   // 4. ---- hot path: extract surfels, attach poses (:523-527) ----
@@ -539,7 +555,10 @@ void LidarOdometry::AddLidarScan(const pcl::PointCloud<hilti_ros::Point>::Ptr &m
   EnsureSurfelCapacity(max_new);
   wc_points desc{d_sweep_xyz_, d_sweep_t_, 3 * sizeof(float), sizeof(double), n_sweep};
   uint64_t n_new = 0;
-  WC_CALL(wc_extract_surfels(ctx_, &desc, sweep_t0, sweep_t1, d_surf_ + n_surfels_, nullptr, max_new, &n_new));
+  // (the sweep's stamps leave the host's buffer - 300 k deque entries, ~0.1 ms - while the extraction runs)
+  WC_CALL(wc_extract_surfels_enqueue(ctx_, &desc, sweep_t0, sweep_t1, d_surf_ + n_surfels_, nullptr, max_new));
+  DropBufferedPoints(n_sweep);
+  WC_CALL(wc_extract_surfels_finish(ctx_, &n_new));
   {
     uint32_t st[64];
     WC_CALL(wc_debug_status(ctx_, st));
@@ -585,7 +604,7 @@ void LidarOdometry::AddLidarScan(const pcl::PointCloud<hilti_ros::Point>::Ptr &m
       ts.push_back(s.timestamp);
       x.insert(x.end(), s.cor, s.cor + 12);
     }
-    std::vector<wc_imu_state> flat(imu_states_.begin(), imu_states_.end());
+    const std::vector<wc_imu_state> &flat = FlatImu();
     const bool fix_first = first_sample_known_ && samples_.front().timestamp == first_sample_time_;  // :556-560
     WC_CALL(wc_window_build(ctx_, d_surf_ + sld_begin_, d_pose_ + sld_begin_, d_pairs_sld_, n_b, d_fix_surf_ + fix_start_, d_fix_pose_ + fix_start_, d_pairs_fix_, n_u,
                             flat.data(), flat.size(), ts.data(), ts.size(), samples_.back().grav, fix_first ? 1 : 0));

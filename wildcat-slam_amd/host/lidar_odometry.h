@@ -112,6 +112,12 @@ class LidarOdometry {
   int pts_cur_ = 0;
   std::deque<Sample> samples_;
   std::deque<wc_imu_state> imu_states_;
+  // contiguous copy of imu_states_ (the C-ABI takes arrays) and whether the device copy follows it: rebuilt / uploaded only after a change
+  // (prediction, post-solve correction, shrink, import) - a sweep flattened and uploaded the ~0.3 MB four to five times
+  std::vector<wc_imu_state> imu_flat_;
+  bool imu_flat_stale_ = true, imu_dev_stale_ = true;
+  void TouchImu() { imu_flat_stale_ = imu_dev_stale_ = true; }
+  const std::vector<wc_imu_state> &FlatImu();
   double ext_quat_[4];
   bool init_sld_win_ = false, sync_done_ = false, first_sample_known_ = false;
   double first_sample_time_ = 0.0;
