@@ -234,7 +234,12 @@ int wc_match_pair(wc_ctx *ctx, const wc_surfel *d_sld_surf, const wc_pose *d_sld
  * SubsetParameterization gauge flag (cc:556-560).  Surfels must already carry poses (wc_update_surfel_poses).
  * The packed per-correspondence records are built once here; the calls below reuse them.
  * 2 <= ns <= 340 (dense normal equations of 12 ns unknowns; the reference's default 6.5 s window has 82 sample states),
- * otherwise WC_ERR_ARG. */
+ * otherwise WC_ERR_ARG.
+ * Ordering: every host argument (h_imu, h_sample_times, h_grav) has been consumed when the call returns, and argument errors the
+ * device finds (a surfel stamp outside the sample-state range, a correspondence that is not (older, newer)) are reported by it;
+ * the call's LAST device work - the records and one copy of host-built lists - may still be in flight on the ctx stream.  The
+ * calls that use the problem (wc_window_solve / _linearize / _evaluate) are enqueued behind it on that stream; a caller that reads
+ * the device arguments' buffers on ANOTHER stream orders itself with an event on the ctx stream, as after any asynchronous call. */
 int wc_window_build(wc_ctx *ctx, const wc_surfel *d_sld_surf, const wc_pose *d_sld_pose, const wc_pair *d_pairs_sld,
                     uint64_t n_pairs_sld, const wc_surfel *d_fix_surf, const wc_pose *d_fix_pose, const wc_pair *d_pairs_fix,
                     uint64_t n_pairs_fix, const wc_imu_state *h_imu, uint64_t n_imu, const double *h_sample_times, uint64_t ns,

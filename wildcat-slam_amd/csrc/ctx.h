@@ -75,6 +75,7 @@ struct wc_ctx {
     bool batch_defer = false, deferred = false;
     unsigned fx_tiles = 0, fx_ngrid = 0;  // the node stage of the current sweep runs as k_fx_walk + k_fx_test (extract_split.inc)  // the spill pool of the fast path overflowed once: sized for the worst case from then on
     bool fx_long_lists = false;  // the last fast sweep walked long record lists: k_fx_merge runs before k_fx_nodes
+    bool fx_long_lists2 = false;  // ... the same for the layer-2 pass
     uint32_t fx_backoff = 0, fx_skip_calls = 0;  // sweeps that go straight to the exact path after fall-backs (exponential)
     bool fx_ctrl_ready = false;  // the fast path's two control blocks are initialised
     int fx_parity = 0;           // which of them the next fast sweep uses

@@ -2020,7 +2020,7 @@ int fx_tail(wc_ctx *ctx, bool layer2) {
     const unsigned tiles = (unsigned)((A.pts.n + kFxTile - 1) / kFxTile);
     k_fx_acc<2><<<tiles, kFxThreads, 0, st>>>(A);
     const unsigned ngrid = std::min<unsigned>(256 * 16, std::max<unsigned>(64, (unsigned)(A.pts.n / 256)));  // (the job buffer's blocks)
-    if (ctx->ex.fx_long_lists) k_fx_merge<2><<<std::min(8192u, std::max(64u, ctx->ex.last_splits)), 128, 0, st>>>(A);
+    if (ctx->ex.fx_long_lists2) k_fx_merge<2><<<std::min(8192u, std::max(64u, ctx->ex.last_splits)), 128, 0, st>>>(A);
     const unsigned g2 = std::min(std::min(256u * 8u, ngrid), std::max(64u, ctx->ex.last_splits));
     if (ctx->ex.fx_split) {
       k_fx_walk<2><<<g2, 64, 0, st>>>(A);
@@ -2346,6 +2346,7 @@ extern "C" int wc_extract_surfels_finish(wc_ctx *ctx, uint64_t *h_n_out) {
     } else {
       const uint32_t n_fast = ctx->h_status[0];
       ctx->ex.fx_long_lists = ctx->h_status[15] != 0u;  // lists of several records per (node, time slot): merged first next time
+      ctx->ex.fx_long_lists2 = ctx->h_status[16] != 0u;  // ... among the layer-2 nodes' lists
       if (h_n_out) *h_n_out = n_fast;
       ctx->ex.fx_parity ^= 1;  // the other control block has been cleared by this sweep's k_slot_emit
       ctx->ex.fx_backoff = 0;
@@ -2457,7 +2458,7 @@ extern "C" int wc_extract_surfels_batch_enqueue(wc_ctx *ctx, const wc_sweep_job 
     s_acc.push_back(s_acc.back() + sub->ex.fx_tiles);
     s_nodes.push_back(s_nodes.back() + sub->ex.fx_ngrid);
     s_g2.push_back(s_g2.back() + g2);
-    const uint32_t f = (sub->ex.layer2_done ? 1u : 0u) | (sub->ex.fx_long_lists ? 2u : 0u);
+    const uint32_t f = (sub->ex.layer2_done ? 1u : 0u) | ((sub->ex.fx_long_lists || sub->ex.fx_long_lists2) ? 2u : 0u);  // (a batch merges both levels or none)
     flags.push_back(f);
     any_l2 = any_l2 || (f & 1u);
     any_merge = any_merge || (f & 2u);
