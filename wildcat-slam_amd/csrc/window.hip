@@ -112,6 +112,7 @@ struct wc_window_state {
   void *h_up = nullptr;  // pinned staging of that arena
   size_t h_up_cap = 0;
   bool status_clear = false;  // W->status is zero at rest
+  uint32_t heads_zero = 0;    // entries of W->heads known to be zero (the segment heads by key: zero at rest)
   hipEvent_t fam_done[2] = {nullptr, nullptr};  // [0]: segment heads in pinned memory; [1]: the build's last upload has left its staging buffer
   bool built = false;
 };
@@ -466,28 +467,16 @@ __global__ void __launch_bounds__(256) k_build_records(FamArgs B, FamArgs U, con
   F.orig_out[k] = o;
 }
 
-// segment heads of a sorted key array (unordered append; the host sorts the few thousand entries).  One append per
-// WORKGROUP of 1024 keys: one per wavefront with a head was ~8 000 atomics on one address, 5 ns each - 42 us for a 4 MB read.
-__global__ void __launch_bounds__(1024) k_seg_heads(const uint32_t *keys, uint32_t n, uint32_t *heads, uint32_t *status) {
-  __shared__ uint32_t s_cnt[16], s_base;
+// segment heads of a sorted key array, BY KEY: heads[key] = position + 1 of the first record with that key (0 = no such record).
+// The array is zero at rest (the host clears it behind its read-back) and the host walks it in key order - which is position order,
+// the keys being sorted: no append counter on the device, no sort of the heads on the host (rounds 1 - 4: an unordered append of
+// (position, key) pairs, one atomic per workgroup, and a std::sort of the ~4 000 pairs on the host - half of the ~75 us the host
+// needs between the heads' arrival and the upload of its lists).
+__global__ void __launch_bounds__(1024) k_seg_heads(const uint32_t *keys, uint32_t n, uint32_t *heads) {
   const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool head = k < n && (k == 0 || keys[k] != keys[k - 1]);
-  const unsigned long long mask = __ballot(head);
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  if (lane == 0) s_cnt[w] = (uint32_t)__popcll(mask);
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    uint32_t tot = 0;
-    for (int i = 0; i < 16; ++i) tot += s_cnt[i];
-    s_base = tot ? atomicAdd(&status[2], tot) : 0u;
-  }
-  __syncthreads();
-  if (head) {
-    uint32_t o = s_base + (uint32_t)__popcll(mask & ((1ull << lane) - 1));
-    for (int i = 0; i < w; ++i) o += s_cnt[i];
-    heads[2 * o] = k;
-    heads[2 * o + 1] = keys[k];
-  }
+  if (k >= n) return;
+  const uint32_t key = keys[k];
+  if (k == 0 || key != keys[k - 1]) heads[key] = k + 1u;
 }
 
 // ---- assembly: one workgroup per piece ------------------------------------------------------------------------------
@@ -1833,10 +1822,10 @@ struct Seg {
 // enqueued by build_families; collect_families waits for the event and orders the heads on the host (the host picks the IMU
 // factors in the meantime).
 struct FamilyJob {
-  uint32_t nb = 0, nu = 0, cap = 0;
+  uint32_t nb = 0, nu = 0, cap = 0;  // cap = number of possible keys (ns^2 + ns + 1)
   int ns = 0;
   const uint32_t *h_st = nullptr;
-  const std::pair<uint32_t, uint32_t> *h_heads = nullptr;
+  const uint32_t *h_heads = nullptr;
   hipEvent_t done = nullptr;
 };
 
@@ -1847,12 +1836,17 @@ int collect_families(wc_ctx *ctx, const FamilyJob &J, std::vector<Seg> &segs_b, 
   const uint32_t *st = J.h_st;
   if (st[1] & 2u) return wc_fail(ctx, WC_ERR_ORDER, "correspondence is not (older, newer)");
   if (st[1] & 1u) return wc_fail(ctx, WC_ERR_RANGE, "surfel timestamp outside the sample-state range");
-  const uint32_t nh = st[2];
-  if (nh > J.cap) return wc_fail(ctx, WC_ERR_RANGE, "more key segments (%u) than distinct keys (%u)", nh, J.cap);
-  std::vector<std::pair<uint32_t, uint32_t>> heads(J.h_heads, J.h_heads + nh);
-  std::sort(heads.begin(), heads.end());
-  const uint32_t ns = (uint32_t)J.ns, ubase = ns * ns;
-  for (uint32_t i = 0; i < nh; ++i) {
+  const uint32_t ns = (uint32_t)J.ns, ubase = ns * ns, n = J.nb + J.nu;
+  std::vector<std::pair<uint32_t, uint32_t>> heads;  // (position, key) in key order = position order (the keys are sorted)
+  heads.reserve(4096);
+  for (uint32_t key = 0; key < J.cap; ++key) {
+    const uint32_t v = J.h_heads[key];
+    if (!v) continue;
+    if (v > n || (!heads.empty() && v - 1u <= heads.back().first)) return wc_fail(ctx, WC_ERR_RANGE, "segment heads out of order (key %u at %u)", key, v - 1u);
+    heads.push_back({v - 1u, key});
+  }
+  const size_t nh = heads.size();
+  for (size_t i = 0; i < nh; ++i) {
     const uint32_t pos = heads[i].first, sk = heads[i].second;
     const bool unary = pos >= J.nb;  // (a key of the other family at the boundary is a head of its own: no segment straddles it)
     const uint32_t fam_end = unary ? J.nb + J.nu : J.nb;
@@ -1893,7 +1887,14 @@ int build_families(wc_ctx *ctx, wc_window_state *W, const FamArgs &B0, const Fam
   const uint32_t nb = B0.n, nu = U0.n, n = nb + nu;
   if (n == 0) return WC_OK;
   const uint64_t ns = (uint64_t)W->ns, maxkey = ns * ns + ns;
-  const uint32_t cap = (uint32_t)(std::min<uint64_t>(nb, ns * ns + 1) + std::min<uint64_t>(nu, ns + 1));  // as many head slots as there can be distinct keys
+  const uint32_t cap = (uint32_t)(maxkey + 1);  // one head slot per possible key
+  {  // the heads' array: zero at rest (cleared behind every read-back); a fresh or longer one is cleared here
+    void *before = W->heads.p;
+    WC_TRY(wc_ensure(ctx, W->heads, (size_t)cap * 4));
+    if (W->heads.p != before) W->heads_zero = 0;
+    if (W->heads_zero < cap) WC_HIP(ctx, hipMemsetAsync(W->heads.p, 0, (size_t)cap * 4, ctx->stream));
+    W->heads_zero = 0;  // (until the memset behind the read-back is enqueued)
+  }
   WC_TRY(wc_ensure(ctx, W->keys_tmp[0], (size_t)n * 4));
   WC_TRY(wc_ensure(ctx, W->keys_tmp[1], (size_t)n * 4));
   WC_TRY(wc_ensure(ctx, W->vals_tmp[0], (size_t)n * 4));
@@ -1921,21 +1922,23 @@ int build_families(wc_ctx *ctx, wc_window_state *W, const FamArgs &B0, const Fam
   while ((1ull << bits) < maxkey + 1) ++bits;
   WC_TRY(sort_u32(ctx, W, (uint32_t *)W->keys_tmp[0].p, (uint32_t *)W->keys_tmp[1].p, (uint32_t *)W->vals_tmp[0].p,
                   (uint32_t *)W->vals_tmp[1].p, n, bits));
-  // heads of the SORT keys (position in the sorted order, key): the host tells the families apart by position.  The heads leave
-  // BEFORE the records are formed: the host cuts pieces and builds the gather's lists (~65 us) while k_build_records runs.
+  // heads of the SORT keys, by key (k_seg_heads); the host tells the families apart by position.  The heads leave BEFORE the records
+  // are formed: the host cuts pieces and builds the gather's lists while k_build_records runs.
   uint32_t *d_heads = (uint32_t *)W->heads.p;
-  k_seg_heads<<<(n + 1023) / 1024, 1024, 0, ctx->stream>>>((const uint32_t *)W->keys_tmp[1].p, n, d_heads, d_st);
+  k_seg_heads<<<(n + 1023) / 1024, 1024, 0, ctx->stream>>>((const uint32_t *)W->keys_tmp[1].p, n, d_heads);
   WC_HIP(ctx, hipGetLastError());
   char *h = (char *)W->h_pin;
   WC_HIP(ctx, hipMemcpyAsync(h, d_st, 16, hipMemcpyDeviceToHost, ctx->stream));
-  WC_HIP(ctx, hipMemcpyAsync(h + 64, d_heads, (size_t)cap * 8, hipMemcpyDeviceToHost, ctx->stream));
+  WC_HIP(ctx, hipMemcpyAsync(h + 64, d_heads, (size_t)cap * 4, hipMemcpyDeviceToHost, ctx->stream));
   WC_HIP(ctx, hipEventRecord(W->fam_done[0], ctx->stream));
+  WC_HIP(ctx, hipMemsetAsync(d_heads, 0, (size_t)cap * 4, ctx->stream));  // (zero at rest again, behind the read-back)
+  W->heads_zero = cap;
   WC_HIP(ctx, hipMemsetAsync(d_st, 0, 16 * 4, ctx->stream));
   W->status_clear = true;
   k_build_records<<<grid, 256, 0, ctx->stream>>>(B, U, (const uint32_t *)W->vals_tmp[1].p, (const uint32_t *)W->keys_tmp[1].p,
                                                 (const double *)W->times_d.p, W->ns, W->wp.sigma0_sq);
   WC_HIP(ctx, hipGetLastError());
-  J.nb = nb, J.nu = nu, J.cap = cap, J.ns = W->ns, J.h_st = (const uint32_t *)h, J.h_heads = (const std::pair<uint32_t, uint32_t> *)(h + 64), J.done = W->fam_done[0];
+  J.nb = nb, J.nu = nu, J.cap = cap, J.ns = W->ns, J.h_st = (const uint32_t *)h, J.h_heads = (const uint32_t *)(h + 64), J.done = W->fam_done[0];
   return WC_OK;
 }
 
@@ -1997,7 +2000,6 @@ static int window_build_impl(wc_ctx *ctx, const wc_surfel *d_sld_surf, const wc_
       WC_HIP(ctx, hipHostMalloc(&W->h_pin, want));
       W->h_pin_cap = want;
     }
-    WC_TRY(wc_ensure(ctx, W->heads, std::max<size_t>(((size_t)W->nb + W->nu) * 8, 16)));
   }
   // (Round 3, measured with WC_WIN_DEBUG: of the odometry step's 0.40 ms build the host waits ~110 us for the binary family's chain
   // - keys, three sort passes of 16 workgroups each, records, segment heads: ~240 us of small launches - and computes for ~65 us;
