@@ -2055,6 +2055,7 @@ static int window_build_impl(wc_ctx *ctx, const wc_surfel *d_sld_surf, const wc_
     std::copy(out.begin(), out.end(), pieces.begin() + first);
   };
   WC_TRY(collect_families(ctx, job, segs_b, segs_u));
+  auto t_b1 = tnow();
   cut(segs_b, 25, true);
   W->npiece_b = (uint32_t)pieces.size();
   by_size(0);
@@ -2081,6 +2082,7 @@ static int window_build_impl(wc_ctx *ctx, const wc_surfel *d_sld_surf, const wc_
   cut(segs_i, 37, false);
   W->npiece_i = (uint32_t)pieces.size() - W->npiece_b - W->npiece_u;
   W->npart_doubles = off;
+  auto t_b2 = tnow();
   if (tdbg) {  // piece sizes per family
     uint32_t hist[3][6] = {{0}};
     for (size_t i = 0; i < pieces.size(); ++i) {
@@ -2148,6 +2150,7 @@ static int window_build_impl(wc_ctx *ctx, const wc_surfel *d_sld_surf, const wc_
   // copies - out of pageable vectors at first: the runtime stages such a copy and returns when it is through, 10 - 35 us each -,
   // then out of a staging buffer the vectors were copied into; a kernel trace of the odometry step showed the device idle for
   // ~190 us between k_build_records and the solve's first kernel while the host copied and enqueued.)
+  auto t_b3 = tnow();
   const size_t n_src = src_begin[npairs], n_gsrc = gsrc_begin[ns];
   struct Part {
     wc_buf *b;
@@ -2176,6 +2179,7 @@ static int window_build_impl(wc_ctx *ctx, const wc_surfel *d_sld_surf, const wc_
     pt.b->p = (char *)W->lists.p + pt.off, pt.b->cap = pt.bytes;
     if (pt.h && pt.bytes) std::memcpy((char *)W->h_up + pt.off, pt.h, pt.bytes);
   }
+  auto t_b4 = tnow();
   {  // CSR source lists, second pass (fill): sources of a pair / block in piece order, straight into the staging buffer
     Src *src = (Src *)((char *)W->h_up + parts[4].off);
     GSrc *gsrc = (GSrc *)((char *)W->h_up + parts[6].off);
@@ -2223,7 +2227,8 @@ static int window_build_impl(wc_ctx *ctx, const wc_surfel *d_sld_surf, const wc_
   WC_HIP(ctx, hipEventRecord(W->fam_done[1], ctx->stream));
   if (tdbg) {
     auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
-    fprintf(stderr, "[win] build: families + imu %.0f us, pieces + source lists (host) %.0f us, uploads + sync %.0f us\n", us(t_a, t_b), us(t_b, t_c), us(t_c, tnow()));
+    fprintf(stderr, "[win] build: families + imu %.0f us, pieces + source lists (host) %.0f us (wait for the heads %.0f, cut %.0f, count %.0f, layout %.0f, fill %.0f), uploads %.0f us\n", us(t_a, t_b),
+            us(t_b, t_c), us(t_b, t_b1), us(t_b1, t_b2), us(t_b2, t_b3), us(t_b3, t_b4), us(t_b4, t_c), us(t_c, tnow()));
   }
   W->built = true;
   return WC_OK;
