@@ -133,6 +133,44 @@ def test_window_errors(gpu, oracle):
     assert e.value.code == 2
 
 
+def test_builds_back_to_back_and_after_a_failed_build(gpu, oracle):
+    """wc_window_build returns with its last copy still in flight and keeps two arrays zero at rest (status words, segment heads by
+    key): a second build right behind the first (another window, no solve in between), a build behind a FAILED build (whose flags and
+    heads were left on the device) and a build with more sample states than the one before must each give the problem a fresh
+    context gives.  Reference: lidar_odometry.cc:541-545 (the problem is constructed anew for every solve)."""
+    from wildcat_slam_amd import lib
+
+    def reference(cfg):
+        fresh = lib.Context(0)
+        try:
+            _, W, keep = _setup(fresh, oracle, **cfg)
+            H, g, c = fresh.window_linearize(np.zeros(12 * W.ns))
+            return H, g, c, W
+        finally:
+            fresh.close()
+
+    small, large = dict(n_scans=3, patches=200, fixed=80, seed=5), dict(n_scans=6, patches=150, fixed=60, seed=7)
+    for first, second in ((small, large), (large, small)):
+        _setup(gpu, oracle, **first)           # built, never solved
+        _, W, keep = _setup(gpu, oracle, **second)  # right behind it
+        H, g, c = gpu.window_linearize(np.zeros(12 * W.ns))
+        H_ref, g_ref, c_ref, W_ref = reference(second)
+        assert np.array_equal(H, H_ref) and np.array_equal(g, g_ref) and c == c_ref
+        H_o, g_o, c_o = W.linearize(np.zeros(12 * W.ns))
+        assert _rel(H, H_o) <= 1e-10 and _rel(g, g_o) <= 1e-10 and abs(c - c_o) <= 1e-11 * c_o
+    # a failed build (a correspondence that is not (older, newer)) leaves flags and heads behind
+    w = synth.surfel_window(2, 50, seed=3)
+    d_surf, d_pose = gpu.to_device(w["surf"]), gpu.to_device(w["pose"])
+    bad = np.zeros(4, R.PAIR)
+    bad["first"], bad["second"] = [5, 1, 2, 3], [5, 40, 41, 42]
+    with pytest.raises(lib.WildcatError):
+        gpu.window_build(d_surf, d_pose, gpu.to_device(bad), len(bad), None, w["sample_times"], w["grav"], True)
+    _, W, keep = _setup(gpu, oracle, **small)
+    H, g, c = gpu.window_linearize(np.zeros(12 * W.ns))
+    H_ref, g_ref, c_ref, _ = reference(small)
+    assert np.array_equal(H, H_ref) and np.array_equal(g, g_ref) and c == c_ref
+
+
 def test_two_rank_sharded_solve_on_one_gpu(gpu, oracle):
     """The multi-GPU scheme of SURVEY 8(e) with both 'ranks' on one device: two contexts, each with a contiguous half of
     the correspondences (IMU factors on rank 0 only, unknowns replicated), the all-reduce callback of the C-ABI summing the
