@@ -859,7 +859,7 @@ def bench_odometry_step(ctx, args, world, rank, dev, torch, dist, cpu=False):
            "roofline": {"bound": "hbm", "achieved": round(total_b / T["total"] / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(total_b / T["total"] / 1e9 / HBM_PEAK_GBS, 5),
                         "algorithmic_bytes": {"extract": b_ext, "pose_update": b_pose, "match": b_match, "assembly_all_iterations": b_asm}},
-           "timing": "wall clock around each C-ABI call (every call is synchronous on return), the median of %d repetitions from the same window state" % reps}
+           "timing": "wall clock around each C-ABI call, the median of %d repetitions from the same window state; every call is synchronous on return except wc_window_build, whose last device work (records, one copy of lists) ends inside the solve stage" % reps}
     try:  # the fixed-window search alone on this context, for its walk statistics
         n_fix_, n_sld_ = sw.n_fix, info["sld"]
         ctx.match_device(_Ptr(sw.d_surf.ptr + 144 * n_fix_), _Ptr(sw.d_pose.ptr + 56 * n_fix_), n_sld_, sw.d_surf, sw.d_pose, n_fix_, False, sw.d_pu, sw.cap_all)
