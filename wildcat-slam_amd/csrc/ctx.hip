@@ -160,6 +160,8 @@ extern "C" int wc_dev_alloc(wc_ctx *ctx, size_t bytes, void **d_ptr) {
   wc_dev_guard dg_(ctx);
   if (!ctx || !d_ptr) return wc_fail(ctx, WC_ERR_ARG, "%s: null or out-of-range argument", __func__);
   WC_HIP(ctx, hipSetDevice(ctx->device));
+  static const bool alloc_dbg = getenv("WC_ALLOC_DEBUG") != nullptr;  // (read once per process)
+  if (alloc_dbg) fprintf(stderr, "[alloc] wc_dev_alloc %zu bytes\n", bytes);
   WC_HIP(ctx, hipMalloc(d_ptr, bytes ? bytes : 1));
   return WC_OK;
 }

@@ -150,7 +150,7 @@ bool LidarOdometry::sample_state(size_t i, SampleStateView *out) const {
 void LidarOdometry::EnsureSurfelCapacity(size_t n) {
   if (n_surfels_ + n <= cap_surfels_) return;
   const size_t live = n_surfels_ - sld_begin_;
-  const size_t cap = std::max<size_t>((live + n) + (live + n) / 2, 1 << 16);
+  const size_t cap = std::max<size_t>((live + n) + (live + n) / 2, 1 << 18);  // (262 k surfels = 57 MB from the start: the room stream's window crossed 65 k in its fifth sweep - five allocations and three copies, 0.5 ms)
   void *ns = nullptr, *np = nullptr, *nb = nullptr, *p1 = nullptr, *p2 = nullptr;
   WC_CALL(wc_dev_alloc(ctx_, cap * sizeof(wc_surfel), &ns));
   WC_CALL(wc_dev_alloc(ctx_, cap * sizeof(wc_pose), &np));
