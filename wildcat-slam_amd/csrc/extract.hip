@@ -56,6 +56,7 @@ struct ExParams {
   uint64_t t_lo_bits;  // ordered bits of the time hint lower bound
   uint64_t t_span_bits;  // ordered bits of the upper bound - t_lo_bits
   int dbg;             // WC_DEBUG_SKIP bits (profiling experiments only)
+  int merge_min;       // a (node, time slot) list of more records than this makes the next sweep run k_fx_merge (default 3; WC_FX_MERGE_MIN: experiments)
 };
 
 __device__ __forceinline__ uint64_t ordered_bits(double t) {
@@ -1865,6 +1866,10 @@ int run_pipeline_fast(wc_ctx *ctx, const wc_points &pts, double t_lo, double t_h
   E.t_span_bits = ordered_bits_host(t_hi) - E.t_lo_bits;
   static const int env_skip = getenv("WC_DEBUG_SKIP") ? atoi(getenv("WC_DEBUG_SKIP")) : 0;
   E.dbg = env_skip;
+  {
+    static const int env_mm = getenv("WC_FX_MERGE_MIN") ? atoi(getenv("WC_FX_MERGE_MIN")) : 3;  // (read once per process)
+    E.merge_min = env_mm;
+  }
   unsigned tbits = 1;
   while (tbits < 64 && (E.t_span_bits >> tbits)) ++tbits;
   A.pts = pts;
@@ -2110,6 +2115,10 @@ int run_pipeline(wc_ctx *ctx, const wc_points &pts, double t_lo, double t_hi, wc
   E.t_lo_bits = ordered_bits_host(t_lo);
   static const int env_skip = getenv("WC_DEBUG_SKIP") ? atoi(getenv("WC_DEBUG_SKIP")) : 0;
   E.dbg = env_skip;
+  {
+    static const int env_mm = getenv("WC_FX_MERGE_MIN") ? atoi(getenv("WC_FX_MERGE_MIN")) : 3;  // (read once per process)
+    E.merge_min = env_mm;
+  }
   const uint64_t span = ordered_bits_host(t_hi) - E.t_lo_bits;
   E.t_span_bits = span;
   unsigned tbits = 1;
