@@ -2001,9 +2001,11 @@ static int window_build_impl(wc_ctx *ctx, const wc_surfel *d_sld_surf, const wc_
       W->h_pin_cap = want;
     }
   }
-  // (Round 3, measured with WC_WIN_DEBUG: of the odometry step's 0.40 ms build the host waits ~110 us for the binary family's chain
-  // - keys, three sort passes of 16 workgroups each, records, segment heads: ~240 us of small launches - and computes for ~65 us;
-  // the unary family on a stream of its own took 20 us off, uploads out of pinned memory nothing: one stream, pageable vectors.)
+  // (Round 3, WC_WIN_DEBUG: of the odometry step's 0.40 ms build the host waited ~110 us for the binary family's chain - keys, three
+  // sort passes, records, segment heads, then the same for the unary family: ~240 us of small launches - and computed for ~65 us.  Round 4:
+  // one chain for both families, the heads leave before the records are formed, the host's lists go out in one copy from pinned staging,
+  // no closing stream wait: 0.22 - 0.25 ms, of which the host now sees ~85 us of enqueueing, ~25 of waiting for the heads and ~65 of its own
+  // work - WC_WIN_DEBUG prints them per phase.)
   FamilyJob job;
   {
     const FamArgs fb{d_sld_surf, d_sld_surf, d_sld_pose, d_sld_pose, d_pairs_sld, W->nb, nullptr, nullptr, nullptr};
