@@ -166,7 +166,7 @@ def main():
     ap.add_argument("--in-flight", type=int, default=3, help="sweeps in flight (contexts) of the extra pipelined measurement")
     args = ap.parse_args()
 
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    if (args.gpus > 1 or os.environ.get("WC_BENCH_FORCE_DIST") == "1") and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` as typed: become the launcher - one rank per GPU through torch.distributed.run (rendezvous on
         # 127.0.0.1: the container's hostname may not resolve); rank 0 of the children prints the JSON line
         import socket
