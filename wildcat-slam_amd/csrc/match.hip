@@ -352,10 +352,15 @@ static int match_impl(wc_ctx *ctx, const wc_surfel *d_q_surf, const wc_pose *d_q
   static const int group_env = getenv("WC_KNN_GROUP") ? atoi(getenv("WC_KNN_GROUP")) : -1;  // (experiments: 0 / 1 pins the walk; read once)
   const bool group_walk = group_env >= 0 ? group_env != 0 : (nq_mine < 750000u || (same_set && nq_mine < 1500000u));
   const int first3 = plan.D % 3 ? plan.D % 3 : 3;
+  // Workgroups of ONE wavefront (eight queries): the groups of a workgroup share nothing, and a 256-thread workgroup holds its four
+  // wavefront slots and its LDS until the slowest of its 32 walks has ended - the next workgroup waits for all of them.  Measured
+  // (profiles/dev/time_match.py pair, time_room_match.py): the step-like pair of searches 1.674 -> 1.605 ms, a room search 0.444 -> 0.439.
+  constexpr int kGroupNT = 64;
 #define WC_KNN_LAUNCH(KK)                                                                                                                            \
   if (nq_mine && group_walk)                                                                                                                         \
-    k_knn_tree_group<KK><<<(nq_mine + 31) / 32, 256, 0, st>>>(d_q_surf, d_q_pose, nq, tree, first3, (const double *)b_world.p, nt, M, (uint32_t *)b_gated.p, \
-                                                              d_knn_idx, d_knn_d2, qorder, q_begin, q_end, gated_shard, stats, status);              \
+    k_knn_tree_group<KK, kGroupNT><<<(nq_mine + kGroupNT / 8 - 1) / (kGroupNT / 8), kGroupNT, 0, st>>>(                                              \
+        d_q_surf, d_q_pose, nq, tree, first3, (const double *)b_world.p, nt, M, (uint32_t *)b_gated.p, d_knn_idx, d_knn_d2, qorder, q_begin, q_end,  \
+        gated_shard, stats, status);                                                                                                                 \
   else if (nq_mine)                                                                                                                                  \
     k_knn_tree<KK><<<(nq_mine + 63) / 64, 64, (size_t)(kNch + 1 + stack_cap) * 64 * 4, st>>>(d_q_surf, d_q_pose, nq, tree, (const double *)b_world.p, nt, M, (uint32_t *)b_gated.p, d_knn_idx, \
                                                        d_knn_d2, qorder, q_begin, q_end, gated_shard, stats, status, stack_cap);
