@@ -506,6 +506,7 @@ void LidarOdometry::ShrinkToFit() {
 
 void LidarOdometry::AddLidarScan(const pcl::PointCloud<hilti_ros::Point>::Ptr &msg) {
   // lidar frame -> imu frame, range / blind-box filter (:489-496): on the device, the points stay there
+  const auto t_entry = std::chrono::steady_clock::now();
   AppendScanOnDevice(*msg);
   if (!SyncHeadingMsgs()) return;
 
@@ -516,6 +517,7 @@ void LidarOdometry::AddLidarScan(const pcl::PointCloud<hilti_ros::Point>::Ptr &m
   // wall time of the stages of a completed sweep (last_stage_ms(); WC_ODOM_DEBUG=1 also prints them on stderr)
   static const bool dbg_t = getenv("WC_ODOM_DEBUG") != nullptr;
   auto t_prev = std::chrono::steady_clock::now();
+  last_append_ms_ = std::chrono::duration<double, std::milli>(t_prev - t_entry).count();
   double (&t_stage)[8] = last_stage_ms_;
   for (double &v : t_stage) v = 0.0;
   last_lm_iterations_ = 0;

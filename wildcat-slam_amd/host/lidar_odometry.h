@@ -55,6 +55,9 @@ class LidarOdometry {
   // wall time [ms] of the last completed sweep's stages: predict + undistort, extract + poses, match, build, solve, update, shrink
   const double *last_stage_ms() const { return last_stage_ms_; }
   int last_lm_iterations() const { return last_lm_iterations_; }
+  // wall time [ms] the message that completed the last sweep spent in front of the stages: upload + pre-filter of its points
+  // (AppendScanOnDevice) and the heading synchronisation
+  double last_append_ms() const { return last_append_ms_; }
   uint64_t last_correspondences(int which) const { return last_corr_[which]; }
   // test hook: keep, for the last completed sweep's last outer iteration, the two surfel timestamps of every correspondence
   // (which = 0: sliding window, 1: fixed window) - what a comparison with another run can match pairs on when surfel ORDER differs
@@ -147,6 +150,7 @@ class LidarOdometry {
   wc_solve_summary last_summary_{};
   double last_stage_ms_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   int last_lm_iterations_ = 0;  // over the sweep's outer iterations
+  double last_append_ms_ = 0.0;
   uint64_t last_corr_[2] = {0, 0};
   bool keep_pair_stamps_ = false;
   std::vector<double> pair_stamps_[2];  // (first, second) stamps, pair after pair

@@ -65,6 +65,9 @@ void wc_odom_stage_ms(void *h, double out[8]) {
   out[7] = (double)o->last_lm_iterations();
 }
 
+// wall time [ms] of the completing message's part in front of those stages (upload + pre-filter of its points, heading synchronisation)
+double wc_odom_append_ms(void *h) { return ((const LidarOdometry *)h)->last_append_ms(); }
+
 // out[2] = sweeps extracted by the default (integer-moment) arithmetic, sweeps extracted in the reference's summation order
 void wc_odom_extract_paths(void *h, int out[2]) {
   out[0] = ((LidarOdometry *)h)->sweeps_fast_path();

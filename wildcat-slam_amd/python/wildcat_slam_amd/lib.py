@@ -538,6 +538,7 @@ class Odometry:
         self.lib = C.CDLL(so)
         self.lib.wc_odom_create.restype = C.c_void_p
         self.lib.wc_odom_num_samples.restype = C.c_uint64
+        self.lib.wc_odom_append_ms.restype = C.c_double
         self.h = C.c_void_p(self.lib.wc_odom_create(C.c_int(device)))
 
     def close(self):
@@ -560,6 +561,7 @@ class Odometry:
         names = ("predict_undistort", "extract_poses", "match", "build", "solve", "update", "shrink")
         d = dict(zip(names, [float(v) for v in out[:7]]))
         d["lm_iterations"] = int(out[7])
+        d["append"] = float(self.lib.wc_odom_append_ms(self.h))  # upload + pre-filter of the completing message, in front of the stages
         return d
 
     def extract_paths(self):
