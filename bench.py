@@ -880,32 +880,15 @@ def bench_odometry_step(ctx, args, world, rank, dev, torch, dist, cpu=False):
         # the SAME step at full size (~15 s of one core); --cpu-seconds below 5: 1/10 of the roots per sweep
         full = args.cpu_seconds >= 5.0
         ws = w if full else synth.g2_scan_sequence(K, max(8, roots // 10), m=32, seed=synth.SEED + 21)
-        with pinned_core() as pc:
-            surf = []
-            for s in ws["scans"][:-1]:
-                surf.append(pyoracle.extract_surfels(s)[0])
-            n_fx = len(surf[0]) + len(surf[1])
-            S = np.concatenate(surf)
-            P = np.zeros(len(S), R.POSE)
-            B = np.zeros(len(S), np.uint8)
-            pyoracle.update_surfel_poses(ws["imu"], S, P, B)
-            t0 = time.perf_counter()
-            new = pyoracle.extract_surfels(ws["scans"][-1])[0]
-            S2 = np.concatenate([S, new])
-            P2 = np.concatenate([P, np.zeros(len(new), R.POSE)])
-            B2 = np.concatenate([B, np.zeros(len(new), np.uint8)])
-            pyoracle.update_surfel_poses(ws["imu"], S2[n_fx:], P2[n_fx:], B2[n_fx:])
-            sl_s, sl_p = np.ascontiguousarray(S2[n_fx:]), np.ascontiguousarray(P2[n_fx:])
-            pb = pyoracle.match(sl_s, sl_p, sl_s, sl_p, True)
-            pu = pyoracle.match(sl_s, sl_p, np.ascontiguousarray(S2[:n_fx]), np.ascontiguousarray(P2[:n_fx]), False)
-            Wc = pyoracle.Window(ws["sample_times"], ws["grav"], False)
-            Wc.add_binary(sl_s, sl_p, pb)
-            Wc.add_unary(np.ascontiguousarray(S2[:n_fx]), np.ascontiguousarray(P2[:n_fx]), sl_s, sl_p, pu)
-            Wc.add_imu(ws["imu"])
-            _, sc, _ = Wc.solve(np.zeros(12 * len(ws["sample_times"])))
-            pyoracle.update_surfel_poses(ws["imu"], sl_s, sl_p, np.ones(len(sl_s), np.uint8))
-            t_cpu = time.perf_counter() - t0
+        with pinned_core() as pc:  # (the same helper the parity tests of the step compare the GPU path with: tests/test_step_gpu.py)
+            ref = pyoracle.odometry_step(ws)
+        t_cpu, sl_s, n_fx, pb, pu, sc = ref["seconds"], ref["sld_surf"], ref["n_fix"], ref["pairs_sld"], ref["pairs_fix"], ref["summary"]
+        same = None
+        if full:  # did the two paths work on the same problem?  (recorded, not asserted: the by-value comparison at this size - surfels,
+            # both pair lists, iterations, cost, corrections - is tests/test_step_gpu.py::test_one_rank_step_at_bench_size_against_the_oracle)
+            same = (len(sl_s), n_fx, len(pb), len(pu), sc.iterations) == (info["sld"], info["fix"], info["binary"], info["unary"], info["iters"])
         out["cpu_baseline"] = {"value": round(1.0 / t_cpu, 4), "unit": "steps/s", "cores": 1, "kind": "port", "pinned_core": pc.core, "cpu": cpu_info()["model"],
+                               "same_counts_and_iterations_as_the_gpu_step": same,
                                "sample": "the same step %s (%d-point sweeps, %d sliding + %d fixed surfels, %d + %d surfel factors, %d LM iterations): %.2f s "
                                          "of single-thread oracle" % ("at FULL size" if full else "at 1/10 scale", len(ws["scans"][-1]), len(sl_s), n_fx, len(pb), len(pu),
                                                                       sc.iterations, t_cpu)}
@@ -914,12 +897,15 @@ def bench_odometry_step(ctx, args, world, rank, dev, torch, dist, cpu=False):
 
 def bench_facade_stream(local_rank, cpu):
     """the drop-in class itself: LidarOdometry::AddLidarScan (lidar_odometry.cc:487-605) through libwildcat_odometry.so
-    (host/lidar_odometry.cc, INTEGRATION.md route A) on the synthetic room stream of tests/test_facade_gpu.py - 4 s of a 32-beam
+    (host/lidar_odometry.cc, INTEGRATION.md route A) on the synthetic room stream of tests/test_facade_gpu.py - 8.2 s of a 32-beam
     scanner at 640 k points/s, messages of 0.1 s, 200 Hz IMU: ms per completed sweep (median behind the first two) with the
     facade's own stage split; beside it the orchestrated CPU oracle (oracle/odometry.cc) on the same messages"""
     from wildcat_slam_amd import lib, synth
 
-    msgs, imu, _ = synth.raw_stream(4.0, pts_per_s=640_000, gyro_bias=(0.0, 0.0, 0.02), t_start=1000.0)
+    # 8.2 s of stream (16 completed sweeps): the sliding window is 6 s, so from sweep 13 on the FIXED window exists - second search,
+    # unary factors, ShrinkToFit (lidar_odometry.cc:228-250) are inside the timed sweeps (VERDICT r4 weak #3; tests/test_facade_gpu.py
+    # compares the same stream with the orchestrated oracle)
+    msgs, imu, _ = synth.raw_stream(8.2, pts_per_s=640_000, gyro_bias=(0.0, 0.0, 0.02), t_start=1000.0)
 
     def drive(odo, stage=None):
         k, times, before = 0, [], 0
@@ -949,6 +935,9 @@ def bench_facade_stream(local_rank, cpu):
                len(times), int(np.mean([len(m) for m in msgs])) * 5, int(min(s_["sld_surfels"] for _, _, s_ in tail)), int(max(s_["sld_surfels"] for _, _, s_ in tail)),
                int(max(s_["fix_surfels"] for _, _, s_ in tail))),
            "ms_per_sweep_median": round(float(np.median(ts)) * 1e3, 4), "ms_per_sweep_max": round(float(ts.max()) * 1e3, 4),
+           "ms_per_sweep": [round(float(t) * 1e3, 3) for t in ts], "lm_iterations_per_sweep": [int(st["lm_iterations"]) for _, st, _ in tail],
+           "ms_per_lm_iteration_median": round(float(np.median([st["solve"] / max(st["lm_iterations"], 1.0) for _, st, _ in tail])), 4),
+           "fix_surfels_per_sweep": [int(s_["fix_surfels"]) for _, _, s_ in tail], "unary_per_sweep": [int(s_["unary"]) for _, _, s_ in tail],
            "stage_ms_median": med, "sweeps_on_the_default_extraction_path": fast, "sweeps_on_the_exact_path": exact,
            "timing": "wall clock around LidarOdometry::AddLidarScan for the message that completes a sweep; stages by the facade's own clock"}
     if cpu:

@@ -46,6 +46,29 @@ void wc_ctx_destroy(wc_ctx *ctx);
 const char *wc_last_error(const wc_ctx *ctx);
 int wc_ctx_set_stream(wc_ctx *ctx, void *hip_stream); /* NULL = the ctx's own stream */
 int wc_ctx_set_params(wc_ctx *ctx, const wc_params *params);
+/* Development options of ONE context - the only way to change what the release library executes besides wc_params.  The release
+ * build reads no environment variable that alters a result or a code path (a stray WC_* variable cannot change what a node runs);
+ * the variables it does read only PRINT: WC_ALLOC_DEBUG, WC_FX_DEBUG, WC_MATCH_DEBUG, WC_MATCH_TIMING, WC_WIN_DEBUG, WC_DEBUG_GATHER
+ * (libwildcat_hip.so) and WC_ODOM_DEBUG (the facade).  A `-DWC_DEV_KNOBS` build (profiles/dev) additionally seeds the options below
+ * from the upper-case WC_<NAME> variables when a context is created.  Options (value 0 / 1 unless stated; -1 = the library decides):
+ *   exact_sums         contexts behave as if wc_params.exact_sums were 1
+ *   debug_skip         knock-out bits of the default extraction path (timing runs only: results are wrong)
+ *   fx_merge_min       list length from which the next sweep merges record lists first (default 3)
+ *   fx_split           node stage of the default extraction: 0 fused kernel, 1 two kernels, -1 by size
+ *   no_bucket_sort     exact path: radix sort instead of the run-binned sort
+ *   kd_leaf            target leaf size of the matcher's kd-tree (0 = 8)
+ *   knn_group          matcher walk: 0 one lane per query, 1 eight lanes per query, -1 by the call's sizes
+ *   match_pair_serial  wc_match_pair runs its two searches one after the other on the ctx
+ *   match_pair_swap    the sliding-window search on the helper context instead of the fixed-window one
+ *   lin_imu_apart, lin_unary_apart, lin_post_apart   factor families / mailbox of a linearisation as launches of their own
+ *   lm_dense, lm_eval_pass, lm_sync, lm_chain         earlier forms of the LM step kept for A/B runs
+ * Tests use it to run both forms of a choice on the same data.  Unknown names return WC_ERR_ARG. */
+int wc_ctx_set_dev_option(wc_ctx *ctx, const char *name, int value);
+/* Optional, for long-running callers (the facade calls it from its constructor): takes one-time costs out of the first calls - loads
+ * the code object of every translation unit of the library, creates wc_match_pair's helper context and host thread, and takes
+ * `reserve_bytes` (0: nothing) of HBM into the device's stream-ordered memory pool, from which every scratch buffer of a context grows
+ * (growing a buffer is then an enqueue of microseconds, not a hipFree + hipMalloc).  No reference counterpart. */
+int wc_ctx_warmup(wc_ctx *ctx, size_t reserve_bytes);
 
 /* device memory helpers so that a host program needs no HIP headers ---------------------------------------------- */
 int wc_dev_alloc(wc_ctx *ctx, size_t bytes, void **d_ptr);

@@ -1,6 +1,6 @@
-"""Both walks of the matcher's tree (csrc/match_tree.inc: one lane per query / eight lanes per query) pinned by WC_KNN_GROUP, which the
-library reads once per process - hence a process of its own (tests/test_match_gpu.py starts it twice): every instantiated k, same-set and
-other-set searches, k-NN tables and pairs against the CPU oracle.  Usage: WC_KNN_GROUP=0|1 python _match_walk_worker.py"""
+"""Both walks of the matcher's tree (csrc/match_tree.inc: one lane per query / eight lanes per query) pinned by the development
+option knn_group (wc_ctx_set_dev_option), each in a process of its own (tests/test_match_gpu.py starts it twice): every instantiated k, same-set and
+other-set searches, k-NN tables and pairs against the CPU oracle.  Usage: python _match_walk_worker.py 0|1"""
 import os
 import sys
 
@@ -21,7 +21,9 @@ def feat(s):
 
 
 def main():
+    group = int(sys.argv[1])
     ctx = lib.Context(0)
+    ctx.set_dev_option("knn_group", group)
     w = synth.surfel_window(4, 2500, seed=77, fixed_patches=3000)  # identity-free poses: features through the oracle's own path
     for k in (1, 2, 3, 5, 8, 10, 12, 16):
         prm = pyoracle.default_params()
@@ -46,7 +48,7 @@ def main():
         _, idx, d2 = ctx.match(s, p, s, p, True, want_knn=True)
         ridx, rd2 = pyoracle.knn6(feat(s), feat(s), 10)
         assert np.array_equal(d2, rd2) and np.array_equal(idx.astype(np.int64), ridx.astype(np.int64)), nt
-    print("walk", os.environ.get("WC_KNN_GROUP"), "ok")
+    print("walk", group, "ok")
 
 
 if __name__ == "__main__":

@@ -320,11 +320,10 @@ def test_query_sharded_match_equals_unsharded(gpu):
 
 
 @pytest.mark.parametrize("serial", [False, True])
-def test_match_pair_equals_the_two_searches_and_the_oracle(gpu, oracle, serial, monkeypatch):
+def test_match_pair_equals_the_two_searches_and_the_oracle(gpu, oracle, serial):
     """wc_match_pair (both KnnSurfelMatcher objects of lidar_odometry.cc:530-538 side by side, the fixed-window search on a helper
     context and host thread) against two wc_match calls and against the oracle; several calls in a row reuse the helper."""
-    if serial:
-        monkeypatch.setenv("WC_MATCH_PAIR_SERIAL", "1")
+    gpu.set_dev_option("match_pair_serial", 1 if serial else 0)  # (both searches on the ctx, one after the other)
     w = synth.surfel_window(4, 2000, seed=31, fixed_patches=1500)
     ns, nf = len(w["surf"]), len(w["fix_surf"])
     d_s, d_p = gpu.to_device(w["surf"]), gpu.to_device(w["pose"])
@@ -339,18 +338,19 @@ def test_match_pair_equals_the_two_searches_and_the_oracle(gpu, oracle, serial, 
         got_b, got_u = d_b.download(R.PAIR, nb), d_u.download(R.PAIR, nu)
         assert np.array_equal(got_b, one_b) and np.array_equal(got_u, one_u)
         assert np.array_equal(got_b, ref_b) and np.array_equal(got_u, ref_u)
+    gpu.set_dev_option("match_pair_serial", 0)
     assert len(ref_b) > 1000 and len(ref_u) > 500
 
 
 @pytest.mark.parametrize("group", ["0", "1"], ids=["lane-per-query", "eight-lanes-per-query"])
 def test_both_walks_every_k(gpu, group):
-    """the matcher picks its walk by the call's sizes (below 750 k queries: eight lanes per query); WC_KNN_GROUP pins it, read once per
-    process - so tests/_match_walk_worker.py runs in a process of its own under each setting: every instantiated k, both kinds of
-    search, trees of one leaf ... two sample stages, against the oracle"""
+    """the matcher picks its walk by the call's sizes (below 750 k queries: eight lanes per query); the development option knn_group
+    (wc_ctx_set_dev_option) pins it - tests/_match_walk_worker.py runs in a process of its own under each setting: every
+    instantiated k, both kinds of search, trees of one leaf ... two sample stages, against the oracle"""
     import os
     import subprocess
     import sys
 
     worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_match_walk_worker.py")
-    r = subprocess.run([sys.executable, worker], env=dict(os.environ, WC_KNN_GROUP=group), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    r = subprocess.run([sys.executable, worker, group], env=dict(os.environ), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
     assert r.returncode == 0 and ("walk %s ok" % group) in r.stdout.decode(), r.stdout.decode()[-3000:]

@@ -5,6 +5,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -16,11 +17,37 @@ struct wc_window_state;  // window.hip
 struct wc_buf {
   void *p = nullptr;
   size_t cap = 0;
+  bool pooled = false;  // from the device's stream-ordered memory pool (hipMallocAsync): released with hipFreeAsync
 };
+
+// Development options of a context (wc_ctx_set_dev_option; include/wildcat_hip.h lists them).  They pin choices the library
+// otherwise makes from the call's sizes, or knock parts of a kernel out for timing runs.  The release build reads NO environment
+// variable that changes the executed path: a `-DWC_DEV_KNOBS` build (profiles/dev) seeds these fields from the WC_* variables of
+// DESIGN 5.1 when a context is created; everything else goes through the explicit call.
+struct wc_dev_opts {
+  int exact_sums = 0;        // contexts behave as if wc_params.exact_sums were 1
+  int debug_skip = 0;        // knock-out bits of the default extraction path (results are WRONG; timing runs only)
+  int fx_merge_min = 3;      // list length from which the next sweep runs k_fx_merge
+  int fx_split = -1;         // node stage of the default extraction: 0 fused, 1 two kernels, -1 by size
+  int no_bucket_sort = 0;    // exact path: radix sort instead of the run-binned sort
+  int kd_leaf = 0;           // matcher: target leaf size of the kd-tree (0: 8)
+  int knn_group = -1;        // matcher walk: 0 one lane per query, 1 eight lanes per query, -1 by size
+  int match_pair_serial = 0; // wc_match_pair runs its searches one after the other on the ctx
+  int match_pair_swap = 0;   // the sliding-window search on the helper instead of the fixed-window one
+  int lin_imu_apart = 0, lin_unary_apart = 0, lin_post_apart = 0;  // the linearisation's families / mailbox as launches of their own
+  int lm_dense = 0;          // round 2's LM step: dense Cholesky of all 12 ns unknowns
+  int lm_sync = 0;           // wait for the stream instead of the mailbox ticket
+  int lm_eval_pass = 0;      // a cost-only pass for the candidate instead of a linearisation
+  int lm_chain = 0;          // the damped solve as the round-4 launch chain instead of the persistent kernel
+};
+// logging-only switches (they print; they never change a result): read once per process from the environment in every build
+inline bool wc_log_env(const char *name) { return getenv(name) != nullptr; }
 
 struct wc_ctx {
   int device = 0;
   wc_params P;
+  wc_dev_opts dev;
+  bool pool_ok = false;  // the device has a stream-ordered memory pool (wc_ensure allocates from it)
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -132,25 +159,41 @@ inline int wc_fail(wc_ctx *ctx, int code, const char *fmt, ...) {
       return wc_fail(ctx, WC_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
   } while (0)
 
-// grow-only device buffer
+// grow-only device buffer.  Memory comes from the device's stream-ordered pool (hipMallocAsync on the ctx stream; wc_ctx_create sets
+// the pool's release threshold so that freed blocks stay with the process): growing a buffer is an enqueue of microseconds, neither
+// the device synchronisation of a hipFree nor the ~0.3 - 1 ms of a hipMalloc - a kernel trace of the facade's stream (round 5) showed a
+// sweep of 15 ms among sweeps of 7 when the window's record buffers crossed their size together, and 19 ms for the first search of a
+// helper context (25 buffers).  Falls back to hipMalloc where the pool is not available.
+inline void wc_buf_release(wc_ctx *ctx, wc_buf &b) {
+  if (!b.p) return;
+  if (b.pooled && ctx && ctx->stream && hipFreeAsync(b.p, ctx->stream) == hipSuccess) {
+  } else {
+    if (ctx && ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(b.p);
+  }
+  b.p = nullptr, b.cap = 0, b.pooled = false;
+}
 inline int wc_ensure(wc_ctx *ctx, wc_buf &b, size_t bytes) {
   if (bytes <= b.cap) return WC_OK;
-  if (b.p) {
-    WC_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    WC_HIP(ctx, hipFree(b.p));
-    b.p = nullptr;
-    b.cap = 0;
-  }
+  wc_buf_release(ctx, b);  // (stream ordered: what is enqueued on the ctx stream still sees the old block)
   // (slack: a window that grows by a sweep per call - the facade's first seconds - re-allocated several buffers on EVERY call with an
-  // eighth of slack, and still ~14 of a context's ~70 per sweep with half - 0.5 - 1 ms of hipStreamSynchronize / hipFree / hipMalloc;
-  // now no buffer is smaller than 16 MB, one below 64 MB doubles, a larger one grows by half: 288 GB of HBM make the slack free.
-  // The floor was 4 MB until the end of round 4: the facade's window (55 k surfels: 6.6 MB of binary records) crossed it, and the
-  // re-allocations showed as sweeps of 6 - 8 ms among sweeps of 4.7 - a hipFree is a device synchronisation, a hipMalloc ~ms.)
+  // eighth of slack; now a buffer that follows the data is never smaller than 16 MB, one below 64 MB doubles, a larger one grows by
+  // half: 288 GB of HBM make the slack free.  The floor is for requests of 64 KB or more; the ~40 buffers of a context that hold
+  // status words, plane tables or mailboxes stay small - with the floor on everything a fully used context pinned 1 - 1.5 GB, times
+  // the helper and batch sub-contexts)
   size_t want = bytes < ((size_t)64 << 20) ? 2 * bytes : bytes + bytes / 2;
-  if (want < ((size_t)16 << 20)) want = (size_t)16 << 20;
-  static const bool alloc_dbg = getenv("WC_ALLOC_DEBUG") != nullptr;  // (read once per process)
+  if (bytes >= ((size_t)64 << 10) && want < ((size_t)16 << 20)) want = (size_t)16 << 20;
+  if (want < 4096) want = 4096;
+  static const bool alloc_dbg = wc_log_env("WC_ALLOC_DEBUG");  // (read once per process)
   if (alloc_dbg) fprintf(stderr, "[alloc] %zu bytes wanted -> %zu\n", bytes, want);
-  WC_HIP(ctx, hipMalloc(&b.p, want));
+  if (ctx->pool_ok && hipMallocAsync(&b.p, want, ctx->stream) == hipSuccess) {
+    b.pooled = true;
+  } else {
+    (void)hipGetLastError();
+    b.p = nullptr;
+    WC_HIP(ctx, hipMalloc(&b.p, want));
+    b.pooled = false;
+  }
   b.cap = want;
   return WC_OK;
 }

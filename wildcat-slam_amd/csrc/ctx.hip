@@ -52,6 +52,33 @@ static int check_params(wc_ctx *ctx, const wc_params *p) {
   return WC_OK;
 }
 
+// the development options by name (wc_ctx_set_dev_option) and - in a -DWC_DEV_KNOBS build - by environment variable
+namespace {
+struct DevOpt {
+  const char *name, *env;
+  int wc_dev_opts::*field;
+  bool flag_only;  // the variable's presence means 1
+};
+const DevOpt kDevOpts[] = {
+    {"exact_sums", "WC_EXACT_SUMS", &wc_dev_opts::exact_sums, true},
+    {"debug_skip", "WC_DEBUG_SKIP", &wc_dev_opts::debug_skip, false},
+    {"fx_merge_min", "WC_FX_MERGE_MIN", &wc_dev_opts::fx_merge_min, false},
+    {"fx_split", "WC_FX_SPLIT", &wc_dev_opts::fx_split, false},
+    {"no_bucket_sort", "WC_NO_BUCKET_SORT", &wc_dev_opts::no_bucket_sort, true},
+    {"kd_leaf", "WC_KD_LEAF", &wc_dev_opts::kd_leaf, false},
+    {"knn_group", "WC_KNN_GROUP", &wc_dev_opts::knn_group, false},
+    {"match_pair_serial", "WC_MATCH_PAIR_SERIAL", &wc_dev_opts::match_pair_serial, true},
+    {"match_pair_swap", "WC_MATCH_PAIR_SWAP", &wc_dev_opts::match_pair_swap, true},
+    {"lin_imu_apart", "WC_LIN_IMU_APART", &wc_dev_opts::lin_imu_apart, true},
+    {"lin_unary_apart", "WC_LIN_UNARY_APART", &wc_dev_opts::lin_unary_apart, true},
+    {"lin_post_apart", "WC_LIN_POST_APART", &wc_dev_opts::lin_post_apart, true},
+    {"lm_dense", "WC_LM_DENSE", &wc_dev_opts::lm_dense, true},
+    {"lm_sync", "WC_LM_SYNC", &wc_dev_opts::lm_sync, true},
+    {"lm_eval_pass", "WC_LM_EVAL_PASS", &wc_dev_opts::lm_eval_pass, true},
+    {"lm_chain", "WC_LM_CHAIN", &wc_dev_opts::lm_chain, true},
+};
+}  // namespace
+
 extern "C" int wc_ctx_create(const wc_params *params, int device, wc_ctx **out) {
   if (!out) return WC_ERR_ARG;
   *out = nullptr;
@@ -84,8 +111,34 @@ extern "C" int wc_ctx_create(const wc_params *params, int device, wc_ctx **out) 
     return WC_ERR_HIP;
   }
   ctx->stream = ctx->own_stream;
+  {  // the device's default memory pool keeps what is freed (release threshold: never give memory back while the process lives)
+    hipMemPool_t pool = nullptr;
+    int supported = 0;
+    if (hipDeviceGetAttribute(&supported, hipDeviceAttributeMemoryPoolsSupported, device) == hipSuccess && supported &&
+        hipDeviceGetDefaultMemPool(&pool, device) == hipSuccess && pool) {
+      uint64_t keep = ~0ull;
+      ctx->pool_ok = hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep) == hipSuccess;
+    }
+    (void)hipGetLastError();
+  }
+#ifdef WC_DEV_KNOBS  // development build only (profiles/dev): the WC_* variables of DESIGN 5.1 seed the context's options
+  for (const DevOpt &o : kDevOpts)
+    if (const char *v = getenv(o.env)) ctx->dev.*(o.field) = o.flag_only ? 1 : atoi(v);
+#endif
   *out = ctx;
   return WC_OK;
+}
+
+extern "C" int wc_ctx_set_dev_option(wc_ctx *ctx, const char *name, int value) {
+  if (!ctx || !name) return wc_fail(ctx, WC_ERR_ARG, "%s: null or out-of-range argument", __func__);
+  for (const DevOpt &o : kDevOpts)
+    if (strcmp(o.name, name) == 0) {
+      ctx->dev.*(o.field) = value;
+      ctx->ex.fx_backoff = ctx->ex.fx_skip_calls = 0;
+      if (ctx->aux) ctx->aux->dev = ctx->dev;
+      return WC_OK;
+    }
+  return wc_fail(ctx, WC_ERR_ARG, "wc_ctx_set_dev_option: unknown option '%s'", name);
 }
 
 void wc_window_free(wc_ctx *ctx);  // window.hip
@@ -111,24 +164,20 @@ extern "C" void wc_ctx_destroy(wc_ctx *ctx) {
                    &ctx->b_slots,        &ctx->b_slot_ids,    &ctx->b_slot_keys[0], &ctx->b_slot_keys[1], &ctx->b_slot_idx[0],
                    &ctx->b_slot_idx[1],  &ctx->b_cand,        &ctx->b_cand_meta,   &ctx->b_status,
                    &ctx->b_ex_ctrl};
-  for (wc_buf *b : all)
-    if (b->p) (void)hipFree(b->p);
-  for (wc_buf &b : ctx->b_misc)
-    if (b.p) (void)hipFree(b.p);
-  for (wc_buf &b : ctx->b_route)
-    if (b.p) (void)hipFree(b.p);
-  if (ctx->b_batch.p) (void)hipFree(ctx->b_batch.p);
-  for (wc_buf &b : ctx->b_kd)
-    if (b.p) (void)hipFree(b.p);
-  if (ctx->b_match_half.p) (void)hipFree(ctx->b_match_half.p);
+  for (wc_buf *b : all) wc_buf_release(ctx, *b);
+  for (wc_buf &b : ctx->b_misc) wc_buf_release(ctx, b);
+  for (wc_buf &b : ctx->b_route) wc_buf_release(ctx, b);
+  wc_buf_release(ctx, ctx->b_batch);
+  for (wc_buf &b : ctx->b_kd) wc_buf_release(ctx, b);
+  wc_buf_release(ctx, ctx->b_match_half);
   for (wc_ctx *sub : ctx->batch_subs) wc_ctx_destroy(sub);
   ctx->batch_subs.clear();
-  for (wc_buf &b : ctx->b_fx)
-    if (b.p) (void)hipFree(b.p);
+  for (wc_buf &b : ctx->b_fx) wc_buf_release(ctx, b);
   if (ctx->h_status) (void)hipHostFree(ctx->h_status);
   if (ctx->h_mail) (void)hipHostFree(ctx->h_mail);
   if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
-  if (ctx->b_stage.p) (void)hipFree(ctx->b_stage.p);
+  wc_buf_release(ctx, ctx->b_stage);
+  (void)hipStreamSynchronize(ctx->stream);  // (the releases are stream ordered)
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
   for (hipEvent_t e : ctx->ex_ev)
@@ -160,7 +209,7 @@ extern "C" int wc_dev_alloc(wc_ctx *ctx, size_t bytes, void **d_ptr) {
   wc_dev_guard dg_(ctx);
   if (!ctx || !d_ptr) return wc_fail(ctx, WC_ERR_ARG, "%s: null or out-of-range argument", __func__);
   WC_HIP(ctx, hipSetDevice(ctx->device));
-  static const bool alloc_dbg = getenv("WC_ALLOC_DEBUG") != nullptr;  // (read once per process)
+  static const bool alloc_dbg = wc_log_env("WC_ALLOC_DEBUG");  // (read once per process)
   if (alloc_dbg) fprintf(stderr, "[alloc] wc_dev_alloc %zu bytes\n", bytes);
   WC_HIP(ctx, hipMalloc(d_ptr, bytes ? bytes : 1));
   return WC_OK;
@@ -258,3 +307,33 @@ extern "C" int wc_timer_stop_ms(wc_ctx *ctx, float *h_ms) {
   WC_HIP(ctx, hipEventElapsedTime(h_ms, ctx->ev0, ctx->ev1));
   return WC_OK;
 }
+
+int wc_touch_extract();
+int wc_touch_match();
+int wc_touch_poses();
+int wc_touch_sweep();
+int wc_touch_route();
+int wc_touch_window();
+int wc_match_pair_prepare(wc_ctx *ctx);  // match.hip
+
+// Everything a long-running caller wants out of its first sweeps (include/wildcat_hip.h): the code objects of all translation units
+// loaded, wc_match_pair's helper context and thread created, `reserve_bytes` of HBM taken into the stream-ordered pool the scratch
+// buffers grow from.
+extern "C" int wc_ctx_warmup(wc_ctx *ctx, size_t reserve_bytes) {
+  wc_dev_guard dg_(ctx);
+  if (!ctx) return wc_fail(ctx, WC_ERR_ARG, "%s: null or out-of-range argument", __func__);
+  if (wc_touch_extract() != WC_OK || wc_touch_match() != WC_OK || wc_touch_poses() != WC_OK || wc_touch_sweep() != WC_OK || wc_touch_route() != WC_OK ||
+      wc_touch_window() != WC_OK)
+    return wc_fail(ctx, WC_ERR_HIP, "wc_ctx_warmup: a code object could not be loaded");
+  hipFuncAttributes a;
+  (void)hipFuncGetAttributes(&a, (const void *)k_pack_strided);
+  WC_TRY(wc_match_pair_prepare(ctx));
+  if (reserve_bytes && ctx->pool_ok) {
+    void *p = nullptr;
+    if (hipMallocAsync(&p, reserve_bytes, ctx->stream) == hipSuccess) (void)hipFreeAsync(p, ctx->stream);
+    (void)hipGetLastError();
+  }
+  WC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return WC_OK;
+}
+

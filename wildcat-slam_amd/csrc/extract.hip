@@ -1841,8 +1841,7 @@ int fx_ensure_zero(wc_ctx *ctx, wc_buf &b, size_t bytes) {
 
 bool fx_applicable(const wc_ctx *ctx, uint64_t n, double t_lo, double t_hi) {
   const wc_params &P = ctx->P;
-  static const bool env_exact = getenv("WC_EXACT_SUMS") != nullptr;  // (debug knobs are read once per process)
-  if (P.exact_sums || env_exact) return false;
+  if (P.exact_sums || ctx->dev.exact_sums) return false;
   if (n < 64 || !(P.voxel_size > 0.0f) || P.voxel_size >= 0.99f) return false;  // |p - centre| 2^32 must fit an int32
   if (!(P.cluster_gap > 1e-6) || !(t_hi > t_lo)) return false;
   if ((t_hi - t_lo) / (P.cluster_gap * 0.999) >= 1048000.0) return false;
@@ -1864,12 +1863,8 @@ int run_pipeline_fast(wc_ctx *ctx, const wc_points &pts, double t_lo, double t_h
   E.gap = P.cluster_gap, E.cluster_min = P.cluster_min_points;
   E.t_lo_bits = ordered_bits_host(t_lo);
   E.t_span_bits = ordered_bits_host(t_hi) - E.t_lo_bits;
-  static const int env_skip = getenv("WC_DEBUG_SKIP") ? atoi(getenv("WC_DEBUG_SKIP")) : 0;
-  E.dbg = env_skip;
-  {
-    static const int env_mm = getenv("WC_FX_MERGE_MIN") ? atoi(getenv("WC_FX_MERGE_MIN")) : 3;  // (read once per process)
-    E.merge_min = env_mm;
-  }
+  E.dbg = ctx->dev.debug_skip;  // (development options: wc_ctx_set_dev_option)
+  E.merge_min = ctx->dev.fx_merge_min;
   unsigned tbits = 1;
   while (tbits < 64 && (E.t_span_bits >> tbits)) ++tbits;
   A.pts = pts;
@@ -1910,11 +1905,8 @@ int run_pipeline_fast(wc_ctx *ctx, const wc_points &pts, double t_lo, double t_h
   const unsigned ngrid = std::min<unsigned>(256 * 16, std::max<unsigned>(64, (unsigned)(n / 256)));  // k_fx_nodes<1>; <2> uses fewer
   WC_TRY(wc_ensure(ctx, ctx->b_fx[6], (size_t)ngrid * kFxJobCap * kFxJobW * 8));  // cluster jobs: written before they are read
   // node stage as two kernels (extract_split.inc) where one round of wavefronts does not hold the sweep's parents: above 2 M points
-  // (WC_FX_SPLIT=0 / 1 pins the choice: tests run both forms on the same clouds)
-  {
-    static const char *env = getenv("WC_FX_SPLIT");
-    ctx->ex.fx_split = ctx->ex.batch_defer || (env ? atoi(env) != 0 : !A.static_map);  // (a batch: K sweeps' parents in one launch)
-  }
+  // (the development option fx_split = 0 / 1 pins the choice: tests run both forms on the same clouds)
+  ctx->ex.fx_split = ctx->ex.batch_defer || (ctx->dev.fx_split >= 0 ? ctx->dev.fx_split != 0 : !A.static_map);  // (a batch: K sweeps' parents in one launch)
   if (ctx->ex.fx_split) {
     A.static_map = 0u;
     A.jobpool_per = (uint32_t)std::max<uint64_t>(4096, n / (uint64_t)std::max(1, P.cluster_min_points) / 2);  // 8 sub-pools: 4 x the worst case
@@ -1962,7 +1954,7 @@ int run_pipeline_fast(wc_ctx *ctx, const wc_points &pts, double t_lo, double t_h
   };
   mark(0);
   mark(1);
-  static const bool dbg = getenv("WC_FX_DEBUG") != nullptr;
+  static const bool dbg = wc_log_env("WC_FX_DEBUG");
   auto dbg_sync = [&](const char *what) {
     if (!dbg) return;
     fprintf(stderr, "[fx] %s ...", what);
@@ -2042,7 +2034,7 @@ int fx_tail(wc_ctx *ctx, bool layer2) {
                                            (const wc_surfel_id *)ctx->b_slot_ids.p, A.status, ctx->ex.d_out, ctx->ex.d_ids, ctx->ex.cap, next_ctrl,
                                            kCtrlWords);
   mark(5);
-  static const bool fx_dbg = getenv("WC_FX_DEBUG") != nullptr;
+  static const bool fx_dbg = wc_log_env("WC_FX_DEBUG");
   if (fx_dbg) fprintf(stderr, "[fx] k_slot_emit (layer2=%d) ... %s\n", (int)layer2, hipGetErrorString(hipStreamSynchronize(st)));
   WC_HIP(ctx, hipGetLastError());
   return WC_OK;
@@ -2113,12 +2105,8 @@ int run_pipeline(wc_ctx *ctx, const wc_points &pts, double t_lo, double t_hi, wc
   E.gap = P.cluster_gap;
   E.cluster_min = P.cluster_min_points;
   E.t_lo_bits = ordered_bits_host(t_lo);
-  static const int env_skip = getenv("WC_DEBUG_SKIP") ? atoi(getenv("WC_DEBUG_SKIP")) : 0;
-  E.dbg = env_skip;
-  {
-    static const int env_mm = getenv("WC_FX_MERGE_MIN") ? atoi(getenv("WC_FX_MERGE_MIN")) : 3;  // (read once per process)
-    E.merge_min = env_mm;
-  }
+  E.dbg = ctx->dev.debug_skip;  // (development options: wc_ctx_set_dev_option)
+  E.merge_min = ctx->dev.fx_merge_min;
   const uint64_t span = ordered_bits_host(t_hi) - E.t_lo_bits;
   E.t_span_bits = span;
   unsigned tbits = 1;
@@ -2289,8 +2277,7 @@ extern "C" int wc_extract_surfels_enqueue(wc_ctx *ctx, const wc_points *pts, dou
   ctx->ex.t_hi = t_hi;
   // after a bin overflow of the run-binned point sort (very many points in few voxels, or points in no spatial order)
   // the next calls go to the radix-sort path directly; the fast path is tried again every 16th call
-  static const bool env_general = getenv("WC_NO_BUCKET_SORT") != nullptr;
-  ctx->ex.general = ctx->ex.general_calls > 0 || env_general;
+  ctx->ex.general = ctx->ex.general_calls > 0 || ctx->dev.no_bucket_sort != 0;
   if (ctx->ex.general_calls > 0) --ctx->ex.general_calls;
   ctx->ex.order_general = false;
   ctx->ex.fx_active = fx_applicable(ctx, pts->n, t_lo, t_hi);
@@ -2579,4 +2566,10 @@ extern "C" int wc_debug_status(wc_ctx *ctx, uint32_t *h_out64) {
   h_out64[24] = cnt;
 #endif
   return WC_OK;
+}
+
+// wc_ctx_warmup: loads this translation unit's code object (the runtime loads it at the first launch of any of its kernels)
+int wc_touch_extract() {
+  hipFuncAttributes a;
+  return hipFuncGetAttributes(&a, (const void *)k_voxel_keys) == hipSuccess ? WC_OK : WC_ERR_HIP;
 }

@@ -182,10 +182,9 @@ struct KdPlan {
   int T = 0, Bd = 0, D = 0, first = 3;
   int stages[4] = {0, 0, 0, 0}, nstage = 0;
 };
-static KdPlan kd_plan(uint32_t nt) {
+static KdPlan kd_plan(uint32_t nt, int leaf_opt) {  // leaf_opt: the development option kd_leaf (0: leaves of 4 - 8 points)
   KdPlan p;
-  static const int leaf_env = getenv("WC_KD_LEAF") ? atoi(getenv("WC_KD_LEAF")) : 0;  // (experiments; read once per process)
-  const double leaf = leaf_env > 0 ? (double)leaf_env : 8.0;
+  const double leaf = leaf_opt > 0 ? (double)leaf_opt : 8.0;
   if (nt > 1024u) p.T = std::min(kKdTMax, (int)std::ceil(std::log2((double)nt / 512.0)));
   const double avg = (double)nt / (double)(1u << p.T);
   p.Bd = std::max(0, std::min(kKdBdMax, (int)std::ceil(std::log2(std::max(avg / leaf, 1.0)))));
@@ -231,7 +230,7 @@ static int kd_build(wc_ctx *ctx, const double *d_feat, uint32_t nt, const KdPlan
     k_kd_scatter<<<(nt + 1023) / 1024, 1024, 0, st>>>(bucket, nt, tcum, count, idx[s & 1]);
     starts_prev = starts[s & 1], idx_prev = idx[s & 1];
   }
-  static const bool kd_dbg = getenv("WC_MATCH_DEBUG") != nullptr;
+  static const bool kd_dbg = wc_log_env("WC_MATCH_DEBUG");
   if (kd_dbg && starts_prev) {  // (debug only: a stream wait and a read-back) sizes of the buckets the bottom levels are built on
     std::vector<uint32_t> h((size_t)nbk + 1);
     if (hipStreamSynchronize(st) == hipSuccess && hipMemcpy(h.data(), starts_prev, h.size() * 4, hipMemcpyDeviceToHost) == hipSuccess) {
@@ -256,6 +255,35 @@ static int kd_build(wc_ctx *ctx, const double *d_feat, uint32_t nt, const KdPlan
   return WC_OK;
 }
 
+// A rank of a query-sharded search that fails BEFORE the all-gather (an allocation, a kernel launch, the tree's sort) must not
+// leave the others waiting in the collective: while this guard is armed, leaving match_impl enters the all-gather with a
+// share of poison words (0xFEFEFEFE: no neighbour index, no kNone); every rank that finds one in the gathered table fails the
+// call (k_peer_poison -> flag 16 of the control block).  The local failure's message is kept.
+constexpr uint32_t kPeerPoison = 0xFEFEFEFEu;
+__global__ void k_peer_poison(const uint32_t *__restrict__ table, const uint32_t *__restrict__ first_word, int world, uint32_t *status) {
+  const int r = threadIdx.x;
+  if (r < world && table[first_word[r]] == kPeerPoison) atomicOr(&status[1], 16u);
+}
+struct MatchPeerGuard {
+  wc_ctx *ctx;
+  uint32_t nq;
+  int k;
+  bool armed;
+  ~MatchPeerGuard() {
+    if (!armed) return;
+    const std::string why = ctx->err;
+    const uint32_t w = (uint32_t)ctx->comm.world, r = (uint32_t)ctx->comm.rank;
+    const uint32_t mine = (uint32_t)(((uint64_t)nq * (r + 1)) / w - ((uint64_t)nq * r) / w);
+    std::vector<uint64_t> bytes((size_t)w);
+    for (uint32_t q = 0; q < w; ++q) bytes[q] = (uint64_t)(((uint64_t)nq * (q + 1)) / w - ((uint64_t)nq * q) / w) * k * 4;
+    if (wc_ensure(ctx, ctx->b_route[2], (size_t)nq * k * 4) == WC_OK && wc_ensure(ctx, ctx->b_route[3], (size_t)(mine + 1) * k * 4) == WC_OK &&
+        hipMemsetAsync(ctx->b_route[3].p, 0xFE, (size_t)(mine + 1) * k * 4, ctx->stream) == hipSuccess &&
+        (ctx->comm.stream_ordered || hipStreamSynchronize(ctx->stream) == hipSuccess))
+      (void)ctx->comm.allgatherv(ctx->comm.user, ctx->b_route[3].p, (uint64_t)mine * k * 4, ctx->b_route[2].p, bytes.data());
+    ctx->err = why;
+  }
+};
+
 // scratch lives in ctx->b_misc[1..7] slots to avoid another state struct.  want_shard: the call is a collective of the ctx's
 // communicator (wc_match_sharded) - every rank makes it with the same replicated arguments
 static int match_impl(wc_ctx *ctx, const wc_surfel *d_q_surf, const wc_pose *d_q_pose, uint64_t nq_, const wc_surfel *d_t_surf,
@@ -267,9 +295,16 @@ static int match_impl(wc_ctx *ctx, const wc_surfel *d_q_surf, const wc_pose *d_q
   *h_n_pairs = 0;
   if (nt_ == 0 || nq_ == 0) return WC_OK;  // knn_surfel_matcher.cc:18-20
   if (nq_ >= (1ull << 31) || nt_ >= (1ull << 30)) return wc_fail(ctx, WC_ERR_ARG, "%s: null or out-of-range argument", __func__);
+  // same_set: the queries ARE the targets (the sliding-window search, knn_surfel_matcher.cc:31-38) - their order is taken from the
+  // tree's target permutation, so the two sets must be one array
+  if (same_set && (nq_ != nt_ || d_q_surf != d_t_surf || d_q_pose != d_t_pose))
+    return wc_fail(ctx, WC_ERR_ARG, "%s: same_set needs the query set to be the target set (nq %llu, nt %llu)", __func__, (unsigned long long)nq_, (unsigned long long)nt_);
   const uint32_t nq = (uint32_t)nq_, nt = (uint32_t)nt_;
   const wc_params &P = ctx->P;
   hipStream_t st = ctx->stream;
+  // several GPUs: decided from arguments every rank shares (a rank-dependent predicate would leave the others in the all-gather)
+  const bool sharded = want_shard && ctx->have_comm && ctx->comm.world > 1 && ctx->comm.allgatherv && nq >= 4096;
+  MatchPeerGuard peer{ctx, nq, P.knn_k, sharded};
   wc_buf &b_feat = ctx->b_misc[1], &b_world = ctx->b_misc[2], &b_gated = ctx->b_misc[4], &b_choice = ctx->b_misc[5],
          &b_scan = ctx->b_misc[7];
   WC_TRY(wc_ensure(ctx, b_feat, (size_t)nt * 6 * 8));
@@ -288,7 +323,7 @@ static int match_impl(wc_ctx *ctx, const wc_surfel *d_q_surf, const wc_pose *d_q
   // 1. features of the targets, 2. their tree - no host round trip: the tree's shape only depends on nt
   WC_HIP(ctx, hipMemsetAsync(status, 0, 64 * 4, st));
   k_features<<<(nt + 255) / 256, 256, 0, st>>>(d_t_surf, d_t_pose, nt, P.center_scale, P.angular_scale, (double *)b_feat.p, (double *)b_world.p, status);
-  const KdPlan plan = kd_plan(nt);
+  const KdPlan plan = kd_plan(nt, ctx->dev.kd_leaf);
   KdTree tree;
   WC_TRY(kd_build(ctx, (const double *)b_feat.p, nt, plan, tree));
   MatchParams M;
@@ -320,8 +355,7 @@ static int match_impl(wc_ctx *ctx, const wc_surfel *d_q_surf, const wc_pose *d_q
   // several GPUs: the queries are independent (knn_surfel_matcher.cc:22-48), the targets are replicated;
   // every rank searches a contiguous share of the queries (in leaf order) and ONE all-gather of the gated lists (4 k bytes per
   // query) gives every rank the whole table; the order-dependent de-duplication below then runs replicated
-  // (the predicate only depends on arguments every rank shares: a rank-dependent one would leave the others in the all-gather)
-  const bool sharded = want_shard && ctx->have_comm && ctx->comm.world > 1 && ctx->comm.allgatherv && nq >= 4096;
+  // (`sharded` is decided at the top, from the replicated arguments alone)
   uint32_t q_begin = 0, q_end = nq;
   if (sharded) {
     const uint32_t w = (uint32_t)ctx->comm.world, r = (uint32_t)ctx->comm.rank;
@@ -340,7 +374,7 @@ static int match_impl(wc_ctx *ctx, const wc_surfel *d_q_surf, const wc_pose *d_q
     if (!e) WC_HIP(ctx, hipEventCreate(&e));
   // pending nodes of a walk: the children of the root's step, then 2^kW - 1 more per further step above the leaves
   const int wide_steps = plan.D > 0 ? 1 + (plan.D - plan.first) / kW : 0, stack_cap = std::max(1, (1 << plan.first) + (kNch - 1) * std::max(0, wide_steps - 2));
-  static const bool tdbg = getenv("WC_MATCH_TIMING") != nullptr;
+  static const bool tdbg = wc_log_env("WC_MATCH_TIMING");
   const auto t_prep = std::chrono::steady_clock::now();
   if (tdbg) WC_HIP(ctx, hipEventRecord(ctx->ev_knn[0], st));
   // Which walk: eight lanes per query (match_tree.inc: k_knn_tree_group; every round trip coalesced, eight independent walks per
@@ -349,8 +383,8 @@ static int match_impl(wc_ctx *ctx, const wc_surfel *d_q_surf, const wc_pose *d_q
   // 0.62 / 0.94 / 1.77 ms, fixed-window 0.62 / 0.96 / 1.13 / 1.35 / 2.28 against 0.31 / 0.54 / 0.80 / 1.23 / 2.15 ms; at a million
   // queries (C4) 2.06 against 2.02 and 3.50 against 3.96 (profiles/dev/time_match_sizes.py, time_match.py).  The rule depends on the
   // call's sizes and kind alone - no timing, no history.
-  static const int group_env = getenv("WC_KNN_GROUP") ? atoi(getenv("WC_KNN_GROUP")) : -1;  // (experiments: 0 / 1 pins the walk; read once)
-  const bool group_walk = group_env >= 0 ? group_env != 0 : (nq_mine < 750000u || (same_set && nq_mine < 1500000u));
+  const int group_opt = ctx->dev.knn_group;  // (development option: 0 / 1 pins the walk)
+  const bool group_walk = group_opt >= 0 ? group_opt != 0 : (nq_mine < 750000u || (same_set && nq_mine < 1500000u));
   const int first3 = plan.D % 3 ? plan.D % 3 : 3;
   // Workgroups of ONE wavefront (eight queries): the groups of a workgroup share nothing, and a 256-thread workgroup holds its four
   // wavefront slots and its LDS until the slowest of its 32 walks has ended - the next workgroup waits for all of them.  Measured
@@ -392,8 +426,18 @@ static int match_impl(wc_ctx *ctx, const wc_surfel *d_q_surf, const wc_pose *d_q
     for (int r = 0; r < w; ++r)
       bytes[r] = (uint64_t)(((uint64_t)nq * (r + 1)) / w - ((uint64_t)nq * r) / w) * P.knn_k * 4;
     if (!ctx->comm.stream_ordered) WC_HIP(ctx, hipStreamSynchronize(st));
+    peer.armed = false;  // this rank enters the collective itself
     if (ctx->comm.allgatherv(ctx->comm.user, gated_shard, (uint64_t)nq_mine * P.knn_k * 4, ctx->b_route[2].p, bytes.data()) != 0)
       return wc_fail(ctx, WC_ERR_HIP, "wc_match: all-gather of the gated neighbour lists failed");
+    // a peer that failed before the collective sent poison (MatchPeerGuard): first word of every rank's share
+    std::vector<uint32_t> firsts((size_t)w);
+    for (int r = 0; r < w; ++r) firsts[r] = (uint32_t)((((uint64_t)nq * r) / w) * P.knn_k);
+    uint32_t *d_first = status + 56;  // (words 56 .. 63 of the control block: free; worlds of up to eight ranks per node)
+    if (w <= 8) {
+      WC_HIP(ctx, hipMemcpyAsync(d_first, firsts.data(), (size_t)w * 4, hipMemcpyHostToDevice, st));
+      WC_HIP(ctx, hipStreamSynchronize(st));  // (`firsts` is a stack-lifetime vector)
+      k_peer_poison<<<1, 64, 0, st>>>((const uint32_t *)ctx->b_route[2].p, d_first, w, status);
+    }
   }
   if (!direct_planes) {
     uint32_t *qpos = (uint32_t *)b_choice.p + nq;  // (choice[1]: free until the resolve rounds)
@@ -416,7 +460,7 @@ static int match_impl(wc_ctx *ctx, const wc_surfel *d_q_surf, const wc_pose *d_q
   volatile uint32_t *h_ctl = ctx->h_status + 64;
   volatile uint32_t *hc8 = h_ctl + 32;
   volatile unsigned long long *h_stats = (volatile unsigned long long *)(h_ctl + 40);
-  static const bool match_dbg = getenv("WC_MATCH_DEBUG") != nullptr;
+  static const bool match_dbg = wc_log_env("WC_MATCH_DEBUG");
   {
     size_t tmp = 0;
     WC_HIP(ctx, rocprim::exclusive_scan(nullptr, tmp, rocprim::make_transform_iterator((const uint32_t *)choice[0], ChoiceFlag{}), offsets, 0u, (size_t)nq,
@@ -465,6 +509,7 @@ static int match_impl(wc_ctx *ctx, const wc_surfel *d_q_surf, const wc_pose *d_q
   }
   const uint32_t n_found = h_ctl[0], fl = h_ctl[1];
   *h_n_pairs = n_found;
+  if (fl & 16u) return wc_fail(ctx, WC_ERR_HIP, "wc_match_sharded: another rank failed before the all-gather of the neighbour lists");
   if (fl & 4u) return wc_fail(ctx, WC_ERR_ARG, "non-finite surfel centre or normal");
   if (fl & 8u) return wc_fail(ctx, WC_ERR_NUMERIC, "wc_match: traversal stack overflow (internal)");
   if (fl & 2u) return wc_fail(ctx, WC_ERR_ORDER, "fixed-window surfel newer than its sliding-window match");
@@ -499,23 +544,14 @@ extern "C" int wc_match_pair_sharded(wc_ctx *ctx, const wc_surfel *d_sld_surf, c
   return wc_match_sharded(ctx, d_sld_surf, d_sld_pose, n_sld, d_fix_surf, d_fix_pose, n_fix, 0, d_pairs_fix, cap_fix, h_n_pairs_fix);
 }
 
-// The two searches of an outer iteration side by side (see include/wildcat_hip.h).  wc_match is synchronous and talks to the
-// host between its launches (the fixed-point rounds of the pair rule), so the second search gets its own context AND its own
-// host thread; both only read the surfels.
-extern "C" int wc_match_pair(wc_ctx *ctx, const wc_surfel *d_sld_surf, const wc_pose *d_sld_pose, uint64_t n_sld,
-                             const wc_surfel *d_fix_surf, const wc_pose *d_fix_pose, uint64_t n_fix, wc_pair *d_pairs_sld,
-                             uint64_t cap_sld, uint64_t *h_n_pairs_sld, wc_pair *d_pairs_fix, uint64_t cap_fix,
-                             uint64_t *h_n_pairs_fix) {
-  if (!ctx || !h_n_pairs_sld || !h_n_pairs_fix) return wc_fail(ctx, WC_ERR_ARG, "%s: null or out-of-range argument", __func__);
-  static const bool serial = getenv("WC_MATCH_PAIR_SERIAL") != nullptr;
-  if (n_sld == 0 || n_fix == 0 || serial) {
-    WC_TRY(wc_match(ctx, d_sld_surf, d_sld_pose, n_sld, d_sld_surf, d_sld_pose, n_sld, 1, d_pairs_sld, cap_sld, h_n_pairs_sld, nullptr, nullptr));
-    return wc_match(ctx, d_sld_surf, d_sld_pose, n_sld, d_fix_surf, d_fix_pose, n_fix, 0, d_pairs_fix, cap_fix, h_n_pairs_fix, nullptr, nullptr);
-  }
+// The helper context (second stream, own scratch) and host thread of wc_match_pair, created at the first call - or ahead of time by
+// wc_ctx_warmup: created inside a sweep it showed as a 19 ms search in the facade's stream (round 5).
+int wc_match_pair_prepare(wc_ctx *ctx) {
   wc_dev_guard dg_(ctx);
   if (!ctx->aux) {
     const int rc = wc_ctx_create(&ctx->P, ctx->device, &ctx->aux);
     if (rc != WC_OK) return wc_fail(ctx, rc, "wc_match_pair: no helper context");
+    ctx->aux->dev = ctx->dev;
     // The helper's stream gets the device's highest priority: its search is prepared (tree, locate, radix passes - small launches)
     // while the other search's walk fills the chip, and those launches wait for slots behind the walk's workgroups.  What a kernel
     // trace of the odometry step shows with it: launches of 256- and 512-thread workgroups get through (k_kd_bottom 77 us next to the
@@ -530,6 +566,32 @@ extern "C" int wc_match_pair(wc_ctx *ctx, const wc_surfel *d_sld_surf, const wc_
       ctx->aux->own_stream = hs, ctx->aux->stream = hs;
     }
   }
+  if (!ctx->pair_worker) {
+    try {
+      ctx->pair_worker = new wc_pair_worker();
+      ctx->pair_worker_free = [](void *p) { delete (wc_pair_worker *)p; };
+    } catch (...) {
+      ctx->pair_worker = nullptr;  // (the second search then runs on the caller's thread)
+    }
+  }
+  return WC_OK;
+}
+
+// The two searches of an outer iteration side by side (see include/wildcat_hip.h).  wc_match is synchronous and talks to the
+// host between its launches (the fixed-point rounds of the pair rule), so the second search gets its own context AND its own
+// host thread; both only read the surfels.
+extern "C" int wc_match_pair(wc_ctx *ctx, const wc_surfel *d_sld_surf, const wc_pose *d_sld_pose, uint64_t n_sld,
+                             const wc_surfel *d_fix_surf, const wc_pose *d_fix_pose, uint64_t n_fix, wc_pair *d_pairs_sld,
+                             uint64_t cap_sld, uint64_t *h_n_pairs_sld, wc_pair *d_pairs_fix, uint64_t cap_fix,
+                             uint64_t *h_n_pairs_fix) {
+  if (!ctx || !h_n_pairs_sld || !h_n_pairs_fix) return wc_fail(ctx, WC_ERR_ARG, "%s: null or out-of-range argument", __func__);
+  const bool serial = ctx->dev.match_pair_serial != 0;  // (development option)
+  if (n_sld == 0 || n_fix == 0 || serial) {
+    WC_TRY(wc_match(ctx, d_sld_surf, d_sld_pose, n_sld, d_sld_surf, d_sld_pose, n_sld, 1, d_pairs_sld, cap_sld, h_n_pairs_sld, nullptr, nullptr));
+    return wc_match(ctx, d_sld_surf, d_sld_pose, n_sld, d_fix_surf, d_fix_pose, n_fix, 0, d_pairs_fix, cap_fix, h_n_pairs_fix, nullptr, nullptr);
+  }
+  wc_dev_guard dg_(ctx);
+  WC_TRY(wc_match_pair_prepare(ctx));
   wc_ctx *aux = ctx->aux;
   WC_TRY(wc_ctx_set_params(aux, &ctx->P));
   // the helper's stream starts behind everything already enqueued on the ctx stream (the producers of the surfels and poses)
@@ -553,22 +615,12 @@ extern "C" int wc_match_pair(wc_ctx *ctx, const wc_surfel *d_sld_surf, const wc_
     }
   };
   // which search runs where: the one on the ctx stream starts at once, the helper's a thread start later (WC_MATCH_PAIR_SWAP: A/B)
-  static const bool swap = getenv("WC_MATCH_PAIR_SWAP") != nullptr;
+  const bool swap = ctx->dev.match_pair_swap != 0;  // (development option)
   wc_ctx *c_fix = swap ? ctx : aux, *c_sld = swap ? aux : ctx;
   auto search_fix = [&] { return wc_match(c_fix, d_sld_surf, d_sld_pose, n_sld, d_fix_surf, d_fix_pose, n_fix, 0, d_pairs_fix, cap_fix, h_n_pairs_fix, nullptr, nullptr); };
   auto search_sld = [&] { return wc_match(c_sld, d_sld_surf, d_sld_pose, n_sld, d_sld_surf, d_sld_pose, n_sld, 1, d_pairs_sld, cap_sld, h_n_pairs_sld, nullptr, nullptr); };
-  bool threaded = true;
-  wc_pair_worker *worker = (wc_pair_worker *)ctx->pair_worker;
-  if (!worker) {
-    try {
-      worker = new wc_pair_worker();
-      ctx->pair_worker = worker;
-      ctx->pair_worker_free = [](void *p) { delete (wc_pair_worker *)p; };
-    } catch (...) {
-      worker = nullptr;
-      threaded = false;
-    }
-  }
+  wc_pair_worker *worker = (wc_pair_worker *)ctx->pair_worker;  // (wc_match_pair_prepare; null: no thread could be started)
+  bool threaded = worker != nullptr;
   if (threaded) {
     try {
       worker->start([&] {
@@ -596,3 +648,8 @@ extern "C" int wc_match_pair(wc_ctx *ctx, const wc_surfel *d_sld_surf, const wc_
   return WC_OK;
 }
 
+
+int wc_touch_match() {
+  hipFuncAttributes a;
+  return hipFuncGetAttributes(&a, (const void *)k_inv_perm) == hipSuccess ? WC_OK : WC_ERR_HIP;
+}

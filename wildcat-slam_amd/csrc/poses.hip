@@ -89,3 +89,8 @@ extern "C" int wc_update_surfel_poses(wc_ctx *ctx, const wc_imu_state *d_imu, ui
   if (ctx->h_status[1]) return wc_fail(ctx, WC_ERR_RANGE, "surfel timestamp outside the IMU state range");
   return WC_OK;
 }
+
+int wc_touch_poses() {
+  hipFuncAttributes a;
+  return hipFuncGetAttributes(&a, (const void *)k_reverse_copy) == hipSuccess ? WC_OK : WC_ERR_HIP;
+}

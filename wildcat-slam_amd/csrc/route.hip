@@ -333,3 +333,8 @@ extern "C" int wc_gather_surfels(wc_ctx *ctx, const wc_surfel *d_local, const wc
   }
   return wc_merge_surfels(ctx, (const wc_surfel *)b_s.p, ids ? (const wc_surfel_id *)b_i.p : nullptr, cnt.data(), world, d_out, d_out_ids);
 }
+
+int wc_touch_route() {
+  hipFuncAttributes a;
+  return hipFuncGetAttributes(&a, (const void *)k_route_count) == hipSuccess ? WC_OK : WC_ERR_HIP;
+}

@@ -12,12 +12,14 @@ __device__ __forceinline__ double rsqrt_nr(double a) {
   return fma(h, fma(-a * inv, inv, 1.0), inv);  // inv + inv/2 (1 - a inv^2)
 }
 
-// sin and cos of a half angle.  The corrections the window solves for are milliradians: when every active lane's |h| is below
-// 0.5 the two Taylor polynomials (to h^15 / h^16: truncation below 1e-19) take the place of the library's sincos - ~20
-// fused multiply-adds instead of ~150 instructions of argument reduction, polynomial selection and sign handling, in a kernel
-// whose phase A is bound by fp64 instruction issue.  One wave-uniform branch; larger angles take the library call.
+// sin and cos of a half angle.  The corrections the window solves for are milliradians: for |h| below 0.5 the two Taylor
+// polynomials (to h^15 / h^16: truncation below 1e-19) take the place of the library's sincos - ~20 fused multiply-adds instead of
+// ~150 instructions of argument reduction, polynomial selection and sign handling, in a kernel whose phase A is bound by fp64
+// instruction issue.  The choice is PER LANE (a wave-uniform `__all` made a factor's bits depend on which other factors
+// shared its wavefront - record order, piece cuts, sharded against unsharded builds); lanes with larger angles take the library
+// call in a divergent branch that a wavefront of small angles skips.
 __device__ __forceinline__ void sincos_half(double h, double *s, double *c) {
-  if (__all(fabs(h) < 0.5)) {
+  if (fabs(h) < 0.5) {
     const double z = h * h;
     double ps = fma(z, -1.0 / 1307674368000.0, 1.0 / 6227020800.0);
     ps = fma(z, ps, -1.0 / 39916800.0);

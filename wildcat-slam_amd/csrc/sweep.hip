@@ -200,3 +200,8 @@ extern "C" int wc_undistort_sweep_packed(wc_ctx *ctx, const void *d_pts_in, uint
                                          float *d_xyz_out, double *d_time_out) {
   return undistort_impl(ctx, d_pts_in, n, d_imu, n_imu, nullptr, d_xyz_out, d_time_out);
 }
+
+int wc_touch_sweep() {
+  hipFuncAttributes a;
+  return hipFuncGetAttributes(&a, (const void *)k_prefilter_flags) == hipSuccess ? WC_OK : WC_ERR_HIP;
+}

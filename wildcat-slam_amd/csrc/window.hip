@@ -1868,8 +1868,8 @@ void wc_window_free(wc_ctx *ctx) {
                    &W->x, &W->xc, &W->lin, &W->lin_alt, &W->Linv, &W->Lmat, &W->reduce, &W->scale, &W->diag, &W->A, &W->y,
                    &W->mail, &W->cost_part, &W->keys_tmp[0], &W->keys_tmp[1], &W->vals_tmp[0], &W->vals_tmp[1], &W->heads, &W->status,
                    &W->pcr_D[0], &W->pcr_D[1], &W->pcr_A[0], &W->pcr_A[1], &W->pcr_R[0], &W->pcr_R[1], &W->yred};
-  for (wc_buf *b : all)
-    if (b->p) (void)hipFree(b->p);
+  for (wc_buf *b : all) wc_buf_release(ctx, *b);
+  (void)hipStreamSynchronize(ctx->stream);  // (the releases are stream ordered)
   if (W->h_pin) (void)hipHostFree(W->h_pin);
   if (W->h_up) (void)hipHostFree(W->h_up);
   for (hipEvent_t e : W->fam_done)
@@ -1985,8 +1985,8 @@ static int window_build_impl(wc_ctx *ctx, const wc_surfel *d_sld_surf, const wc_
   std::vector<Seg> segs_b, segs_u;
   W->nb = (uint32_t)n_pairs_sld;
   W->nu = (uint32_t)n_pairs_fix;
-  static const bool tdbg = getenv("WC_WIN_DEBUG") != nullptr;  // (debug knobs: read once per process, never on a later call)
-  static const bool gdbg = getenv("WC_DEBUG_GATHER") != nullptr;
+  static const bool tdbg = wc_log_env("WC_WIN_DEBUG");  // (debug knobs: read once per process, never on a later call)
+  static const bool gdbg = wc_log_env("WC_DEBUG_GATHER");
   auto tnow = [] { return std::chrono::steady_clock::now(); };
   auto t_a = tnow();
   {  // staging for both families' (status, heads); heads of both in one device buffer
@@ -2172,7 +2172,9 @@ static int window_build_impl(wc_ctx *ctx, const wc_surfel *d_sld_surf, const wc_
     WC_HIP(ctx, hipStreamSynchronize(ctx->stream));  // (copies of an earlier build out of the old buffer)
     if (W->h_up) (void)hipHostFree(W->h_up);
     W->h_up = nullptr, W->h_up_cap = 0;
-    const size_t want = std::max<size_t>(2 * total, (size_t)4 << 20);
+    // (never below 32 MB: pinning pages costs ~1 ms per MB, and with a 4 MB floor the facade's growing window re-pinned 8 MB inside
+    // a sweep - a build of 8 ms among builds of 0.25, round 5)
+    const size_t want = std::max<size_t>(2 * total, (size_t)32 << 20);
     WC_HIP(ctx, hipHostMalloc(&W->h_up, want));
     W->h_up_cap = want;
   }
@@ -2376,8 +2378,8 @@ int enqueue_linearize(wc_ctx *ctx, wc_window_state *W, const double *d_x, int ma
   // (Round 3, tried: k_lin_imu - 14.5 us of dependent fp64 chains in a few hundred workgroups - on a stream of its own beside the
   // surfel families, fork / join by events: 1 650 LM it/s against 1 790 at C4, odometry-step solve 2.58 against 2.39 ms - the two
   // cross-stream waits cost more than the launch they hide.  One stream.)
-  static const bool imu_apart = getenv("WC_LIN_IMU_APART") != nullptr;  // (A/B: the IMU family as a launch of its own)
-  static const bool unary_in = getenv("WC_LIN_UNARY_APART") == nullptr;  // (A/B: the unary family as a launch of its own)
+  const bool imu_apart = ctx->dev.lin_imu_apart != 0;  // (A/B: the IMU family as a launch of its own)
+  const bool unary_in = ctx->dev.lin_unary_apart == 0;  // (A/B: the unary family as a launch of its own)
   const bool fused = W->npiece_b && W->npiece_i && !imu_apart;
   const bool fused_u = fused && unary_in && W->npiece_u;
   if (fused_u)
@@ -2418,7 +2420,7 @@ int enqueue_linearize(wc_ctx *ctx, wc_window_state *W, const double *d_x, int ma
   ga.nheavy = W->nheavy, ga.npairs = W->npairs, ga.npieces = W->npiece_b + W->npiece_u + W->npiece_i;
   ga.nb_pieces = W->npiece_b, ga.nu_pieces = W->npiece_u, ga.ns = W->ns, ga.fix_first = W->wp.fix_first;
   // max |g| + the mailbox by the last of k_gather's g / cost workgroups (one GPU; behind an all-reduce k_post_reduce stays a launch)
-  static const bool post_apart = getenv("WC_LIN_POST_APART") != nullptr;
+  const bool post_apart = ctx->dev.lin_post_apart != 0;
   ga.post = (post && !packed && !post_apart) ? 1 : 0;
   ga.mail_slot = mail_slot, ga.done = (uint32_t *)((double *)W->mail.p + 60), ga.mail = (double *)W->mail.p, ga.host_mail = host_mail, ga.ticket = ticket;
   k_gather<<<W->nheavy + (W->npairs + kGG * kLightSets - 1) / (kGG * kLightSets) + W->ns + 1, 144 * kGG, 0, st>>>(ga);
@@ -2543,7 +2545,7 @@ extern "C" int wc_window_solve(wc_ctx *ctx, double *h_x_inout, wc_solve_summary 
   double *mail = (double *)W->mail.p;
   int *fail = (int *)((double *)W->mail.p + 32);
   std::vector<double> best(h_x_inout, h_x_inout + n), cur(best);
-  static const bool lm_dense = getenv("WC_LM_DENSE") != nullptr;
+  const bool lm_dense = ctx->dev.lm_dense != 0;
   const bool use_schur = !lm_dense && W->ns >= 4;  // (two super-blocks at least: the reduction has a level)
   if (use_schur) {
     const int ns_al = std::max(W->ns, 96), M_al = (ns_al + 1) / 2, ldr_al = ((6 * ns_al + 1 + 63) / 64) * 64;  // (as in wc_window_build: no re-allocation while a window grows)
@@ -2555,7 +2557,7 @@ extern "C" int wc_window_solve(wc_ctx *ctx, double *h_x_inout, wc_solve_summary 
     WC_TRY(wc_ensure(ctx, W->yred, (size_t)(6 * ns_al + kNB + 64) * 8));
   }
 
-  static const bool poll_mail = getenv("WC_LM_SYNC") == nullptr;  // (WC_LM_SYNC=1: wait for the stream instead of the ticket)
+  const bool poll_mail = ctx->dev.lm_sync == 0;  // (WC_LM_SYNC=1: wait for the stream instead of the ticket)
   double *h_mail_dev = nullptr, *h_stage_dev = nullptr;  // device addresses of the pinned mailbox and of its staging area
   {
     void *dp = nullptr;
@@ -2594,7 +2596,7 @@ extern "C" int wc_window_solve(wc_ctx *ctx, double *h_x_inout, wc_solve_summary 
   // cost-only pass over the same records: an accepted step - the rule - then needs no second pass (one pass over the factors
   // per iteration instead of two, -0.05 ms of 0.6 at C4), a rejected one has formed an H nobody uses (+0.1 ms).  Its cost and
   // max |g| arrive with the iteration's mailbox, so nothing is pending between iterations.  WC_LM_EVAL_PASS=1: round 2's flow.
-  static const bool cand_lin = getenv("WC_LM_EVAL_PASS") == nullptr;
+  const bool cand_lin = ctx->dev.lm_eval_pass == 0;
   auto resolve_pending = [&]() {
     cost = ctx->h_mail[0];
     gmax = ctx->h_mail[1];
@@ -2769,4 +2771,9 @@ extern "C" int wc_window_solve(wc_ctx *ctx, double *h_x_inout, wc_solve_summary 
   summary->final_cost = min_cost;
   std::memcpy(h_x_inout, best.data(), (size_t)n * 8);
   return WC_OK;
+}
+
+int wc_touch_window() {
+  hipFuncAttributes a;
+  return hipFuncGetAttributes(&a, (const void *)k_pair_keys) == hipSuccess ? WC_OK : WC_ERR_HIP;
 }

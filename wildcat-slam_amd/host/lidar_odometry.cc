@@ -89,6 +89,10 @@ LidarOdometry::LidarOdometry(int device) {
     std::fprintf(stderr, "[wildcat] FATAL: no MI355X context (rc=%d); there is no CPU fallback\n", rc);
     std::abort();
   }
+  // one-time costs out of the first sweeps: code objects, the matcher's helper context and thread, 2 GB of HBM taken into the pool
+  // the library's scratch buffers grow from (a 6.5 s window of a 640 k points/s scanner uses ~1 GB of them)
+  rc = wc_ctx_warmup(ctx_, (size_t)2 << 30);
+  if (rc != WC_OK) std::fprintf(stderr, "[wildcat] wc_ctx_warmup: %s\n", wc_last_error(ctx_));
   stq(ext_quat_, quat_from_matrix(config_.ext_rotation));
 }
 
@@ -349,7 +353,9 @@ void LidarOdometry::LogResiduals(const std::vector<double> &x, const char *when)
     double c = 0;
     for (size_t i = first; i < first + n; ++i) {
       hist.Add(r[i]);
-      const double q = r[i] * r[i], s = q / (1.0 - q / cb);  // (r'^2 = s / (1 + s / b) < b)
+      // (r'^2 = s / (1 + s / b) < b; for a strong outlier r'^2 rounds to b itself: the denominator is clamped, the logged cost stays
+      // finite where the reference prints a finite rho - ADVICE r4)
+      const double q = r[i] * r[i], s = q / std::max(1.0 - q / cb, 2.220446049250313e-16);
       c += cb * std::log1p(s / cb);
     }
     std::snprintf(buf, sizeof(buf), " Surfel residuals, cost: %g, dist: ", 0.5 * c);
@@ -515,7 +521,7 @@ void LidarOdometry::AddLidarScan(const pcl::PointCloud<hilti_ros::Point>::Ptr &m
   if (point_times_.back() < sweep_endtime || imu_buff_.empty() || imu_buff_.back().timestamp < sweep_endtime) return;
 
   // wall time of the stages of a completed sweep (last_stage_ms(); WC_ODOM_DEBUG=1 also prints them on stderr)
-  static const bool dbg_t = getenv("WC_ODOM_DEBUG") != nullptr;
+  static const bool dbg_t = getenv("WC_ODOM_DEBUG") != nullptr;  // (prints only; the one variable the facade reads)
   auto t_prev = std::chrono::steady_clock::now();
   last_append_ms_ = std::chrono::duration<double, std::milli>(t_prev - t_entry).count();
   double (&t_stage)[8] = last_stage_ms_;

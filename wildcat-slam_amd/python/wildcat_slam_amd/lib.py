@@ -140,6 +140,10 @@ class Context:
         self.params = params
         self._ck(self.lib.wc_ctx_set_params(self.h, C.byref(params)))
 
+    def set_dev_option(self, name, value):
+        """a development option of this context (include/wildcat_hip.h: wc_ctx_set_dev_option)"""
+        self._ck(self.lib.wc_ctx_set_dev_option(self.h, name.encode(), C.c_int(int(value))))
+
     def set_stream(self, stream_ptr):
         self._ck(self.lib.wc_ctx_set_stream(self.h, C.c_void_p(stream_ptr)))
 

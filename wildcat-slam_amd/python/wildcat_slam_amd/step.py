@@ -32,7 +32,8 @@ class StepWindow:
     """device-resident window in front of the step: the surfels of sweeps 0 .. K-2 (extracted, posed; the first `n_fix` form the
     fixed window), the newest sweep's points, the IMU states and sample times"""
 
-    def __init__(self, ctx, w, rank=0, world=1):
+    def __init__(self, ctx, w, rank=0, world=1, keep_ids=False):
+        """keep_ids: the surfel ids of every sweep are kept next to the surfels (d_ids; the parity tests identify surfels by them)"""
         self.ctx, self.w, self.rank, self.world = ctx, w, rank, world
         scans, imu = w["scans"], w["imu"]
         self.imu = imu
@@ -43,16 +44,18 @@ class StepWindow:
         self.cap_all = roots_cap
         self.d_surf, self.d_pose, self.d_inb = ctx.alloc(144 * roots_cap), ctx.alloc(56 * roots_cap), ctx.alloc(roots_cap)
         ctx._ck(ctx.lib.wc_memset(ctx.h, C.c_void_p(self.d_inb.ptr), 0, C.c_size_t(roots_cap)))
+        self.d_ids = ctx.alloc(16 * roots_cap) if keep_ids else None
         counts, n_have = [], 0
         for s in scans[:-1]:  # the window before the step (every rank extracts it: replicated state, outside the step)
             d = ctx.to_device(s)
-            ctx.extract_enqueue(ctx.points_desc(d, len(s)), _Ptr(self.d_surf.ptr + 144 * n_have), None, roots_cap - n_have, float(s["time"][0]),
-                                float(s["time"][-1]))
+            ctx.extract_enqueue(ctx.points_desc(d, len(s)), _Ptr(self.d_surf.ptr + 144 * n_have), _Ptr(self.d_ids.ptr + 16 * n_have) if keep_ids else None,
+                                roots_cap - n_have, float(s["time"][0]), float(s["time"][-1]))
             m = ctx.extract_finish()
             counts.append(m)
             n_have += m
         ctx.update_surfel_poses(self.d_imu, len(imu), self.d_surf, self.d_pose, self.d_inb, n_have)
         self.n_have, self.n_fix = n_have, counts[0] + counts[1]  # the two oldest sweeps: fixed window
+        self.counts = counts
         self.d_pb, self.d_pu = ctx.alloc(8 * roots_cap), ctx.alloc(8 * roots_cap)
         # the newest sweep: all of it on one rank, this rank's time-contiguous slice on several
         lo, cnt = wdist.shard_range(self.n_pts, rank, world)
@@ -83,11 +86,12 @@ class StepWindow:
         T = {}
         t0 = time.perf_counter()
         dst = _Ptr(self.d_surf.ptr + 144 * self.n_have)
+        dst_ids = _Ptr(self.d_ids.ptr + 16 * self.n_have) if self.d_ids else None
         if sharded:
             _, _, m_loc, _ = ctx.extract_surfels_sharded(self.d_new, self.slice_n, self.t_lo, self.t_hi, out=(self.d_loc, self.d_loc_ids, self.cap_new))
-            m = ctx.gather_surfels_device(self.d_loc, self.d_loc_ids, m_loc, dst, None, self.cap_all - self.n_have)
+            m = ctx.gather_surfels_device(self.d_loc, self.d_loc_ids, m_loc, dst, dst_ids, self.cap_all - self.n_have)
         else:
-            ctx.extract_enqueue(ctx.points_desc(self.d_new, self.n_pts), dst, None, self.cap_all - self.n_have, self.t_lo, self.t_hi)
+            ctx.extract_enqueue(ctx.points_desc(self.d_new, self.n_pts), dst, dst_ids, self.cap_all - self.n_have, self.t_lo, self.t_hi)
             m = ctx.extract_finish()
         T["extract"] = time.perf_counter() - t0
         n_all = self.n_have + m
@@ -111,5 +115,5 @@ class StepWindow:
         T["pose_update2"] = time.perf_counter() - t1
         T["total"] = time.perf_counter() - t0
         info = dict(new_surfels=m, sld=n_sld, fix=n_fix, binary=nb, unary=nu, iters=summ.iterations, cost=[summ.initial_cost, summ.final_cost],
-                    term=summ.termination, imu=max(0, len(self.imu) - 2), allreduce_bytes=ctx.window_reduce_bytes())
+                    term=summ.termination, imu=max(0, len(self.imu) - 2), allreduce_bytes=ctx.window_reduce_bytes(), counts=self.counts + [m])
         return T, info, x
