@@ -328,6 +328,27 @@ extern "C" int wc_ctx_warmup(wc_ctx *ctx, size_t reserve_bytes) {
   hipFuncAttributes a;
   (void)hipFuncGetAttributes(&a, (const void *)k_pack_strided);
   WC_TRY(wc_match_pair_prepare(ctx));
+  {  // the copy engines: a copy above the runtime's small-copy limit takes another path than a small one, and the first use of a path
+    // creates its queue (~10 ms, seen as a window build of 12 ms when the segment heads' read-back crossed 16 KB - round 5); every
+    // direction and both size classes once, on the ctx stream and on the helper's
+    void *hp = nullptr, *dp = nullptr;
+    const size_t big = (size_t)1 << 20;
+    if (hipHostMalloc(&hp, big) == hipSuccess && hipMalloc(&dp, 2 * big) == hipSuccess) {
+      std::memset(hp, 0, big);
+      hipStream_t sts[2] = {ctx->stream, ctx->aux ? ctx->aux->stream : ctx->stream};
+      for (hipStream_t st : sts)
+        for (size_t bytes : {(size_t)256, (size_t)12 << 10, (size_t)48 << 10, big}) {
+          (void)hipMemcpyAsync(dp, hp, bytes, hipMemcpyHostToDevice, st);
+          (void)hipMemcpyAsync((char *)dp + big, dp, bytes, hipMemcpyDeviceToDevice, st);
+          (void)hipMemcpyAsync(hp, (char *)dp + big, bytes, hipMemcpyDeviceToHost, st);
+          (void)hipMemsetAsync(dp, 0, bytes, st);
+        }
+      for (hipStream_t st : sts) (void)hipStreamSynchronize(st);
+    }
+    if (dp) (void)hipFree(dp);
+    if (hp) (void)hipHostFree(hp);
+    (void)hipGetLastError();
+  }
   if (reserve_bytes && ctx->pool_ok) {
     void *p = nullptr;
     if (hipMallocAsync(&p, reserve_bytes, ctx->stream) == hipSuccess) (void)hipFreeAsync(p, ctx->stream);

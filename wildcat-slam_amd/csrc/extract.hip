@@ -1885,6 +1885,13 @@ int run_pipeline_fast(wc_ctx *ctx, const wc_points &pts, double t_lo, double t_h
   while ((uint64_t)tr * 4 < n) tr *= 2;
   A.tr_mask = tr - 1;
   A.static_map = n <= 2000000ull ? 1u : 0u;  // (up to ~2 M points the node wavefronts are one round)
+  {  // the two layouts k_fx_acc has wide loads for (anything else: element-wise loads)
+    const uintptr_t px = (uintptr_t)pts.xyz, pt = (uintptr_t)pts.time;
+    if (pts.xyz_stride == 48u && pts.time_stride == 48u && pt == px + 24u && px % 16u == 0u)
+      A.fmt = 1u;
+    else if (pts.xyz_stride == 12u && pts.time_stride == 8u && px % 16u == 0u && pt % 16u == 0u)
+      A.fmt = 2u;
+  }
   const unsigned tiles = (unsigned)((n + kFxTile - 1) / kFxTile);
   A.rec_tiles = tiles;
   // spill pool (partials the tile's 256-cell LDS hash could not take): eight banks by tile index.  A tile spills at most one
