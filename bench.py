@@ -77,10 +77,70 @@ class pinned_core:
                 pass
 
 
+def _short_kernel(name):
+    return name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
+
+
+def pmc_traffic_measured(kernels, roots):
+    """HBM bytes per sweep of the extraction stage MEASURED IN THIS RUN: two child processes under `rocprofv3 --kernel-trace --pmc
+    FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes: the TCC counters do not fit one, MI355X_MICROARCH.md) run 20 extractions of the
+    same C2 sweep (profiles/exp_g1.py); per kernel the mean over its dispatches, reads x2 (the guide's gfx950 correction for wide
+    coalesced reads), writes as reported.  None when rocprofv3 is not on the box or a pass fails (the caller then quotes the
+    committed summary, labelled)."""
+    import csv
+    import shutil
+    import subprocess
+    import tempfile
+
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if not exe or os.environ.get("WC_BENCH_NO_PMC"):
+        return None
+    per = {}
+    tmp = tempfile.mkdtemp(prefix="wc_pmc_", dir="/tmp")
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, ctr)
+            cmd = [exe, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "b", "--", sys.executable,
+                   os.path.join(ROOT, "profiles", "exp_g1.py"), "g2", str(roots * 256), "20"]
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=240)
+            found = None
+            for base, _, files in os.walk(d):
+                for f in files:
+                    if f.endswith("counter_collection.csv"):
+                        found = os.path.join(base, f)
+            if r.returncode != 0 or not found:
+                return None
+            acc = {}
+            for row in csv.DictReader(open(found)):
+                if row.get("Counter_Name") == ctr:
+                    acc.setdefault(_short_kernel(row["Kernel_Name"]), []).append(float(row["Counter_Value"]))
+            for k, v in acc.items():
+                per.setdefault(k, {})[ctr] = (sum(v) / len(v), len(v))
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    tot, detail, missing = 0.0, {}, []
+    most = max([per[k]["FETCH_SIZE"][1] for k in kernels if k in per and "FETCH_SIZE" in per[k]] or [1])
+    for k in kernels:
+        if k not in per or "FETCH_SIZE" not in per[k] or "WRITE_SIZE" not in per[k]:
+            missing.append(k)
+            continue
+        rd, wr = 2 * per[k]["FETCH_SIZE"][0] * 1024, per[k]["WRITE_SIZE"][0] * 1024  # KiB per dispatch as reported
+        share = per[k]["FETCH_SIZE"][1] / most  # a kernel that only ran in some sweeps (the layer-2 pair) counts pro rata
+        detail[k] = {"read_bytes": round(rd), "write_bytes": round(wr), "dispatches": per[k]["FETCH_SIZE"][1]}
+        tot += (rd + wr) * share
+    if not detail:
+        return None
+    return {"bytes_per_launch": round(tot), "source": "measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE, separate passes, 20 "
+            "sweeps of the same C2 workload in a child process (profiles/exp_g1.py); reads x2 (gfx950 correction), per sweep",
+            "per_kernel": detail, "kernels_missing_from_summary": missing}
+
+
 def pmc_traffic(kernels):
     """HBM bytes per launch (reads x2-corrected + writes) summed over `kernels`, from the newest committed PMC summary
-    (profiles/<tag>_pmc.json, written by profiles/summarize.py from separate rocprofv3 --pmc passes).  Not measured in this run:
-    the returned object names its source."""
+    (profiles/<tag>_pmc.json, written by profiles/summarize.py from separate rocprofv3 --pmc passes).  The fallback when the run cannot
+    measure it itself (pmc_traffic_measured): the returned object names its source."""
     import glob
 
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")))
@@ -97,10 +157,11 @@ def pmc_traffic(kernels):
             tot += (ks[name]["read_bytes_per_launch"] + ks[name]["write_bytes_per_launch"]) * ks[name]["launches_sampled"] / most
         else:
             missing.append(name)
-    return {"bytes_per_launch": round(tot), "source": "profiles/" + os.path.basename(files[-1]), "kernels_missing_from_summary": missing}
+    return {"bytes_per_launch": round(tot), "source": "NOT measured in this run (rocprofv3 unavailable or a pass failed): profiles/" + os.path.basename(files[-1]),
+            "kernels_missing_from_summary": missing}
 
 
-def extraction_stage(ctx, step, n_pts, n_surfels, steps):
+def extraction_stage(ctx, step, n_pts, n_surfels, steps, measure_roots=None):
     """per-stage device time (HIP events on the ctx stream around every kernel group of the stage) -> (stages_ms, roofline)"""
     ctx.extract_profile(True)
     acc = {}
@@ -126,9 +187,17 @@ def extraction_stage(ctx, step, n_pts, n_surfels, steps):
             "definition": "SURVEY 8(d): (20 B x points + 144 B x surfels) / device time of ALL kernels of the stage (one pair of HIP events "
                           "on the ctx stream around them; stages_ms is a separate run with an event after every kernel group)",
             "algorithmic_bytes_per_step": algo, "stage_device_ms": round(stage_ms, 5),
-            "traffic": pmc_traffic([n for s in stages if s != "init" for n in STAGE_KERNELS.get(s, s).split(" + ")]),
+            "traffic": None,
             "dominant_kernel": {"kernel": STAGE_KERNELS.get(dom, dom), "avg_ms": round(stages[dom], 5),
                                 "frac_if_it_ran_alone": round(algo / (stages[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}}
+    # HBM traffic of the stage: measured in this run for the headline workload (measure_roots), the committed summary otherwise
+    kernels = [n for s in stages if s != "init" for n in STAGE_KERNELS.get(s, s).split(" + ")]
+    if measure_roots is not None:  # (-1: the headline workload on a rank that does not profile - the committed summary)
+        roof["traffic"] = (pmc_traffic_measured(kernels, measure_roots) if measure_roots > 0 else None) or pmc_traffic(kernels)
+        if roof["traffic"]:
+            roof["traffic"]["over_algorithmic"] = round(roof["traffic"]["bytes_per_launch"] / algo, 3)
+    else:
+        roof["traffic"] = {"bytes_per_launch": None, "source": "not collected for this workload in the run: profiles/r5_pmc_clouds.md (firing order, 10 M points, batch)"}
     return stages, roof
 
 
@@ -138,7 +207,7 @@ def time_extract(ctx, desc, out_p, ids_p, cap, t_lo, t_hi, steps, warmup, expect
     for _ in range(max(1, warmup)):
         enq()
         n_s = fin()
-    if expect is not None and not os.environ.get("WC_DEBUG_SKIP"):
+    if expect is not None and not os.environ.get("WC_BENCH_NO_ASSERT"):
         assert n_s == expect, (n_s, expect)
     ctx.sync()
     t0 = time.perf_counter()
@@ -270,7 +339,7 @@ def main():
 
     for _ in range(args.warmup):
         n_s = step()
-    assert os.environ.get("WC_DEBUG_SKIP") or n_s == exp_surfels, (n_s, exp_surfels)
+    assert os.environ.get("WC_BENCH_NO_ASSERT") or n_s == exp_surfels, (n_s, exp_surfels)
 
     ctx.sync()
     barrier()
@@ -283,7 +352,7 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = world * n_pts / (elapsed / args.steps) / 1e6  # Mpts/s, whole job
 
-    stages, roofline = extraction_stage(ctx, step, n_pts, exp_surfels, args.steps)
+    stages, roofline = extraction_stage(ctx, step, n_pts, exp_surfels, args.steps, measure_roots=args.roots if (rank == 0 and world == 1) else -1)
     # measured ceiling of this device: a 1 GiB device-to-device copy, bytes read + written per second
     copy_gbs = None
     try:
@@ -342,7 +411,7 @@ def main():
             ring.append((c2, _Ptr(o2.data_ptr()), _Ptr(i2.data_ptr()), (o2, i2)))
             for _ in range(3):
                 c2.extract_enqueue(desc, ring[-1][1], ring[-1][2], cap, t_lo, t_hi)
-                assert c2.extract_finish() == exp_surfels or os.environ.get("WC_DEBUG_SKIP")
+                assert c2.extract_finish() == exp_surfels or os.environ.get("WC_BENCH_NO_ASSERT")
         barrier()
         t0 = time.perf_counter()
         for i in range(args.steps):  # sweep i is enqueued on context i mod F as soon as that context's previous sweep is done
@@ -428,6 +497,10 @@ def main():
                     result["facade_stream"] = bench_facade_stream(local_rank, cpu)
                 except Exception as e:
                     result["facade_stream"] = {"error": repr(e)}
+                try:
+                    result["multi_gpu_model"] = multi_gpu_model(result, local_rank)
+                except Exception as e:
+                    result["multi_gpu_model"] = {"error": repr(e)}
 
     if world == 1:
         extras()
@@ -509,7 +582,7 @@ def bench_batched(ctx, args, world, rank, dev, torch, dist, to_dev):
         for _ in range(5):
             enq()
             counts = fin()
-        assert all(c == exp for c in counts) or os.environ.get("WC_DEBUG_SKIP"), counts
+        assert all(c == exp for c in counts) or os.environ.get("WC_BENCH_NO_ASSERT"), counts
         reps = max(5, args.steps // 10)
         ctx.sync()
         t0 = time.perf_counter()
@@ -780,6 +853,46 @@ def ring_allreduce_model_us(nbytes, world):
     if world < 2 or not nbytes:
         return 0.0
     return 2.0 * (world - 1) / world * nbytes / 153e9 * 1e6 + 2 * (world - 1) * 1.5  # + ~1.5 us per hop
+
+
+def multi_gpu_model(result, local_rank):
+    """north_star: >= 6 x residual-assembly throughput at 8 GPUs.  No 2+-GPU box is reachable from a 1-GPU run, so this object states
+    what a 1-GPU run CAN: the all-reduce payload of one linearisation, RCCL's floor for it measured with a world-of-one
+    communicator on the ctx stream (enqueue -> completion; no wire), a ring model over xGMI, and the modelled assembly speed-up of
+    the library AS BUILT (one all-reduce behind k_gather, exposed) next to the two-collective design of DESIGN 6 (not built)."""
+    from wildcat_slam_amd import lib
+    from wildcat_slam_amd import dist as wdist
+
+    out = {"definition": "assembly = k_lin_fused + k_gather of one linearisation (+ the exposed part of its all-reduce); modelled, not measured at N > 1"}
+    probe = {}
+    try:
+        c = lib.Context(local_rank)
+        c.comm_rccl_init(0, 1, lib.rccl_unique_id())
+        for ns in (64, 127):
+            cnt = wdist.packed_count(ns)
+            probe["ns_%d" % ns] = {"payload_bytes": 8 * cnt, "rccl_world_of_one_us": round(c.comm_allreduce_probe(cnt, 50), 2)}
+        c.comm_rccl_destroy()
+        c.close()
+    except Exception as e:
+        probe["error"] = repr(e)
+    out["allreduce"] = probe
+    w = result.get("window", {})
+    lin_us = 1e3 * w.get("linearize_ms", 0.0)
+    if lin_us > 0:
+        payload = 8 * wdist.packed_count(127)
+        imu_floor_us = 14.5  # the IMU family's dependent chains: a launch of their own lasts this long whatever the window (DESIGN 3.4)
+        rows = {}
+        for n in (2, 4, 8):
+            ring = ring_allreduce_model_us(payload, n)
+            shard = max(lin_us / n, imu_floor_us)
+            rows[str(n)] = {"shard_assembly_us": round(shard, 1), "allreduce_ring_model_us": round(ring, 1),
+                            "speedup_as_built": round(lin_us / (shard + ring), 2),
+                            "speedup_two_collectives_design": round(lin_us / (shard + ring_allreduce_model_us(16, n)), 2)}
+        out["c4_window"] = {"assembly_one_gpu_us": round(lin_us, 1), "allreduce_exposed_us_as_built": "all of it: issued behind k_gather on the ctx stream, the solve waits for it",
+                            "by_ranks": rows,
+                            "two_collectives_design": "cost + max|g| (16 bytes) first - the trust-region decision needs nothing else -, {H, g} behind the bias "
+                                                      "elimination (k_pcr_*: 50 - 90 us that read IMU blocks only, with the IMU factors replicated): DESIGN 6; not built"}
+    return out
 
 
 def bench_match_room(ctx):

@@ -144,6 +144,9 @@ int wc_ctx_set_comm(wc_ctx *ctx, const wc_comm *comm); /* NULL removes it */
 int wc_comm_rccl_unique_id(char out128[128]);
 int wc_comm_rccl_init(wc_ctx *ctx, int rank, int world, const char id128[128]);
 int wc_comm_rccl_destroy(wc_ctx *ctx);
+/* measurement helper (bench.py): microseconds per in-place all-reduce of `count` doubles through the ctx's communicator, `reps` of
+ * them enqueued back to back on the ctx stream between two HIP events; a collective - every rank of the communicator calls it */
+int wc_comm_allreduce_probe(wc_ctx *ctx, uint64_t count, int reps, double *h_us);
 /* owner rank of a root voxel (VoxelLoc index, surfel_extraction.h:59-64): hash(kx,ky,kz) mod world; needs no GPU */
 int wc_route_owner(int32_t kx, int32_t ky, int32_t kz, int world);
 /* stable partition of this rank's points by owner: d_send (capacity pts->n records) receives `world` consecutive segments

@@ -179,3 +179,26 @@ extern "C" int wc_comm_rccl_destroy(wc_ctx *ctx) {
   ctx->rccl = nullptr;
   return WC_OK;
 }
+
+// Measurement helper (bench.py: multi_gpu_model): `reps` in-place all-reduces of `count` doubles through the ctx's communicator,
+// enqueued back to back on the ctx stream between two HIP events -> microseconds per all-reduce, enqueue to completion.  With the
+// in-library RCCL communicator of a world of one this is RCCL's floor for the payload (no wire); with N ranks every rank must call it.
+extern "C" int wc_comm_allreduce_probe(wc_ctx *ctx, uint64_t count, int reps, double *h_us) {
+  wc_dev_guard dg_(ctx);
+  if (!ctx || !h_us || reps < 1 || count == 0) return wc_fail(ctx, WC_ERR_ARG, "%s: null or out-of-range argument", __func__);
+  if (!ctx->have_comm || !ctx->comm.allreduce_f64) return wc_fail(ctx, WC_ERR_ARG, "%s: no communicator installed", __func__);
+  WC_TRY(wc_ensure(ctx, ctx->b_route[0], (size_t)count * 8));
+  WC_HIP(ctx, hipMemsetAsync(ctx->b_route[0].p, 0, (size_t)count * 8, ctx->stream));
+  for (int warm = 0; warm < 3; ++warm)
+    if (ctx->comm.allreduce_f64(ctx->comm.user, (double *)ctx->b_route[0].p, count) != 0) return wc_fail(ctx, WC_ERR_HIP, "all-reduce failed");
+  WC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  WC_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  for (int r = 0; r < reps; ++r)
+    if (ctx->comm.allreduce_f64(ctx->comm.user, (double *)ctx->b_route[0].p, count) != 0) return wc_fail(ctx, WC_ERR_HIP, "all-reduce failed");
+  WC_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+  WC_HIP(ctx, hipEventSynchronize(ctx->ev1));
+  float ms = 0.f;
+  WC_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+  *h_us = (double)ms * 1e3 / reps;
+  return WC_OK;
+}

@@ -1490,11 +1490,24 @@ __device__ __forceinline__ void slot_emit_body(const SlotEmitArgs &E, const uint
     else if (out_ids)
       *(double2 *)(out_ids + o) = d;
   };
-  for (uint32_t r = sub; r < c; r += 12) {  // two passes' loads in flight before the first store
-    const bool on0 = (uint64_t)base + r < cap, on1 = r + 6 < c && (uint64_t)base + r + 6 < cap;
+  if (c <= 12u) {  // the usual bucket of a sweep: two passes' loads in flight before the first store
+    const uint32_t r = sub;
+    const bool on0 = r < c && (uint64_t)base + r < cap, on1 = r + 6 < c && (uint64_t)base + r + 6 < cap;
     const double2 d0 = load(r, on0), d1 = load(r + 6, on1);
     store(r, on0, d0);
     store(r + 6, on1, d1);
+    return;
+  }
+  for (uint32_t r = sub; r < c; r += 24) {  // large clouds (~76 surfels per bucket at 10 M points): four passes in flight
+    bool on[4];
+    double2 d[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      on[q] = r + 6u * q < c && (uint64_t)base + r + 6u * q < cap;
+      d[q] = load(r + 6u * q, on[q]);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) store(r + 6u * q, on[q], d[q]);
   }
 }
 

@@ -312,6 +312,12 @@ class Context:
         buf = C.create_string_buffer(bytes(unique_id), 128)
         self._ck(self.lib.wc_comm_rccl_init(self.h, C.c_int(rank), C.c_int(world), buf))
 
+    def comm_allreduce_probe(self, count, reps=50):
+        """microseconds per all-reduce of `count` doubles through the installed communicator (wc_comm_allreduce_probe)"""
+        us = C.c_double(0)
+        self._ck(self.lib.wc_comm_allreduce_probe(self.h, C.c_uint64(int(count)), C.c_int(int(reps)), C.byref(us)))
+        return float(us.value)
+
     def comm_rccl_destroy(self):
         self._ck(self.lib.wc_comm_rccl_destroy(self.h))
 
