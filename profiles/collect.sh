@@ -4,7 +4,7 @@
 # The traced runs use --no-extras: kernel averages are those of C2 (extraction) and C4 (window), not a mix of sizes.
 # Usage: gpurun -- 'bash profiles/collect.sh r1'   -> gpurun_out/<tag>/...; then python profiles/summarize.py <tag>
 set -u
-TAG=${1:-r4}
+TAG=${1:-r5}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
