@@ -96,6 +96,10 @@ int wc_selftest_so3(wc_ctx *ctx, const double v[3], int on_device, double out52[
 int wc_selftest_so3_fused(wc_ctx *ctx, const double v[3], double out25[25]);
 int wc_selftest_eig3(wc_ctx *ctx, const double a9[9], int on_device, double out12[12]);
 int wc_selftest_quat(wc_ctx *ctx, const double in12[12], int on_device, double out11[11]);
+/* the damped solve's diagonal-block kernel on its own (tests/test_kat_gpu.py, profiles/dev/factor32.py): Cholesky factor L and L^-1 of a
+ * 32 x 32 SPD matrix (row-major, lower part read); variant 0 = the library's block form (256 threads, fp64 matrix-core rank-4 updates);
+ * h_clk[0] = shader clocks of the fastest of `reps` runs, h_clk[1] = 1 when every pivot was positive */
+int wc_selftest_factor32(wc_ctx *ctx, int variant, int reps, const double *h_A, double *h_L, double *h_X, long long *h_clk);
 
 /* surfel extraction --------------------------------------------------------------------------------------------- */
 /* Replaces BuildSurfels(const std::vector<hilti_ros::Point>&, std::deque<Surfel::Ptr>&, GlobalMap&)

@@ -84,3 +84,19 @@ def test_fused_so3_forms_of_the_factor_kernels(gpu):
         assert np.allclose(out[16:25].reshape(3, 3), d["jr_inv"], rtol=0, atol=1e-9), v
         # Jr_inv(v) Jr(v) = I (utils_test.cc:5-12 with v -> -v)
         assert np.allclose(out[16:25].reshape(3, 3) @ out[4:13].reshape(3, 3), np.eye(3), atol=1e-9), v
+
+
+def test_diagonal_block_factor_and_inverse(gpu):
+    """the damped solve's 32 x 32 diagonal-block kernel on its own (csrc/window.hip: factor_inv32_blk, the critical path of every panel
+    step): L and L^-1 of random SPD matrices against numpy, and a matrix that is not positive definite is reported"""
+    rng = np.random.default_rng(5)
+    for trial in range(4):
+        b = rng.normal(size=(32, 40))
+        a = b @ b.T + (1e-3 if trial == 0 else 0.5) * np.eye(32)
+        L, X, clk, ok = gpu.selftest_factor32(a, 0, 2)
+        Lr = np.linalg.cholesky(a)
+        Xr = np.linalg.inv(Lr)
+        assert ok and clk > 0
+        assert np.abs(np.tril(L) - Lr).max() <= 1e-13 * np.abs(Lr).max()
+        assert np.abs(np.tril(X) - Xr).max() <= 1e-12 * np.abs(Xr).max()
+    assert not gpu.selftest_factor32(-np.eye(32), 0, 1)[3]

@@ -1413,6 +1413,12 @@ __device__ __forceinline__ bool factor_inv32_blk(double (*sB)[kNB + 1], double (
   return ok;
 }
 
+// (Round 5 tried this factor + inverse by ONE wavefront, a column of [A | I] per lane, in two forms - measured on their own with
+// wc_selftest_factor32 / profiles/dev/factor32.py against the block form's 11.7 - 12.8 k shader clocks: the columns in LDS, the pivot
+// column as LDS broadcasts, one fma per row below the pivot: 73 k clocks (every row is a load - fma - store round trip; the compiler
+// cannot move a row's loads above the previous row's store); the columns in registers, all 32 steps unrolled, the pivot column by
+// v_readlane: 23.5 k (1 500 readlane -> fma pairs, each through an SGPR with its wait states).  Both exact to 1e-15, neither kept: the
+// matrix-core rank-4 updates of the block form are what make it fast.)
 // Damping and the factor of the first diagonal block in ONE launch: grid row 0 holds one workgroup that forms the damped
 // 32 x 32 corner itself (the same expression as the other rows' threads) and factors + inverts it - a launch of its own for
 // that block was 9 - 11 us of every LM iteration behind a 5 - 7 us k_damp.  It also owns the failure flag of the factorisation.
@@ -2776,4 +2782,42 @@ extern "C" int wc_window_solve(wc_ctx *ctx, double *h_x_inout, wc_solve_summary 
 int wc_touch_window() {
   hipFuncAttributes a;
   return hipFuncGetAttributes(&a, (const void *)k_pair_keys) == hipSuccess ? WC_OK : WC_ERR_HIP;
+}
+
+// ---- self-test / micro-benchmark of the diagonal-block factor (tests/test_kat_gpu.py, profiles/dev/factor32.py) -------------------------
+namespace {
+__global__ void __launch_bounds__(256) k_selftest_factor(const double *Ain, int variant, int reps, double *Lout, double *Xout, long long *clk) {
+  __shared__ double sB[kNB][kNB + 1];
+  __shared__ double sXi[kNB][kNB + 1];
+  long long best = 0x7fffffffffffffffll;
+  bool ok = true;
+  for (int r = 0; r < reps; ++r) {
+    for (int e = threadIdx.x; e < kNB * kNB; e += 256) sB[e / kNB][e % kNB] = (e % kNB <= e / kNB) ? Ain[e] : 0.0;
+    __syncthreads();
+    const long long t0 = clock64();
+    ok = factor_inv32_blk(sB, sXi);
+    __syncthreads();
+    const long long t1 = clock64();
+    best = t1 - t0 < best ? t1 - t0 : best;
+  }
+  for (int e = threadIdx.x; e < kNB * kNB; e += 256) Lout[e] = sB[e / kNB][e % kNB], Xout[e] = sXi[e / kNB][e % kNB];
+  if (threadIdx.x == 0) clk[0] = best, clk[1] = ok ? 1 : 0;
+}
+}  // namespace
+
+// h_A: 32 x 32 row-major SPD (lower part read); h_L, h_X: L and L^-1 (lower); h_clk[0]: shader clocks of the fastest of `reps` runs,
+// h_clk[1]: 1 = all pivots positive.  (variant: 0 = factor_inv32_blk, the only form in the library; kept as an argument for experiments)
+extern "C" int wc_selftest_factor32(wc_ctx *ctx, int variant, int reps, const double *h_A, double *h_L, double *h_X, long long *h_clk) {
+  wc_dev_guard dg_(ctx);
+  if (!ctx || !h_A || !h_L || !h_X || !h_clk || reps < 1) return wc_fail(ctx, WC_ERR_ARG, "%s: null or out-of-range argument", __func__);
+  WC_TRY(wc_ensure(ctx, ctx->b_route[0], (size_t)(3 * kNB * kNB + 2) * 8));
+  double *d = (double *)ctx->b_route[0].p;
+  WC_HIP(ctx, hipMemcpyAsync(d, h_A, (size_t)kNB * kNB * 8, hipMemcpyHostToDevice, ctx->stream));
+  k_selftest_factor<<<1, 256, 0, ctx->stream>>>(d, variant, reps, d + kNB * kNB, d + 2 * kNB * kNB, (long long *)(d + 3 * kNB * kNB));
+  WC_HIP(ctx, hipGetLastError());
+  WC_HIP(ctx, hipMemcpyAsync(h_L, d + kNB * kNB, (size_t)kNB * kNB * 8, hipMemcpyDeviceToHost, ctx->stream));
+  WC_HIP(ctx, hipMemcpyAsync(h_X, d + 2 * kNB * kNB, (size_t)kNB * kNB * 8, hipMemcpyDeviceToHost, ctx->stream));
+  WC_HIP(ctx, hipMemcpyAsync(h_clk, d + 3 * kNB * kNB, 16, hipMemcpyDeviceToHost, ctx->stream));
+  WC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return WC_OK;
 }

@@ -140,6 +140,14 @@ class Context:
         self.params = params
         self._ck(self.lib.wc_ctx_set_params(self.h, C.byref(params)))
 
+    def selftest_factor32(self, a, variant, reps=5):
+        """-> (L, L^-1, shader clocks, ok) of the 32 x 32 SPD matrix a by the solve's diagonal-block kernel (wc_selftest_factor32)"""
+        a = np.ascontiguousarray(a, np.float64)
+        L, X = np.zeros((32, 32)), np.zeros((32, 32))
+        clk = (C.c_longlong * 2)()
+        self._ck(self.lib.wc_selftest_factor32(self.h, C.c_int(variant), C.c_int(reps), R.ptr(a), R.ptr(L), R.ptr(X), clk))
+        return L, X, int(clk[0]), bool(clk[1])
+
     def set_dev_option(self, name, value):
         """a development option of this context (include/wildcat_hip.h: wc_ctx_set_dev_option)"""
         self._ck(self.lib.wc_ctx_set_dev_option(self.h, name.encode(), C.c_int(int(value))))
