@@ -1,5 +1,7 @@
 """GPU parity of wc_extract_surfels against the CPU oracle (BuildSurfels, surfel_extraction.cc:316-337).
 Bar (north_star): voxel indices and surfel counts bit-exact, normals within 1e-6 relative."""
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -350,3 +352,27 @@ def test_batched_sweeps_equal_single_sweeps(gpu, oracle):
         helpers.check_surfels(keep[1][1].download(R.SURFEL, counts[1]), keep[1][2].download(R.SURFEL_ID, counts[1]), s_o, id_o, tol=1e-6, t_tol=1e-4)
     finally:
         ctx.close()
+
+
+def test_development_options_and_warmup(gpu, oracle):
+    """wc_ctx_set_dev_option replaces the environment knobs of rounds 2 - 4 (nothing in the release library reads the environment to
+    decide what to execute): an unknown name is an argument error; both forms of the default path's node stage (fx_split 0 / 1) give the
+    oracle's surfels on the same cloud; wc_ctx_warmup can be called on a used context (and twice)"""
+    from wildcat_slam_amd import lib
+
+    with pytest.raises(lib.WildcatError):
+        gpu.set_dev_option("no_such_option", 1)
+    pts, _ = synth.g2_lattice(300, m=32)
+    s_ref, id_ref, _ = oracle.extract_surfels(pts)
+    try:
+        for form in (0, 1):
+            gpu.set_dev_option("fx_split", form)
+            s_gpu, id_gpu = gpu.extract_surfels(pts)
+            assert gpu.extract_path_info()["fast"]
+            helpers.check_surfels(s_gpu, id_gpu, s_ref, id_ref, tol=1e-6, t_tol=1e-5)
+    finally:
+        gpu.set_dev_option("fx_split", -1)
+    for _ in range(2):
+        gpu._ck(gpu.lib.wc_ctx_warmup(gpu.h, C.c_size_t(64 << 20)))
+    s_gpu, id_gpu = gpu.extract_surfels(pts)
+    helpers.check_surfels(s_gpu, id_gpu, s_ref, id_ref, tol=1e-6, t_tol=1e-5)
