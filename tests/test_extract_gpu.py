@@ -240,6 +240,9 @@ def test_unordered_small_sweep_stays_on_the_run_binned_path(gpu, oracle):
     dict(min_points=8, cluster_min_points=8),           # denser head table / more candidate slots per point
     dict(cluster_gap=2e-4),                             # many temporal clusters per node (every scan line its own)
     dict(voxel_size=0.5, planer_threshold=0.02),        # other grid, other gate
+    dict(voxel_size=0.3),                               # a voxel size that is no short binary fraction (round 5: the moments are taken
+    dict(voxel_size=0.95),                              # about the voxel centre itself, exact in fp64 for ANY float voxel size;
+    dict(voxel_size=0.125, planer_threshold=0.002),     # 0.95: the largest grid the default arithmetic takes, |p - centre| 2^32 < 2^31)
     dict(view_point=(3.0, -2.0, 1.0), min_plane_likeness=0.3),
 ])
 def test_non_default_parameters(gpu, oracle, override):
@@ -376,3 +379,29 @@ def test_development_options_and_warmup(gpu, oracle):
         gpu._ck(gpu.lib.wc_ctx_warmup(gpu.h, C.c_size_t(64 << 20)))
     s_gpu, id_gpu = gpu.extract_surfels(pts)
     helpers.check_surfels(s_gpu, id_gpu, s_ref, id_ref, tol=1e-6, t_tol=1e-5)
+
+
+def test_displaced_root_keeps_its_layer2_nodes(gpu, oracle):
+    """regression (round 5): two root voxels with one home slot in the default path's hash; k_fx_nodes<1> clears the entry of the one
+    that queued nothing for layer 2, and the layer-2 pass's look-up of the other - displaced behind it - stopped at the now empty slot:
+    its points were skipped and a layer-2 surfel went missing, silently, in two runs of three (which tile inserts first is a race).
+    The lattice at voxel size 0.95 has such a pair; every repetition, in both forms of the node stage, must give the oracle's ids."""
+    params = oracle.default_params()
+    params.voxel_size = 0.95
+    gpu.set_params(params)
+    gpu.params = params
+    try:
+        pts = synth.g2_lattice(120, m=40)[0]
+        s_ref, id_ref, _ = oracle.extract_surfels(pts, params)
+        want = set(helpers.id_tuples(id_ref))
+        assert sum(1 for t in want if (t[3] & 3) == 2) >= 40  # layer-2 surfels are in play
+        for form in (0, 1):
+            gpu.set_dev_option("fx_split", form)
+            for _ in range(6):
+                s_gpu, id_gpu = gpu.extract_surfels(pts)
+                assert gpu.extract_path_info()["fast"]
+                assert set(helpers.id_tuples(id_gpu)) == want
+    finally:
+        gpu.set_dev_option("fx_split", -1)
+        gpu.params = oracle.default_params()
+        gpu.set_params(gpu.params)
