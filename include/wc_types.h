@@ -153,7 +153,8 @@ typedef struct wc_solve_summary {
   int32_t termination;           /* 0 = convergence, 1 = no convergence (max iters), 2 = failure */
   int32_t n_linearizations;
   int32_t n_cost_evaluations;
-  double first_step[16];         /* unused tail; first_step_norm kept in [0]          */
+  double first_step[16];         /* [0] first_step_norm; [1] steps re-formed by the dense factorisation (a rejected or
+                                  * invalid step of the bias elimination, wildcat_hip.h: wc_window_solve); rest unused */
 } wc_solve_summary;
 
 #ifdef __cplusplus

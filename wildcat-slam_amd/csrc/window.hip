@@ -2626,77 +2626,83 @@ extern "C" int wc_window_solve(wc_ctx *ctx, double *h_x_inout, wc_solve_summary 
         break;
       }
       ++iter;
-      // LevenbergMarquardtStrategy::ComputeStep on the device
-      if (use_schur) {
-        // bias unknowns first, by parallel cyclic reduction (window_schur.inc); the dense panel steps run on the pose half
-        const int ns = W->ns, npz = 6 * ns, M = (ns + 1) / 2;
-        const int ldr = ((npz + 1 + 63) / 64) * 64, nch = (ldr + 255) / 256;
-        const int np2 = ((npz + 1 + kNB - 1) / kNB) * kNB, ld2 = np2, nblk2 = np2 / kNB;
-        double *Dp[2] = {(double *)W->pcr_D[0].p, (double *)W->pcr_D[1].p}, *Ap[2] = {(double *)W->pcr_A[0].p, (double *)W->pcr_A[1].p};
-        double *Rp[2] = {(double *)W->pcr_R[0].p, (double *)W->pcr_R[1].p}, *yred = (double *)W->yred.p;
-        const PcrSrc src{H, g, scale, n, ns, radius, diag};
-        int cur = 0, nlev = 0;
-        for (int s = 1; s < M; s *= 2) ++nlev;
-        double *X = nullptr;
-        k_pcr_init<<<dim3(M, nch), 256, 0, st>>>(src, Dp[0], Ap[0], Rp[0], ldr, fail);
-        for (int s = 1, lev = 0; lev < nlev; s *= 2, ++lev) {  // (ns >= 4: at least one level)
-          const bool last = lev == nlev - 1;
-          const dim3 grid(M, nch);
-          if (last)
-            k_pcr_level<true><<<grid, 256, 0, st>>>(s, M, Dp[cur], Ap[cur], Rp[cur], Dp[cur ^ 1], Ap[cur ^ 1], Rp[cur ^ 1], ldr, fail);
-          else
-            k_pcr_level<false><<<grid, 256, 0, st>>>(s, M, Dp[cur], Ap[cur], Rp[cur], Dp[cur ^ 1], Ap[cur ^ 1], Rp[cur ^ 1], ldr, fail);
-          cur ^= 1;
-        }
-        X = Rp[cur];  // the last level wrote X = T^-1 [C | bB] where the others write R'
-        k_schur_form<<<dim3((np2 + 255) / 256, 1 + ns + (np2 - npz)), 256, 0, st>>>(H, g, scale, X, n, ns, ldr, np2, ld2, radius, A, diag, Lmat, (double *)W->Linv.p, fail);
-        for (int k = 0; k + 1 < nblk2; ++k) {
-          const int tiles = ((nblk2 - k - 1) * kNB + 63) / 64;
-          k_chol_step<<<1 + tiles * (tiles + 1) / 2, 256, 0, st>>>(A, ld2, k, nblk2, Lmat, (double *)W->Linv.p, fail, npz);
-        }
-        const StepArgs sa{x, scale, g, diag, lin_cost(W), xc, mail, h_stage_dev, 0};
-        const double *zsrc = Lmat + (size_t)npz * ld2;
-        for (int hi = (npz + kNB - 1) / kNB; hi > 0;) {
-          const int lo = std::max(0, hi - kBackChunk);
-          k_chol_back_chunk<<<1, 1024, 0, st>>>(Lmat, ld2, npz, (const double *)W->Linv.p, zsrc, yred, lo, hi, sa);
-          if (lo > 0) k_chol_back_gemv<<<lo, 1024, 0, st>>>(Lmat, ld2, npz, zsrc, yred, lo, hi);
-          zsrc = yred;
-          hi = lo;
-        }
-        k_schur_bias_y<<<(npz + 3) / 4, 256, 0, st>>>(X, yred, ns, ldr, y);
-        k_lm_step<<<1, 1024, 0, st>>>(sa, y, n);
-      } else {
-        {
-          dim3 grid((np + 255) / 256, np);
-          grid.y += 1;  // (+ the workgroup of the first diagonal block)
-          k_damp_first<<<grid, 256, 0, st>>>(H, g, scale, n, np, ld, radius, A, diag, Lmat, (double *)W->Linv.p, fail);
-        }
-        for (int k = 0; k + 1 < nblk; ++k) {
-          const int tiles = ((nblk - k - 1) * kNB + 63) / 64;
-          k_chol_step<<<1 + tiles * (tiles + 1) / 2, 256, 0, st>>>(A, ld, k, nblk, Lmat, (double *)W->Linv.p, fail, n);
-        }
-        {  // back substitution, chunk by chunk from the last block row
-          const double *zsrc = Lmat + (size_t)n * ld;
-          for (int hi = (n + kNB - 1) / kNB; hi > 0;) {
+      // One attempt of the iteration: the damped step (bias elimination + dense factor of the pose half, or - schur = false - round 2's
+      // dense factor of all unknowns), the candidate, its linearisation, the mailbox.
+      auto attempt = [&](bool schur) -> int {
+        // LevenbergMarquardtStrategy::ComputeStep on the device
+        if (schur) {
+          // bias unknowns first, by parallel cyclic reduction (window_schur.inc); the dense panel steps run on the pose half
+          const int ns = W->ns, npz = 6 * ns, M = (ns + 1) / 2;
+          const int ldr = ((npz + 1 + 63) / 64) * 64, nch = (ldr + 255) / 256;
+          const int np2 = ((npz + 1 + kNB - 1) / kNB) * kNB, ld2 = np2, nblk2 = np2 / kNB;
+          double *Dp[2] = {(double *)W->pcr_D[0].p, (double *)W->pcr_D[1].p}, *Ap[2] = {(double *)W->pcr_A[0].p, (double *)W->pcr_A[1].p};
+          double *Rp[2] = {(double *)W->pcr_R[0].p, (double *)W->pcr_R[1].p}, *yred = (double *)W->yred.p;
+          const PcrSrc src{H, g, scale, n, ns, radius, diag};
+          int cur = 0, nlev = 0;
+          for (int s = 1; s < M; s *= 2) ++nlev;
+          double *X = nullptr;
+          k_pcr_init<<<dim3(M, nch), 256, 0, st>>>(src, Dp[0], Ap[0], Rp[0], ldr, fail);
+          for (int s = 1, lev = 0; lev < nlev; s *= 2, ++lev) {  // (ns >= 4: at least one level)
+            const bool last = lev == nlev - 1;
+            const dim3 grid(M, nch);
+            if (last)
+              k_pcr_level<true><<<grid, 256, 0, st>>>(s, M, Dp[cur], Ap[cur], Rp[cur], Dp[cur ^ 1], Ap[cur ^ 1], Rp[cur ^ 1], ldr, fail);
+            else
+              k_pcr_level<false><<<grid, 256, 0, st>>>(s, M, Dp[cur], Ap[cur], Rp[cur], Dp[cur ^ 1], Ap[cur ^ 1], Rp[cur ^ 1], ldr, fail);
+            cur ^= 1;
+          }
+          X = Rp[cur];  // the last level wrote X = T^-1 [C | bB] where the others write R'
+          k_schur_form<<<dim3((np2 + 255) / 256, 1 + ns + (np2 - npz)), 256, 0, st>>>(H, g, scale, X, n, ns, ldr, np2, ld2, radius, A, diag, Lmat, (double *)W->Linv.p, fail);
+          for (int k = 0; k + 1 < nblk2; ++k) {
+            const int tiles = ((nblk2 - k - 1) * kNB + 63) / 64;
+            k_chol_step<<<1 + tiles * (tiles + 1) / 2, 256, 0, st>>>(A, ld2, k, nblk2, Lmat, (double *)W->Linv.p, fail, npz);
+          }
+          const StepArgs sa{x, scale, g, diag, lin_cost(W), xc, mail, h_stage_dev, 0};
+          const double *zsrc = Lmat + (size_t)npz * ld2;
+          for (int hi = (npz + kNB - 1) / kNB; hi > 0;) {
             const int lo = std::max(0, hi - kBackChunk);
-            const StepArgs sa{x, scale, g, diag, lin_cost(W), xc, mail, h_stage_dev, lo == 0 ? 1 : 0};
-            k_chol_back_chunk<<<1, 1024, 0, st>>>(Lmat, ld, n, (const double *)W->Linv.p, zsrc, y, lo, hi, sa);
-            if (lo > 0) k_chol_back_gemv<<<lo, 1024, 0, st>>>(Lmat, ld, n, zsrc, y, lo, hi);
-            zsrc = y;
+            k_chol_back_chunk<<<1, 1024, 0, st>>>(Lmat, ld2, npz, (const double *)W->Linv.p, zsrc, yred, lo, hi, sa);
+            if (lo > 0) k_chol_back_gemv<<<lo, 1024, 0, st>>>(Lmat, ld2, npz, zsrc, yred, lo, hi);
+            zsrc = yred;
             hi = lo;
           }
+          k_schur_bias_y<<<(npz + 3) / 4, 256, 0, st>>>(X, yred, ns, ldr, y);
+          k_lm_step<<<1, 1024, 0, st>>>(sa, y, n);
+        } else {
+          {
+            dim3 grid((np + 255) / 256, np);
+            grid.y += 1;  // (+ the workgroup of the first diagonal block)
+            k_damp_first<<<grid, 256, 0, st>>>(H, g, scale, n, np, ld, radius, A, diag, Lmat, (double *)W->Linv.p, fail);
+          }
+          for (int k = 0; k + 1 < nblk; ++k) {
+            const int tiles = ((nblk - k - 1) * kNB + 63) / 64;
+            k_chol_step<<<1 + tiles * (tiles + 1) / 2, 256, 0, st>>>(A, ld, k, nblk, Lmat, (double *)W->Linv.p, fail, n);
+          }
+          {  // back substitution, chunk by chunk from the last block row
+            const double *zsrc = Lmat + (size_t)n * ld;
+            for (int hi = (n + kNB - 1) / kNB; hi > 0;) {
+              const int lo = std::max(0, hi - kBackChunk);
+              const StepArgs sa{x, scale, g, diag, lin_cost(W), xc, mail, h_stage_dev, lo == 0 ? 1 : 0};
+              k_chol_back_chunk<<<1, 1024, 0, st>>>(Lmat, ld, n, (const double *)W->Linv.p, zsrc, y, lo, hi, sa);
+              if (lo > 0) k_chol_back_gemv<<<lo, 1024, 0, st>>>(Lmat, ld, n, zsrc, y, lo, hi);
+              zsrc = y;
+              hi = lo;
+            }
+          }
         }
-      }
-      unsigned long long ticket = 0;
-      if (cand_lin && poll_mail && !multi_gpu(ctx, W) && h_mail_dev) ticket = ++ctx->mail_ticket;
-      if (cand_lin)
-        WC_TRY(enqueue_linearize(ctx, W, xc, 5, /*post=*/true, /*other=*/true, multi_gpu(ctx, W) ? nullptr : h_mail_dev, ticket));  // mail[5] = cost, [6] = max |g| at the candidate
-      else
-        WC_TRY(enqueue_evaluate(ctx, W, xc, nullptr, 5, h_mail_dev));
-      WC_HIP(ctx, hipGetLastError());
-      // (one GPU: k_sum_blocks has stored the mailbox to pinned host memory itself; with an all-reduce behind it, copy)
-      if (multi_gpu(ctx, W) || !h_mail_dev) WC_HIP(ctx, hipMemcpyAsync(ctx->h_mail, mail, 40 * 8, hipMemcpyDeviceToHost, st));
-      WC_TRY(wait_mail(ctx, ticket));
+        unsigned long long ticket = 0;
+        if (cand_lin && poll_mail && !multi_gpu(ctx, W) && h_mail_dev) ticket = ++ctx->mail_ticket;
+        if (cand_lin)
+          WC_TRY(enqueue_linearize(ctx, W, xc, 5, /*post=*/true, /*other=*/true, multi_gpu(ctx, W) ? nullptr : h_mail_dev, ticket));  // mail[5] = cost, [6] = max |g| at the candidate
+        else
+          WC_TRY(enqueue_evaluate(ctx, W, xc, nullptr, 5, h_mail_dev));
+        WC_HIP(ctx, hipGetLastError());
+        // (one GPU: k_sum_blocks has stored the mailbox to pinned host memory itself; with an all-reduce behind it, copy)
+        if (multi_gpu(ctx, W) || !h_mail_dev) WC_HIP(ctx, hipMemcpyAsync(ctx->h_mail, mail, 40 * 8, hipMemcpyDeviceToHost, st));
+        WC_TRY(wait_mail(ctx, ticket));
+        return WC_OK;
+      };
+      WC_TRY(attempt(use_schur));
       if (lin_pending) {
         resolve_pending();
         if (gmax <= 1e-10) {  // GradientToleranceReached at the point this iteration started from
@@ -2708,7 +2714,26 @@ extern "C" int wc_window_solve(wc_ctx *ctx, double *h_x_inout, wc_solve_summary 
       summary->n_cost_evaluations++;
       int hfail;
       std::memcpy(&hfail, &ctx->h_mail[32], 4);
-      const double model_change = ctx->h_mail[2], step_norm = ctx->h_mail[3], cand_cost = ctx->h_mail[5];
+      double model_change = ctx->h_mail[2], step_norm = ctx->h_mail[3], cand_cost = ctx->h_mail[5];
+      // A step the trust region is about to REJECT (or an invalid one) that came from the bias elimination is formed again by the dense
+      // factorisation of all unknowns before the decision is taken (round 5).  The elimination computes S = P - C^T T^-1 C through a
+      // parallel cyclic reduction without pivoting; on ill-conditioned windows (a free gauge held by the IMU factors alone, a large
+      // radius, dozens of iterations) its step can be worse than a direct factorisation's - profiles/stress_window.py found solves that
+      // rejected steps the oracle (and round 2's dense path) accepted and then needed 38 iterations for the oracle's 27, or hit the
+      // iteration limit.  Accepted steps - the rule: all of them in the bench's windows, the odometry step and the facade's stream - cost
+      // nothing extra; a genuine rejection costs one dense step.
+      if (use_schur && cand_lin) {
+        const bool invalid = hfail || !(model_change > 0) || !std::isfinite(step_norm);
+        const double dc = cost - cand_cost;
+        const bool rejected = !invalid && step_norm > 1e-8 * (x_norm + 1e-8) && std::fabs(dc) > 1e-6 * cost && !(dc / model_change > 1e-3);
+        if (invalid || rejected) {
+          WC_TRY(attempt(false));
+          summary->n_cost_evaluations++;
+          summary->first_step[1] += 1.0;  // (dense re-tries of this solve)
+          std::memcpy(&hfail, &ctx->h_mail[32], 4);
+          model_change = ctx->h_mail[2], step_norm = ctx->h_mail[3], cand_cost = ctx->h_mail[5];
+        }
+      }
       if (hfail || !(model_change > 0) || !std::isfinite(step_norm)) {  // HandleInvalidStep
         if (++consecutive_invalid >= 5) {
           summary->termination = 2;
