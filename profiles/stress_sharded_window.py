@@ -1,0 +1,96 @@
+"""Randomised stress of the SHARDED window (wc_window_build_sharded + wc_window_solve on 2 ... 5 thread-ranks, dist.ThreadComm standing in
+for RCCL) against the one-rank solve of the same random window (gauge held; random loss / weights / quirks as profiles/stress_window.py):
+the ranks must end bitwise equal among themselves, with the one-rank solve's iterations, accepted steps and termination; corrections
+1e-6 on converged solves of at most 30 iterations, the final cost 1e-6 otherwise.  python profiles/stress_sharded_window.py [seconds]"""
+import os, sys, time, threading
+R_ = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [R_ + "/wildcat-slam_amd/python", R_ + "/oracle"]
+import numpy as np
+import pyoracle
+from wildcat_slam_amd import lib, synth, records as R
+from wildcat_slam_amd import dist as wdist
+
+def rel(a, b):
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300))
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 200.0
+t_end = time.time() + budget
+one = lib.Context(0)
+n = bad = 0
+worst = 0.0
+seed = 0
+while time.time() < t_end:
+    seed += 1
+    rng = np.random.default_rng(66_000 + seed)
+    scans, patches = int(rng.integers(2, 9)), int(10 ** rng.uniform(1.5, 3.3))
+    fixed = int(rng.choice([0, patches // 2, patches]))
+    w = synth.surfel_window(scans, patches, seed=int(rng.integers(1, 1 << 30)), fixed_patches=fixed,
+                            pose_err=(float(10 ** rng.uniform(-3, -1.5)), float(10 ** rng.uniform(-5, -3))))
+    prm = pyoracle.default_params()
+    prm.reference_quirks = int(rng.integers(0, 2))
+    prm.cauchy_a = float(rng.choice([0.4, 0.4, 10 ** rng.uniform(-1, 1)]))
+    with_imu = bool(rng.random() < 0.85)
+    fix_first = True if (not with_imu or not fixed) else bool(rng.integers(0, 2))
+    pairs = pyoracle.match(w["surf"], w["pose"], w["surf"], w["pose"], True, prm)
+    pf = pyoracle.match(w["surf"], w["pose"], w["fix_surf"], w["fix_pose"], False, prm) if fixed else np.zeros(0, R.PAIR)
+    if len(pairs) < 20:
+        continue
+    use_fix = bool(fixed and len(pf))
+    world = int(rng.integers(2, 6))
+    x0 = np.zeros(12 * len(w["sample_times"]))
+
+    def build(c, sharded):
+        c.set_params(prm)
+        k = [c.to_device(w["surf"]), c.to_device(w["pose"]), c.to_device(pairs)]
+        kf = [c.to_device(w["fix_surf"]), c.to_device(w["fix_pose"]), c.to_device(pf)] if use_fix else [None, None, None]
+        c.window_build(k[0], k[1], k[2], len(pairs), w["imu"] if with_imu else None, w["sample_times"], w["grav"], fix_first,
+                       kf[0], kf[1], kf[2], len(pf) if use_fix else 0, sharded=sharded)
+        return k, kf
+
+    keep = build(one, False)
+    x1, s1, _ = one.window_solve(x0)
+    ctxs = [lib.Context(0) for _ in range(world)]
+    shared = wdist.ThreadComm.shared(world)
+    res, errors = [None] * world, []
+
+    def run(r):
+        try:
+            c = ctxs[r]
+            c.set_comm(wdist.ThreadComm(shared, r, c))
+            kk = build(c, True)
+            res[r] = c.window_solve(x0) + (kk,)
+        except Exception as e:
+            errors.append(repr(e)[:200])
+            shared["bar"].abort()
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=120)
+    n += 1
+    what = []
+    if errors:
+        what.append("errors %s" % errors[:2])
+    else:
+        for r in range(1, world):
+            if not np.array_equal(res[r][0], res[0][0]):
+                what.append("rank %d diverged from rank 0" % r)
+        s = res[0][1]
+        if (s.iterations, s.successful_steps, s.termination) != (s1.iterations, s1.successful_steps, s1.termination):
+            what.append("iterations %d / %d, accepted %d / %d, termination %d / %d" % (s.iterations, s1.iterations, s.successful_steps, s1.successful_steps, s.termination, s1.termination))
+        else:
+            dcost = abs(s.final_cost - s1.final_cost) / max(s1.final_cost, 1e-300)
+            if s1.termination == 0 and s1.iterations <= 30:
+                worst = max(worst, rel(res[0][0], x1))
+                if not (dcost <= 1e-8 and rel(res[0][0], x1) <= 1e-6):
+                    what.append("values: cost %.1e x %.1e" % (dcost, rel(res[0][0], x1)))
+            elif not dcost <= 1e-6:
+                what.append("final cost %.1e" % dcost)
+    if what:
+        bad += 1
+        print("MISMATCH seed", seed, "world", world, "scans", scans, "patches", patches, "fixed", fixed, "pairs", len(pairs), len(pf), "imu", with_imu, "fix_first", fix_first,
+              "iters", s1.iterations, "|", "; ".join(what))
+    for c in ctxs:
+        c.close()
+print("windows %d, mismatches %d, worst deviation of the corrections from the one-rank solve %.1e, last seed %d" % (n, bad, worst, seed))
