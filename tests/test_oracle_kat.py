@@ -84,3 +84,23 @@ def test_eig3_against_lapack(oracle):
         assert np.abs(ev - ev2).max() <= 4e-15 * ev2.max()
         assert np.abs(a @ v - v * ev).max() <= 1e-14 * ev2.max()
         assert np.abs(v.T @ v - np.eye(3)).max() < 1e-14
+
+
+def test_orchestrated_step_helper_is_deterministic_and_consistent(oracle):
+    """pyoracle.odometry_step - the ONE implementation behind bench.py's cpu_baseline of `odometry_step` and the by-value tests of
+    wildcat_slam_amd/step.py (lidar_odometry.cc:523-566) - on a small window: 8 surfels per root and sweep, pairs that point from older to
+    newer surfels inside their sets, a solve that lowers the cost, and the same bytes on a second run"""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "wildcat-slam_amd", "python"))
+    from wildcat_slam_amd import synth
+
+    w = synth.g2_scan_sequence(4, 60, m=32, seed=synth.SEED + 5)
+    a, b = oracle.odometry_step(w), oracle.odometry_step(w)
+    assert a["new"] == 8 * 60 and [len(i) for i in a["ids"]] == [480] * 4 and a["n_fix"] == 960
+    n_sld = len(a["sld_surf"])
+    pb, pu = a["pairs_sld"], a["pairs_fix"]
+    assert len(pb) > 400 and (pb["first"] < pb["second"]).all() and pb["second"].max() < n_sld
+    assert len(pu) > 100 and pu["first"].max() < a["n_fix"] and pu["second"].max() < n_sld
+    s = a["summary"]
+    assert s.iterations >= 2 and s.final_cost < s.initial_cost
+    assert a["x"].tobytes() == b["x"].tobytes() and pb.tobytes() == b["pairs_sld"].tobytes() and pu.tobytes() == b["pairs_fix"].tobytes()
