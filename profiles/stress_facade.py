@@ -11,12 +11,18 @@ from wildcat_slam_amd import lib, synth
 from test_facade_gpu import _feed, _state_diff, _pair_set_difference
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 200.0
+only = [int(a) for a in sys.argv[2].split(",")] if len(sys.argv) > 2 else None  # replay these seeds
+dense = len(sys.argv) > 3 and sys.argv[3] == "dense"  # ... with round 2's dense LM step (development option lm_dense)
 t_end = time.time() + budget
 streams = sweeps = bad = 0
 worst = 0.0
 seed = 0
 while time.time() < t_end:
     seed += 1
+    if only is not None:
+        if not only:
+            break
+        seed = only.pop(0)
     rng = np.random.default_rng(31_000 + seed)
     dur = float(rng.uniform(1.7, 8.4))
     pps = int(rng.choice([60_000, 100_000, 150_000, 250_000, 400_000]))
@@ -30,6 +36,8 @@ while time.time() < t_end:
         print("generator refused", kw, repr(e)[:100])
         continue
     odo, ref = lib.Odometry(0), pyoracle.Odometry()
+    if dense:
+        odo.set_dev_option("lm_dense", 1)
     odo.set_exact_sums(exact); odo.set_quirks(quirks); ref.set_quirks(quirks); odo.set_keep_pair_stamps(True)
     notes = []
 

@@ -105,6 +105,10 @@ class LidarOdometry {
 
   LioConfig config_;
   wc_ctx *ctx_ = nullptr;
+ public:
+  // the library context behind this object (tests and profiling scripts set development options on it: wc_ctx_set_dev_option)
+  wc_ctx *gpu_context() const { return ctx_; }
+ private:
   std::deque<ImuData> imu_buff_;
   // points_buff_ of the reference (lidar_odometry.h:56) lives in HBM: the pre-filtered points of the scans not yet
   // consumed are d_pts_[pts_cur_][pts_begin_ .. pts_end_); the host keeps only their timestamps

@@ -13,6 +13,8 @@ extern "C" {
 
 void *wc_odom_create(int device) { return new LidarOdometry(device); }
 void wc_odom_destroy(void *h) { delete (LidarOdometry *)h; }
+// a development option of the facade's library context (include/wildcat_hip.h: wc_ctx_set_dev_option) - stress scripts only
+int wc_odom_set_dev_option(void *h, const char *name, int value) { return wc_ctx_set_dev_option(((LidarOdometry *)h)->gpu_context(), name, value); }
 
 void wc_odom_add_imu(void *h, double t, const double acc[3], const double gyr[3]) {
   ImuData d;

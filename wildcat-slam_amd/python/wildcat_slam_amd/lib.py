@@ -617,6 +617,11 @@ class Odometry:
         self.lib.wc_odom_residual_log(self.h, buf, C.c_uint64(n + 1))
         return buf.value.decode()
 
+    def set_dev_option(self, name, value):
+        rc = self.lib.wc_odom_set_dev_option(self.h, name.encode(), C.c_int(int(value)))
+        if rc != 0:
+            raise WildcatError(rc, "wc_odom_set_dev_option(%s)" % name)
+
     def set_quirks(self, on):
         self.lib.wc_odom_set_quirks(self.h, C.c_int(1 if on else 0))
 
