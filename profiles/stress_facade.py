@@ -38,6 +38,8 @@ while time.time() < t_end:
     odo, ref = lib.Odometry(0), pyoracle.Odometry()
     if dense:
         odo.set_dev_option("lm_dense", 1)
+    if len(sys.argv) > 3 and sys.argv[3].startswith("radius"):
+        odo.set_dev_option("lm_dense_radius", int(sys.argv[3][6:]))
     odo.set_exact_sums(exact); odo.set_quirks(quirks); ref.set_quirks(quirks); odo.set_keep_pair_stamps(True)
     notes = []
 

@@ -66,12 +66,13 @@ while time.time() < t_end:
     if not (abs(c - c_ref) <= 1e-10 * c_ref and rel(H, H_ref) <= 1e-9 and rel(g, g_ref) <= 1e-9 and np.array_equal(H, H.T)):
         what.append("linearize cost %.1e H %.1e g %.1e" % (abs(c - c_ref) / c_ref, rel(H, H_ref), rel(g, g_ref)))
     x0 = np.zeros(12 * W.ns)
-    x_ref, s_ref, _ = W.solve(x0)
-    xg, s, _ = ctx.window_solve(x0)
+    x_ref, s_ref, f_ref = W.solve(x0)
+    xg, s, f_s = ctx.window_solve(x0)
     if only is not None:
         ctx.set_dev_option("lm_dense", 1)
-        xd, sd, _ = ctx.window_solve(x0)
+        xd, sd, f_d = ctx.window_solve(x0)
         ctx.set_dev_option("lm_dense", 0)
+        print("seed %d first step against the oracle's: default %.1e, dense %.1e" % (seed, rel(f_s, f_ref), rel(f_d, f_ref)))
         print("seed %d ns %d: oracle it %d acc %d term %d cost %.9e | default it %d acc %d term %d cost %.9e x %.1e | dense it %d acc %d term %d cost %.9e x %.1e" % (
             seed, W.ns, s_ref.iterations, s_ref.successful_steps, s_ref.termination, s_ref.final_cost, s.iterations, s.successful_steps, s.termination, s.final_cost,
             rel(xg, x_ref), sd.iterations, sd.successful_steps, sd.termination, sd.final_cost, rel(xd, x_ref)))

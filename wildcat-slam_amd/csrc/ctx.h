@@ -38,7 +38,7 @@ struct wc_dev_opts {
   int lm_dense = 0;          // round 2's LM step: dense Cholesky of all 12 ns unknowns
   int lm_sync = 0;           // wait for the stream instead of the mailbox ticket
   int lm_eval_pass = 0;      // a cost-only pass for the candidate instead of a linearisation
-  int lm_chain = 0;          // the damped solve as the round-4 launch chain instead of the persistent kernel
+  int lm_dense_radius = 10;  // iterations whose trust-region radius exceeds 10^value take the dense step (0: never)
 };
 // logging-only switches (they print; they never change a result): read once per process from the environment in every build
 inline bool wc_log_env(const char *name) { return getenv(name) != nullptr; }

@@ -75,7 +75,7 @@ const DevOpt kDevOpts[] = {
     {"lm_dense", "WC_LM_DENSE", &wc_dev_opts::lm_dense, true},
     {"lm_sync", "WC_LM_SYNC", &wc_dev_opts::lm_sync, true},
     {"lm_eval_pass", "WC_LM_EVAL_PASS", &wc_dev_opts::lm_eval_pass, true},
-    {"lm_chain", "WC_LM_CHAIN", &wc_dev_opts::lm_chain, true},
+    {"lm_dense_radius", "WC_LM_DENSE_RADIUS", &wc_dev_opts::lm_dense_radius, false},
 };
 }  // namespace
 

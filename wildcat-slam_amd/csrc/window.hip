@@ -2702,7 +2702,13 @@ extern "C" int wc_window_solve(wc_ctx *ctx, double *h_x_inout, wc_solve_summary 
         WC_TRY(wait_mail(ctx, ticket));
         return WC_OK;
       };
-      WC_TRY(attempt(use_schur));
+      // Above a radius of 1e10 - a dozen very successful steps in a row - the damping has all but left the bias block T, whose own
+      // conditioning (random-walk factors tying neighbouring biases, weak absolute information) then shows: the cyclic reduction's explicit
+      // 12 x 12 inverses lose digits a direct factorisation keeps.  Seen in profiles/stress_facade.py on sparse streams (a sweep of 38
+      // iterations for the oracle's 35, states 2.5e-4 apart; with the dense step from 1e10 on: 35 iterations, 1e-5).  Such iterations
+      // take round 2's dense step (development option lm_dense_radius: the exponent, 0 = never).
+      const bool schur_now = use_schur && !(ctx->dev.lm_dense_radius > 0 && radius > std::pow(10.0, (double)ctx->dev.lm_dense_radius));
+      WC_TRY(attempt(schur_now));
       if (lin_pending) {
         resolve_pending();
         if (gmax <= 1e-10) {  // GradientToleranceReached at the point this iteration started from
@@ -2722,7 +2728,7 @@ extern "C" int wc_window_solve(wc_ctx *ctx, double *h_x_inout, wc_solve_summary 
       // rejected steps the oracle (and round 2's dense path) accepted and then needed 38 iterations for the oracle's 27, or hit the
       // iteration limit.  Accepted steps - the rule: all of them in the bench's windows, the odometry step and the facade's stream - cost
       // nothing extra; a genuine rejection costs one dense step.
-      if (use_schur && cand_lin) {
+      if (schur_now && cand_lin) {
         const bool invalid = hfail || !(model_change > 0) || !std::isfinite(step_norm);
         const double dc = cost - cand_cost;
         const bool rejected = !invalid && step_norm > 1e-8 * (x_norm + 1e-8) && std::fabs(dc) > 1e-6 * cost && !(dc / model_change > 1e-3);
