@@ -1,6 +1,6 @@
 """Randomised PARAMETER + cloud stress of the default (integer-moment) extraction against the CPU oracle, several repetitions per
 configuration (a race shows as a repetition that differs) in both forms of the node stage.  Round 5 wrote it after a parameter test
-found a displaced-root race of the layer-2 pass.  python profiles/stress_params.py [seconds] [seed0]"""
+found a displaced-root race of the layer-2 pass.  python profiles/stress_params.py [seconds] [seed0] [exact]  (exact: also two runs in the exact arithmetic, byte for byte)"""
 import os, sys, time
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [R + "/wildcat-slam_amd/python", R + "/oracle", R + "/tests"]
@@ -13,7 +13,8 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 ctx = lib.Context(0)
 t_end = time.time() + budget
-n_cfg = n_bad = n_fast = n_runs = 0
+n_cfg = n_bad = n_fast = n_runs = n_exact = 0
+exact_too = len(sys.argv) > 3 and sys.argv[3] == "exact"
 seed = seed0
 while time.time() < t_end:
     seed += 1
@@ -41,6 +42,16 @@ while time.time() < t_end:
     want = set(helpers.id_tuples(id_ref))
     ctx.set_params(prm); ctx.params = prm
     n_cfg += 1
+    if exact_too:  # the exact arithmetic (the path every fall-back ends on): the oracle's bytes, in the oracle's order
+        ctx.set_exact_sums(True)
+        for rep in range(2):
+            s, i = ctx.extract_surfels(pts)
+            n_exact += 1
+            if not (i.tobytes() == id_ref.tobytes() and all(np.array_equal(s[f], s_ref[f], equal_nan=True) for f in ("t", "center", "cov", "normal", "sigma", "resolution"))):
+                n_bad += 1
+                print("EXACT MISMATCH seed", seed, "kind", kind, "rep", rep, "n", len(pts), "vs", prm.voxel_size, "layers", prm.max_layer, "min", prm.min_points, prm.cluster_min_points,
+                      "gap", prm.cluster_gap, "surfels", len(s), len(s_ref), "ids equal", i.tobytes() == id_ref.tobytes())
+        ctx.set_exact_sums(False)
     for form in (0, 1):
         ctx.set_dev_option("fx_split", form)
         for rep in range(3):
@@ -69,4 +80,4 @@ while time.time() < t_end:
                       "gap", prm.cluster_gap, "thr", prm.planer_threshold, "like", prm.min_plane_likeness, "surfels", len(s), len(s_ref), "fast", info["fast"],
                       "missing", sorted(want - got)[:3], "extra", sorted(got - want)[:3])
 ctx.set_dev_option("fx_split", -1)
-print("configurations %d, runs %d (%d completed by the default path), mismatches %d, last seed %d" % (n_cfg, n_runs, n_fast, n_bad, seed))
+print("configurations %d, runs %d (%d completed by the default path), exact-arithmetic runs %d, mismatches %d, last seed %d" % (n_cfg, n_runs, n_fast, n_exact, n_bad, seed))
