@@ -22,8 +22,13 @@ def rel_err(a, b):
     return float(np.abs(a - b).max() / denom)
 
 
-def check_surfels(s_gpu, id_gpu, s_ref, id_ref, tol=1e-6, t_tol=None):
-    """counts and ids bit-exact; geometry within `tol` relative (north_star: 1e-6)."""
+def check_surfels(s_gpu, id_gpu, s_ref, id_ref, tol=1e-6, t_tol=None, strict_sigma=False):
+    """counts and ids bit-exact; geometry within `tol` relative (north_star: 1e-6).
+    sigma = sqrt(lambda_0) of a cluster whose points lie EXACTLY in a plane (every stretch of one scan line on a surface: line direction x
+    ray direction) is the reference's own rounding noise - NaN or ~1e-7 by the luck of its un-centred sums.  strict_sigma (the exact
+    arithmetic, which reproduces those sums): the NaN pattern and every value must agree.  Otherwise (the default arithmetic, exact
+    integer sums): where the reference's sigma is NaN or below the noise floor sqrt(16 sqrt(n) |c|^2 eps) ~ 3e-5 x |c|, the other side
+    must be NaN or below twice that floor, and nothing more is compared."""
     p = match_by_id(id_ref, id_gpu)
     g = s_gpu[p]
     n = len(s_ref)
@@ -38,8 +43,15 @@ def check_surfels(s_gpu, id_gpu, s_ref, id_ref, tol=1e-6, t_tol=None):
     cov_scale = np.maximum(np.abs(s_ref["cov"]).max(axis=1, keepdims=True), 1e-300)
     dcov = (np.abs(g["cov"] - s_ref["cov"]) / cov_scale).max()
     nan_ref = np.isnan(s_ref["sigma"])
-    assert np.array_equal(np.isnan(g["sigma"]), nan_ref)
-    ok = ~nan_ref
+    if strict_sigma:
+        assert np.array_equal(np.isnan(g["sigma"]), nan_ref)
+        ok = ~nan_ref
+    else:
+        floor = 3e-5 * np.sqrt((s_ref["center"] ** 2).sum(axis=1) + 1.0)
+        noise = nan_ref | (s_ref["sigma"] <= floor)
+        assert np.all(np.isnan(g["sigma"][noise]) | (g["sigma"][noise] <= 2 * floor[noise]))
+        assert not np.isnan(g["sigma"][~noise]).any()
+        ok = ~noise
     dsig = (np.abs(g["sigma"][ok] - s_ref["sigma"][ok]).max() / max(np.abs(s_ref["sigma"][ok]).max(), 1e-300)) if ok.any() else 0.0
     assert np.array_equal(g["resolution"], s_ref["resolution"])
     assert dn <= tol and dc <= tol and dcov <= tol and dsig <= tol, (dn, dc, dcov, dsig)
@@ -71,7 +83,7 @@ def check_fast_and_exact(gpu, oracle, pts, params=None, expect_fast=None, **kw):
         if exact:
             assert not path["fast"]
             assert id_gpu.tobytes() == id_ref.tobytes()  # the ORDER is the oracle's too: stamp, then voxel index and node id (Q7)
-            info = check_surfels(s_gpu, id_gpu, s_ref, id_ref, tol=1e-6, t_tol=1e-5) if len(s_ref) else dict(n=0)
+            info = check_surfels(s_gpu, id_gpu, s_ref, id_ref, tol=1e-6, t_tol=1e-5, strict_sigma=True) if len(s_ref) else dict(n=0)
         else:
             if expect_fast:
                 assert path["fast"], path

@@ -1912,7 +1912,9 @@ int run_pipeline_fast(wc_ctx *ctx, const wc_points &pts, double t_lo, double t_h
   // sweep in firing order, e.g. 75 k points of a 40 m room, puts three quarters of its points there) and, sticky, on any context
   // whose pool has overflowed once; larger clouds start with n / 32 per bank
   const uint64_t spill_full = ((uint64_t)tiles + 7) / 8 * kFxTile;
-  A.spill_per = (uint32_t)((n <= 2000000ull || ctx->ex.fx_spill_full) ? spill_full : std::max<uint64_t>(1024, n / 32));
+  // (round 5: full size up to 8 M points - a 4 M-point room in firing order overflowed the n / 32 pool on every fresh context, whose first
+  // two calls then ran on the exact path; 128 bytes per point of never-cleared memory are nothing on this card)
+  A.spill_per = (uint32_t)((n <= 8000000ull || ctx->ex.fx_spill_full) ? spill_full : std::max<uint64_t>(1024, n / 32));
   A.rec_cap = tiles * (uint32_t)kFxRecTile + 8u * A.spill_per;
   const uint64_t total_slots = (n * (uint64_t)(P.max_layer + 1)) / (uint64_t)P.cluster_min_points + 1;
   uint32_t bin_cap = 64;
