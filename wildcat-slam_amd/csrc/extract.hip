@@ -55,7 +55,7 @@ struct ExParams {
   int cluster_min;
   uint64_t t_lo_bits;  // ordered bits of the time hint lower bound
   uint64_t t_span_bits;  // ordered bits of the upper bound - t_lo_bits
-  int dbg;             // WC_DEBUG_SKIP bits (profiling experiments only)
+  int dbg;             // development option debug_skip: knock-out bits (profiling experiments only)
   int merge_min;       // a (node, time slot) list of more records than this makes the next sweep run k_fx_merge (default 3; WC_FX_MERGE_MIN: experiments)
 };
 
@@ -1004,7 +1004,7 @@ __global__ void __launch_bounds__(64) k_roots_banks(RootsArgs A, const K *__rest
         //      v_readlane for the masks, one LDS read, four EXEC-masked adds ----
         const unsigned long long GE = G0 | G1;
         unsigned long long todo = (PHASE == 1) ? ((nvalid == 64) ? ~0ull : ((1ull << nvalid) - 1ull)) : IN;
-        if (P.dbg & 1) todo = 0;  // WC_DEBUG_SKIP=1: profiling experiments only
+        if (P.dbg & 1) todo = 0;  // development option debug_skip = 1: profiling experiments only
         while (todo) {
           const unsigned long long evs = GE & todo;
           unsigned long long seg = evs ? (todo & ((evs & (0ull - evs)) - 1ull)) : todo;  // the points in front of the next cluster end

@@ -2563,7 +2563,7 @@ extern "C" int wc_window_solve(wc_ctx *ctx, double *h_x_inout, wc_solve_summary 
     WC_TRY(wc_ensure(ctx, W->yred, (size_t)(6 * ns_al + kNB + 64) * 8));
   }
 
-  const bool poll_mail = ctx->dev.lm_sync == 0;  // (WC_LM_SYNC=1: wait for the stream instead of the ticket)
+  const bool poll_mail = ctx->dev.lm_sync == 0;  // (development option lm_sync: wait for the stream instead of the ticket)
   double *h_mail_dev = nullptr, *h_stage_dev = nullptr;  // device addresses of the pinned mailbox and of its staging area
   {
     void *dp = nullptr;
@@ -2601,7 +2601,7 @@ extern "C" int wc_window_solve(wc_ctx *ctx, double *h_x_inout, wc_solve_summary 
   // Round 3: the candidate's cost comes from a LINEARISATION at the candidate (into the other {H, g, cost} buffer) instead of a
   // cost-only pass over the same records: an accepted step - the rule - then needs no second pass (one pass over the factors
   // per iteration instead of two, -0.05 ms of 0.6 at C4), a rejected one has formed an H nobody uses (+0.1 ms).  Its cost and
-  // max |g| arrive with the iteration's mailbox, so nothing is pending between iterations.  WC_LM_EVAL_PASS=1: round 2's flow.
+  // max |g| arrive with the iteration's mailbox, so nothing is pending between iterations.  Development option lm_eval_pass: round 2's flow.
   const bool cand_lin = ctx->dev.lm_eval_pass == 0;
   auto resolve_pending = [&]() {
     cost = ctx->h_mail[0];
