@@ -102,7 +102,7 @@ def pmc_traffic_measured(kernels, roots):
             d = os.path.join(tmp, ctr)
             cmd = [exe, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "b", "--", sys.executable,
                    os.path.join(ROOT, "profiles", "exp_g1.py"), "g2", str(roots * 256), "20"]
-            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=240)
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=120)
             found = None
             for base, _, files in os.walk(d):
                 for f in files:

@@ -18,6 +18,7 @@ struct wc_buf {
   void *p = nullptr;
   size_t cap = 0;
   bool pooled = false;  // from the device's stream-ordered memory pool (hipMallocAsync): released with hipFreeAsync
+  bool plain = false;   // never from the pool: buffers handed to the communicator's collectives (RCCL sees ordinary hipMalloc memory)
 };
 
 // Development options of a context (wc_ctx_set_dev_option; include/wildcat_hip.h lists them).  They pin choices the library
@@ -186,7 +187,7 @@ inline int wc_ensure(wc_ctx *ctx, wc_buf &b, size_t bytes) {
   if (want < 4096) want = 4096;
   static const bool alloc_dbg = wc_log_env("WC_ALLOC_DEBUG");  // (read once per process)
   if (alloc_dbg) fprintf(stderr, "[alloc] %zu bytes wanted -> %zu\n", bytes, want);
-  if (ctx->pool_ok && hipMallocAsync(&b.p, want, ctx->stream) == hipSuccess) {
+  if (ctx->pool_ok && !b.plain && hipMallocAsync(&b.p, want, ctx->stream) == hipSuccess) {
     b.pooled = true;
   } else {
     (void)hipGetLastError();

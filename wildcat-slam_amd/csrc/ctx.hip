@@ -111,6 +111,7 @@ extern "C" int wc_ctx_create(const wc_params *params, int device, wc_ctx **out) 
     return WC_ERR_HIP;
   }
   ctx->stream = ctx->own_stream;
+  for (wc_buf &b : ctx->b_route) b.plain = true;  // (all-to-all / all-gather buffers of the sharded extraction and matcher)
   {  // the device's default memory pool keeps what is freed (release threshold: never give memory back while the process lives)
     hipMemPool_t pool = nullptr;
     int supported = 0;

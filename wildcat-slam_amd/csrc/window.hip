@@ -1958,7 +1958,10 @@ static int window_build_impl(wc_ctx *ctx, const wc_surfel *d_sld_surf, const wc_
   if (!ctx || !h_sample_times || ns_ < 2 || ns_ > 340 || !h_grav) return wc_fail(ctx, WC_ERR_ARG, "%s: null or out-of-range argument", __func__);  // 12 ns <= 4096 unknowns: dense H (134 MB), the largest window the solve has been exercised on; the reference's default window has 82 sample states
   if (n_pairs_sld >= (1ull << 31) || n_pairs_fix >= (1ull << 31)) return wc_fail(ctx, WC_ERR_ARG, "%s: null or out-of-range argument", __func__);
   WC_HIP(ctx, hipSetDevice(ctx->device));
-  if (!ctx->win) ctx->win = new wc_window_state;
+  if (!ctx->win) {
+    ctx->win = new wc_window_state;
+    ctx->win->reduce.plain = ctx->win->mail.plain = true;  // (the all-reduce's buffers: ordinary hipMalloc memory for RCCL)
+  }
   wc_window_state *W = ctx->win;
   W->built = false;
   W->sharded = sharded;
@@ -2530,7 +2533,10 @@ extern "C" int wc_window_linearize(wc_ctx *ctx, const double *h_x, double *d_H, 
 extern "C" int wc_window_set_allreduce(wc_ctx *ctx, int (*fn)(void *user, double *d_buf, uint64_t count), void *user) {
   wc_dev_guard dg_(ctx);
   if (!ctx) return wc_fail(ctx, WC_ERR_ARG, "%s: null or out-of-range argument", __func__);
-  if (!ctx->win) ctx->win = new wc_window_state;
+  if (!ctx->win) {
+    ctx->win = new wc_window_state;
+    ctx->win->reduce.plain = ctx->win->mail.plain = true;
+  }
   ctx->win->allreduce = fn;
   ctx->win->allreduce_user = user;
   return WC_OK;
