@@ -56,6 +56,7 @@ int wc_ctx_set_params(wc_ctx *ctx, const wc_params *params);
  *   fx_merge_min       list length from which the next sweep merges record lists first (default 3)
  *   fx_split           node stage of the default extraction: 0 fused kernel, 1 two kernels, -1 by size
  *   no_bucket_sort     exact path: radix sort instead of the run-binned sort
+ *   ex_sync            wc_extract_surfels_finish waits for the stream instead of the sweep's completion ticket
  *   kd_leaf            target leaf size of the matcher's kd-tree (0 = 8)
  *   knn_group          matcher walk: 0 one lane per query, 1 eight lanes per query, -1 by the call's sizes
  *   match_pair_serial  wc_match_pair runs its two searches one after the other on the ctx

@@ -381,6 +381,31 @@ def test_development_options_and_warmup(gpu, oracle):
     helpers.check_surfels(s_gpu, id_gpu, s_ref, id_ref, tol=1e-6, t_tol=1e-5)
 
 
+def test_completion_ticket_and_stream_wait_agree(gpu, oracle):
+    """wc_extract_surfels_finish waits for the sweep's completion ticket in the pinned mailbox (one thread behind the sweep's last kernel;
+    development option ex_sync = 1: the stream wait of rounds 1 - 4).  Sweeps of different clouds alternate 150 times under each form: a
+    count or a flag read before it has arrived would show as the other cloud's count, a record read early as other bytes."""
+    clouds = [synth.g2_lattice(300, m=32)[0], synth.g2_lattice(77, m=24)[0], synth.g1_room(60000, seed=5)]
+    want = []
+    gpu.set_dev_option("ex_sync", 1)
+    try:
+        for pts in clouds:
+            s_ref, id_ref, _ = oracle.extract_surfels(pts)
+            s_gpu, id_gpu = gpu.extract_surfels(pts)
+            helpers.check_surfels(s_gpu, id_gpu, s_ref, id_ref, tol=1e-6, t_tol=1e-5)
+            want.append((len(s_gpu), s_gpu.tobytes(), id_gpu.tobytes()))
+        assert len({w[0] for w in want}) == len(clouds)
+        for form in (0, 1):
+            gpu.set_dev_option("ex_sync", form)
+            for rep in range(150):
+                i = (rep * 7 + rep // 3) % len(clouds)
+                s_gpu, id_gpu = gpu.extract_surfels(clouds[i])
+                assert i == 2 or gpu.extract_path_info()["fast"]  # (the lattices are completed by the default path itself)
+                assert (len(s_gpu), s_gpu.tobytes(), id_gpu.tobytes()) == want[i], (form, rep, i, len(s_gpu), want[i][0])
+    finally:
+        gpu.set_dev_option("ex_sync", 0)
+
+
 def test_displaced_root_keeps_its_layer2_nodes(gpu, oracle):
     """regression (round 5): two root voxels with one home slot in the default path's hash; k_fx_nodes<1> clears the entry of the one
     that queued nothing for layer 2, and the layer-2 pass's look-up of the other - displaced behind it - stopped at the now empty slot:

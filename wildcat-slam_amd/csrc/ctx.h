@@ -31,6 +31,7 @@ struct wc_dev_opts {
   int fx_merge_min = 3;      // list length from which the next sweep runs k_fx_merge
   int fx_split = -1;         // node stage of the default extraction: 0 fused, 1 two kernels, -1 by size
   int no_bucket_sort = 0;    // exact path: radix sort instead of the run-binned sort
+  int ex_sync = 0;           // extraction: finish waits for the stream instead of the completion ticket
   int kd_leaf = 0;           // matcher: target leaf size of the kd-tree (0: 8)
   int knn_group = -1;        // matcher walk: 0 one lane per query, 1 eight lanes per query, -1 by size
   int match_pair_serial = 0; // wc_match_pair runs its searches one after the other on the ctx
@@ -69,6 +70,7 @@ struct wc_ctx {
   bool have_comm = false;
   void *rccl = nullptr;  // the in-library RCCL communicator (comm.hip), if any
   // pinned host mailbox
+  uint32_t *h_status_dev = nullptr;  // the device's address of h_status
   uint32_t *h_status = nullptr;  // pinned, 128 words: [0] n_emitted, [1] flags, ... ; [64..95]: the matcher's read-backs (round words, walk statistics)
   unsigned long long mail_ticket = 0;  // last ticket handed to a k_post_reduce (window.hip: wait_mail)
   wc_buf b_stage;                 // wc_d2h_strided: the packed elements on the device
@@ -93,6 +95,7 @@ struct wc_ctx {
     uint32_t last_splits = 256;  // roots the previous call queued for the layer-2 pass (sizes / gates that launch)
     // the tail of the pipeline (layer-2 pass, surfel order, status read-back) is re-run by finish() when the call skipped
     // the layer-2 launch and roots were queued for it after all
+    uint32_t ticket = 0, ticket_seq = 0;  // completion ticket of the sweep in flight (0: none - finish waits for the stream)
     bool fx_active = false;      // this call runs on the fast (integer-moment) path
     bool fx_dirty = false;       // the fast path's tables may hold garbage (an aborted sweep): memset before the next use
     uint32_t fx_last_flags = 0, fx_fallbacks = 0, fx_last_why = 0;

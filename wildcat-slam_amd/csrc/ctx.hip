@@ -65,6 +65,7 @@ const DevOpt kDevOpts[] = {
     {"fx_merge_min", "WC_FX_MERGE_MIN", &wc_dev_opts::fx_merge_min, false},
     {"fx_split", "WC_FX_SPLIT", &wc_dev_opts::fx_split, false},
     {"no_bucket_sort", "WC_NO_BUCKET_SORT", &wc_dev_opts::no_bucket_sort, true},
+    {"ex_sync", "WC_EX_SYNC", &wc_dev_opts::ex_sync, true},
     {"kd_leaf", "WC_KD_LEAF", &wc_dev_opts::kd_leaf, false},
     {"knn_group", "WC_KNN_GROUP", &wc_dev_opts::knn_group, false},
     {"match_pair_serial", "WC_MATCH_PAIR_SERIAL", &wc_dev_opts::match_pair_serial, true},
@@ -111,6 +112,11 @@ extern "C" int wc_ctx_create(const wc_params *params, int device, wc_ctx **out) 
     return WC_ERR_HIP;
   }
   ctx->stream = ctx->own_stream;
+  {
+    void *dp = nullptr;
+    if (hipHostGetDevicePointer(&dp, ctx->h_status, 0) == hipSuccess) ctx->h_status_dev = (uint32_t *)dp;
+    for (int q = 0; q < 128; ++q) ctx->h_status[q] = 0;
+  }
   for (wc_buf &b : ctx->b_route) b.plain = true;  // (all-to-all / all-gather buffers of the sharded extraction and matcher)
   {  // the device's default memory pool keeps what is freed (release threshold: never give memory back while the process lives)
     hipMemPool_t pool = nullptr;

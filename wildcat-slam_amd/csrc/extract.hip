@@ -25,6 +25,7 @@
 #include <hip/hip_runtime.h>
 #include <type_traits>
 
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
 #include <rocprim/rocprim.hpp>
@@ -2027,6 +2028,11 @@ int run_pipeline_fast(wc_ctx *ctx, const wc_points &pts, double t_lo, double t_h
   return fx_tail(ctx, P.max_layer >= 2 && ctx->ex.last_splits > 0);
 }
 
+constexpr int kMailTicket = 120;  // word of the pinned mailbox (ctx->h_status) that carries the extraction's completion ticket
+__global__ void k_ex_ticket(uint32_t *host_word, uint32_t ticket) {
+  __hip_atomic_store(host_word, ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // layer-2 pair (optional), time order + gather
 int fx_tail(wc_ctx *ctx, bool layer2) {
   hipStream_t st = ctx->stream;
@@ -2056,6 +2062,15 @@ int fx_tail(wc_ctx *ctx, bool layer2) {
                                            (const wc_surfel_id *)ctx->b_slot_ids.p, A.status, ctx->ex.d_out, ctx->ex.d_ids, ctx->ex.cap, next_ctrl,
                                            kCtrlWords);
   mark(5);
+  // the completion ticket: ONE thread behind the sweep's last kernel stores it to the pinned mailbox and wc_extract_surfels_finish reads
+  // host memory instead of waiting for the stream (the LM loop's wait_mail).  Behind a kernel boundary nothing has to be fenced inside
+  // k_slot_emit (what round 3's last-workgroup ticket paid for): every store of the sweep has left its L2 when this kernel starts.
+  ctx->ex.ticket = 0;
+  if (ctx->h_status_dev && !ctx->ex_prof && !ctx->dev.ex_sync) {
+    if (++ctx->ex.ticket_seq == 0u) ++ctx->ex.ticket_seq;
+    ctx->ex.ticket = ctx->ex.ticket_seq;
+    k_ex_ticket<<<1, 1, 0, st>>>(ctx->h_status_dev + kMailTicket, ctx->ex.ticket);
+  }
   static const bool fx_dbg = wc_log_env("WC_FX_DEBUG");
   if (fx_dbg) fprintf(stderr, "[fx] k_slot_emit (layer2=%d) ... %s\n", (int)layer2, hipGetErrorString(hipStreamSynchronize(st)));
   WC_HIP(ctx, hipGetLastError());
@@ -2326,8 +2341,18 @@ extern "C" int wc_extract_surfels_finish(wc_ctx *ctx, uint64_t *h_n_out) {
   // workgroups" needs a count with a device-scope release in front of every workgroup's increment, and on this chip - one L2 per
   // XCD - that fence writes the XCD's L2 back: 43 -> 70 us per sweep with a two-stage count, 130 us with one counter.  Without the
   // fences a copy on another stream could read the surfels before they have left L2.  The stream wait stays.)
-  auto wait = [&]() -> int {  // stream done; fold the mailbox flag words (raise_flag) into h_status[1]
-    WC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  auto wait = [&]() -> int {  // sweep done (its ticket has arrived, or the stream is idle); fold the mailbox flag words (raise_flag) into h_status[1]
+    bool arrived = false;
+    if (const uint32_t ticket = ctx->ex.ticket) {  // (fx_tail: the ticket kernel was the last thing enqueued)
+      ctx->ex.ticket = 0;
+      const uint32_t *w = (const uint32_t *)ctx->h_status + kMailTicket;
+      const auto t0 = std::chrono::steady_clock::now();
+      for (uint32_t spin = 0; !arrived; ++spin) {
+        arrived = __atomic_load_n(w, __ATOMIC_ACQUIRE) == ticket;
+        if ((spin & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) break;
+      }
+    }
+    if (!arrived) WC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     for (int i = 0; i < 7; ++i)
       if (ctx->h_status[8 + i]) ctx->h_status[1] |= 1u << i;
     return WC_OK;
