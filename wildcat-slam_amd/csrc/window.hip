@@ -516,7 +516,17 @@ struct LinTailTable {
 __constant__ const LinTailTable<24> kLinTail24{};
 __constant__ const LinTailTable<12> kLinTail12{};
 
-// LDS of a surfel piece in doubles: V (later the per-slice partial blocks) + the wavefronts' cost sums
+// LDS of a surfel piece in doubles: V (later the per-slice partial blocks) + the wavefronts' cost sums.
+// Round 5: the rows of a binary piece pass through LDS in ROUNDS of kPiece / RND rows (every thread keeps its row in registers
+// until its round comes: 50 VGPRs) and the slices' partial blocks are folded in groups of NSH - a full piece took 53 KB, which
+// capped a CU at three pieces = 12 wavefronts of dependent fp64 chains (the kernel is bound by how many such
+// chains a CU interleaves, not by their instruction count).
+#ifndef WC_LIN_ROUNDS
+#define WC_LIN_ROUNDS 2
+#endif
+#ifndef WC_LIN_WG_PER_CU
+#define WC_LIN_WG_PER_CU 4
+#endif
 template <int W>
 struct LinSurfelLds {
   static constexpr int T = W + 1;
@@ -524,9 +534,13 @@ struct LinSurfelLds {
   static constexpr int NBLK = NB * (NB + 1) / 2;    // blocks (bi <= bj) of the Gram matrix
   static constexpr int NS = kPiece / NBLK;          // record slices
   static constexpr int TS = T + (T & 1);            // row stride in LDS: even, so that a row's 4-column blocks are 16-byte aligned (ds_read_b128)
-  static constexpr int VSZ = kPiece * TS + 4;       // + 4: the padded columns of the last block read past the last row
+  static constexpr int RND = W == 24 ? WC_LIN_ROUNDS : 1;  // rounds of rows through LDS
+  static constexpr int RH = kPiece / RND;           // rows per round
+  static constexpr int VSZ = RH * TS + 4;           // + 4: the padded columns of the last block read past the last row
   static constexpr int PB = 17;                     // doubles per partial block in LDS: 16 + 1 (a stride of 16 doubles puts every second lane on the same banks)
-  static constexpr int PSZ = NS * NBLK * PB;
+  static constexpr int NSH = VSZ / (NBLK * PB) > NS ? NS : VSZ / (NBLK * PB);  // slices per fold of the partial blocks (they take V's storage)
+  static_assert(NSH >= 1, "a fold of the partial blocks fits V's storage");
+  static constexpr int PSZ = NSH * NBLK * PB;
   static constexpr int VMAX = VSZ > PSZ ? VSZ : PSZ;
   static constexpr int DOUBLES = VMAX + 4;
 };
@@ -534,9 +548,22 @@ template <int W, bool UNARY>
 __device__ __forceinline__ void lin_surfel_body(const WinParams &wp, const Piece pc, const double *rec, uint32_t nrec, const double *x,
                                                 double *partial, double *smem /* 16-byte aligned, LinSurfelLds<W>::DOUBLES */) {
   using L = LinSurfelLds<W>;
-  constexpr int T = L::T, NB = L::NB, NBLK = L::NBLK, NS = L::NS, TS = L::TS, PB = L::PB;
+  constexpr int T = L::T, NB = L::NB, NBLK = L::NBLK, NS = L::NS, TS = L::TS, PB = L::PB, RH = L::RH, NSH = L::NSH;
   double *sV = smem, *sC = smem + L::VMAX;
   const int tid = threadIdx.x;
+  // where this thread's output entries sit in the partial blocks: requested first (a table look-up in the tail was a global-memory
+  // round trip on every piece's critical path, behind the last barrier)
+  constexpr int NOUT = T * (T + 1) / 2, NTE = (NOUT + kPiece - 1) / kPiece;
+  static_assert(W == 24 || W == 12, "tail tables exist for the binary and the unary family");
+  int toff[NTE];
+  {
+    const uint16_t *tail_off = W == 24 ? kLinTail24.off : kLinTail12.off;
+#pragma unroll
+    for (int i = 0; i < NTE; ++i) toff[i] = tid + i * kPiece < NOUT ? (int)tail_off[tid + i * kPiece] : -1;
+  }
+#if defined(WC_LIN_KNOCK) && (WC_LIN_KNOCK & 16)  // timing knock-out: the launch alone
+  if (pc.count < 100000) return;
+#endif
 #ifdef WC_PROF_LIN
   long long lt_[6];
   lt_[0] = clock64();
@@ -547,24 +574,31 @@ __device__ __forceinline__ void lin_surfel_body(const WinParams &wp, const Piece
   asm volatile("" ::"s"(pc.count), "s"(pc.begin));
   la_[0] = clock64();  // descriptor has arrived
 #endif
+  double v[W], r = 0.0;
   if (tid < (int)pc.count) {
-    double v[W], r;
     const uint32_t k = pc.begin + tid;
     constexpr int NF = UNARY ? 11 : 15;
     double rv[NF];
+#if defined(WC_LIN_KNOCK) && (WC_LIN_KNOCK & 4)  // timing knock-out: no record loads
+#pragma unroll
+    for (int f = 0; f < NF; ++f) rv[f] = 1e-3 * (double)(k + f);
+#else
 #pragma unroll
     for (int f = 0; f < NF; ++f) rv[f] = rec[(size_t)f * nrec + k];
+#endif
 #ifdef WC_PROF_LIN
     asm volatile("" ::"v"(rv[0]), "v"(rv[NF - 1]), "v"(rv[5]));
     la_[1] = clock64();  // records have arrived
 #endif
+#if defined(WC_LIN_KNOCK) && (WC_LIN_KNOCK & 2)  // timing knock-out: no evaluation (the loads stay)
+    for (int i = 0; i < W; ++i) v[i] = rv[i % NF];
+    r = rv[1], c = rv[2];
+#else
     if (UNARY)
       eval_unary(wp, rv, 1, 0, pc.key, x, r, c, v);  // one key per piece: the sample blocks are wave-uniform
     else
       eval_binary(wp, rv, 1, 0, pc.key, x, r, c, v);
-#pragma unroll
-    for (int i = 0; i < W; ++i) sV[tid * TS + i] = v[i];
-    sV[tid * TS + W] = r;
+#endif
   }
   // cost of the piece: fixed shuffle tree per wavefront, the four wavefront sums are added in the tail
 #pragma unroll
@@ -572,10 +606,7 @@ __device__ __forceinline__ void lin_surfel_body(const WinParams &wp, const Piece
   if ((tid & 63) == 0) sC[tid >> 6] = c;
 #ifdef WC_PROF_LIN
   lt_[1] = clock64();
-#endif
-  __syncthreads();
-#ifdef WC_PROF_LIN
-  lt_[2] = clock64();
+  lt_[2] = lt_[1];
 #endif
   double acc[4][4] = {{0.0}};
   const int blk = tid % NBLK, slice = tid / NBLK;
@@ -585,48 +616,82 @@ __device__ __forceinline__ void lin_surfel_body(const WinParams &wp, const Piece
     ++bi;
   }
   const int bj = bi + remb;
-  if (slice < NS) {
-    // the slices partition the piece's records [0, count); columns past T (last block) belong to the next record (or, for
-    // the last record, to unwritten storage): those products land in accumulator entries that are never read
-    const int sl = (((int)pc.count + NS - 1) / NS) | 1;  // odd: the slices that share a wavefront then start on different banks
-    const int k0 = min(slice * sl, (int)pc.count), k1 = min(k0 + sl, (int)pc.count);
-    const double *pi = sV + 4 * bi, *pj = sV + 4 * bj;
-    for (int k = k0; k < k1; ++k) {
-      double a[4], c4[4];
-      {
-        const double2 a01 = *(const double2 *)(pi + k * TS), a23 = *(const double2 *)(pi + k * TS + 2);
-        const double2 c01 = *(const double2 *)(pj + k * TS), c23 = *(const double2 *)(pj + k * TS + 2);
-        a[0] = a01.x, a[1] = a01.y, a[2] = a23.x, a[3] = a23.y;
-        c4[0] = c01.x, c4[1] = c01.y, c4[2] = c23.x, c4[3] = c23.y;
+  const double *pi = sV + 4 * bi, *pj = sV + 4 * bj;
+  // the rows go through LDS in rounds of RH (the piece's count is uniform over the workgroup: so are the rounds and their barriers)
+#pragma unroll 1
+  for (int h = 0; h * RH < (int)pc.count; ++h) {
+    if (h) __syncthreads();  // the round before has been read
+#if defined(WC_LIN_KNOCK) && (WC_LIN_KNOCK & 32)  // timing knock-out: no row writes
+    if (tid < (int)pc.count && tid / RH == h && v[0] == 12345.0) {
+#else
+    if (tid < (int)pc.count && tid / RH == h) {
+#endif
+      const int row = tid - h * RH;
+#pragma unroll
+      for (int i = 0; i < W; ++i) sV[row * TS + i] = v[i];
+      sV[row * TS + W] = r;
+    }
+    __syncthreads();
+    if (slice < NS) {
+      // the slices partition the round's rows [0, cnt); columns past T (last block) belong to the next row (or, for the last
+      // row, to unwritten storage): those products land in accumulator entries that are never read
+      const int cnt = min((int)pc.count - h * RH, RH);
+      const int sl = ((cnt + NS - 1) / NS) | 1;  // odd: the slices that share a wavefront then start on different banks
+#if defined(WC_LIN_KNOCK) && (WC_LIN_KNOCK & 1)  // timing knock-out: no Gram loop
+      const int k0 = min(slice * sl, cnt), k1 = min(k0 + 1, cnt);
+#else
+      const int k0 = min(slice * sl, cnt), k1 = min(k0 + sl, cnt);
+#endif
+      for (int k = k0; k < k1; ++k) {
+        double a[4], c4[4];
+        {
+          const double2 a01 = *(const double2 *)(pi + k * TS), a23 = *(const double2 *)(pi + k * TS + 2);
+          const double2 c01 = *(const double2 *)(pj + k * TS), c23 = *(const double2 *)(pj + k * TS + 2);
+          a[0] = a01.x, a[1] = a01.y, a[2] = a23.x, a[3] = a23.y;
+          c4[0] = c01.x, c4[1] = c01.y, c4[2] = c23.x, c4[3] = c23.y;
+        }
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) acc[p][q] = fma(a[p], c4[q], acc[p][q]);
       }
-#pragma unroll
-      for (int p = 0; p < 4; ++p)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) acc[p][q] = fma(a[p], c4[q], acc[p][q]);
     }
   }
 #ifdef WC_PROF_LIN
   lt_[3] = clock64();
 #endif
-  __syncthreads();  // everybody is done with V: its storage takes the partial blocks
-  if (slice < NS) {
+#if defined(WC_LIN_KNOCK) && (WC_LIN_KNOCK & 64)  // timing knock-out: no partial blocks, no tail
+  if (acc[0][0] != 12345.0) return;
+#endif
+  // everybody is done with V: its storage takes the partial blocks, NSH slices at a time (slice s is added onto slot s % NSH in
+  // the order of s: fixed, bitwise reproducible)
+#pragma unroll 1
+  for (int base = 0; base < NS; base += NSH) {
+    __syncthreads();
+    if (slice >= base && slice < base + NSH && slice < NS) {
+      double *dst = sV + ((slice - base) * NBLK + blk) * PB;
 #pragma unroll
-    for (int p = 0; p < 4; ++p)
+      for (int p = 0; p < 4; ++p)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) sV[(slice * NBLK + blk) * PB + p * 4 + q] = acc[p][q];
+        for (int q = 0; q < 4; ++q) dst[p * 4 + q] = base ? dst[p * 4 + q] + acc[p][q] : acc[p][q];
+    }
   }
   __syncthreads();
-  constexpr int NOUT = T * (T + 1) / 2;
-  static_assert(W == 24 || W == 12, "tail tables exist for the binary and the unary family");
-  const uint16_t *tail_off = W == 24 ? kLinTail24.off : kLinTail12.off;
-  for (int e = tid; e < NOUT; e += kPiece) {
-    const int off = tail_off[e];
+#if defined(WC_LIN_KNOCK) && (WC_LIN_KNOCK & 8)  // timing knock-out: one output entry per piece
+  for (int i = 0; i < 1; ++i) {
+    const int e = tid + i * kPiece, off = e < 1 ? toff[i] : -1;
+#else
+#pragma unroll
+  for (int i = 0; i < NTE; ++i) {
+    const int e = tid + i * kPiece, off = toff[i];
+#endif
+    if (off < 0) continue;
     double out = 0.0;
     if (off == 0xFFFF) {
       out = kPiece == 256 ? (sC[0] + sC[1]) + (sC[2] + sC[3]) : kPiece == 128 ? sC[0] + sC[1] : sC[0];
     } else {
 #pragma unroll
-      for (int sl = 0; sl < NS; ++sl) out += sV[sl * NBLK * PB + off];
+      for (int sl = 0; sl < NSH; ++sl) out += sV[sl * NBLK * PB + off];
     }
     partial[pc.part_off + e] = out;
   }
@@ -757,13 +822,13 @@ __global__ void __launch_bounds__(256) k_lin_imu(WinParams wp, const Piece *piec
 // launch 0.177 -> 0.166 - 0.172 ms per linearisation at C4 (1 775 -> 1 795 - 1 820 LM it/s), odometry-step solve 2.42 -> 2.30 ms;
 // the unary pieces inside too (at the binary pieces' LDS: three workgroups per CU instead of four, but no drain between the
 // families): solve 2.30 -> 2.25 ms, C4 unchanged.
-static_assert(kPiece == 256, "k_lin_imu's workgroups have 256 threads");
+// (k_lin_imu's workgroups have 256 threads: with -DWC_PIECE below 256, an experiment, the families are launches of their own)
 template <bool WITH_UNARY>
-__global__ void __launch_bounds__(256, 3) k_lin_fused(WinParams wp, const Piece *pieces, uint32_t n_imu, uint32_t n_b, uint32_t n_u, const double *brec,
+__global__ void __launch_bounds__(256, WC_LIN_WG_PER_CU) k_lin_fused(WinParams wp, const Piece *pieces, uint32_t n_imu, uint32_t n_b, uint32_t n_u, const double *brec,
                                                      uint32_t nb, const double *urec, uint32_t nu, const ImuRec *irec, const double *times,
                                                      const double *x, double *partial) {
-  constexpr int SZ = LinSurfelLds<24>::DOUBLES > kLinImuLds ? LinSurfelLds<24>::DOUBLES : kLinImuLds;
-  static_assert(LinSurfelLds<12>::DOUBLES <= SZ, "the unary pieces fit the binary pieces' LDS");
+  constexpr int SZ0 = LinSurfelLds<24>::DOUBLES > kLinImuLds ? LinSurfelLds<24>::DOUBLES : kLinImuLds;
+  constexpr int SZ = LinSurfelLds<12>::DOUBLES > SZ0 ? LinSurfelLds<12>::DOUBLES : SZ0;
   __shared__ __attribute__((aligned(16))) double smem[SZ];
   const uint32_t b = blockIdx.x;
   if (b < n_imu)
@@ -2389,7 +2454,7 @@ int enqueue_linearize(wc_ctx *ctx, wc_window_state *W, const double *d_x, int ma
   // cross-stream waits cost more than the launch they hide.  One stream.)
   const bool imu_apart = ctx->dev.lin_imu_apart != 0;  // (A/B: the IMU family as a launch of its own)
   const bool unary_in = ctx->dev.lin_unary_apart == 0;  // (A/B: the unary family as a launch of its own)
-  const bool fused = W->npiece_b && W->npiece_i && !imu_apart;
+  const bool fused = W->npiece_b && W->npiece_i && !imu_apart && kPiece == 256;
   const bool fused_u = fused && unary_in && W->npiece_u;
   if (fused_u)
     k_lin_fused<true><<<W->npiece_i + W->npiece_b + W->npiece_u, 256, 0, st>>>(W->wp, pcs, W->npiece_i, W->npiece_b, W->npiece_u, (const double *)W->brec.p, W->nb,
