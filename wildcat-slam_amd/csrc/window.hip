@@ -538,7 +538,11 @@ struct LinSurfelLds {
   static constexpr int RH = kPiece / RND;           // rows per round
   static constexpr int VSZ = RH * TS + 4;           // + 4: the padded columns of the last block read past the last row
   static constexpr int PB = 17;                     // doubles per partial block in LDS: 16 + 1 (a stride of 16 doubles puts every second lane on the same banks)
-  static constexpr int NSH = VSZ / (NBLK * PB) > NS ? NS : VSZ / (NBLK * PB);  // slices per fold of the partial blocks (they take V's storage)
+#ifndef WC_LIN_LDS_DOUBLES
+#define WC_LIN_LDS_DOUBLES (VSZ)
+#endif
+  static constexpr int BUD = WC_LIN_LDS_DOUBLES > VSZ ? WC_LIN_LDS_DOUBLES : VSZ;   // doubles the partial blocks may take
+  static constexpr int NSH = BUD / (NBLK * PB) > NS ? NS : BUD / (NBLK * PB);  // slices per fold of the partial blocks (they take V's storage)
   static_assert(NSH >= 1, "a fold of the partial blocks fits V's storage");
   static constexpr int PSZ = NSH * NBLK * PB;
   static constexpr int VMAX = VSZ > PSZ ? VSZ : PSZ;
