@@ -74,6 +74,10 @@ struct GSrc {
   uint32_t part_off;
   uint8_t p, w, T, pad;
 };
+struct FarJob {  // a block pair more than two sample blocks apart with at most kHeavySrc sources (surfel factors only: its 6 x 6 pose corner)
+  uint32_t begin, end, pid;
+  uint16_t I, J;
+};
 
 struct WinParams {
   double sigma0_sq, cauchy_b, inv_cauchy_b, w_gyr, w_acc, w_bg, w_ba, dt, grav[3];
@@ -91,9 +95,9 @@ struct wc_window_state {
   std::vector<double> times;
   // device buffers
   wc_buf times_d, brec, bkey, borig, urec, ukey, uorig, irec, pieces, partial, src, src_begin, gsrc, gsrc_begin;
-  wc_buf lin, lin_alt, Linv, heavy, Lmat, reduce;  // lin_alt: the linearisation at the LM candidate (see wc_window_solve)
+  wc_buf lin, lin_alt, Linv, heavy, near_l, far_l, Lmat, reduce;  // lin_alt: the linearisation at the LM candidate (see wc_window_solve)
   int lin_sel = 0;                                 // which of the two holds the linearisation at the current point
-  uint32_t nheavy = 0;  // lin = [H (n*n) | g (np) | cost, spare]
+  uint32_t nheavy = 0, nnear = 0, nfar = 0;  // lin = [H (n*n) | g (np) | cost, spare]
   // multi-GPU: sharded = this problem holds one rank's share of the factors (wc_window_build_sharded, or a caller that shards
   // itself and installs wc_window_set_allreduce); only then are linearisation and cost evaluation collectives.  pair_off[pid] =
   // offset of block pair pid in the reduction buffer: 144 doubles for a pair of sample blocks at most two apart (IMU factors
@@ -534,12 +538,18 @@ struct LinSurfelLds {
   static constexpr int NBLK = NB * (NB + 1) / 2;    // blocks (bi <= bj) of the Gram matrix
   static constexpr int NS = kPiece / NBLK;          // record slices
   static constexpr int TS = T + (T & 1);            // row stride in LDS: even, so that a row's 4-column blocks are 16-byte aligned (ds_read_b128)
+#ifdef WC_LIN_RH
+  static constexpr int RH = W == 24 ? WC_LIN_RH : kPiece;  // rows per round
+#else
   static constexpr int RND = W == 24 ? WC_LIN_ROUNDS : 1;  // rounds of rows through LDS
   static constexpr int RH = kPiece / RND;           // rows per round
+#endif
   static constexpr int VSZ = RH * TS + 4;           // + 4: the padded columns of the last block read past the last row
   static constexpr int PB = 17;                     // doubles per partial block in LDS: 16 + 1 (a stride of 16 doubles puts every second lane on the same banks)
+  // (four pieces per CU leave 40 KB each: the partial blocks of all slices fit - 34.3 KB - and are not folded; with V's 26.7 KB
+  // as the budget, nine slices in folds of 7 + 2, the kernel took 4 us longer at C4: a barrier and a read-modify-write round more)
 #ifndef WC_LIN_LDS_DOUBLES
-#define WC_LIN_LDS_DOUBLES (VSZ)
+#define WC_LIN_LDS_DOUBLES 4300
 #endif
   static constexpr int BUD = WC_LIN_LDS_DOUBLES > VSZ ? WC_LIN_LDS_DOUBLES : VSZ;   // doubles the partial blocks may take
   static constexpr int NSH = BUD / (NBLK * PB) > NS ? NS : BUD / (NBLK * PB);  // slices per fold of the partial blocks (they take V's storage)
@@ -550,7 +560,8 @@ struct LinSurfelLds {
 };
 template <int W, bool UNARY>
 __device__ __forceinline__ void lin_surfel_body(const WinParams &wp, const Piece pc, const double *rec, uint32_t nrec, const double *x,
-                                                double *partial, double *smem /* 16-byte aligned, LinSurfelLds<W>::DOUBLES */) {
+                                                double *partial, double *smem /* 16-byte aligned, LinSurfelLds<W>::DOUBLES */,
+                                                uint32_t cost_slot /* the piece's entry of the cost array behind the partials */) {
   using L = LinSurfelLds<W>;
   constexpr int T = L::T, NB = L::NB, NBLK = L::NBLK, NS = L::NS, TS = L::TS, PB = L::PB, RH = L::RH, NSH = L::NSH;
   double *sV = smem, *sC = smem + L::VMAX;
@@ -693,6 +704,7 @@ __device__ __forceinline__ void lin_surfel_body(const WinParams &wp, const Piece
     double out = 0.0;
     if (off == 0xFFFF) {
       out = kPiece == 256 ? (sC[0] + sC[1]) + (sC[2] + sC[3]) : kPiece == 128 ? sC[0] + sC[1] : sC[0];
+      partial[cost_slot] = out;  // (k_gather's cost workgroup reads the costs as ONE contiguous array)
     } else {
 #pragma unroll
       for (int sl = 0; sl < NSH; ++sl) out += sV[sl * NBLK * PB + off];
@@ -709,9 +721,9 @@ __device__ __forceinline__ void lin_surfel_body(const WinParams &wp, const Piece
 }
 template <int W, bool UNARY>
 __global__ void __launch_bounds__(kPiece) k_lin_surfel(WinParams wp, const Piece *pieces, const double *rec, const uint32_t *keys,
-                                                      uint32_t nrec, const double *x, double *partial) {
+                                                      uint32_t nrec, const double *x, double *partial, uint32_t cost_slot0) {
   __shared__ __attribute__((aligned(16))) double smem[LinSurfelLds<W>::DOUBLES];
-  lin_surfel_body<W, UNARY>(wp, pieces[blockIdx.x], rec, nrec, x, partial, smem);
+  lin_surfel_body<W, UNARY>(wp, pieces[blockIdx.x], rec, nrec, x, partial, smem, cost_slot0 + blockIdx.x);
 }
 
 using f64x4 = __attribute__((ext_vector_type(4))) double;
@@ -739,7 +751,7 @@ __constant__ const ImuGramOrder kImuGram{};
 constexpr int kImuMax = 8;  // (16: 30 us at C4, 8: 24 us - one round of 252 workgroups, 4: 37 us - two rounds)
 constexpr int kLinImuLds = kImuMax * 12 * 37 + kImuMax;  // doubles: the pieces' rows + the factors' costs
 __device__ __forceinline__ void lin_imu_body(const WinParams &wp, const Piece pc, const ImuRec *recs, const double *x, const double *times,
-                                             double *partial, double *smem /* kLinImuLds */) {
+                                             double *partial, double *smem /* kLinImuLds */, uint32_t cost_slot) {
   constexpr int T = 37;
   double *sV = smem, *sC = smem + kImuMax * 12 * T;
   const int tid = threadIdx.x;
@@ -797,6 +809,7 @@ __device__ __forceinline__ void lin_imu_body(const WinParams &wp, const Piece pc
     double acc = 0.0;
     if (i == 36) {
       for (uint32_t k = 0; k < pc.count; ++k) acc += sC[k];
+      partial[cost_slot] = acc;
     } else {
       for (int k = 0; k < (int)pc.count; ++k) {
 #pragma unroll
@@ -814,9 +827,9 @@ __device__ __forceinline__ void lin_imu_body(const WinParams &wp, const Piece pc
   }
 }
 __global__ void __launch_bounds__(256) k_lin_imu(WinParams wp, const Piece *pieces, const ImuRec *recs, const double *x,
-                                                const double *times, double *partial) {
+                                                const double *times, double *partial, uint32_t cost_slot0) {
   __shared__ double smem[kLinImuLds];
-  lin_imu_body(wp, pieces[blockIdx.x], recs, x, times, partial, smem);
+  lin_imu_body(wp, pieces[blockIdx.x], recs, x, times, partial, smem, cost_slot0 + blockIdx.x);
 }
 
 // ALL families of a linearisation in one launch (round 3): workgroups [0, n_imu) take the IMU pieces - dispatched first: a few
@@ -830,17 +843,17 @@ __global__ void __launch_bounds__(256) k_lin_imu(WinParams wp, const Piece *piec
 template <bool WITH_UNARY>
 __global__ void __launch_bounds__(256, WC_LIN_WG_PER_CU) k_lin_fused(WinParams wp, const Piece *pieces, uint32_t n_imu, uint32_t n_b, uint32_t n_u, const double *brec,
                                                      uint32_t nb, const double *urec, uint32_t nu, const ImuRec *irec, const double *times,
-                                                     const double *x, double *partial) {
+                                                     const double *x, double *partial, uint32_t cost_slot0) {
   constexpr int SZ0 = LinSurfelLds<24>::DOUBLES > kLinImuLds ? LinSurfelLds<24>::DOUBLES : kLinImuLds;
   constexpr int SZ = LinSurfelLds<12>::DOUBLES > SZ0 ? LinSurfelLds<12>::DOUBLES : SZ0;
   __shared__ __attribute__((aligned(16))) double smem[SZ];
   const uint32_t b = blockIdx.x;
   if (b < n_imu)
-    lin_imu_body(wp, pieces[n_b + n_u + b], irec, x, times, partial, smem);
+    lin_imu_body(wp, pieces[n_b + n_u + b], irec, x, times, partial, smem, cost_slot0 + n_b + n_u + b);
   else if (!WITH_UNARY || b < n_imu + n_b)
-    lin_surfel_body<24, false>(wp, pieces[b - n_imu], brec, nb, x, partial, smem);
+    lin_surfel_body<24, false>(wp, pieces[b - n_imu], brec, nb, x, partial, smem, cost_slot0 + b - n_imu);
   else
-    lin_surfel_body<12, true>(wp, pieces[b - n_imu], urec, nu, x, partial, smem);
+    lin_surfel_body<12, true>(wp, pieces[b - n_imu], urec, nu, x, partial, smem, cost_slot0 + b - n_imu);
 }
 
 // Gather of the piece partials into the dense normal equations, g and the cost: ONE launch with four roles by workgroup
@@ -855,6 +868,7 @@ __global__ void __launch_bounds__(256, WC_LIN_WG_PER_CU) k_lin_fused(WinParams w
 // (bitwise reproducible, no atomics).
 constexpr int kGG = 7;
 constexpr int kLightSets = 2;  // block pairs per group of a light gather workgroup
+constexpr int kFarGroups = 144 * kGG / 36, kFarSets = 2;  // 36-lane groups of a far-pair workgroup, pairs per group
 constexpr int kHeavyIlp = 8;   // sources in flight per thread of a heavy pair (with the next eight descriptors: 48 VGPRs -
                                // above 64 only ONE 1008-thread workgroup fits a CU; 16 in flight measured no faster)
 struct GatherArgs {
@@ -863,10 +877,11 @@ struct GatherArgs {
   const GSrc *gsrc;
   const uint32_t *gsrc_begin;
   const Piece *pieces;
-  const uint32_t *heavy;
+  const uint32_t *heavy, *near;  // pairs with long source lists; the other pairs at most two sample blocks apart
+  const FarJob *far;
   const double *partial;
   double *H, *g, *cost;
-  uint32_t nheavy, npairs, npieces, nb_pieces, nu_pieces;
+  uint32_t nheavy, nnear, nfar, npairs, npieces, nb_pieces, nu_pieces, cost_base;
   int ns, fix_first;
   int packed;  // H = the multi-GPU reduction buffer: block pairs in pair order at pair_off[pid] (144 doubles, or the 6 x 6 pose
                // corner of a pair more than two sample blocks apart); else the dense n x n matrix
@@ -967,13 +982,87 @@ __device__ __forceinline__ void gather_post(const GatherArgs &a, double local_ma
 __global__ void __launch_bounds__(144 * kGG, 8) k_gather(GatherArgs a) {
   __shared__ double sred[kGG * 144];
   const int tid = threadIdx.x;
-  const uint32_t nlight = (a.npairs + kGG * kLightSets - 1) / (kGG * kLightSets);
+  const uint32_t nlight = (a.nnear + kGG * kLightSets - 1) / (kGG * kLightSets);
+  const uint32_t nfarwg = (a.nfar + kFarGroups * kFarSets - 1) / (kFarGroups * kFarSets);
   // dispatch order: g and the cost first (few workgroups with the longest chains of dependent loads), then the heavy pairs,
   // then the rest - dispatched last they only started when everything else had drained (47 us instead of ~30)
   const uint32_t nfirst = (uint32_t)a.ns + 1u;
-  uint32_t blk = blockIdx.x < nfirst ? a.nheavy + nlight + blockIdx.x : blockIdx.x - nfirst;
+  uint32_t blk = blockIdx.x < nfirst ? a.nheavy + nlight + nfarwg + blockIdx.x : blockIdx.x - nfirst;
+  if (blk >= a.nheavy + nlight && blk < a.nheavy + nlight + nfarwg) {
+    // FAR pairs (round 5): 28 groups of 36 lanes, one thread per entry of the pair's 6 x 6 pose corner - the 144-lane groups above
+    // kept 108 lanes idle on them and wrote the 108 zeros of the rest of the block (and of its mirror) on every linearisation: three
+    // quarters of H's 18.6 MB at C4.  Those entries are zero from the build (window_build_impl clears both linearisation buffers)
+    // and nobody writes them.  Sources in list order, as everywhere.
+#ifdef WC_GATHER_KNOCK
+    if (WC_GATHER_KNOCK & 2) return;
+#endif
+    const int grp = tid / 36, e = tid % 36, u = e / 6, v = e % 6;
+    const uint2 *src2 = (const uint2 *)a.src;
+    const int n = 12 * a.ns;
+    FarJob job[kFarSets];
+    bool live[kFarSets];
+    uint2 d[kFarSets][4];
+#pragma unroll
+    for (int k = 0; k < kFarSets; ++k) {
+      const uint32_t idx = ((blk - a.nheavy - nlight) * kFarSets + k) * kFarGroups + grp;
+      live[k] = idx < a.nfar;
+      job[k] = a.far[live[k] ? idx : 0u];
+    }
+#pragma unroll
+    for (int k = 0; k < kFarSets; ++k)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) d[k][q] = src2[(live[k] && job[k].begin + q < job[k].end) ? job[k].begin + q : 0u];
+    double val[kFarSets][4];
+#pragma unroll
+    for (int k = 0; k < kFarSets; ++k)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const uint32_t sp = d[k][q].y & 0xFFu, sq_ = (d[k][q].y >> 8) & 0xFFu, sT = d[k][q].y >> 24;
+        val[k][q] = a.partial[d[k][q].x + tri_index(sp * 6u + (uint32_t)u, sq_ * 6u + (uint32_t)v, sT)];  // (p < q: row < column)
+      }
+#pragma unroll
+    for (int k = 0; k < kFarSets; ++k) {
+      double acc = 0.0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (live[k] && job[k].begin + q < job[k].end) acc += val[k][q];
+      for (uint32_t s0 = job[k].begin + 4u; live[k] && s0 < job[k].end; s0 += 4u) {  // (rare: more than four sources)
+        uint2 dd[4];
+        double vv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dd[q] = src2[s0 + q < job[k].end ? s0 + q : s0];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const uint32_t sp = dd[q].y & 0xFFu, sq_ = (dd[q].y >> 8) & 0xFFu, sT = dd[q].y >> 24;
+          vv[q] = a.partial[dd[q].x + tri_index(sp * 6u + (uint32_t)u, sq_ * 6u + (uint32_t)v, sT)];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (s0 + q < job[k].end) acc += vv[q];
+      }
+      const int I = job[k].I, J = job[k].J, gi = I * 12 + u, gj = J * 12 + v;
+      if (a.fix_first && ((gi >= 3 && gi < 6) || (gj >= 3 && gj < 6))) acc = 0.0;  // SubsetParameterization(12,{3,4,5})
+      if (a.packed) {
+        if (live[k]) a.H[(size_t)a.pair_off[job[k].pid] + e] = acc;
+        continue;
+      }
+      __syncthreads();  // (the previous set's mirror has been read)
+      sred[tid] = acc;
+      __syncthreads();
+      if (live[k] && job[k].begin < job[k].end) {  // (a far pair without sources stays what the build made it: zero)
+        a.H[(size_t)gi * n + gj] = acc;
+        a.H[(size_t)(J * 12 + u) * n + I * 12 + v] = sred[grp * 36 + v * 6 + u];  // the mirror block, row-wise too
+      }
+    }
+    return;
+  }
+  if (blk >= a.nheavy + nlight) blk -= nfarwg;
   if (blk < a.nheavy + nlight) {
     const bool heavy = blk < a.nheavy;
+#ifdef WC_GATHER_KNOCK  // timing knock-outs (results wrong on purpose): 1 no heavy pairs, 2 no light pairs, 4 no g, 8 no cost
+    if ((WC_GATHER_KNOCK & 1) && heavy) return;
+    if ((WC_GATHER_KNOCK & 2) && !heavy) return;
+#endif
     const int grp = tid / 144, e = tid % 144;
     const int u = e / 12, v = e % 12;
     // A heavy workgroup sums ONE pair; a light one kLightSets x kGG pairs, kLightSets per group, whose first four sources
@@ -1001,8 +1090,9 @@ __global__ void __launch_bounds__(144 * kGG, 8) k_gather(GatherArgs a) {
       uint32_t bk[kLightSets], ek[kLightSets];
 #pragma unroll
       for (int k = 0; k < kLightSets; ++k) {
-        pidk[k] = (set0 + k) * kGG + grp;
-        const bool valid = pidk[k] < a.npairs;
+        const uint32_t idx = (set0 + k) * kGG + grp;
+        const bool valid = idx < a.nnear;
+        pidk[k] = valid ? a.near[idx] : 0u;
         bk[k] = valid ? a.src_begin[pidk[k]] : 0u, ek[k] = valid ? a.src_begin[pidk[k] + 1] : 0u;
         writek[k] = valid && ek[k] - bk[k] <= kHeavySrc;  // (a pair with more sources is summed by its heavy workgroup)
       }
@@ -1080,6 +1170,16 @@ __global__ void __launch_bounds__(144 * kGG, 8) k_gather(GatherArgs a) {
     return;
   }
   blk -= a.nheavy + nlight;
+#ifdef WC_GATHER_KNOCK
+  if ((WC_GATHER_KNOCK & 4) && blk < (uint32_t)a.ns) {
+    if (a.post) gather_post(a, 0.0);
+    return;
+  }
+  if ((WC_GATHER_KNOCK & 8) && blk >= (uint32_t)a.ns) {
+    if (a.post) gather_post(a, 0.0);
+    return;
+  }
+#endif
   if (blk < (uint32_t)a.ns) {  // g = J^T r of sample block blk
     // all 84 groups of 12 lanes stride over the block's source list (~320 sources: one trip of four each)
     constexpr int NGg = 144 * kGG / 12;
@@ -1123,16 +1223,12 @@ __global__ void __launch_bounds__(144 * kGG, 8) k_gather(GatherArgs a) {
     }
     return;
   }
-  {  // cost: deterministic sum of the cost slots of all partials
+  {  // cost: deterministic sum of the pieces' costs (one contiguous array behind the partials since round 5: as the corner of
+     // every piece's partial they were 12 k scattered lines behind 12 k descriptor loads through ONE CU - 14 us at C4, the longest
+     // chain of the kernel; same sums in the same order)
     constexpr int NT = 144 * kGG;
     double acc = 0.0;
-    // (the piece descriptors of the next trip are requested behind this trip's values, as in gather_pair_sum)
-    uint32_t off[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const uint32_t p = (uint32_t)tid + q * NT;
-      off[q] = a.pieces[p < a.npieces ? p : 0u].part_off;
-    }
+    const double *pcost = a.partial + a.cost_base;
     for (uint32_t p0 = tid; p0 < a.npieces; p0 += 4 * NT) {
       double val[4];
       bool ok[4];
@@ -1140,14 +1236,7 @@ __global__ void __launch_bounds__(144 * kGG, 8) k_gather(GatherArgs a) {
       for (int q = 0; q < 4; ++q) {
         const uint32_t p = p0 + q * NT;
         ok[q] = p < a.npieces;
-        const uint32_t pp = ok[q] ? p : p0;
-        const uint32_t T = pp < a.nb_pieces ? 25 : (pp < a.nb_pieces + a.nu_pieces ? 13 : 37);
-        val[q] = a.partial[ok[q] ? off[q] + T * (T + 1) / 2 - 1 : 0u];
-      }
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const uint32_t p = p0 + 4 * NT + q * NT;
-        off[q] = a.pieces[p < a.npieces ? p : 0u].part_off;
+        val[q] = pcost[ok[q] ? p : p0];
       }
 #pragma unroll
       for (int q = 0; q < 4; ++q)
@@ -2222,9 +2311,25 @@ static int window_build_impl(wc_ctx *ctx, const wc_surfel *d_sld_surf, const wc_
     pair_off[npairs] = o;
     W->red_H = o;
   }
-  for (uint32_t i = 0; i < npairs; ++i)
-    if (src_begin[i + 1] - src_begin[i] > kHeavySrc) heavy.push_back(i);
-  W->nheavy = (uint32_t)heavy.size();
+  // who sums which pair in k_gather: heavy (long source lists), far (more than two sample blocks apart, surfel sources only: the
+  // 6 x 6 pose corner; a far pair without sources is only written into the multi-GPU reduction buffer - in H its entries are zero
+  // from the build), near (the rest)
+  std::vector<uint32_t> near_list;
+  std::vector<FarJob> far_list;
+  {
+    uint32_t pid = 0;
+    for (int I = 0; I < ns; ++I)
+      for (int J = I; J < ns; ++J, ++pid) {
+        const uint32_t cnt = src_begin[pid + 1] - src_begin[pid];
+        if (cnt > kHeavySrc)
+          heavy.push_back(pid);
+        else if (J - I > 2) {
+          far_list.push_back({src_begin[pid], src_begin[pid + 1], pid, (uint16_t)I, (uint16_t)J});
+        } else
+          near_list.push_back(pid);
+      }
+  }
+  W->nheavy = (uint32_t)heavy.size(), W->nnear = (uint32_t)near_list.size(), W->nfar = (uint32_t)far_list.size();
   // Every list the host builds lives in ONE device arena and leaves in ONE copy out of ONE pinned staging buffer, in which the two
   // large ones (the gather's source lists, ~0.5 MB in the odometry step) are written in place.  (Rounds 3 - 4: eight buffers, eight
   // copies - out of pageable vectors at first: the runtime stages such a copy and returns when it is through, 10 - 35 us each -,
@@ -2240,7 +2345,8 @@ static int window_build_impl(wc_ctx *ctx, const wc_surfel *d_sld_surf, const wc_
   Part parts[] = {{&W->irec, irecs.data(), irecs.size() * sizeof(ImuRec), 0}, {&W->pair_off, pair_off.data(), pair_off.size() * 4, 0},
                   {&W->heavy, heavy.data(), heavy.size() * 4, 0},             {&W->pieces, pieces.data(), pieces.size() * sizeof(Piece), 0},
                   {&W->src, nullptr, n_src * sizeof(Src), 0},                 {&W->src_begin, src_begin.data(), src_begin.size() * 4, 0},
-                  {&W->gsrc, nullptr, n_gsrc * sizeof(GSrc), 0},              {&W->gsrc_begin, gsrc_begin.data(), gsrc_begin.size() * 4, 0}};
+                  {&W->gsrc, nullptr, n_gsrc * sizeof(GSrc), 0},              {&W->gsrc_begin, gsrc_begin.data(), gsrc_begin.size() * 4, 0},
+                  {&W->near_l, near_list.data(), near_list.size() * 4, 0},    {&W->far_l, far_list.data(), far_list.size() * sizeof(FarJob), 0}};
   size_t total = 0;
   for (Part &pt : parts) {
     pt.off = total;
@@ -2289,11 +2395,14 @@ static int window_build_impl(wc_ctx *ctx, const wc_surfel *d_sld_surf, const wc_
   // window has 82 -: a window that gains ten sample states per sweep, the facade's first seconds, otherwise re-allocates four of them on
   // most calls, 0.1 - 0.7 ms of hipFree / hipMalloc each time; 4 x 10.6 MB)
   const size_t n = W->n, n_al = std::max<size_t>(n, 12 * 96), np_al = ((n_al + 1 + kNB - 1) / kNB) * kNB;
-  WC_TRY(wc_ensure(ctx, W->partial, std::max<size_t>((size_t)off * 8, 64)));
+  WC_TRY(wc_ensure(ctx, W->partial, ((size_t)off + pieces.size()) * 8 + 64));  // the pieces' partials, then one cost per piece
   WC_TRY(wc_ensure(ctx, W->x, n_al * 8));
   WC_TRY(wc_ensure(ctx, W->xc, n_al * 8));
   WC_TRY(wc_ensure(ctx, W->lin, (n_al * n_al + np_al + 2) * 8));
   WC_TRY(wc_ensure(ctx, W->lin_alt, (n_al * n_al + np_al + 2) * 8));
+  // (k_gather writes a far pair's 6 x 6 pose corner only: the rest of those blocks is zero from here on)
+  WC_HIP(ctx, hipMemsetAsync(W->lin.p, 0, n * n * 8, ctx->stream));
+  WC_HIP(ctx, hipMemsetAsync(W->lin_alt.p, 0, n * n * 8, ctx->stream));
   W->lin_sel = 0;
   WC_TRY(wc_ensure(ctx, W->Linv, np_al * kNB * 8));
   WC_TRY(wc_ensure(ctx, W->scale, n_al * 8));
@@ -2463,24 +2572,25 @@ int enqueue_linearize(wc_ctx *ctx, wc_window_state *W, const double *d_x, int ma
   if (fused_u)
     k_lin_fused<true><<<W->npiece_i + W->npiece_b + W->npiece_u, 256, 0, st>>>(W->wp, pcs, W->npiece_i, W->npiece_b, W->npiece_u, (const double *)W->brec.p, W->nb,
                                                                              (const double *)W->urec.p, W->nu, (const ImuRec *)W->irec.p,
-                                                                             (const double *)W->times_d.p, d_x, partial);
+                                                                             (const double *)W->times_d.p, d_x, partial, W->npart_doubles);
   else if (fused)
     k_lin_fused<false><<<W->npiece_i + W->npiece_b, 256, 0, st>>>(W->wp, pcs, W->npiece_i, W->npiece_b, W->npiece_u, (const double *)W->brec.p, W->nb,
                                                                  (const double *)W->urec.p, W->nu, (const ImuRec *)W->irec.p, (const double *)W->times_d.p,
-                                                                 d_x, partial);
+                                                                 d_x, partial, W->npart_doubles);
   else if (W->npiece_b)
     k_lin_surfel<24, false><<<W->npiece_b, kPiece, 0, st>>>(W->wp, pcs, (const double *)W->brec.p, (const uint32_t *)W->bkey.p, W->nb,
-                                                          d_x, partial);
+                                                          d_x, partial, W->npart_doubles);
   if (W->npiece_u && !fused_u)
     k_lin_surfel<12, true><<<W->npiece_u, kPiece, 0, st>>>(W->wp, pcs + W->npiece_b, (const double *)W->urec.p,
-                                                         (const uint32_t *)W->ukey.p, W->nu, d_x, partial);
+                                                         (const uint32_t *)W->ukey.p, W->nu, d_x, partial, W->npart_doubles + W->npiece_b);
   if (W->npiece_i && !fused)
     k_lin_imu<<<W->npiece_i, 256, 0, st>>>(W->wp, pcs + W->npiece_b + W->npiece_u, (const ImuRec *)W->irec.p, d_x,
-                                          (const double *)W->times_d.p, partial);
+                                          (const double *)W->times_d.p, partial, W->npart_doubles + W->npiece_b + W->npiece_u);
   GatherArgs ga;
   ga.src = (const Src *)W->src.p, ga.src_begin = (const uint32_t *)W->src_begin.p;
   ga.gsrc = (const GSrc *)W->gsrc.p, ga.gsrc_begin = (const uint32_t *)W->gsrc_begin.p;
   ga.pieces = pcs, ga.heavy = (const uint32_t *)W->heavy.p, ga.partial = partial;
+  ga.near = (const uint32_t *)W->near_l.p, ga.far = (const FarJob *)W->far_l.p, ga.nnear = W->nnear, ga.nfar = W->nfar;
   // multi-GPU: the ranks reduce the upper block triangle only (pair order, 144 doubles per block pair, then g and the cost):
   // half the bytes of the dense matrix on the wire; one more kernel spreads the sum into both triangles
   const bool packed = multi_gpu(ctx, W);
@@ -2497,11 +2607,12 @@ int enqueue_linearize(wc_ctx *ctx, wc_window_state *W, const double *d_x, int ma
   ga.packed = packed ? 1 : 0;
   ga.nheavy = W->nheavy, ga.npairs = W->npairs, ga.npieces = W->npiece_b + W->npiece_u + W->npiece_i;
   ga.nb_pieces = W->npiece_b, ga.nu_pieces = W->npiece_u, ga.ns = W->ns, ga.fix_first = W->wp.fix_first;
+  ga.cost_base = W->npart_doubles;
   // max |g| + the mailbox by the last of k_gather's g / cost workgroups (one GPU; behind an all-reduce k_post_reduce stays a launch)
   const bool post_apart = ctx->dev.lin_post_apart != 0;
   ga.post = (post && !packed && !post_apart) ? 1 : 0;
   ga.mail_slot = mail_slot, ga.done = (uint32_t *)((double *)W->mail.p + 60), ga.mail = (double *)W->mail.p, ga.host_mail = host_mail, ga.ticket = ticket;
-  k_gather<<<W->nheavy + (W->npairs + kGG * kLightSets - 1) / (kGG * kLightSets) + W->ns + 1, 144 * kGG, 0, st>>>(ga);
+  k_gather<<<W->nheavy + (W->nnear + kGG * kLightSets - 1) / (kGG * kLightSets) + (W->nfar + kFarGroups * kFarSets - 1) / (kFarGroups * kFarSets) + W->ns + 1, 144 * kGG, 0, st>>>(ga);
   WC_HIP(ctx, hipGetLastError());
   if (packed) {
     WC_TRY(do_allreduce(ctx, W, red, red_count));  // the ONE collective of a linearisation
