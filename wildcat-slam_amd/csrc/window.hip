@@ -980,7 +980,7 @@ __device__ __forceinline__ void gather_post(const GatherArgs &a, double local_ma
 }
 
 __global__ void __launch_bounds__(144 * kGG, 8) k_gather(GatherArgs a) {
-  __shared__ double sred[kGG * 144];
+  __shared__ double sred[kGG * 144], sred2[kGG * 144];
   const int tid = threadIdx.x;
   const uint32_t nlight = (a.nnear + kGG * kLightSets - 1) / (kGG * kLightSets);
   const uint32_t nfarwg = (a.nfar + kFarGroups * kFarSets - 1) / (kFarGroups * kFarSets);
@@ -1074,14 +1074,22 @@ __global__ void __launch_bounds__(144 * kGG, 8) k_gather(GatherArgs a) {
     double acck[kLightSets];
     bool writek[kLightSets];
     if (heavy) {
-      const uint32_t pid = a.heavy[blk];
+      // Round 5: the pair's SURFEL sources (6 x 6 corners: hundreds on the diagonal band) go to 28 groups of 36 lanes, its IMU sources
+      // (12 x 12, a handful, last in the list) to the seven groups of 144 - with 144 lanes per source three quarters of the lanes
+      // idled and 350 sources were seven dependent trips of eight per group; now two.  Partial sums combined in fixed order.
+      const uint32_t pid = a.heavy[2 * blk], mid = a.heavy[2 * blk + 1];
       const uint32_t b = a.src_begin[pid], eend = a.src_begin[pid + 1];
-      double acc = gather_pair_sum<kGG, kHeavyIlp>(a.src, a.partial, b + grp, eend, u, v);  // (up to 350 sources: 50 per group)
-      sred[grp * 144 + e] = acc;
+      const int g36 = tid / 36, e36 = tid % 36;
+      const double acc6 = gather_pair_sum<kFarGroups, kHeavyIlp>(a.src, a.partial, b + g36, mid, e36 / 6, e36 % 6);
+      double acc = gather_pair_sum<kGG, 4>(a.src, a.partial, mid + grp, eend, u, v);
+      sred[tid] = acc6;
+      sred2[grp * 144 + e] = acc;
       __syncthreads();
       if (grp == 0) {
         acc = 0.0;
-        for (int q = 0; q < kGG; ++q) acc += sred[q * 144 + e];
+        if (u < 6 && v < 6)
+          for (int q = 0; q < kFarGroups; ++q) acc += sred[q * 36 + u * 6 + v];
+        for (int q = 0; q < kGG; ++q) acc += sred2[q * 144 + e];
       }
 #pragma unroll
       for (int k = 0; k < kLightSets; ++k) pidk[k] = pid, acck[k] = acc, writek[k] = k == 0 && grp == 0;
@@ -2231,6 +2239,7 @@ static int window_build_impl(wc_ctx *ctx, const wc_surfel *d_sld_surf, const wc_
   const uint32_t npairs = (uint32_t)(ns * (ns + 1) / 2);
   W->npairs = npairs;
   src_begin.assign(npairs + 1, 0), gsrc_begin.assign(ns + 1, 0);
+  std::vector<uint32_t> imu_cnt(npairs, 0);
   auto pair_id = [&](int I, int J) { return (uint32_t)(I * ns - I * (I - 1) / 2 + (J - I)); };
   for (size_t pi = 0; pi < pieces.size(); ++pi) {  // (binary pieces only: blocks_of below, first branch)
     const Piece &pc = pieces[pi];
@@ -2295,7 +2304,10 @@ static int window_build_impl(wc_ctx *ctx, const wc_surfel *d_sld_surf, const wc_
     const int nblk = blocks_of(pi, blk, w, T);
     for (int p = 0; p < nblk; ++p) {
       gsrc_begin[blk[p] + 1]++;
-      for (int q = p; q < nblk; ++q) src_begin[pair_id(blk[p], blk[q]) + 1]++;
+      for (int q = p; q < nblk; ++q) {
+        src_begin[pair_id(blk[p], blk[q]) + 1]++;
+        if (w == 12) imu_cnt[pair_id(blk[p], blk[q])]++;  // (a pair's sources are in piece order: the IMU pieces' come last)
+      }
     }
   }
   for (uint32_t i = 0; i < npairs; ++i) src_begin[i + 1] += src_begin[i];
@@ -2322,14 +2334,14 @@ static int window_build_impl(wc_ctx *ctx, const wc_surfel *d_sld_surf, const wc_
       for (int J = I; J < ns; ++J, ++pid) {
         const uint32_t cnt = src_begin[pid + 1] - src_begin[pid];
         if (cnt > kHeavySrc)
-          heavy.push_back(pid);
+          heavy.push_back(pid), heavy.push_back(src_begin[pid + 1] - imu_cnt[pid]);  // {pair, where its IMU sources begin}
         else if (J - I > 2) {
           far_list.push_back({src_begin[pid], src_begin[pid + 1], pid, (uint16_t)I, (uint16_t)J});
         } else
           near_list.push_back(pid);
       }
   }
-  W->nheavy = (uint32_t)heavy.size(), W->nnear = (uint32_t)near_list.size(), W->nfar = (uint32_t)far_list.size();
+  W->nheavy = (uint32_t)heavy.size() / 2, W->nnear = (uint32_t)near_list.size(), W->nfar = (uint32_t)far_list.size();
   // Every list the host builds lives in ONE device arena and leaves in ONE copy out of ONE pinned staging buffer, in which the two
   // large ones (the gather's source lists, ~0.5 MB in the odometry step) are written in place.  (Rounds 3 - 4: eight buffers, eight
   // copies - out of pageable vectors at first: the runtime stages such a copy and returns when it is through, 10 - 35 us each -,
