@@ -299,6 +299,9 @@ int wc_window_counts(wc_ctx *ctx, uint64_t counts[4]);
 int wc_window_evaluate(wc_ctx *ctx, const double *h_x, double *h_cost, double *d_residuals);
 /* one linearisation: dense row-major H = J^T J (12ns x 12ns) and g = J^T r, loss-corrected, gauge columns zeroed */
 int wc_window_linearize(wc_ctx *ctx, const double *h_x, double *d_H, double *d_g, double *h_cost);
+/* measurement: `reps` linearisations at h_x back to back on the ctx stream between two HIP events; *h_ms = device time of one
+ * (the kernels and the gap between them - no upload, no wait for the mailbox, no caller between two of them) */
+int wc_window_linearize_timed(wc_ctx *ctx, const double *h_x, int reps, float *h_ms_per_linearisation);
 /* ceres::Solve with the reference's options (lidar_odometry.cc:551-561): trust-region LM, <= max_iterations.
  * h_x_inout: corrections in / optimised corrections out; h_first_step (may be NULL) receives the first LM increment. */
 int wc_window_solve(wc_ctx *ctx, double *h_x_inout, wc_solve_summary *summary, double *h_first_step);

@@ -2718,6 +2718,25 @@ extern "C" int wc_window_linearize(wc_ctx *ctx, const double *h_x, double *d_H, 
   return WC_OK;
 }
 
+// Measurement: `reps` linearisations at h_x enqueued back to back on the ctx stream between two HIP events - the device time of
+// one linearisation (k_lin_fused + k_gather and the gap between them).  wc_window_linearize called in a loop also times its
+// upload of x out of pageable memory, the wait for the mailbox and the caller's interpreter between two calls (~15 us of 125 at C4).
+extern "C" int wc_window_linearize_timed(wc_ctx *ctx, const double *h_x, int reps, float *h_ms_per_linearisation) {
+  wc_dev_guard dg_(ctx);
+  if (!ctx || !ctx->win || !ctx->win->built || !h_x || reps < 1 || !h_ms_per_linearisation)
+    return wc_fail(ctx, WC_ERR_ARG, "%s: null or out-of-range argument", __func__);
+  wc_window_state *W = ctx->win;
+  WC_HIP(ctx, hipMemcpyAsync(W->x.p, h_x, (size_t)W->n * 8, hipMemcpyHostToDevice, ctx->stream));
+  WC_TRY(enqueue_linearize(ctx, W, (const double *)W->x.p, 0));
+  WC_TRY(wc_timer_start(ctx));
+  for (int r = 0; r < reps; ++r) WC_TRY(enqueue_linearize(ctx, W, (const double *)W->x.p, 0));
+  float ms = 0.f;
+  WC_TRY(wc_timer_stop_ms(ctx, &ms));
+  WC_TRY(read_mail(ctx, W, 2));
+  *h_ms_per_linearisation = ms / (float)reps;
+  return WC_OK;
+}
+
 // Multi-GPU: correspondences are sharded over ranks, the unknowns stay replicated.  The caller installs a callback that
 // sums a device buffer of doubles over all ranks (RCCL all-reduce over xGMI via torch.distributed or rccl directly);
 // it is invoked once per linearisation on the packed buffer {H, g, cost} and once per candidate-cost evaluation on one

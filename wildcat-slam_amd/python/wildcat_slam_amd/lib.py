@@ -474,6 +474,13 @@ class Context:
         self._ck(self.lib.wc_window_linearize(self.h, R.ptr(x), C.c_void_p(0), C.c_void_p(0), C.byref(cost)))
         return cost.value
 
+    def window_linearize_timed(self, x, reps=20):
+        """device ms of one linearisation: `reps` of them back to back between two HIP events"""
+        x = np.ascontiguousarray(x, np.float64)
+        ms = C.c_float(0)
+        self._ck(self.lib.wc_window_linearize_timed(self.h, R.ptr(x), int(reps), C.byref(ms)))
+        return ms.value
+
     def window_solve(self, x):
         x = np.ascontiguousarray(x, np.float64).copy()
         s = R.SolveSummary()
