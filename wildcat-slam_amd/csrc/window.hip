@@ -1871,6 +1871,13 @@ __device__ __forceinline__ void lm_step(const double *x, const double *y, const 
 // and the facade's 9 - 11 are ONE launch instead of chunk + gemv + chunk, and C4's 24 are 16 + 8: correct, and no faster - 1 807 against
 // 1 858 LM it/s at C4, the step's solve 2.29 against 2.25 ms: a step inside the wide chunk lasts as much longer as the launches saved.)
 constexpr int kBackChunk = 8;
+// (Round 5, measured against this kernel's 14.4 us per chunk of eight block rows at C4 and not kept: two LDS barriers per block row
+// instead of four - the column sums of Linv^T z inside half a wavefront by shuffles, a column's update by neighbouring lanes -: 14.2 us,
+// i.e. nothing, the barriers and the serial sums are not what a block row's 1.8 us are; on top of it the loads of L / Linv two block
+// rows ahead in registers of their own (the eight steps unrolled, so that no copy of a stage waits for the load just issued) with
+// this kernel's thread mapping: 19.5 us; the same with every load unconditional (clamped addresses, masked values - behind predicated
+// loads the compiler waits with vmcnt(0)): 20 - 24 us.  More requests in flight through ONE CU make it slower: the chunk's ~290 KB
+// of L arrive at ~20 GB/s, the request rate of a single CU - the bound the chunking itself (several CUs) was built against.)
 __global__ void __launch_bounds__(1024) k_chol_back_chunk(const double *A, int ld, int n, const double *Linv, const double *zsrc,
                                                          double *y, int lo_blk, int hi_blk, StepArgs S) {
   __shared__ double sz[kBackChunk * kNB];
