@@ -1,10 +1,10 @@
 """Randomised stress of the SHARDED window (wc_window_build_sharded + wc_window_solve on 2 ... 5 thread-ranks, dist.ThreadComm standing in
 for RCCL) against the one-rank solve of the same random window (gauge held; random loss / weights / quirks as profiles/stress_window.py):
 the ranks must end bitwise equal among themselves, with the one-rank solve's iterations, accepted steps and termination; corrections
-1e-6 on converged solves of at most 30 iterations, the final cost 1e-6 otherwise.  python profiles/stress_sharded_window.py [seconds]"""
+1e-6 on converged solves of at most 30 iterations, the final cost 1e-6 otherwise (1e-3 for a solve that ends at max_iterations unconverged).  python profiles/stress_sharded_window.py [seconds] [seed,seed,...]"""
 import os, sys, time, threading
 R_ = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path[:0] = [R_ + "/wildcat-slam_amd/python", R_ + "/oracle"]
+sys.path[:0] = [os.environ.get("WC_TREE", R_) + "/wildcat-slam_amd/python", R_ + "/oracle"]  # (WC_TREE: another build's tree, e.g. ab_var/<name>)
 import numpy as np
 import pyoracle
 from wildcat_slam_amd import lib, synth, records as R
@@ -14,6 +14,7 @@ def rel(a, b):
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300))
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 200.0
+only = [int(a) for a in sys.argv[2].split(",")] if len(sys.argv) > 2 else None  # replay these seeds
 t_end = time.time() + budget
 one = lib.Context(0)
 n = bad = 0
@@ -21,6 +22,10 @@ worst = 0.0
 seed = 0
 while time.time() < t_end:
     seed += 1
+    if only is not None:
+        if not only:
+            break
+        seed = only.pop(0)
     rng = np.random.default_rng(66_000 + seed)
     scans, patches = int(rng.integers(2, 9)), int(10 ** rng.uniform(1.5, 3.3))
     fixed = int(rng.choice([0, patches // 2, patches]))
@@ -77,7 +82,13 @@ while time.time() < t_end:
             if not np.array_equal(res[r][0], res[0][0]):
                 what.append("rank %d diverged from rank 0" % r)
         s = res[0][1]
-        if (s.iterations, s.successful_steps, s.termination) != (s1.iterations, s1.successful_steps, s1.termination):
+        dc_ = abs(s.final_cost - s1.final_cost) / max(s1.final_cost, 1e-300)
+        if s1.termination != 0 and s.termination == s1.termination and s.iterations == s1.iterations:
+            # a solve that ran into max_iterations without converging (gauge-free windows without IMU factors): a hundred iterations
+            # amplify the ranks' different summation order into different accept / reject decisions - held by its final cost
+            if not dc_ <= 1e-3:  # (seed 378: 100 iterations, 62 against 58 accepted steps, costs 1.8e-4 apart - with the round's first library too)
+                what.append("unconverged solve: final cost %.1e (accepted %d / %d)" % (dc_, s.successful_steps, s1.successful_steps))
+        elif (s.iterations, s.successful_steps, s.termination) != (s1.iterations, s1.successful_steps, s1.termination):
             what.append("iterations %d / %d, accepted %d / %d, termination %d / %d" % (s.iterations, s1.iterations, s.successful_steps, s1.successful_steps, s.termination, s1.termination))
         else:
             dcost = abs(s.final_cost - s1.final_cost) / max(s1.final_cost, 1e-300)
