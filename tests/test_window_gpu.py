@@ -116,6 +116,33 @@ def test_lm_solve_matches_oracle(gpu, oracle, cfg):
         assert s_ref.final_cost < 0.7 * s_ref.initial_cost  # the solve really removed the injected pose error
 
 
+def test_far_pairs_stay_zero_across_builds_and_timed_linearisation(gpu, oracle):
+    """k_gather writes only the 6 x 6 pose corner of a block pair more than two sample blocks apart; the rest of such a block is
+    zero from the build (round 5).  Windows of different sizes built back to back on ONE context - the dense H moves in memory with
+    its leading dimension - must each match the oracle entry by entry, also after the back-to-back timed linearisations."""
+    rng = np.random.default_rng(3)
+    for cfg in (dict(n_scans=10, patches=80, fixed=40), dict(n_scans=3, patches=300, fixed=120), dict(n_scans=7, patches=120, fixed=0, fix_first=False),
+                dict(n_scans=10, patches=80, fixed=40, with_imu=False)):
+        w, W, keep = _setup(gpu, oracle, **cfg)
+        x = 1e-3 * rng.normal(size=12 * W.ns)
+        H_ref, g_ref, cl_ref = W.linearize(x)
+        ms = gpu.window_linearize_timed(x, 5)
+        assert 0.0 < ms < 50.0
+        H, g, cl = gpu.window_linearize(x)
+        assert abs(cl - cl_ref) <= 1e-11 * cl_ref
+        assert _rel(H, H_ref) <= 1e-10 and _rel(g, g_ref) <= 1e-10
+        assert np.array_equal(H, H.T)
+        far_zero = np.ones_like(H, bool)  # entries the far pairs never write
+        ns = W.ns
+        for i in range(ns):
+            for j in range(ns):
+                if abs(i - j) <= 2:
+                    far_zero[12 * i:12 * i + 12, 12 * j:12 * j + 12] = False
+                else:
+                    far_zero[12 * i:12 * i + 6, 12 * j:12 * j + 6] = False
+        assert not H[far_zero].any() and not H_ref[far_zero].any()
+
+
 def test_window_errors(gpu, oracle):
     from wildcat_slam_amd import lib
 
