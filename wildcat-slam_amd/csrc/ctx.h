@@ -40,6 +40,7 @@ struct wc_dev_opts {
   int lm_dense = 0;          // round 2's LM step: dense Cholesky of all 12 ns unknowns
   int lm_sync = 0;           // wait for the stream instead of the mailbox ticket
   int lm_eval_pass = 0;      // a cost-only pass for the candidate instead of a linearisation
+  int pcr_ahead = 1;         // the bias elimination's level 0 of the NEXT iteration enqueued behind the candidate's linearisation (0: at the iteration's start)
   int lm_dense_radius = 10;  // iterations whose trust-region radius exceeds 10^value take the dense step (0: never)
 };
 // logging-only switches (they print; they never change a result): read once per process from the environment in every build

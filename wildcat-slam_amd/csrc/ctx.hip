@@ -76,6 +76,7 @@ const DevOpt kDevOpts[] = {
     {"lm_dense", "WC_LM_DENSE", &wc_dev_opts::lm_dense, true},
     {"lm_sync", "WC_LM_SYNC", &wc_dev_opts::lm_sync, true},
     {"lm_eval_pass", "WC_LM_EVAL_PASS", &wc_dev_opts::lm_eval_pass, true},
+    {"pcr_ahead", "WC_PCR_AHEAD", &wc_dev_opts::pcr_ahead, true},
     {"lm_dense_radius", "WC_LM_DENSE_RADIUS", &wc_dev_opts::lm_dense_radius, false},
 };
 }  // namespace

@@ -2827,6 +2827,8 @@ extern "C" int wc_window_solve(wc_ctx *ctx, double *h_x_inout, wc_solve_summary 
   // per iteration instead of two, -0.05 ms of 0.6 at C4), a rejected one has formed an H nobody uses (+0.1 ms).  Its cost and
   // max |g| arrive with the iteration's mailbox, so nothing is pending between iterations.  Development option lm_eval_pass: round 2's flow.
   const bool cand_lin = ctx->dev.lm_eval_pass == 0;
+  const bool spec_ok = ctx->dev.pcr_ahead != 0;  // (development option pcr_ahead: 0 = level 0 formed at the start of every iteration, as in rounds 3 - 4)
+  const void *pcr_ready_for = nullptr;           // the H whose undamped level-0 blocks sit in pcr_D / A / R [0]
   auto resolve_pending = [&]() {
     cost = ctx->h_mail[0];
     gmax = ctx->h_mail[1];
@@ -2861,18 +2863,28 @@ extern "C" int wc_window_solve(wc_ctx *ctx, double *h_x_inout, wc_solve_summary 
           const int np2 = ((npz + 1 + kNB - 1) / kNB) * kNB, ld2 = np2, nblk2 = np2 / kNB;
           double *Dp[2] = {(double *)W->pcr_D[0].p, (double *)W->pcr_D[1].p}, *Ap[2] = {(double *)W->pcr_A[0].p, (double *)W->pcr_A[1].p};
           double *Rp[2] = {(double *)W->pcr_R[0].p, (double *)W->pcr_R[1].p}, *yred = (double *)W->yred.p;
-          const PcrSrc src{H, g, scale, n, ns, radius, diag};
           int cur = 0, nlev = 0;
           for (int s = 1; s < M; s *= 2) ++nlev;
           double *X = nullptr;
-          k_pcr_init<<<dim3(M, nch), 256, 0, st>>>(src, Dp[0], Ap[0], Rp[0], ldr, fail);
+          // level 0 from H, UNDAMPED (radius 0) - unless it is there already: enqueued behind the linearisation this H came from,
+          // before the host knew that its step would be accepted (pcr_ahead below)
+          if (pcr_ready_for != (const void *)H || !spec_ok) {
+            const PcrSrc src{H, g, scale, n, ns, 0.0, diag};
+            k_pcr_init<<<dim3(M, nch), 256, 0, st>>>(src, Dp[0], Ap[0], Rp[0], ldr, fail);
+          }
+          pcr_ready_for = nullptr;  // (the levels overwrite level 0)
+          const PcrDamp damp{radius, ns, diag}, nodamp{0.0, ns, diag};
           for (int s = 1, lev = 0; lev < nlev; s *= 2, ++lev) {  // (ns >= 4: at least one level)
-            const bool last = lev == nlev - 1;
+            const bool last = lev == nlev - 1, first = lev == 0;
             const dim3 grid(M, nch);
-            if (last)
-              k_pcr_level<true><<<grid, 256, 0, st>>>(s, M, Dp[cur], Ap[cur], Rp[cur], Dp[cur ^ 1], Ap[cur ^ 1], Rp[cur ^ 1], ldr, fail);
+            if (last && first)
+              k_pcr_level<true, true><<<grid, 256, 0, st>>>(s, M, Dp[cur], Ap[cur], Rp[cur], Dp[cur ^ 1], Ap[cur ^ 1], Rp[cur ^ 1], ldr, fail, damp);
+            else if (last)
+              k_pcr_level<true, false><<<grid, 256, 0, st>>>(s, M, Dp[cur], Ap[cur], Rp[cur], Dp[cur ^ 1], Ap[cur ^ 1], Rp[cur ^ 1], ldr, fail, nodamp);
+            else if (first)
+              k_pcr_level<false, true><<<grid, 256, 0, st>>>(s, M, Dp[cur], Ap[cur], Rp[cur], Dp[cur ^ 1], Ap[cur ^ 1], Rp[cur ^ 1], ldr, fail, damp);
             else
-              k_pcr_level<false><<<grid, 256, 0, st>>>(s, M, Dp[cur], Ap[cur], Rp[cur], Dp[cur ^ 1], Ap[cur ^ 1], Rp[cur ^ 1], ldr, fail);
+              k_pcr_level<false, false><<<grid, 256, 0, st>>>(s, M, Dp[cur], Ap[cur], Rp[cur], Dp[cur ^ 1], Ap[cur ^ 1], Rp[cur ^ 1], ldr, fail, nodamp);
             cur ^= 1;
           }
           X = Rp[cur];  // the last level wrote X = T^-1 [C | bB] where the others write R'
@@ -2923,6 +2935,15 @@ extern "C" int wc_window_solve(wc_ctx *ctx, double *h_x_inout, wc_solve_summary 
         WC_HIP(ctx, hipGetLastError());
         // (one GPU: k_sum_blocks has stored the mailbox to pinned host memory itself; with an all-reduce behind it, copy)
         if (multi_gpu(ctx, W) || !h_mail_dev) WC_HIP(ctx, hipMemcpyAsync(ctx->h_mail, mail, 40 * 8, hipMemcpyDeviceToHost, st));
+        if (cand_lin && use_schur && spec_ok) {
+          // pcr_ahead: the next iteration's level 0 from the CANDIDATE's H, while the host waits for this iteration's mailbox and decides
+          // (the blocks do not depend on the radius).  An accepted step - the rule - finds them there; a rejected one forms its own.
+          // (Behind the mailbox's copy: k_pcr_init clears the factorisation's fail flag, which that copy carries.)
+          const int ns = W->ns, npz = 6 * ns, M = (ns + 1) / 2, ldr = ((npz + 1 + 63) / 64) * 64, nch = (ldr + 255) / 256;
+          const PcrSrc src{lin_H(W, true), lin_g(W, true), scale, n, ns, 0.0, diag};
+          k_pcr_init<<<dim3(M, nch), 256, 0, st>>>(src, (double *)W->pcr_D[0].p, (double *)W->pcr_A[0].p, (double *)W->pcr_R[0].p, ldr, fail);
+          pcr_ready_for = (const void *)lin_H(W, true);
+        }
         WC_TRY(wait_mail(ctx, ticket));
         return WC_OK;
       };
