@@ -840,8 +840,11 @@ __global__ void __launch_bounds__(256) k_lin_imu(WinParams wp, const Piece *piec
 // the unary pieces inside too (at the binary pieces' LDS: three workgroups per CU instead of four, but no drain between the
 // families): solve 2.30 -> 2.25 ms, C4 unchanged.
 // (k_lin_imu's workgroups have 256 threads: with -DWC_PIECE below 256, an experiment, the families are launches of their own)
-template <bool WITH_UNARY>
-__global__ void __launch_bounds__(256, WC_LIN_WG_PER_CU) k_lin_fused(WinParams wp, const Piece *pieces, uint32_t n_imu, uint32_t n_b, uint32_t n_u, const double *brec,
+// OCC = workgroups per CU the register budget is cut for: 4 (128 VGPRs - the IMU body, a latency chain of a few hundred workgroups,
+// then spills 47 registers) when the surfel pieces outnumber the chip's workgroup slots, 3 (168 VGPRs, no spills) for the small windows
+// of a real stream, where the IMU chain IS the kernel (facade: 15.7 -> 13.5 us)
+template <bool WITH_UNARY, int OCC>
+__global__ void __launch_bounds__(256, OCC) k_lin_fused(WinParams wp, const Piece *pieces, uint32_t n_imu, uint32_t n_b, uint32_t n_u, const double *brec,
                                                      uint32_t nb, const double *urec, uint32_t nu, const ImuRec *irec, const double *times,
                                                      const double *x, double *partial, uint32_t cost_slot0) {
   constexpr int SZ0 = LinSurfelLds<24>::DOUBLES > kLinImuLds ? LinSurfelLds<24>::DOUBLES : kLinImuLds;
@@ -2588,14 +2591,25 @@ int enqueue_linearize(wc_ctx *ctx, wc_window_state *W, const double *d_x, int ma
   const bool unary_in = ctx->dev.lin_unary_apart == 0;  // (A/B: the unary family as a launch of its own)
   const bool fused = W->npiece_b && W->npiece_i && !imu_apart && kPiece == 256;
   const bool fused_u = fused && unary_in && W->npiece_u;
-  if (fused_u)
-    k_lin_fused<true><<<W->npiece_i + W->npiece_b + W->npiece_u, 256, 0, st>>>(W->wp, pcs, W->npiece_i, W->npiece_b, W->npiece_u, (const double *)W->brec.p, W->nb,
-                                                                             (const double *)W->urec.p, W->nu, (const ImuRec *)W->irec.p,
-                                                                             (const double *)W->times_d.p, d_x, partial, W->npart_doubles);
-  else if (fused)
-    k_lin_fused<false><<<W->npiece_i + W->npiece_b, 256, 0, st>>>(W->wp, pcs, W->npiece_i, W->npiece_b, W->npiece_u, (const double *)W->brec.p, W->nb,
-                                                                 (const double *)W->urec.p, W->nu, (const ImuRec *)W->irec.p, (const double *)W->times_d.p,
-                                                                 d_x, partial, W->npart_doubles);
+#ifndef WC_LIN_FEW
+#define WC_LIN_FEW (6u * 256u)  // two rounds of the chip's slots at three per CU (facade, 244 linearisations: 13.4 us on average with OCC = 4 throughout, 12.2 with 768, 11.9 - 12.4 with 1 536 / 3 072; the step's 2 989 pieces: 26.8 us with OCC = 4, 29.1 with 3)
+#endif
+  const bool few = W->npiece_b + W->npiece_u <= WC_LIN_FEW;
+  auto fused_launch = [&](auto kern, uint32_t grid) {
+    kern<<<grid, 256, 0, st>>>(W->wp, pcs, W->npiece_i, W->npiece_b, W->npiece_u, (const double *)W->brec.p, W->nb, (const double *)W->urec.p, W->nu,
+                               (const ImuRec *)W->irec.p, (const double *)W->times_d.p, d_x, partial, W->npart_doubles);
+  };
+  if (fused_u) {
+    if (few)
+      fused_launch(k_lin_fused<true, 3>, W->npiece_i + W->npiece_b + W->npiece_u);
+    else
+      fused_launch(k_lin_fused<true, WC_LIN_WG_PER_CU>, W->npiece_i + W->npiece_b + W->npiece_u);
+  } else if (fused) {
+    if (few)
+      fused_launch(k_lin_fused<false, 3>, W->npiece_i + W->npiece_b);
+    else
+      fused_launch(k_lin_fused<false, WC_LIN_WG_PER_CU>, W->npiece_i + W->npiece_b);
+  }
   else if (W->npiece_b)
     k_lin_surfel<24, false><<<W->npiece_b, kPiece, 0, st>>>(W->wp, pcs, (const double *)W->brec.p, (const uint32_t *)W->bkey.p, W->nb,
                                                           d_x, partial, W->npart_doubles);
