@@ -12,7 +12,7 @@ for opt in sys.argv[2:]:
     k, v = opt.split("=")
     ctx.set_dev_option(k, int(v))
 out = []
-for scans, patches in ((20, 50000), (10, 25000)):
+for scans, patches in (((20, 50000), (10, 25000)) if not os.environ.get("SIZES") else [tuple(int(a) for a in z.split("x")) for z in os.environ["SIZES"].split(",")]):
     w = synth.surfel_window(scans, patches, seed=synth.SEED + 7, fixed_patches=patches)
     n_s = len(w["surf"])
     d_surf, d_pose = ctx.to_device(w["surf"]), ctx.to_device(w["pose"])
