@@ -52,7 +52,8 @@ int wc_ctx_set_params(wc_ctx *ctx, const wc_params *params);
  * (libwildcat_hip.so) and WC_ODOM_DEBUG (the facade).  A `-DWC_DEV_KNOBS` build (profiles/dev) additionally seeds the options below
  * from the upper-case WC_<NAME> variables when a context is created.  Options (value 0 / 1 unless stated; -1 = the library decides):
  *   exact_sums         contexts behave as if wc_params.exact_sums were 1
- *   debug_skip         knock-out bits of the default extraction path (timing runs only: results are wrong)
+ *   debug_skip         knock-out bits of the default extraction path (timing runs only: results are wrong; the bits exist in a
+ *                      -DWC_DEV_KNOBS build only - the release kernels carry no profiling branch and ignore the option)
  *   fx_merge_min       list length from which the next sweep merges record lists first (default 3)
  *   fx_split           node stage of the default extraction: 0 fused kernel, 1 two kernels, -1 by size
  *   no_bucket_sort     exact path: radix sort instead of the run-binned sort

@@ -36,3 +36,33 @@ def test_prep_stress_short(gpu):
     out = _run("stress_prep.py", 8)
     last = out.strip().splitlines()[-1]
     assert "mismatches 0" in last and "MISMATCH" not in out, out[-3000:]
+
+
+# Round 6 (VERDICT r5 weak #3 / item 6 iii): the four scripts that found round 5's LM and facade defects, as short runs (~10 s of
+# random configurations each; every script draws its seeds in a fixed order, so a short run repeats the first seeds of the long one)
+def test_window_stress_short(gpu):
+    out = _run("stress_window.py", 10)
+    last = out.strip().splitlines()[-1]
+    assert "mismatches 0" in last and "MISMATCH" not in out, out[-3000:]
+    assert int(last.split("windows ")[1].split(" ")[0]) >= 5
+
+
+def test_step_stress_short(gpu):
+    out = _run("stress_step.py", 10)
+    last = out.strip().splitlines()[-1]
+    assert "mismatches 0" in last and "MISMATCH" not in out, out[-3000:]
+    assert int(last.split("steps ")[1].split(",")[0]) >= 2
+
+
+def test_facade_stress_short(gpu):
+    out = _run("stress_facade.py", 10)
+    last = out.strip().splitlines()[-1]
+    assert "streams with a note 0" in last and "MISMATCH" not in out, out[-3000:]
+    assert int(last.split("streams ")[1].split(",")[0]) >= 1
+
+
+def test_sharded_window_stress_short(gpu):
+    out = _run("stress_sharded_window.py", 10)
+    last = out.strip().splitlines()[-1]
+    assert "mismatches 0" in last and "MISMATCH" not in out, out[-3000:]
+    assert int(last.split("windows ")[1].split(",")[0]) >= 2

@@ -21,6 +21,21 @@ struct wc_buf {
   bool plain = false;   // never from the pool: buffers handed to the communicator's collectives (RCCL sees ordinary hipMalloc memory)
 };
 
+// Knock-out bits of the extraction kernels (development option debug_skip) exist in a -DWC_DEV_KNOBS build only: the release kernels
+// carry no profiling branch; the same switch gates the compile-time instrumentation of window.hip
+// (WC_LIN_KNOCK, WC_GATHER_KNOCK, WC_PROF_LIN, WC_PROF_CHOL, WC_PCR_NOINV, WC_PCR_NOR).
+#ifdef WC_DEV_KNOBS
+#define WC_DBG(P, bit) ((P).dbg & (bit))
+#else
+#define WC_DBG(P, bit) 0
+#undef WC_LIN_KNOCK
+#undef WC_GATHER_KNOCK
+#undef WC_PROF_LIN
+#undef WC_PROF_CHOL
+#undef WC_PCR_NOINV
+#undef WC_PCR_NOR
+#endif
+
 // Development options of a context (wc_ctx_set_dev_option; include/wildcat_hip.h lists them).  They pin choices the library
 // otherwise makes from the call's sizes, or knock parts of a kernel out for timing runs.  The release build reads NO environment
 // variable that changes the executed path: a `-DWC_DEV_KNOBS` build (profiles/dev) seeds these fields from the WC_* variables of
@@ -51,6 +66,7 @@ struct wc_ctx {
   wc_params P;
   wc_dev_opts dev;
   bool pool_ok = false;  // the device has a stream-ordered memory pool (wc_ensure allocates from it)
+  hipMemPool_t pool = nullptr;  // the process's private pool on this device (ctx.hip: wc_pool_acquire), shared by its contexts
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -164,8 +180,8 @@ inline int wc_fail(wc_ctx *ctx, int code, const char *fmt, ...) {
       return wc_fail(ctx, WC_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
   } while (0)
 
-// grow-only device buffer.  Memory comes from the device's stream-ordered pool (hipMallocAsync on the ctx stream; wc_ctx_create sets
-// the pool's release threshold so that freed blocks stay with the process): growing a buffer is an enqueue of microseconds, neither
+// grow-only device buffer.  Memory comes from the process's private stream-ordered pool on the device (hipMallocFromPoolAsync on the ctx
+// stream; the pool's release threshold keeps freed blocks until the last context on the device is destroyed): growing a buffer is an enqueue of microseconds, neither
 // the device synchronisation of a hipFree nor the ~0.3 - 1 ms of a hipMalloc - a kernel trace of the facade's stream (round 5) showed a
 // sweep of 15 ms among sweeps of 7 when the window's record buffers crossed their size together, and 19 ms for the first search of a
 // helper context (25 buffers).  Falls back to hipMalloc where the pool is not available.
@@ -191,7 +207,7 @@ inline int wc_ensure(wc_ctx *ctx, wc_buf &b, size_t bytes) {
   if (want < 4096) want = 4096;
   static const bool alloc_dbg = wc_log_env("WC_ALLOC_DEBUG");  // (read once per process)
   if (alloc_dbg) fprintf(stderr, "[alloc] %zu bytes wanted -> %zu\n", bytes, want);
-  if (ctx->pool_ok && !b.plain && hipMallocAsync(&b.p, want, ctx->stream) == hipSuccess) {
+  if (ctx->pool_ok && !b.plain && hipMallocFromPoolAsync(&b.p, want, ctx->pool, ctx->stream) == hipSuccess) {
     b.pooled = true;
   } else {
     (void)hipGetLastError();

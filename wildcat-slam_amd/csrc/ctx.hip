@@ -3,6 +3,7 @@
 
 #include <cmath>
 #include <cstring>
+#include <mutex>
 
 extern "C" const char *wc_version(void) { return "wildcat_hip 0.1 (gfx950)"; }
 
@@ -81,6 +82,52 @@ const DevOpt kDevOpts[] = {
 };
 }  // namespace
 
+namespace {
+struct DevPool {
+  hipMemPool_t pool = nullptr;
+  int refs = 0;
+};
+std::mutex g_pool_mu;
+DevPool g_pools[64];
+}  // namespace
+hipMemPool_t wc_pool_acquire(int device) {
+  if (device < 0 || device >= 64) return nullptr;
+  std::lock_guard<std::mutex> lk(g_pool_mu);
+  DevPool &d = g_pools[device];
+  if (!d.pool) {
+    int supported = 0;
+    if (hipDeviceGetAttribute(&supported, hipDeviceAttributeMemoryPoolsSupported, device) != hipSuccess || !supported) {
+      (void)hipGetLastError();
+      return nullptr;
+    }
+    hipMemPoolProps props;
+    std::memset(&props, 0, sizeof(props));
+    props.allocType = hipMemAllocationTypePinned;
+    props.handleTypes = hipMemHandleTypeNone;
+    props.location.type = hipMemLocationTypeDevice;
+    props.location.id = device;
+    hipMemPool_t p = nullptr;
+    if (hipMemPoolCreate(&p, &props) != hipSuccess || !p) {
+      (void)hipGetLastError();
+      return nullptr;
+    }
+    uint64_t keep = ~0ull;
+    if (hipMemPoolSetAttribute(p, hipMemPoolAttrReleaseThreshold, &keep) != hipSuccess) (void)hipGetLastError();
+    d.pool = p;
+  }
+  ++d.refs;
+  return d.pool;
+}
+void wc_pool_release(int device, hipMemPool_t pool) {
+  if (!pool || device < 0 || device >= 64) return;
+  std::lock_guard<std::mutex> lk(g_pool_mu);
+  DevPool &d = g_pools[device];
+  if (d.pool == pool && --d.refs == 0) {
+    (void)hipMemPoolDestroy(d.pool);  // (every block was released stream-ordered and the streams were synchronised: the memory returns to the driver)
+    d.pool = nullptr;
+  }
+}
+
 extern "C" int wc_ctx_create(const wc_params *params, int device, wc_ctx **out) {
   if (!out) return WC_ERR_ARG;
   *out = nullptr;
@@ -119,16 +166,12 @@ extern "C" int wc_ctx_create(const wc_params *params, int device, wc_ctx **out) 
     for (int q = 0; q < 128; ++q) ctx->h_status[q] = 0;
   }
   for (wc_buf &b : ctx->b_route) b.plain = true;  // (all-to-all / all-gather buffers of the sharded extraction and matcher)
-  {  // the device's default memory pool keeps what is freed (release threshold: never give memory back while the process lives)
-    hipMemPool_t pool = nullptr;
-    int supported = 0;
-    if (hipDeviceGetAttribute(&supported, hipDeviceAttributeMemoryPoolsSupported, device) == hipSuccess && supported &&
-        hipDeviceGetDefaultMemPool(&pool, device) == hipSuccess && pool) {
-      uint64_t keep = ~0ull;
-      ctx->pool_ok = hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep) == hipSuccess;
-    }
-    (void)hipGetLastError();
-  }
+  ctx->b_status.plain = true;  // (handed to collectives too: gather_counts, the count exchange, the poison all-reduce - ADVICE r5)
+  // a PRIVATE stream-ordered memory pool per (process, device), shared by the contexts on that device and destroyed with the last of
+  // them (rounds 4 - 5 raised the release threshold of the device's DEFAULT pool - a process-global side effect on every
+  // other hipMallocAsync user, and the memory parked by wc_ctx_warmup outlived wc_ctx_destroy).  The pool keeps what is freed.
+  ctx->pool = wc_pool_acquire(device);
+  ctx->pool_ok = ctx->pool != nullptr;
 #ifdef WC_DEV_KNOBS  // development build only (profiles/dev): the WC_* variables of DESIGN 5.1 seed the context's options
   for (const DevOpt &o : kDevOpts)
     if (const char *v = getenv(o.env)) ctx->dev.*(o.field) = o.flag_only ? 1 : atoi(v);
@@ -144,6 +187,7 @@ extern "C" int wc_ctx_set_dev_option(wc_ctx *ctx, const char *name, int value) {
       ctx->dev.*(o.field) = value;
       ctx->ex.fx_backoff = ctx->ex.fx_skip_calls = 0;
       if (ctx->aux) ctx->aux->dev = ctx->dev;
+      for (wc_ctx *sub : ctx->batch_subs) sub->dev = ctx->dev, sub->ex.fx_backoff = sub->ex.fx_skip_calls = 0;
       return WC_OK;
     }
   return wc_fail(ctx, WC_ERR_ARG, "wc_ctx_set_dev_option: unknown option '%s'", name);
@@ -191,6 +235,7 @@ extern "C" void wc_ctx_destroy(wc_ctx *ctx) {
   for (hipEvent_t e : ctx->ex_ev)
     if (e) (void)hipEventDestroy(e);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+  wc_pool_release(ctx->device, ctx->pool);
   delete ctx;
 }
 
@@ -359,7 +404,7 @@ extern "C" int wc_ctx_warmup(wc_ctx *ctx, size_t reserve_bytes) {
   }
   if (reserve_bytes && ctx->pool_ok) {
     void *p = nullptr;
-    if (hipMallocAsync(&p, reserve_bytes, ctx->stream) == hipSuccess) (void)hipFreeAsync(p, ctx->stream);
+    if (hipMallocFromPoolAsync(&p, reserve_bytes, ctx->pool, ctx->stream) == hipSuccess) (void)hipFreeAsync(p, ctx->stream);
     (void)hipGetLastError();
   }
   WC_HIP(ctx, hipStreamSynchronize(ctx->stream));

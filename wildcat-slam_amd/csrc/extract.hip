@@ -539,7 +539,7 @@ __global__ void __launch_bounds__(64) k_roots(RootsArgs A, const K *__restrict__
 
       WC_TICK(1);  // staging (incl. waiting for the gather)
       // ---- stream the staged points in time order ----
-      int j = (P.dbg & 1) ? nvalid : 0;
+      int j = (WC_DBG(P, 1)) ? nvalid : 0;
       while (j < nvalid) {
         const unsigned long long rem = ev >> j;
         const int je = rem ? j + (__ffsll((long long)rem) - 1) : nvalid;  // next event (or end of chunk)
@@ -663,7 +663,7 @@ __global__ void __launch_bounds__(64) k_roots(RootsArgs A, const K *__restrict__
     __threadfence_block();
     __syncthreads();
     WC_TICK(3);  // write-back + open-cluster flush + fence
-    if (P.dbg & 2) return;
+    if (WC_DBG(P, 2)) return;
 
     // ---- ONE pass of 3x3 PCAs for the node tests (InitOctoTree / CutOctoTree gates, cc:129-138, :170-183) and for
     //      the candidate clusters (ClusterSurfels' second loop, cc:32-64): lanes [0, ntab) take the nodes, the lanes
@@ -701,9 +701,9 @@ __global__ void __launch_bounds__(64) k_roots(RootsArgs A, const K *__restrict__
       }
       WC_TICK(4);  // moments loaded
       Pca rr;
-      if (have && !(P.dbg & 4)) pca_from_moments(mom, rr);
+      if (have && !(WC_DBG(P, 4))) pca_from_moments(mom, rr);
       WC_TICK(5);  // eigen-solves
-      if (P.dbg & 4) { rr.ev[0] = 1e-5; rr.ev[1] = rr.ev[2] = 1e-2; rr.like = 0.9; rr.tmean = mom[1] / mom[0]; for (int i = 0; i < 3; ++i) { rr.c[i] = mom[2 + i] / mom[0]; rr.nrm[i] = 0.577; } for (int i = 0; i < 9; ++i) rr.cov[i] = 0; }
+      if (WC_DBG(P, 4)) { rr.ev[0] = 1e-5; rr.ev[1] = rr.ev[2] = 1e-2; rr.like = 0.9; rr.tmean = mom[1] / mom[0]; for (int i = 0; i < 3; ++i) { rr.c[i] = mom[2 + i] / mom[0]; rr.nrm[i] = 0.577; } for (int i = 0; i < 9; ++i) rr.cov[i] = 0; }
       if (batch == 0) {
         const bool plane = node_lane && have && (rr.ev[0] < P.thr) && (rr.like > P.min_like);  // cc:106-111
         plane_mask = __ballot(plane);
@@ -1005,7 +1005,7 @@ __global__ void __launch_bounds__(64) k_roots_banks(RootsArgs A, const K *__rest
         //      v_readlane for the masks, one LDS read, four EXEC-masked adds ----
         const unsigned long long GE = G0 | G1;
         unsigned long long todo = (PHASE == 1) ? ((nvalid == 64) ? ~0ull : ((1ull << nvalid) - 1ull)) : IN;
-        if (P.dbg & 1) todo = 0;  // development option debug_skip = 1: profiling experiments only
+        if (WC_DBG(P, 1)) todo = 0;  // development option debug_skip = 1: profiling experiments only
         while (todo) {
           const unsigned long long evs = GE & todo;
           unsigned long long seg = evs ? (todo & ((evs & (0ull - evs)) - 1ull)) : todo;  // the points in front of the next cluster end
@@ -2286,6 +2286,7 @@ extern "C" int wc_extract_surfels_enqueue(wc_ctx *ctx, const wc_points *pts, dou
   if (!ctx || !pts) return wc_fail(ctx, WC_ERR_ARG, "%s: null or out-of-range argument", __func__);
   if (pts->n >= (1ull << 32)) return wc_fail(ctx, WC_ERR_ARG, "at most 2^32-1 points per call");
   ctx->ex.active = true;
+  ctx->ex.ticket = 0;  // (only this call's fx_tail may arm the completion ticket - a stale one would let finish skip its wait)
   ctx->ex.pts = *pts;
   ctx->ex.d_out = d_out;
   ctx->ex.d_ids = d_ids;
@@ -2480,6 +2481,10 @@ extern "C" int wc_extract_surfels_batch_enqueue(wc_ctx *ctx, const wc_sweep_job 
     wc_ctx *sub = ctx->batch_subs[k];
     if (sub->stream != st) WC_TRY(wc_ctx_set_stream(sub, st));
     if (std::memcmp(&sub->P, &ctx->P, sizeof(wc_params)) != 0) WC_TRY(wc_ctx_set_params(sub, &ctx->P));
+    if (std::memcmp(&sub->dev, &ctx->dev, sizeof(wc_dev_opts)) != 0) {  // (the parent's development options reach the sweeps)
+      sub->dev = ctx->dev;
+      sub->ex.fx_backoff = sub->ex.fx_skip_calls = 0;
+    }
     sub->ex.batch_defer = true;
     sub->ex.deferred = false;
     const int rc = wc_extract_surfels_enqueue(sub, &jobs[k].pts, jobs[k].t_lo, jobs[k].t_hi, jobs[k].d_out, jobs[k].d_ids, jobs[k].cap);

@@ -304,6 +304,9 @@ static int match_impl(wc_ctx *ctx, const wc_surfel *d_q_surf, const wc_pose *d_q
   hipStream_t st = ctx->stream;
   // several GPUs: decided from arguments every rank shares (a rank-dependent predicate would leave the others in the all-gather)
   const bool sharded = want_shard && ctx->have_comm && ctx->comm.world > 1 && ctx->comm.allgatherv && nq >= 4096;
+  // (the peer-poison table holds one word per rank in the control block's eight free words - a larger world would skip the
+  // check and could feed a failed rank's poison to the resolve kernels as neighbour indices.  Every rank sees the same world: all refuse.)
+  if (sharded && ctx->comm.world > 8) return wc_fail(ctx, WC_ERR_ARG, "wc_match_sharded: at most 8 ranks (one node), got %d", ctx->comm.world);
   MatchPeerGuard peer{ctx, nq, P.knn_k, sharded};
   wc_buf &b_feat = ctx->b_misc[1], &b_world = ctx->b_misc[2], &b_gated = ctx->b_misc[4], &b_choice = ctx->b_misc[5],
          &b_scan = ctx->b_misc[7];
@@ -433,11 +436,9 @@ static int match_impl(wc_ctx *ctx, const wc_surfel *d_q_surf, const wc_pose *d_q
     std::vector<uint32_t> firsts((size_t)w);
     for (int r = 0; r < w; ++r) firsts[r] = (uint32_t)((((uint64_t)nq * r) / w) * P.knn_k);
     uint32_t *d_first = status + 56;  // (words 56 .. 63 of the control block: free; worlds of up to eight ranks per node)
-    if (w <= 8) {
-      WC_HIP(ctx, hipMemcpyAsync(d_first, firsts.data(), (size_t)w * 4, hipMemcpyHostToDevice, st));
-      WC_HIP(ctx, hipStreamSynchronize(st));  // (`firsts` is a stack-lifetime vector)
-      k_peer_poison<<<1, 64, 0, st>>>((const uint32_t *)ctx->b_route[2].p, d_first, w, status);
-    }
+    WC_HIP(ctx, hipMemcpyAsync(d_first, firsts.data(), (size_t)w * 4, hipMemcpyHostToDevice, st));  // (w <= 8: checked at the top)
+    WC_HIP(ctx, hipStreamSynchronize(st));  // (`firsts` is a stack-lifetime vector)
+    k_peer_poison<<<1, 64, 0, st>>>((const uint32_t *)ctx->b_route[2].p, d_first, w, status);
   }
   if (!direct_planes) {
     uint32_t *qpos = (uint32_t *)b_choice.p + nq;  // (choice[1]: free until the resolve rounds)
