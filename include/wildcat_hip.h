@@ -63,7 +63,7 @@ int wc_ctx_set_params(wc_ctx *ctx, const wc_params *params);
  *   match_pair_serial  wc_match_pair runs its two searches one after the other on the ctx
  *   match_pair_swap    the sliding-window search on the helper context instead of the fixed-window one
  *   lin_imu_apart, lin_unary_apart, lin_post_apart   factor families / mailbox of a linearisation as launches of their own
- *   lm_dense, lm_eval_pass, lm_sync                   earlier forms of the LM step kept for A/B runs
+ *   lm_dense, lm_eval_pass, lm_sync, lm_back_chunks   earlier forms of the LM step kept for A/B runs
  *   pcr_ahead (1)                                     0: the bias elimination's level 0 at the start of an iteration (rounds 3 - 4)
  *   lm_dense_radius    iterations whose trust-region radius exceeds 10^value take the dense step (default 10; 0 = never)
  * Tests use it to run both forms of a choice on the same data.  Unknown names return WC_ERR_ARG. */

@@ -1,7 +1,7 @@
 """the damped solve's diagonal-block kernel on its own against numpy, with its shader clocks (wc_selftest_factor32); round 5 ran two
 single-wavefront forms through it (note in csrc/window.hip)"""
 import os, sys
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "wildcat-slam_amd", "python"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", os.environ.get("AB_LM_TREE", "."), "wildcat-slam_amd", "python"))
 import numpy as np
 from wildcat_slam_amd import lib
 ctx = lib.Context(0)

@@ -19,5 +19,9 @@ for r in rows[a:b]:
     t[0] += 1; t[1] += (e - s) / 1e3; t[2] += max(0, s - prev) / 1e3
     prev = e
 print("iteration span %.1f us, %d launches" % ((int(rows[b]["Start_Timestamp"]) - t0) / 1e3, b - a))
+if len(sys.argv) > 3:  # every launch of the iteration: start offset, duration, workgroups
+    for r in rows[a:b]:
+        gx = int(r.get("Grid_Size_X", r.get("Grid_Size", 0)) or 0) // max(1, int(r.get("Workgroup_Size_X", r.get("Workgroup_Size", 1)) or 1))
+        print("  %8.1f  %6.1f us  %5d wg  %s" % ((int(r["Start_Timestamp"]) - t0) / 1e3, (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3, gx, short(r["Kernel_Name"])))
 for n, (c, d, g) in sorted(tot.items(), key=lambda kv: -kv[1][1]):
     print("%-28s x%3d  busy %7.1f us  idle before %6.1f us" % (n, c, d, g))

