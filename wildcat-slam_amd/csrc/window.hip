@@ -1582,6 +1582,115 @@ __device__ __forceinline__ bool factor_inv32_blk(double (*sB)[kNB + 1], double (
   return ok;
 }
 
+template <int WV>
+__device__ __forceinline__ bool factor_inv32_role(double (*sB)[kNB + 1], double (*sXi)[kNB + 1]) {
+  const int tid = threadIdx.x;
+  constexpr int w = WV;
+  const int lane = tid & 63, li = lane & 15, lk = lane >> 4;
+  constexpr int rt = w >> 1, ct = w & 1;
+  const int ra = 16 * rt + li, cb = 16 * ct + li;  // this lane's row of the A operand / column of the B operand
+  const double mk[4] = {lk == 0 ? 1.0 : 0.0, lk == 1 ? 1.0 : 0.0, lk == 2 ? 1.0 : 0.0, lk == 3 ? 1.0 : 0.0};
+  // sXi starts as the identity: rows below the current block step hold W = E - L X (right-looking substitution), rows
+  // above it the finished rows of X = L^-1
+  for (int e = tid; e < kNB * kNB; e += 256) sXi[e / kNB][e % kNB] = (e / kNB == e % kNB) ? 1.0 : 0.0;
+  bool ok = true;
+  Piv4 prev;
+  __syncthreads();
+  // The update tile of a wavefront stays in registers for the whole factorisation (MFMA C / D layout: register r4 of a
+  // lane = element (16 rt + lk + 4 r4, cb)): LDS only carries what OTHER wavefronts read - the next step's panel columns
+  // and W's next pivot rows.  A column holds the trailing block until its block step, then W (whose untouched part below
+  // the diagonal is zero).
+  f64x4 cc = {0.0, 0.0, 0.0, 0.0};
+  if (w != 1) {
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) cc[r4] = sB[16 * rt + lk + 4 * r4][cb];
+  }
+  for (int j0 = 0; j0 < kNB; j0 += 4) {
+    // the pivot block first: the chain below waits for nothing else
+    const double p00 = sB[j0][j0], p10 = sB[j0 + 1][j0], p11 = sB[j0 + 1][j0 + 1], p20 = sB[j0 + 2][j0], p21 = sB[j0 + 2][j0 + 1],
+                 p22 = sB[j0 + 2][j0 + 2], p30 = sB[j0 + 3][j0], p31 = sB[j0 + 3][j0 + 1], p32 = sB[j0 + 3][j0 + 2],
+                 p33 = sB[j0 + 3][j0 + 3];
+    // operands of this wavefront's update tile, requested before the pivot chain
+    const bool tile = (w != 1) && (16 * rt + 15 >= j0 + 4);  // wave-uniform
+    const bool bt = cb >= j0 + 4;                             // this lane's column: trailing block (else a column of W)
+    if ((cb >> 2) == (j0 >> 2)) cc = f64x4{0.0, 0.0, 0.0, 0.0};  // the pivot columns turn into columns of W
+    double va[4] = {0.0, 0.0, 0.0, 0.0}, vb[4] = {0.0, 0.0, 0.0, 0.0};
+    if (tile) {
+      const double *o = bt ? &sB[cb][j0] : &sXi[j0][cb];  // row cb of the panel / column cb of W's pivot rows
+      const int os = bt ? 1 : kNB + 1;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) va[t] = sB[ra][j0 + t], vb[t] = o[t * os];
+    }
+    Fin4 fin;
+    if (w == 1) fin = factor_finish_load(sB, sXi, j0 > 0 ? j0 - 4 : 0, tid);  // wavefront 1 has no tile: it finishes the previous step
+    // ---- 4x4 pivot block: factor + inverse, every thread on its own ----
+    // (explicit fma: the solve is compared with the oracle at 1e-6, not bit for bit)
+    Piv4 q;
+    // pivots in pairs: 1 / l11 = sqrt(p00) rsqrt(p00 p11 - p10^2), so the two reciprocal square roots of a 2x2 block run
+    // side by side (the determinant carries the same cancellation as p11 - l10^2); same for the 2x2 Schur complement
+    q.i00 = rsqrt_nr(p00);
+    const double det01 = fma(p00, p11, -(p10 * p10));
+    const double rd01 = rsqrt_nr(det01);
+    q.l00 = p00 * q.i00, q.l10 = p10 * q.i00, q.l20 = p20 * q.i00, q.l30 = p30 * q.i00;
+    q.i11 = q.l00 * rd01;
+    q.l11 = (det01 * rd01) * q.i00;
+    q.l21 = fma(-q.l20, q.l10, p21) * q.i11, q.l31 = fma(-q.l30, q.l10, p31) * q.i11;
+    const double s22 = fma(-q.l21, q.l21, fma(-q.l20, q.l20, p22));
+    const double s32 = fma(-q.l31, q.l21, fma(-q.l30, q.l20, p32));
+    const double s33 = fma(-q.l31, q.l31, fma(-q.l30, q.l30, p33));
+    q.i22 = rsqrt_nr(s22);
+    const double det23 = fma(s22, s33, -(s32 * s32));
+    const double rd23 = rsqrt_nr(det23);
+    q.l22 = s22 * q.i22, q.l32 = s32 * q.i22;
+    q.i33 = q.l22 * rd23;
+    q.l33 = (det23 * rd23) * q.i22;
+    if (!(p00 > 0.0 && det01 > 0.0 && s22 > 0.0 && det23 > 0.0)) ok = false;
+    if (w == 1) {  // the off-diagonal part of Lp^-1 is only needed to finish the step
+      q.i10 = -(q.l10 * q.i00) * q.i11;
+      q.i21 = -(q.l21 * q.i11) * q.i22;
+      q.i20 = -fma(q.l20, q.i00, q.l21 * q.i10) * q.i22;
+      q.i32 = -(q.l32 * q.i22) * q.i33;
+      q.i31 = -fma(q.l31, q.i11, q.l32 * q.i21) * q.i33;
+      q.i30 = -fma(q.l30, q.i00, fma(q.l31, q.i10, q.l32 * q.i20)) * q.i33;
+    }
+    // ---- rank-4 update of this wavefront's tile ----
+    const double fa = piv_solve_elem(q, va[0], va[1], va[2], va[3], mk);
+    const double fb = piv_solve_elem(q, vb[0], vb[1], vb[2], vb[3], mk);
+    if (tile) {
+      cc = __builtin_amdgcn_mfma_f64_16x16x4f64(ra >= j0 + 4 ? -fa : 0.0, fb, cc, 0, 0, 0);
+      if (bt) {
+        if (cb < j0 + 8) {  // the next step's panel (and pivot block): lower part, rows from the next pivot block on
+#pragma unroll
+          for (int r4 = 0; r4 < 4; ++r4) {
+            const int row = 16 * rt + lk + 4 * r4;
+            if (row >= j0 + 4 && cb <= row) sB[row][cb] = cc[r4];
+          }
+        }
+      } else {  // W's next pivot rows j0+4 .. j0+7: row j0 + 4 + lk is register (j0 + 4 - 16 rt) / 4 of this lane
+        const int rn = j0 + 4 - 16 * rt;
+        if (rn >= 0 && rn < 16) sXi[j0 + 4 + lk][cb] = rn == 0 ? cc[0] : (rn == 4 ? cc[1] : (rn == 8 ? cc[2] : cc[3]));
+      }
+    }
+    if (w == 1 && j0 > 0) factor_finish_store(fin, j0 - 4, prev, tid);
+    prev = q;
+    __syncthreads();
+  }
+  if (w == 1) factor_finish_store(factor_finish_load(sB, sXi, kNB - 4, tid), kNB - 4, prev, tid);
+  return ok;
+}
+
+// Round 6: the same routine with the wavefront's role (its tile, or the finishing role of wavefront 1) as a compile-time constant: one
+// branch on the wavefront at the top instead of ~25 wave-uniform predicates per block step, which the fully unrolled body kept in SGPRs
+// spilled to VGPR lanes (two v_readlane + wait states per use).
+__device__ __forceinline__ bool factor_inv32_roles(double (*sB)[kNB + 1], double (*sXi)[kNB + 1]) {
+  switch (threadIdx.x >> 6) {
+    case 0: return factor_inv32_role<0>(sB, sXi);
+    case 1: return factor_inv32_role<1>(sB, sXi);
+    case 2: return factor_inv32_role<2>(sB, sXi);
+    default: return factor_inv32_role<3>(sB, sXi);
+  }
+}
+
 // (Round 6 rebuilt this routine twice around measured costs - profiles/micro/dep64.hip: a dependent fp64 operation 9 clocks, v_rsq_f64 20, a
 // matrix-core step 68 - 81, an LDS round trip inside a wavefront 108, barrier + LDS ~150 - with the pivot chain on ONE wavefront instead of
 // redundantly in all four, and the two 4 x 4 forward substitutions of the update replaced by matrix-core products with Lp^-1 as a 16 x 4
@@ -1613,7 +1722,7 @@ __global__ void __launch_bounds__(256) k_damp_first(const double *H, const doubl
       sB[r][c] = c <= r ? damped_entry(H, g, scale, n, radius, r, c, nullptr) : 0.0;
     }
     __syncthreads();
-    const bool ok = factor_inv32_blk(sB, sXi);
+    const bool ok = factor_inv32_roles(sB, sXi);
     if (threadIdx.x == 0) *fail = ok ? 0 : 1;
     __syncthreads();
     for (int e = threadIdx.x; e < kNB * kNB; e += 256) {
@@ -1680,7 +1789,7 @@ __device__ __forceinline__ void chol_lead(const double *A, int ld, int k, int nb
   }
   __syncthreads();
   WC_CT(3);
-  const bool ok = factor_inv32_blk(sD, sP);  // in: lower part of sD; out: sD = L, sP = L^-1
+  const bool ok = factor_inv32_roles(sD, sP);  // in: lower part of sD; out: sD = L, sP = L^-1
   __syncthreads();
   WC_CT(4);
 #ifdef WC_PROF_CHOL
@@ -3097,7 +3206,7 @@ extern "C" int wc_window_solve(wc_ctx *ctx, double *h_x_inout, wc_solve_summary 
           const PcrDamp damp{radius, ns, diag}, nodamp{0.0, ns, diag};
           for (int s = 1, lev = 0; lev < nlev; s *= 2, ++lev) {  // (ns >= 4: at least one level)
             const bool last = lev == nlev - 1, first = lev == 0;
-            const dim3 grid(M, nch);
+            const dim3 grid(M * nch);
             if (last && first)
               k_pcr_level<true, true><<<grid, 256, 0, st>>>(s, M, Dp[cur], Ap[cur], Rp[cur], Dp[cur ^ 1], Ap[cur ^ 1], Rp[cur ^ 1], ldr, fail, damp);
             else if (last)
@@ -3109,7 +3218,7 @@ extern "C" int wc_window_solve(wc_ctx *ctx, double *h_x_inout, wc_solve_summary 
             cur ^= 1;
           }
           X = Rp[cur];  // the last level wrote X = T^-1 [C | bB] where the others write R'
-          k_schur_form<<<dim3((np2 + 255) / 256, 1 + ns + (np2 - npz)), 256, 0, st>>>(H, g, scale, X, n, ns, ldr, np2, ld2, radius, A, diag, Lmat, (double *)W->Linv.p, fail);
+          k_schur_form<<<((np2 + 255) / 256) * (1 + ns + (np2 - npz)), 256, 0, st>>>(H, g, scale, X, n, ns, ldr, np2, ld2, radius, A, diag, Lmat, (double *)W->Linv.p, fail, (np2 + 255) / 256);
           // (development option lm_back_chunks: rounds 2 - 5's back substitution - chunk solves + products - and k_schur_bias_y / k_lm_step
           // as launches of their own, for A/B runs; default: identity rows appended to the factorisation, k_back_mul, one fused tail)
           const bool back_mul = ctx->dev.lm_back_chunks == 0;
@@ -3324,7 +3433,7 @@ __global__ void __launch_bounds__(256) k_selftest_factor(const double *Ain, int 
     for (int e = threadIdx.x; e < kNB * kNB; e += 256) sB[e / kNB][e % kNB] = (e % kNB <= e / kNB) ? Ain[e] : 0.0;
     __syncthreads();
     const long long t0 = clock64();
-    ok = factor_inv32_blk(sB, sXi);
+    ok = variant == 1 ? factor_inv32_roles(sB, sXi) : factor_inv32_blk(sB, sXi);
     __syncthreads();
     const long long t1 = clock64();
     best = t1 - t0 < best ? t1 - t0 : best;
