@@ -894,22 +894,41 @@ def ring_allreduce_model_us(nbytes, world):
     return 2.0 * (world - 1) / world * nbytes / 153e9 * 1e6 + 2 * (world - 1) * 1.5  # + ~1.5 us per hop
 
 
+def direct_allreduce_model_us(nbytes, world):
+    """modelled time of a ONE-SHOT all-reduce on the fully connected xGMI mesh of an 8-GPU MI355X node (7 links per GPU, one to every
+    peer): reduce-scatter + all-gather, every rank sending 1/N of the buffer to each peer over its own link at once - (N-1)/N of the
+    payload per phase spread over N-1 links -, one hop of latency per phase; a payload of a few cache lines is ONE phase (every rank
+    writes its value to every peer: 1 hop).  Link: ~64 GB/s per direction sustained (153 GB/s is the link's two-direction peak);
+    hop ~2 us (device-side flag through the fabric).  A printed estimate, not a measurement."""
+    if world < 2 or not nbytes:
+        return 0.0
+    hop, link = 2.0, 64e9
+    if nbytes <= 4096:
+        return hop + nbytes / link * 1e6
+    per_link = nbytes / world  # bytes a rank sends to ONE peer per phase
+    return 2.0 * (hop + per_link / link * 1e6)
+
+
 def multi_gpu_model(result, local_rank):
     """north_star: >= 6 x residual-assembly throughput at 8 GPUs.  No 2+-GPU box is reachable from a 1-GPU run, so this object states
-    what a 1-GPU run CAN: the all-reduce payload of one linearisation, RCCL's floor for it measured with a world-of-one
-    communicator on the ctx stream (enqueue -> completion; no wire), a ring model over xGMI, and the modelled assembly speed-up of
-    the library AS BUILT (one all-reduce behind k_gather, exposed) next to the two-collective design of DESIGN 6 (not built)."""
+    what a 1-GPU run CAN: the payloads of one linearisation, RCCL's floor for them measured with a world-of-one communicator on the ctx
+    stream (enqueue -> completion; no wire), two wire models over xGMI (ring; one-shot on the fully connected mesh) and the MODELLED
+    assembly speed-up of rounds 3 - 5's form (one all-reduce behind k_gather, exposed) next to the two-collective form that is the
+    default of wc_window_build_sharded since round 6 (16 bytes exposed, the pose corners beside the bias elimination)."""
     from wildcat_slam_amd import lib
     from wildcat_slam_amd import dist as wdist
 
-    out = {"definition": "assembly = k_lin_fused + k_gather of one linearisation (+ the exposed part of its all-reduce); modelled, not measured at N > 1"}
+    out = {"definition": "assembly = k_lin_fused + k_gather of one linearisation (+ the exposed part of its collectives); MODELLED, NOT MEASURED at N > 1 "
+                         "(no multi-GPU box is reachable from this run)"}
     probe = {}
     try:
         c = lib.Context(local_rank)
         c.comm_rccl_init(0, 1, lib.rccl_unique_id())
         for ns in (64, 127):
-            cnt = wdist.packed_count(ns)
-            probe["ns_%d" % ns] = {"payload_bytes": 8 * cnt, "rccl_world_of_one_us": round(c.comm_allreduce_probe(cnt, 50), 2)}
+            cnt, cnt2 = wdist.packed_count(ns), wdist.corner_count(ns) - 2
+            probe["ns_%d" % ns] = {"one_collective_payload_bytes": 8 * cnt, "two_collective_payload_bytes": [16, 8 * cnt2],
+                                   "rccl_world_of_one_us": {"16_bytes": round(c.comm_allreduce_probe(2, 50), 2), "corners": round(c.comm_allreduce_probe(cnt2, 50), 2),
+                                                            "one_collective": round(c.comm_allreduce_probe(cnt, 50), 2)}}
         c.comm_rccl_destroy()
         c.close()
     except Exception as e:
@@ -918,19 +937,27 @@ def multi_gpu_model(result, local_rank):
     w = result.get("window", {})
     lin_us = 1e3 * w.get("linearize_ms", 0.0)
     if lin_us > 0:
-        payload = 8 * wdist.packed_count(127)
+        payload1, payload2 = 8 * wdist.packed_count(127), 8 * (wdist.corner_count(127) - 2)
         imu_floor_us = 14.5  # the IMU family's dependent chains: a launch of their own lasts this long whatever the window
+        hide_us = 70.0       # the bias elimination of an iteration at 127 sample states (k_pcr_*: reads IMU blocks only): what the large collective hides behind
         rows = {}
         for n in (2, 4, 8):
-            ring = ring_allreduce_model_us(payload, n)
             shard = max(lin_us / n, imu_floor_us)
-            rows[str(n)] = {"shard_assembly_us": round(shard, 1), "allreduce_ring_model_us": round(ring, 1),
-                            "speedup_as_built": round(lin_us / (shard + ring), 2),
-                            "speedup_two_collectives_design": round(lin_us / (shard + ring_allreduce_model_us(16, n)), 2)}
-        out["c4_window"] = {"assembly_one_gpu_us": round(lin_us, 1), "allreduce_exposed_us_as_built": "all of it: issued behind k_gather on the ctx stream, the solve waits for it",
-                            "by_ranks": rows,
-                            "two_collectives_design": "cost + max|g| (16 bytes) first - the trust-region decision needs nothing else -, {H, g} behind the bias "
-                                                      "elimination (k_pcr_*: 50 - 90 us that read IMU blocks only, with the IMU factors replicated): DESIGN 6; not built"}
+            r = {"shard_assembly_us": round(shard, 1)}
+            for name, fn in (("ring", ring_allreduce_model_us), ("direct", direct_allreduce_model_us)):
+                one, small, big = fn(payload1, n), fn(16, n), fn(payload2, n)
+                exposed_two = small + max(0.0, big - hide_us)
+                r[name] = {"one_collective_us": round(one, 1), "sixteen_bytes_us": round(small, 1), "corners_us": round(big, 1),
+                           "speedup_one_collective": round(lin_us / (shard + one), 2), "speedup_two_collectives": round(lin_us / (shard + exposed_two), 2)}
+            rows[str(n)] = r
+        out["c4_window"] = {"assembly_one_gpu_us": round(lin_us, 1), "by_ranks": rows,
+                            "which_algorithm": "RCCL picks by size and topology: for 16 bytes its low-latency (LL) protocol - on a fully connected node a direct exchange, "
+                                               "one hop -; for 2.3 MB at 8 ranks LL128 / Simple over rings or the direct one-shot path.  The model prints both; "
+                                               "a measured 8-GPU run decides (RCCL's small-message floor in practice is nearer 10 - 20 us than the model's 2).",
+                            "two_collectives_form": "BUILT (round 6; default of wc_window_build_sharded, development option lm_one_collective for the old form): IMU factors "
+                                                    "replicated; {surfel cost} (16 bytes) first - the trust-region decision needs nothing else -; pose corners + pose half "
+                                                    "of g (2.3 MB at 127 sample states, was 2.7) on a side stream beside the bias elimination, joined in front of "
+                                                    "k_schur_form; tested on 2 - 5 thread-ranks, two processes and two gloo ranks; modelled, not measured"}
     return out
 
 

@@ -14,7 +14,7 @@ def rel(a, b):
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300))
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 200.0
-only = [int(a) for a in sys.argv[2].split(",")] if len(sys.argv) > 2 else None  # replay these seeds
+only = [int(a) for a in sys.argv[2].split(",")] if len(sys.argv) > 2 and sys.argv[2] else None  # replay these seeds
 t_end = time.time() + budget
 one = lib.Context(0)
 n = bad = 0
@@ -55,6 +55,9 @@ while time.time() < t_end:
     keep = build(one, False)
     x1, s1, _ = one.window_solve(x0)
     ctxs = [lib.Context(0) for _ in range(world)]
+    for c_ in ctxs:  # (argv[3]: development options for every rank, e.g. "lm_side_stream=2" or "lm_one_collective=1")
+        for kv in (sys.argv[3].split(",") if len(sys.argv) > 3 and sys.argv[3] else []):
+            c_.set_dev_option(kv.split("=")[0], int(kv.split("=")[1]))
     shared = wdist.ThreadComm.shared(world)
     res, errors = [None] * world, []
 

@@ -142,7 +142,7 @@ def test_n_rank_odometry_step_equals_the_one_rank_step(gpu, world):
         _, info, x, _ = res[r]
         for key in ("new_surfels", "sld", "fix", "binary", "unary", "iters", "term"):
             assert info[key] == info1[key], (r, key, info[key], info1[key])
-        assert info["allreduce_bytes"] == 8 * wdist.packed_count(ns) < 2_000_000
+        assert info["allreduce_bytes"] == 8 * wdist.corner_count(ns) < 2_000_000
         assert np.array_equal(x, res[0][2]), "ranks diverged"
         # north_star: pose increments within 1e-6 relative of the single-GPU step
         assert np.abs(x - x1).max() <= 1e-6 * max(np.abs(x1).max(), 1e-12), np.abs(x - x1).max()
@@ -189,5 +189,5 @@ def test_two_processes_on_one_gpu_run_the_n_rank_step(gpu, tmp_path):
     for r in range(2):
         for key in ("new_surfels", "sld", "fix", "binary", "unary", "iters", "term"):
             assert int(res[r][key]) == info1[key], (r, key, res[r][key], info1[key])
-        assert int(res[r]["allreduce_bytes"]) == 8 * wdist.packed_count(len(w["sample_times"]))
+        assert int(res[r]["allreduce_bytes"]) == 8 * wdist.corner_count(len(w["sample_times"]))
         assert np.abs(res[r]["x"] - x1).max() <= 1e-6 * max(np.abs(x1).max(), 1e-12)

@@ -275,6 +275,58 @@ def test_two_rank_sharded_solve_on_one_gpu(gpu, oracle):
     del keep_all
 
 
+@pytest.mark.parametrize("option", [("lm_side_stream", 2), ("lm_side_stream", 0), ("lm_one_collective", 1)])
+def test_sharded_solve_forms(gpu, oracle, option):
+    """the forms of a sharded window's linearisation (round 6) on three thread-ranks: the two-collective form with the large
+    collective on the side stream (its event choreography, forced for a communicator of callbacks) and on the ctx stream, and rounds
+    3 - 5's one all-reduce: ranks bitwise equal, iterations of the one-rank solve, corrections 1e-6, and the payload each form quotes"""
+    import threading
+
+    from wildcat_slam_amd import dist as wdist
+    from wildcat_slam_amd import lib
+
+    w = synth.surfel_window(4, 260, seed=31, fixed_patches=130)
+    params = oracle.default_params()
+    pairs = oracle.match(w["surf"], w["pose"], w["surf"], w["pose"], True, params)
+    pf = oracle.match(w["surf"], w["pose"], w["fix_surf"], w["fix_pose"], False, params)
+    ns = len(w["sample_times"])
+    x0 = np.zeros(12 * ns)
+    keep = [gpu.to_device(a) for a in (w["surf"], w["pose"], pairs, w["fix_surf"], w["fix_pose"], pf)]
+    gpu.window_build(keep[0], keep[1], keep[2], len(pairs), w["imu"], w["sample_times"], w["grav"], True, keep[3], keep[4], keep[5], len(pf))
+    x_ref, s_ref, _ = gpu.window_solve(x0)
+    world = 3
+    ctxs = [lib.Context(0) for _ in range(world)]
+    shared = wdist.ThreadComm.shared(world)
+    res, errors = [None] * world, []
+
+    def run(r):
+        try:
+            c = ctxs[r]
+            c.set_dev_option(*option)
+            c.set_comm(wdist.ThreadComm(shared, r, c))
+            k = [c.to_device(a) for a in (w["surf"], w["pose"], pairs, w["fix_surf"], w["fix_pose"], pf)]
+            c.window_build(k[0], k[1], k[2], len(pairs), w["imu"], w["sample_times"], w["grav"], True, k[3], k[4], k[5], len(pf), sharded=True)
+            want = wdist.packed_count(ns) if option[0] == "lm_one_collective" else wdist.corner_count(ns)
+            assert c.window_reduce_bytes() == 8 * want
+            res[r] = c.window_solve(x0) + (k,)
+        except Exception as e:  # pragma: no cover
+            errors.append(e)
+            shared["bar"].abort()
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=120)
+    assert not errors, errors
+    for r in range(1, world):
+        assert np.array_equal(res[0][0], res[r][0]), "ranks diverged"
+    assert res[0][1].iterations == s_ref.iterations and res[0][1].successful_steps == s_ref.successful_steps
+    assert _rel(res[0][0], x_ref) < 1e-6
+    for c in ctxs:
+        c.close()
+
+
 def test_sharded_solve_through_the_ctx_communicator(gpu, oracle):
     """the same lock-step solve through wc_window_build_sharded: every rank passes the SAME replicated arguments, the library
     takes the rank's share of the correspondences and of the IMU triples and the all-reduce goes through the ctx's wc_comm (the
@@ -314,7 +366,7 @@ def test_sharded_solve_through_the_ctx_communicator(gpu, oracle):
             c.window_build(k[0], k[1], k[2], len(pairs), w["imu"], w["sample_times"], w["grav"], True, sharded=True)
             nb, _, ni, _ = c.window_counts()
             assert nb == wdist.shard_range(len(pairs), r, world)[1] and 0 < ni < len(w["imu"]) - 2
-            assert c.window_reduce_bytes() == 8 * wdist.packed_count(ns)
+            assert c.window_reduce_bytes() == 8 * wdist.corner_count(ns)
             res[r] = c.window_solve(x0) + (k,)
         except Exception as e:  # pragma: no cover
             errors.append(e)

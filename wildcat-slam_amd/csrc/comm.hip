@@ -132,6 +132,15 @@ int rc_allgatherv(void *user, const void *d_send, uint64_t send_bytes, void *d_r
 
 }  // namespace
 
+// the in-library binding's all-reduce on a stream OTHER than the ctx stream (window.hip: the large collective of the two-collective form
+// runs beside the bias elimination).  -1: the ctx's communicator is not this binding.  The caller orders the streams with events so
+// that the communicator's collectives stay totally ordered.
+int wc_rccl_allreduce_on(wc_ctx *ctx, double *d_buf, uint64_t count, hipStream_t st) {
+  if (!ctx || !ctx->rccl || ctx->comm.user != ctx->rccl) return -1;
+  RcclComm *c = (RcclComm *)ctx->rccl;
+  return c->api->AllReduce(d_buf, d_buf, (size_t)count, ncclDouble, ncclSum, c->comm, st) == ncclSuccess ? 0 : 1;
+}
+
 extern "C" int wc_comm_rccl_unique_id(char out128[128]) {
   if (!out128) return WC_ERR_ARG;
   RcclApi *api = rccl_api(nullptr);

@@ -53,6 +53,8 @@ struct wc_dev_opts {
   int match_pair_swap = 0;   // the sliding-window search on the helper instead of the fixed-window one
   int lin_imu_apart = 0, lin_unary_apart = 0, lin_post_apart = 0;  // the linearisation's families / mailbox as launches of their own
   int lm_dense = 0;          // round 2's LM step: dense Cholesky of all 12 ns unknowns
+  int lm_side_stream = 1;    // two-collective form: the large collective on a side stream (1: with the in-library RCCL binding; 0: never; 2: always - tests)
+  int lm_one_collective = 0; // sharded windows: rounds 3 - 5's ONE all-reduce per linearisation (IMU triples sharded too) instead of the two-collective form
   int dbg_lm = 0;            // experiment bits of the LM solve's kernels (timing runs of a development session; results may be WRONG)
   int lm_back_chunks = 0;    // rounds 2 - 5's back substitution (chunk solves + products) and tail launches instead of k_back_mul + the fused tail
   int lm_sync = 0;           // wait for the stream instead of the mailbox ticket
@@ -220,6 +222,7 @@ inline int wc_ensure(wc_ctx *ctx, wc_buf &b, size_t bytes) {
   b.cap = want;
   return WC_OK;
 }
+int wc_rccl_allreduce_on(wc_ctx *ctx, double *d_buf, uint64_t count, hipStream_t st);  // comm.hip: the RCCL binding on a given stream (-1: not installed)
 #define WC_TRY(expr)            \
   do {                          \
     int rc_ = (expr);           \

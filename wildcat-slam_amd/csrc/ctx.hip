@@ -77,6 +77,8 @@ const DevOpt kDevOpts[] = {
     {"lm_dense", "WC_LM_DENSE", &wc_dev_opts::lm_dense, true},
     {"lm_back_chunks", "WC_LM_BACK_CHUNKS", &wc_dev_opts::lm_back_chunks, true},
     {"dbg_lm", "WC_DBG_LM", &wc_dev_opts::dbg_lm, false},
+    {"lm_one_collective", "WC_LM_ONE_COLLECTIVE", &wc_dev_opts::lm_one_collective, true},
+    {"lm_side_stream", "WC_LM_SIDE_STREAM", &wc_dev_opts::lm_side_stream, false},
     {"lm_sync", "WC_LM_SYNC", &wc_dev_opts::lm_sync, true},
     {"lm_eval_pass", "WC_LM_EVAL_PASS", &wc_dev_opts::lm_eval_pass, true},
     {"pcr_ahead", "WC_PCR_AHEAD", &wc_dev_opts::pcr_ahead, true},

@@ -103,6 +103,13 @@ struct wc_window_state {
   // offset of block pair pid in the reduction buffer: 144 doubles for a pair of sample blocks at most two apart (IMU factors
   // reach that far, cost_functor.h:264-355), 36 - the pose x pose corner - for the others (surfel factors only, :16-179)
   bool sharded = false;
+  uint32_t lin_count = 0;  // linearisations enqueued in the two-collective form (parity of the late max |g| slot)
+  // the large collective + k_expand_corners on a stream of their own, beside the bias elimination (ordered by events; joined in front of
+  // whatever reads pose blocks or writes the buffers again)
+  hipStream_t side = nullptr;
+  hipEvent_t ev_side_go = nullptr, ev_side_done = nullptr;
+  bool side_pending = false;
+  bool two_coll = false;  // sharded by wc_window_build_sharded with the IMU factors replicated: two collectives per linearisation
   wc_buf pcr_D[2], pcr_A[2], pcr_R[2], yred;  // bias elimination by parallel cyclic reduction (window_schur.inc)
   wc_buf pair_off;
   uint32_t red_H = 0;  // doubles of the reduction buffer in front of {g (np), cost, spare}
@@ -889,6 +896,14 @@ struct GatherArgs {
   int packed;  // H = the multi-GPU reduction buffer: block pairs in pair order at pair_off[pid] (144 doubles, or the 6 x 6 pose
                // corner of a pair more than two sample blocks apart); else the dense n x n matrix
   const uint32_t *pair_off;
+  // Round 6, the two-collective form of a sharded window: the IMU factors are REPLICATED on every rank, the surfel factors
+  // sharded; a linearisation gathers twice -
+  //   only = 1 (with packed): sources of SURFEL pieces alone (local block width 6) -> the 6 x 6 pose corner of EVERY pair at 36 pid, the
+  //            pose half of g at 36 npairs + 6 I, the surfel pieces' cost: what the ranks sum (one all-reduce, needed by k_schur_form);
+  //   only = 2 (dense): sources of IMU pieces alone (width 12) -> near / heavy pairs of H, g, the IMU pieces' cost: complete on every
+  //            rank without a collective, and all the bias elimination reads
+  // only = 0: every source (one GPU, or the one-collective form).
+  int only;
   // post != 0: the last of the ns + 1 workgroups that form g and the cost also forms max |g| and stores the mailbox (what
   // k_post_reduce does as a launch of its own): `done` counts them, and is left at zero
   int post, mail_slot;
@@ -903,7 +918,7 @@ struct GatherArgs {
 // the kernel lasts as long as its longest heavy pair (350 sources, 50 per group), 39.7 us of 41 by per-workgroup stamps.
 template <int STRIDE, int ILP>
 __device__ __forceinline__ double gather_pair_sum(const Src *src, const double *partial, uint32_t s0, uint32_t eend, int u, int v,
-                                                  double acc = 0.0) {
+                                                  double acc = 0.0, uint32_t want_w = 0u /* 6 / 12: sources of that block width only */) {
   const uint2 *src2 = (const uint2 *)src;
   static_assert(sizeof(Src) == 8, "descriptor = two words");
   uint2 d[ILP];
@@ -920,7 +935,7 @@ __device__ __forceinline__ double gather_pair_sum(const Src *src, const double *
       const uint32_t sq = s + q * STRIDE;
       const bool live = sq < eend;
       const uint32_t part_off = d[q].x, sp = d[q].y & 0xFFu, sq_ = (d[q].y >> 8) & 0xFFu, sw = (d[q].y >> 16) & 0xFFu, sT = d[q].y >> 24;
-      ok[q] = live && (uint32_t)u < sw && (uint32_t)v < sw;
+      ok[q] = live && (uint32_t)u < sw && (uint32_t)v < sw && (want_w == 0u || sw == want_w);
       uint32_t r = sp * sw + u, c = sq_ * sw + v;
       if (r > c) {
         const uint32_t t = r;
@@ -999,6 +1014,7 @@ __global__ void __launch_bounds__(144 * kGG, 8) k_gather(GatherArgs a) {
 #ifdef WC_GATHER_KNOCK
     if (WC_GATHER_KNOCK & 2) return;
 #endif
+    if (a.only == 2) return;  // (far pairs have surfel sources only)
     const int grp = tid / 36, e = tid % 36, u = e / 6, v = e % 6;
     const uint2 *src2 = (const uint2 *)a.src;
     const int n = 12 * a.ns;
@@ -1046,7 +1062,7 @@ __global__ void __launch_bounds__(144 * kGG, 8) k_gather(GatherArgs a) {
       const int I = job[k].I, J = job[k].J, gi = I * 12 + u, gj = J * 12 + v;
       if (a.fix_first && ((gi >= 3 && gi < 6) || (gj >= 3 && gj < 6))) acc = 0.0;  // SubsetParameterization(12,{3,4,5})
       if (a.packed) {
-        if (live[k]) a.H[(size_t)a.pair_off[job[k].pid] + e] = acc;
+        if (live[k]) a.H[a.only ? (size_t)36 * job[k].pid + e : (size_t)a.pair_off[job[k].pid] + e] = acc;
         continue;
       }
       __syncthreads();  // (the previous set's mirror has been read)
@@ -1068,6 +1084,7 @@ __global__ void __launch_bounds__(144 * kGG, 8) k_gather(GatherArgs a) {
 #endif
     const int grp = tid / 144, e = tid % 144;
     const int u = e / 12, v = e % 12;
+    const uint32_t want_w = a.only == 1 ? 6u : (a.only == 2 ? 12u : 0u);
     // A heavy workgroup sums ONE pair; a light one kLightSets x kGG pairs, kLightSets per group, whose first four sources
     // are requested together: a light pair is a chain of three round trips (list bounds, descriptors, values) and hardly any
     // arithmetic, and with one pair per group the 1 162 light workgroups of C4 queued for the 512 workgroup slots of the chip
@@ -1083,8 +1100,13 @@ __global__ void __launch_bounds__(144 * kGG, 8) k_gather(GatherArgs a) {
       const uint32_t pid = a.heavy[2 * blk], mid = a.heavy[2 * blk + 1];
       const uint32_t b = a.src_begin[pid], eend = a.src_begin[pid + 1];
       const int g36 = tid / 36, e36 = tid % 36;
-      const double acc6 = gather_pair_sum<kFarGroups, kHeavyIlp>(a.src, a.partial, b + g36, mid, e36 / 6, e36 % 6);
-      double acc = gather_pair_sum<kGG, 4>(a.src, a.partial, mid + grp, eend, u, v);
+      const double acc6 = a.only == 2 ? 0.0 : gather_pair_sum<kFarGroups, kHeavyIlp>(a.src, a.partial, b + g36, mid, e36 / 6, e36 % 6);
+      // (only = 2: the IMU sources one after the other by group 0 - the order of the light pairs' sums.  A pair is heavy on one rank and
+      // light on another - the ranks hold different surfel shares -, and these sums do not pass through a collective that would make the
+      // ranks agree: every rank must form them the same way, to the bit)
+      double acc = a.only == 1 ? 0.0
+                   : a.only == 2 ? (grp == 0 ? gather_pair_sum<1, 4>(a.src, a.partial, mid, eend, u, v) : 0.0)
+                                 : gather_pair_sum<kGG, 4>(a.src, a.partial, mid + grp, eend, u, v);
       sred[tid] = acc6;
       sred2[grp * 144 + e] = acc;
       __syncthreads();
@@ -1120,7 +1142,7 @@ __global__ void __launch_bounds__(144 * kGG, 8) k_gather(GatherArgs a) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const uint32_t part_off = d[k][q].x, sp = d[k][q].y & 0xFFu, sq_ = (d[k][q].y >> 8) & 0xFFu, sw = (d[k][q].y >> 16) & 0xFFu, sT = d[k][q].y >> 24;
-          ok[k][q] = writek[k] && bk[k] + q < ek[k] && (uint32_t)u < sw && (uint32_t)v < sw;
+          ok[k][q] = writek[k] && bk[k] + q < ek[k] && (uint32_t)u < sw && (uint32_t)v < sw && (want_w == 0u || sw == want_w);
           uint32_t r = sp * sw + u, c = sq_ * sw + v;
           if (r > c) {
             const uint32_t t = r;
@@ -1134,7 +1156,7 @@ __global__ void __launch_bounds__(144 * kGG, 8) k_gather(GatherArgs a) {
 #pragma unroll
         for (int q = 0; q < 4; ++q)
           if (ok[k][q]) acc += val[k][q];
-        if (writek[k] && ek[k] - bk[k] > 4u) acc = gather_pair_sum<1, 8>(a.src, a.partial, bk[k] + 4u, ek[k], u, v, acc);  // (same order: onto acc)
+        if (writek[k] && ek[k] - bk[k] > 4u) acc = gather_pair_sum<1, 8>(a.src, a.partial, bk[k] + 4u, ek[k], u, v, acc, want_w);  // (same order: onto acc)
         acck[k] = acc;
       }
     }
@@ -1161,7 +1183,9 @@ __global__ void __launch_bounds__(144 * kGG, 8) k_gather(GatherArgs a) {
       if (a.fix_first && ((gi >= 3 && gi < 6) || (gj >= 3 && gj < 6))) acc = 0.0;  // SubsetParameterization(12,{3,4,5})
       if (a.packed) {
         if (write) {
-          if (J - I <= 2)
+          if (a.only) {
+            if (u < 6 && v < 6) a.H[(size_t)36 * pid + u * 6 + v] = acc;  // (surfel factors touch pose corners only)
+          } else if (J - I <= 2)
             a.H[(size_t)a.pair_off[pid] + e] = acc;
           else if (u < 6 && v < 6)
             a.H[(size_t)a.pair_off[pid] + u * 6 + v] = acc;  // (the rest of a far pair's block is zero: no IMU factor reaches it)
@@ -1196,6 +1220,41 @@ __global__ void __launch_bounds__(144 * kGG, 8) k_gather(GatherArgs a) {
     constexpr int NGg = 144 * kGG / 12;
     const int I = (int)blk, grp = tid / 12, u = tid % 12;
     double acc = 0.0;
+    if (a.only == 2) {
+      // the IMU pieces' sources are the tail of the block's list (piece order); where it begins depends on this rank's surfel share, the
+      // sum must not: group j fetches IMU source j, lane u adds them in list order (rank-independent, to the bit)
+      __shared__ uint32_t s_mid;
+      const uint32_t b0 = a.gsrc_begin[I], eend = a.gsrc_begin[I + 1];
+      if (tid == 0) s_mid = eend;
+      __syncthreads();
+      for (uint32_t s = b0 + tid; s < eend; s += 144 * kGG)
+        if (a.gsrc[s].w == 12) atomicMin(&s_mid, s);
+      __syncthreads();
+      const uint32_t mid = s_mid;
+      double tot = 0.0;
+      for (uint32_t c0 = mid; c0 < eend; c0 += NGg) {
+        const uint32_t sq = c0 + grp;
+        double val = 0.0;
+        if (sq < eend) {
+          const GSrc sr = a.gsrc[sq];
+          if (u < sr.w) val = a.partial[sr.part_off + tri_index(sr.p * sr.w + u, sr.T - 1, sr.T)];
+        }
+        __syncthreads();
+        sred[tid] = val;
+        __syncthreads();
+        if (tid < 12) {
+          const uint32_t m = min((uint32_t)NGg, eend - c0);
+          for (uint32_t q = 0; q < m; ++q) tot += sred[q * 12 + u];
+        }
+      }
+      acc = tot;
+      if (tid < 12) {
+        const int gi = I * 12 + u;
+        if (a.fix_first && gi >= 3 && gi < 6) acc = 0.0;
+        a.g[gi] = acc;
+      }
+      return;
+    }
     {
       const uint32_t eend = a.gsrc_begin[I + 1];
       for (uint32_t s = a.gsrc_begin[I] + grp; s < eend; s += 4 * NGg) {
@@ -1206,7 +1265,7 @@ __global__ void __launch_bounds__(144 * kGG, 8) k_gather(GatherArgs a) {
           const uint32_t sq = s + q * NGg;
           const bool live = sq < eend;
           const GSrc sr = a.gsrc[live ? sq : s];
-          ok[q] = live && u < sr.w;
+          ok[q] = live && u < sr.w && (a.only == 0 || (a.only == 1) == (sr.w == 6));
           val[q] = a.partial[sr.part_off + (ok[q] ? tri_index(sr.p * sr.w + u, sr.T - 1, sr.T) : 0u)];
         }
 #pragma unroll
@@ -1221,7 +1280,11 @@ __global__ void __launch_bounds__(144 * kGG, 8) k_gather(GatherArgs a) {
       for (int q = 0; q < NGg; ++q) acc += sred[q * 12 + u];
       const int gi = I * 12 + u;
       if (a.fix_first && gi >= 3 && gi < 6) acc = 0.0;
-      a.g[gi] = acc;
+      if (a.only == 1) {
+        if (u < 6) a.g[I * 6 + u] = acc;  // (the pose half, packed)
+      } else {
+        a.g[gi] = acc;
+      }
     }
     if (a.post) {
       double mx = tid < 12 ? fabs(acc) : 0.0;  // (lanes 0 .. 11 of wavefront 0 hold the block's entries)
@@ -1239,14 +1302,17 @@ __global__ void __launch_bounds__(144 * kGG, 8) k_gather(GatherArgs a) {
      // chain of the kernel; same sums in the same order)
     constexpr int NT = 144 * kGG;
     double acc = 0.0;
-    const double *pcost = a.partial + a.cost_base;
-    for (uint32_t p0 = tid; p0 < a.npieces; p0 += 4 * NT) {
+    const uint32_t nsurf = a.nb_pieces + a.nu_pieces;
+    const uint32_t pbeg = a.only == 2 ? nsurf : 0u, pend = a.only == 1 ? nsurf : a.npieces;  // (surfel pieces first, then the IMU pieces)
+    const double *pcost = a.partial + a.cost_base + pbeg;
+    const uint32_t npc = pend - pbeg;
+    for (uint32_t p0 = tid; p0 < npc; p0 += 4 * NT) {
       double val[4];
       bool ok[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const uint32_t p = p0 + q * NT;
-        ok[q] = p < a.npieces;
+        ok[q] = p < npc;
         val[q] = pcost[ok[q] ? p : p0];
       }
 #pragma unroll
@@ -1294,6 +1360,67 @@ __global__ void __launch_bounds__(144) k_expand_pairs(const double *packed, uint
     v = packed[(size_t)pair_off[pid] + u * 6 + w];
   H[(size_t)gi * n + gj] = v;
   H[(size_t)gj * n + gi] = v;
+}
+
+// The two-collective form: what the ranks summed - the 6 x 6 pose corner of every pair (36 doubles at 36 pid), the pose
+// half of g - joins what every rank holds complete: near pairs' corners ADD to the IMU factors' sums k_gather (only = 2) has just
+// written, far pairs' corners are the sum itself.  Workgroup npairs: g's pose half, then max |g| over all unknowns -> mail[gslot] and -
+// late_host != nullptr - the pinned mailbox's late slot (the LM loop reads it with the NEXT iteration's ticket: the trust-region decision
+// needs the cost alone, which k_post_cost has sent ahead).
+__global__ void __launch_bounds__(64) k_expand_corners(const double *red, uint32_t npairs, int ns, double *H, double *g, double *mail, int gslot,
+                                                      double *late_host) {
+  const uint32_t pid = blockIdx.x;
+  const int e = threadIdx.x;
+  const int n = 12 * ns;
+  if (pid == npairs) {
+    __shared__ double smx[64];
+    const double *rg = red + (size_t)36 * npairs;
+    for (int i = e; i < 6 * ns; i += 64) g[12 * (i / 6) + i % 6] += rg[i];
+    __syncthreads();
+    double mx = 0.0;
+    for (int i = e; i < n; i += 64) mx = fmax(mx, fabs(g[i]));
+    smx[e] = mx;
+    __syncthreads();
+    for (int st = 32; st > 0; st >>= 1) {
+      if (e < st) smx[e] = fmax(smx[e], smx[e + st]);
+      __syncthreads();
+    }
+    if (e == 0) {
+      mail[gslot] = smx[0];
+      if (late_host) *late_host = smx[0];
+    }
+    return;
+  }
+  if (e >= 36) return;
+  const float f = 2.f * ns + 1.f;
+  int I = (int)((f - sqrtf(fmaxf(f * f - 8.f * (float)pid, 0.f))) * 0.5f);
+  I = max(0, min(I, ns - 1));
+  while (I > 0 && (uint32_t)(I * ns - I * (I - 1) / 2) > pid) --I;
+  while ((uint32_t)((I + 1) * ns - (I + 1) * I / 2) <= pid) ++I;
+  const int J = I + (int)(pid - (uint32_t)(I * ns - I * (I - 1) / 2));
+  const int u = e / 6, w = e % 6, gi = I * 12 + u, gj = J * 12 + w;
+  double v = red[(size_t)36 * pid + e];
+  if (J - I <= 2) v += H[(size_t)gi * n + gj];  // (the IMU factors' part, written by this linearisation's second gather)
+  H[(size_t)gi * n + gj] = v;
+  if (I != J) H[(size_t)gj * n + gi] = v;  // (a diagonal block's thread (u, w) owns entry (u, w) alone: (w, u) is thread (w, u)'s)
+}
+
+// the linearisation's cost = the IMU factors' (every rank's own sum: mail[54]) + the surfel factors' (summed over the ranks: mail[52]),
+// sent to the host as soon as the 16-byte collective is through
+__global__ void __launch_bounds__(64) k_post_cost(double *mail, int slot, double *cost_out, double *host_mail, unsigned long long ticket) {
+  const int tid = threadIdx.x;
+  const double c = mail[54] + mail[52];
+  if (tid == 0) mail[slot] = c, cost_out[0] = c;
+  if (host_mail) {
+    if (tid < 40) host_mail[tid] = tid == slot ? c : mail[tid];
+    if (ticket) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (tid == 0) {
+        __threadfence_system();
+        __hip_atomic_store((unsigned long long *)(host_mail + 48), ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+  }
 }
 
 // ---- cost-only evaluation (candidate step; problem.Evaluate) ----------------------------------------------------------
@@ -2372,6 +2499,12 @@ void wc_window_free(wc_ctx *ctx) {
   if (W->h_up) (void)hipHostFree(W->h_up);
   for (hipEvent_t e : W->fam_done)
     if (e) (void)hipEventDestroy(e);
+  if (W->side) {
+    (void)hipStreamSynchronize(W->side);
+    (void)hipStreamDestroy(W->side);
+  }
+  if (W->ev_side_go) (void)hipEventDestroy(W->ev_side_go);
+  if (W->ev_side_done) (void)hipEventDestroy(W->ev_side_done);
   delete W;
   ctx->win = nullptr;
 }
@@ -2457,6 +2590,7 @@ static int window_build_impl(wc_ctx *ctx, const wc_surfel *d_sld_surf, const wc_
   wc_window_state *W = ctx->win;
   W->built = false;
   W->sharded = sharded;
+  W->two_coll = false;  // (wc_window_build_sharded sets it behind a successful build)
   const wc_params &P = ctx->P;
   const int ns = (int)ns_;
   W->ns = ns;
@@ -2798,7 +2932,15 @@ extern "C" int wc_window_build_sharded(wc_ctx *ctx, const wc_surfel *d_sld_surf,
   share(n_pairs_sld, lo_b, n_b);
   share(n_pairs_fix, lo_u, n_u);
   const uint64_t n_fac = (h_imu && n_imu >= 3) ? n_imu - 2 : 0;
-  share(n_fac, lo_i, n_i);
+  // Round 6: the IMU factors are REPLICATED - a few hundred to two thousand factors whose family is a latency chain of ~15 us
+  // whatever the window - so that everything the bias elimination reads (bias x bias, bias x pose, the bias half of g) is complete on every
+  // rank without a collective, and the ranks only sum the surfel factors' pose corners.  (development option lm_one_collective: rounds 3 - 5's
+  // form - the IMU triples sharded too, ONE all-reduce of {upper block pairs, g, cost} per linearisation.)
+  const bool two = ctx->dev.lm_one_collective == 0;
+  if (two)
+    lo_i = 0, n_i = n_fac;
+  else
+    share(n_fac, lo_i, n_i);
   const int rc_local = window_build_impl(ctx, d_sld_surf, d_sld_pose, d_pairs_sld ? d_pairs_sld + lo_b : nullptr, n_b, d_fix_surf, d_fix_pose,
                                          d_pairs_fix ? d_pairs_fix + lo_u : nullptr, n_u, n_i ? h_imu + lo_i : nullptr, n_i ? n_i + 2 : 0,
                                          h_sample_times, ns_, h_grav, fix_first_pos, true);
@@ -2823,6 +2965,7 @@ extern "C" int wc_window_build_sharded(wc_ctx *ctx, const wc_surfel *d_sld_surf,
     if (h_imu[i + 2].t > W->times.back()) break;
     ++ni_all;
   }
+  W->two_coll = two;
   const double mine[4] = {(double)W->nb, (double)W->nu, (double)W->ni, 1.0};
   double *chk = (double *)W->mail.p + 48;
   WC_HIP(ctx, hipMemcpyAsync(chk, mine, sizeof(mine), hipMemcpyHostToDevice, ctx->stream));
@@ -2831,7 +2974,8 @@ extern "C" int wc_window_build_sharded(wc_ctx *ctx, const wc_surfel *d_sld_surf,
   double all[4];
   WC_HIP(ctx, hipMemcpyAsync(all, chk, sizeof(all), hipMemcpyDeviceToHost, ctx->stream));
   WC_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  if (all[0] != (double)n_pairs_sld || all[1] != (double)n_pairs_fix || all[2] != (double)ni_all || all[3] != (double)w) {
+  const double imu_expected = two ? (double)(w * ni_all) : (double)ni_all;  // (replicated: every rank holds all of them)
+  if (all[0] != (double)n_pairs_sld || all[1] != (double)n_pairs_fix || all[2] != imu_expected || all[3] != (double)w) {
     W->built = false;
     return wc_fail(ctx, WC_ERR_ARG,
                    "wc_window_build_sharded: the ranks' shares do not add up to the problem this rank was given (binary %.0f of %llu, unary %.0f of "
@@ -2894,10 +3038,19 @@ int do_allreduce(wc_ctx *ctx, wc_window_state *W, double *d_buf, size_t count) {
   return WC_OK;
 }
 
+// the ctx stream waits for the side stream's last expand (two-collective form); a no-op when nothing is in flight there
+int join_side(wc_ctx *ctx, wc_window_state *W) {
+  if (!W->side_pending) return WC_OK;
+  WC_HIP(ctx, hipStreamWaitEvent(ctx->stream, W->ev_side_done, 0));
+  W->side_pending = false;
+  return WC_OK;
+}
+
 // all kernels of one linearisation at x (device): partials -> H, g ; cost -> mail[slot], max|g| -> mail[slot+1]
 int enqueue_linearize(wc_ctx *ctx, wc_window_state *W, const double *d_x, int mail_slot, bool post = true, bool other = false,
                       double *host_mail = nullptr, unsigned long long ticket = 0) {
   hipStream_t st = ctx->stream;
+  WC_TRY(join_side(ctx, W));  // (the reduction buffer and the linearisation buffers are written again below)
   const Piece *pcs = (const Piece *)W->pieces.p;
   double *partial = (double *)W->partial.p;
   // (Round 3, tried: k_lin_imu - 14.5 us of dependent fp64 chains in a few hundred workgroups - on a stream of its own beside the
@@ -2943,8 +3096,9 @@ int enqueue_linearize(wc_ctx *ctx, wc_window_state *W, const double *d_x, int ma
   // multi-GPU: the ranks reduce the upper block triangle only (pair order, 144 doubles per block pair, then g and the cost):
   // half the bytes of the dense matrix on the wire; one more kernel spreads the sum into both triangles
   const bool packed = multi_gpu(ctx, W);
+  const bool two = packed && W->two_coll && !W->allreduce;  // (the two-collective form: IMU factors replicated by wc_window_build_sharded)
   double *red = nullptr;
-  const size_t red_count = (size_t)W->red_H + W->np + 2;
+  const size_t red_count = two ? (size_t)36 * W->npairs + 6 * (size_t)W->ns : (size_t)W->red_H + W->np + 2;
   if (packed) {
     WC_TRY(wc_ensure(ctx, W->reduce, red_count * 8));
     red = (double *)W->reduce.p;
@@ -2961,7 +3115,55 @@ int enqueue_linearize(wc_ctx *ctx, wc_window_state *W, const double *d_x, int ma
   const bool post_apart = ctx->dev.lin_post_apart != 0;
   ga.post = (post && !packed && !post_apart) ? 1 : 0;
   ga.mail_slot = mail_slot, ga.done = (uint32_t *)((double *)W->mail.p + 60), ga.mail = (double *)W->mail.p, ga.host_mail = host_mail, ga.ticket = ticket;
-  k_gather<<<W->nheavy + (W->nnear + kGG * kLightSets - 1) / (kGG * kLightSets) + (W->nfar + kFarGroups * kFarSets - 1) / (kFarGroups * kFarSets) + W->ns + 1, 144 * kGG, 0, st>>>(ga);
+  const uint32_t gather_grid = W->nheavy + (W->nnear + kGG * kLightSets - 1) / (kGG * kLightSets) + (W->nfar + kFarGroups * kFarSets - 1) / (kFarGroups * kFarSets) + W->ns + 1;
+  ga.only = 0;
+  if (two) {
+    // Two gathers, two collectives: the surfel factors' sums into the compact buffer + their cost; the (replicated) IMU factors'
+    // sums straight into H / g + their cost.  The 16-byte sum of the costs goes first and k_post_cost sends the linearisation's cost to the
+    // host: the trust-region decision does not wait for the 0.6 - 2.3 MB of pose corners, which only k_schur_form needs.
+    double *mail = (double *)W->mail.p;
+    ga.only = 1, ga.packed = 1, ga.H = red, ga.g = red + (size_t)36 * W->npairs, ga.cost = mail + 52, ga.post = 0;
+    k_gather<<<gather_grid, 144 * kGG, 0, st>>>(ga);
+    ga.only = 2, ga.packed = 0, ga.H = lin_H(W, other), ga.g = lin_g(W, other), ga.cost = mail + 54;
+    k_gather<<<gather_grid, 144 * kGG, 0, st>>>(ga);
+    WC_HIP(ctx, hipGetLastError());
+    WC_TRY(do_allreduce(ctx, W, mail + 52, 2));  // collective 1: {cost of the surfel factors, spare}
+    k_post_cost<<<1, 64, 0, st>>>(mail, mail_slot, lin_cost(W, other), post ? host_mail : nullptr, post ? ticket : 0ull);
+    double *late = nullptr;
+    if (host_mail) late = host_mail + 40 + (W->lin_count & 1u);
+    ++W->lin_count;
+    // collective 2 (pose corners + the pose half of g) and the expansion: on the side stream when the communicator enqueues (the in-library
+    // RCCL binding) - the ctx stream goes on with the bias elimination, which reads nothing of it, and waits in front of k_schur_form
+    // (join_side).  Development option lm_side_stream: 0 = on the ctx stream, 2 = the side stream's choreography also with a communicator
+    // of callbacks (tests: the callback then runs with both streams drained).
+    const bool rccl_side = ctx->comm.stream_ordered && ctx->rccl && ctx->comm.user == ctx->rccl;
+    const bool side = ctx->dev.lm_side_stream == 2 || (ctx->dev.lm_side_stream == 1 && rccl_side);
+    if (side) {
+      if (!W->side) {
+        WC_HIP(ctx, hipStreamCreateWithFlags(&W->side, hipStreamNonBlocking));
+        WC_HIP(ctx, hipEventCreateWithFlags(&W->ev_side_go, hipEventDisableTiming));
+        WC_HIP(ctx, hipEventCreateWithFlags(&W->ev_side_done, hipEventDisableTiming));
+      }
+      WC_HIP(ctx, hipEventRecord(W->ev_side_go, st));
+      WC_HIP(ctx, hipStreamWaitEvent(W->side, W->ev_side_go, 0));
+      if (rccl_side) {
+        if (wc_rccl_allreduce_on(ctx, red, (uint64_t)red_count, W->side) != 0) return wc_fail(ctx, WC_ERR_HIP, "all-reduce (side stream) failed");
+      } else {
+        WC_HIP(ctx, hipStreamSynchronize(W->side));
+        WC_TRY(do_allreduce(ctx, W, red, red_count));
+      }
+      k_expand_corners<<<W->npairs + 1, 64, 0, W->side>>>(red, W->npairs, W->ns, lin_H(W, other), lin_g(W, other), mail, mail_slot + 1, late);
+      WC_HIP(ctx, hipGetLastError());
+      WC_HIP(ctx, hipEventRecord(W->ev_side_done, W->side));
+      W->side_pending = true;
+      return WC_OK;
+    }
+    WC_TRY(do_allreduce(ctx, W, red, red_count));
+    k_expand_corners<<<W->npairs + 1, 64, 0, st>>>(red, W->npairs, W->ns, lin_H(W, other), lin_g(W, other), mail, mail_slot + 1, late);
+    WC_HIP(ctx, hipGetLastError());
+    return WC_OK;
+  }
+  k_gather<<<gather_grid, 144 * kGG, 0, st>>>(ga);
   WC_HIP(ctx, hipGetLastError());
   if (packed) {
     WC_TRY(do_allreduce(ctx, W, red, red_count));  // the ONE collective of a linearisation
@@ -3004,6 +3206,16 @@ int enqueue_evaluate(wc_ctx *ctx, wc_window_state *W, const double *d_x, double 
   if (gi)
     k_eval_imu<<<gi, 256, 0, st>>>(W->wp, (const ImuRec *)W->irec.p, W->ni, d_x, (const double *)W->times_d.p,
                                   d_res ? d_res + W->nb + W->nu : nullptr, cp + gb + gu);
+  if (multi_gpu(ctx, W) && W->two_coll && !W->allreduce) {  // (the IMU factors are on every rank: their cost is added behind the sum of the surfel factors')
+    double *mail = (double *)W->mail.p;
+    k_sum_blocks<<<1, 1024, 0, st>>>(cp, gb + gu, mail, 52, nullptr);
+    k_sum_blocks<<<1, 1024, 0, st>>>(cp + gb + gu, gi, mail, 54, nullptr);
+    WC_HIP(ctx, hipGetLastError());
+    WC_TRY(do_allreduce(ctx, W, mail + 52, 2));
+    k_post_cost<<<1, 64, 0, st>>>(mail, mail_slot, mail + 55, nullptr, 0ull);
+    WC_HIP(ctx, hipGetLastError());
+    return WC_OK;
+  }
   k_sum_blocks<<<1, 1024, 0, st>>>(cp, gb + gu + gi, (double *)W->mail.p, mail_slot, multi_gpu(ctx, W) ? nullptr : host_mail);
   WC_HIP(ctx, hipGetLastError());
   WC_TRY(do_allreduce(ctx, W, (double *)W->mail.p + mail_slot, 1));
@@ -3028,6 +3240,7 @@ extern "C" int wc_window_counts(wc_ctx *ctx, uint64_t counts[4]) {
 
 extern "C" uint64_t wc_window_reduce_bytes(wc_ctx *ctx) {
   if (!ctx || !ctx->win || !ctx->win->built || !multi_gpu(ctx, ctx->win)) return 0;
+  if (ctx->win->two_coll && !ctx->win->allreduce) return ((uint64_t)36 * ctx->win->npairs + 6 * (uint64_t)ctx->win->ns + 2) * 8;  // (+ the 16-byte cost collective)
   return ((uint64_t)ctx->win->red_H + ctx->win->np + 2) * 8;
 }
 
@@ -3048,6 +3261,7 @@ extern "C" int wc_window_linearize(wc_ctx *ctx, const double *h_x, double *d_H, 
   wc_window_state *W = ctx->win;
   WC_HIP(ctx, hipMemcpyAsync(W->x.p, h_x, (size_t)W->n * 8, hipMemcpyHostToDevice, ctx->stream));
   WC_TRY(enqueue_linearize(ctx, W, (const double *)W->x.p, 0));
+  WC_TRY(join_side(ctx, W));
   if (d_H) WC_HIP(ctx, hipMemcpyAsync(d_H, lin_H(W), (size_t)W->n * W->n * 8, hipMemcpyDeviceToDevice, ctx->stream));
   if (d_g) WC_HIP(ctx, hipMemcpyAsync(d_g, lin_g(W), (size_t)W->n * 8, hipMemcpyDeviceToDevice, ctx->stream));
   WC_TRY(read_mail(ctx, W, 2));
@@ -3067,6 +3281,7 @@ extern "C" int wc_window_linearize_timed(wc_ctx *ctx, const double *h_x, int rep
   WC_TRY(enqueue_linearize(ctx, W, (const double *)W->x.p, 0));
   WC_TRY(wc_timer_start(ctx));
   for (int r = 0; r < reps; ++r) WC_TRY(enqueue_linearize(ctx, W, (const double *)W->x.p, 0));
+  WC_TRY(join_side(ctx, W));
   float ms = 0.f;
   WC_TRY(wc_timer_stop_ms(ctx, &ms));
   WC_TRY(read_mail(ctx, W, 2));
@@ -3125,6 +3340,9 @@ extern "C" int wc_window_solve(wc_ctx *ctx, double *h_x_inout, wc_solve_summary 
     h_mail_dev = (double *)dp;
     h_stage_dev = h_mail_dev + 64;
   }
+  // the two-collective form of a sharded window: the cost of a linearisation reaches the host behind the 16-byte collective (ticket), its
+  // max |g| behind the large one - in a late slot of the pinned mailbox the loop reads with the NEXT ticket (two_late)
+  const bool two = multi_gpu(ctx, W) && W->two_coll && !W->allreduce;
   WC_HIP(ctx, hipMemcpyAsync(x, cur.data(), (size_t)n * 8, hipMemcpyHostToDevice, st));
   if (poll_mail && !multi_gpu(ctx, W)) {
     // the first linearisation's cost / max |g| through the pinned mailbox and its ticket, like every later one (the stream
@@ -3136,6 +3354,7 @@ extern "C" int wc_window_solve(wc_ctx *ctx, double *h_x_inout, wc_solve_summary 
     WC_TRY(wait_mail(ctx, ticket));
   } else {
     WC_TRY(enqueue_linearize(ctx, W, x, 0));
+    WC_TRY(join_side(ctx, W));
     k_scale_init<<<(n + 255) / 256, 256, 0, st>>>(H, n, scale);
     WC_TRY(read_mail(ctx, W, 2));
   }
@@ -3152,6 +3371,8 @@ extern "C" int wc_window_solve(wc_ctx *ctx, double *h_x_inout, wc_solve_summary 
   // region radius, which is known).  If that read-back shows a gradient below tolerance, the iteration that was enqueued
   // on top of it is discarded - the reference stops before it.
   bool lin_pending = false;
+  bool two_late = false;  // (two-collective form) max |g| of the accepted point has not been looked at yet: it sits in h_mail[40 + two_at]
+  int two_slot = 0, two_at = 0;
   // Round 3: the candidate's cost comes from a LINEARISATION at the candidate (into the other {H, g, cost} buffer) instead of a
   // cost-only pass over the same records: an accepted step - the rule - then needs no second pass (one pass over the factors
   // per iteration instead of two, -0.05 ms of 0.6 at C4), a rejected one has formed an H nobody uses (+0.1 ms).  Its cost and
@@ -3177,7 +3398,7 @@ extern "C" int wc_window_solve(wc_ctx *ctx, double *h_x_inout, wc_solve_summary 
         summary->termination = 1;
         break;
       }
-      if ((!lin_pending && gmax <= 1e-10) || radius <= 1e-32) {
+      if ((!lin_pending && !two_late && gmax <= 1e-10) || radius <= 1e-32) {
         summary->termination = 0;
         break;
       }
@@ -3218,6 +3439,7 @@ extern "C" int wc_window_solve(wc_ctx *ctx, double *h_x_inout, wc_solve_summary 
             cur ^= 1;
           }
           X = Rp[cur];  // the last level wrote X = T^-1 [C | bB] where the others write R'
+          WC_TRY(join_side(ctx, W));  // (the pose blocks and the pose half of g: summed over the ranks on the side stream)
           k_schur_form<<<((np2 + 255) / 256) * (1 + ns + (np2 - npz)), 256, 0, st>>>(H, g, scale, X, n, ns, ldr, np2, ld2, radius, A, diag, Lmat, (double *)W->Linv.p, fail, (np2 + 255) / 256);
           // (development option lm_back_chunks: rounds 2 - 5's back substitution - chunk solves + products - and k_schur_bias_y / k_lm_step
           // as launches of their own, for A/B runs; default: identity rows appended to the factorisation, k_back_mul, one fused tail)
@@ -3270,6 +3492,7 @@ extern "C" int wc_window_solve(wc_ctx *ctx, double *h_x_inout, wc_solve_summary 
           {
             dim3 grid((np + 255) / 256, np);
             grid.y += 1;  // (+ the workgroup of the first diagonal block)
+            WC_TRY(join_side(ctx, W));
             k_damp_first<<<grid, 256, 0, st>>>(H, g, scale, n, np, ld, radius, A, diag, Lmat, (double *)W->Linv.p, fail);
           }
           for (int k = 0; k + 1 < nblk; ++k) {
@@ -3289,14 +3512,15 @@ extern "C" int wc_window_solve(wc_ctx *ctx, double *h_x_inout, wc_solve_summary 
           }
         }
         unsigned long long ticket = 0;
-        if (cand_lin && poll_mail && !multi_gpu(ctx, W) && h_mail_dev) ticket = ++ctx->mail_ticket;
+        if (cand_lin && poll_mail && (!multi_gpu(ctx, W) || two) && h_mail_dev) ticket = ++ctx->mail_ticket;
+        if (cand_lin && two) two_slot = (int)(W->lin_count & 1u);  // (where this linearisation's max |g| will land)
         if (cand_lin)
-          WC_TRY(enqueue_linearize(ctx, W, xc, 5, /*post=*/true, /*other=*/true, multi_gpu(ctx, W) ? nullptr : h_mail_dev, ticket));  // mail[5] = cost, [6] = max |g| at the candidate
+          WC_TRY(enqueue_linearize(ctx, W, xc, 5, /*post=*/true, /*other=*/true, (multi_gpu(ctx, W) && !two) ? nullptr : h_mail_dev, ticket));  // mail[5] = cost, [6] = max |g| at the candidate
         else
           WC_TRY(enqueue_evaluate(ctx, W, xc, nullptr, 5, h_mail_dev));
         WC_HIP(ctx, hipGetLastError());
         // (one GPU: k_sum_blocks has stored the mailbox to pinned host memory itself; with an all-reduce behind it, copy)
-        if (multi_gpu(ctx, W) || !h_mail_dev) WC_HIP(ctx, hipMemcpyAsync(ctx->h_mail, mail, 40 * 8, hipMemcpyDeviceToHost, st));
+        if ((multi_gpu(ctx, W) && !(two && cand_lin)) || !h_mail_dev) WC_HIP(ctx, hipMemcpyAsync(ctx->h_mail, mail, 40 * 8, hipMemcpyDeviceToHost, st));
         if (cand_lin && use_schur && spec_ok) {
           // pcr_ahead: the next iteration's level 0 from the CANDIDATE's H, while the host waits for this iteration's mailbox and decides
           // (the blocks do not depend on the radius).  An accepted step - the rule - finds them there; a rejected one forms its own.
@@ -3316,6 +3540,15 @@ extern "C" int wc_window_solve(wc_ctx *ctx, double *h_x_inout, wc_solve_summary 
       // take round 2's dense step (development option lm_dense_radius: the exponent, 0 = never).
       const bool schur_now = use_schur && !(ctx->dev.lm_dense_radius > 0 && radius > std::pow(10.0, (double)ctx->dev.lm_dense_radius));
       WC_TRY(attempt(schur_now));
+      if (two_late) {  // max |g| at the point this iteration started from has arrived with the iteration's ticket (its kernels ran behind that expand)
+        gmax = ctx->h_mail[40 + two_at];
+        two_late = false;
+        if (gmax <= 1e-10) {  // GradientToleranceReached there: the reference stops before this iteration
+          --iter;
+          summary->termination = 0;
+          break;
+        }
+      }
       if (lin_pending) {
         resolve_pending();
         if (gmax <= 1e-10) {  // GradientToleranceReached at the point this iteration started from
@@ -3385,6 +3618,7 @@ extern "C" int wc_window_solve(wc_ctx *ctx, double *h_x_inout, wc_solve_summary 
           W->lin_sel ^= 1;
           H = lin_H(W), g = lin_g(W);
           cost = cand_cost, gmax = ctx->h_mail[6];
+          if (two) gmax = 1.0, two_late = true, two_at = two_slot;  // (not there yet: looked at behind the next iteration's ticket)
           if (cost < min_cost) {
             min_cost = cost;
             best = cur;
@@ -3410,6 +3644,10 @@ extern "C" int wc_window_solve(wc_ctx *ctx, double *h_x_inout, wc_solve_summary 
     WC_HIP(ctx, hipMemcpyAsync(ctx->h_mail, mail, 2 * 8, hipMemcpyDeviceToHost, st));
     WC_HIP(ctx, hipStreamSynchronize(st));
     resolve_pending();
+  }
+  if (W->side_pending) {  // (the last linearisation's expansion may still run on the side stream: nothing of this solve outlives the call)
+    WC_TRY(join_side(ctx, W));
+    WC_HIP(ctx, hipStreamSynchronize(st));
   }
   summary->iterations = iter;
   summary->final_cost = min_cost;

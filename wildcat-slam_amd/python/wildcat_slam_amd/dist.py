@@ -43,6 +43,48 @@ def packed_count(ns):
     return pair_offsets(ns)[1] + _padded(12 * ns) + 2
 
 
+def corner_count(ns):
+    """doubles the ranks of a sharded window sum per linearisation in the two-collective form (round 6, csrc/window.hip: k_gather only = 1):
+    the 6 x 6 pose corner of EVERY upper block pair (36 npairs), the pose half of g (6 ns) - the large collective - and {cost of the
+    surfel factors, spare} - the 16-byte collective that goes first"""
+    return 36 * (ns * (ns + 1) // 2) + 6 * ns + 2
+
+
+def pack_corners(H, g):
+    """the surfel factors' H, g of ONE rank (their bias rows and columns are zero) -> the large collective's buffer"""
+    n = len(g)
+    ns = n // 12
+    buf = np.zeros(corner_count(ns) - 2)
+    pid = 0
+    for i in range(ns):
+        for j in range(i, ns):
+            blk = H[12 * i : 12 * i + 12, 12 * j : 12 * j + 12]
+            assert not blk[6:, :].any() and not blk[:, 6:].any(), "a surfel factor touched a bias unknown"
+            buf[36 * pid : 36 * pid + 36] = blk[:6, :6].reshape(-1)
+            pid += 1
+    gg = np.asarray(g).reshape(ns, 12)
+    assert not gg[:, 6:].any()
+    buf[36 * pid :] = gg[:, :6].reshape(-1)
+    return buf
+
+
+def add_corners(buf, H_imu, g_imu):
+    """the summed buffer on top of the (replicated) IMU factors' H, g -> the window's H, g (what k_expand_corners does on the device)"""
+    n = len(g_imu)
+    ns = n // 12
+    H, g = np.array(H_imu, copy=True), np.array(g_imu, copy=True)
+    pid = 0
+    for i in range(ns):
+        for j in range(i, ns):
+            c = buf[36 * pid : 36 * pid + 36].reshape(6, 6)
+            H[12 * i : 12 * i + 6, 12 * j : 12 * j + 6] += c
+            if i != j:
+                H[12 * j : 12 * j + 6, 12 * i : 12 * i + 6] += c.T
+            pid += 1
+    g.reshape(ns, 12)[:, :6] += buf[36 * pid :].reshape(ns, 6)
+    return H, g
+
+
 def pack(H, g, cost):
     """dense H (n x n), g, cost -> the reduction buffer (the layout k_gather writes for a sharded problem)"""
     n = len(g)
