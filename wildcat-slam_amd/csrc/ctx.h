@@ -53,6 +53,8 @@ struct wc_dev_opts {
   int match_pair_swap = 0;   // the sliding-window search on the helper instead of the fixed-window one
   int lin_imu_apart = 0, lin_unary_apart = 0, lin_post_apart = 0;  // the linearisation's families / mailbox as launches of their own
   int lm_dense = 0;          // round 2's LM step: dense Cholesky of all 12 ns unknowns
+  int lin_unary_chunks = 0;  // chunks of 256 records per unary piece (0: the library's 4; 1: rounds 2 - 5's pieces)
+  int pcr_full_width = 0;    // bias elimination: every reduction level over all columns of the right-hand sides (rounds 3 - 5) instead of their bands
   int lm_side_stream = 1;    // two-collective form: the large collective on a side stream (1: with the in-library RCCL binding; 0: never; 2: always - tests)
   int lm_one_collective = 0; // sharded windows: rounds 3 - 5's ONE all-reduce per linearisation (IMU triples sharded too) instead of the two-collective form
   int dbg_lm = 0;            // experiment bits of the LM solve's kernels (timing runs of a development session; results may be WRONG)

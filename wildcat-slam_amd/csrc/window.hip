@@ -52,6 +52,7 @@ namespace {
 #endif
 constexpr int kPiece = WC_PIECE;   // records per piece (= threads per assembly workgroup)
 constexpr int kNB = 32;       // Cholesky block size
+constexpr int kLinChunksU = 4;  // chunks of kPiece records a unary piece may hold (round 6)
 constexpr uint32_t kHeavySrc = 24;  // block pairs with more gather sources than this get the multi-group gather
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -103,6 +104,7 @@ struct wc_window_state {
   // offset of block pair pid in the reduction buffer: 144 doubles for a pair of sample blocks at most two apart (IMU factors
   // reach that far, cost_functor.h:264-355), 36 - the pose x pose corner - for the others (surfel factors only, :16-179)
   bool sharded = false;
+  bool unary_multi = false;  // unary pieces hold several chunks of kPiece records: the family is a launch of its own (k_lin_surfel<12, true, true>)
   uint32_t lin_count = 0;  // linearisations enqueued in the two-collective form (parity of the late max |g| slot)
   // the large collective + k_expand_corners on a stream of their own, beside the bias elimination (ordered by events; joined in front of
   // whatever reads pose blocks or writes the buffers again)
@@ -565,7 +567,7 @@ struct LinSurfelLds {
   static constexpr int VMAX = VSZ > PSZ ? VSZ : PSZ;
   static constexpr int DOUBLES = VMAX + 4;
 };
-template <int W, bool UNARY>
+template <int W, bool UNARY, bool MULTI = false>
 __device__ __forceinline__ void lin_surfel_body(const WinParams &wp, const Piece pc, const double *rec, uint32_t nrec, const double *x,
                                                 double *partial, double *smem /* 16-byte aligned, LinSurfelLds<W>::DOUBLES */,
                                                 uint32_t cost_slot /* the piece's entry of the cost array behind the partials */) {
@@ -596,9 +598,31 @@ __device__ __forceinline__ void lin_surfel_body(const WinParams &wp, const Piece
   asm volatile("" ::"s"(pc.count), "s"(pc.begin));
   la_[0] = clock64();  // descriptor has arrived
 #endif
+  double acc[4][4] = {{0.0}};
+  const int blk = tid % NBLK, slice = tid / NBLK;
+  int bi = 0, remb = blk;
+  while (remb >= NB - bi) {
+    remb -= NB - bi;
+    ++bi;
+  }
+  const int bj = bi + remb;
+  const double *pi = sV + 4 * bi, *pj = sV + 4 * bj;
+  // Round 6: a piece may hold SEVERAL chunks of kPiece records (the unary family: up to kLinChunksU; a unary key of C4 has ~7.9 k
+  // records, i.e. 31 pieces of 256 with 31 descriptors, 31 exchanges of partial blocks, 31 tails and 31 gather sources for the same
+  // two sample blocks).  The workgroup evaluates a chunk, passes its rows through LDS, adds their Gram blocks onto the SAME register
+  // accumulators, and goes on with the next chunk: partial blocks, tail and output once per piece.
+  // (MULTI only in k_lin_surfel's unary instantiation, a launch of its own with the full register file: inside k_lin_fused - 128 VGPRs at
+  // four workgroups per CU - the loop spilled 50 - 170 registers and the kernel took 112 us instead of 87 at C4)
+  constexpr uint32_t kMaxCh = (UNARY && MULTI) ? (uint32_t)kLinChunksU : 1u;
+#pragma unroll 1
+  for (uint32_t chi = 0; chi < kMaxCh; ++chi) {
+  const uint32_t ch0 = chi * (uint32_t)kPiece;
+  if (chi && ch0 >= pc.count) break;
+  const int ccount = (int)min((uint32_t)kPiece, pc.count - ch0);  // records of this chunk (uniform over the workgroup)
+  if (chi) __syncthreads();  // (the rows of the chunk before have been read)
   double v[W], r = 0.0;
-  if (tid < (int)pc.count) {
-    const uint32_t k = pc.begin + tid;
+  if (tid < ccount) {
+    const uint32_t k = pc.begin + ch0 + tid;
     constexpr int NF = UNARY ? 11 : 15;
     double rv[NF];
 #if defined(WC_LIN_KNOCK) && (WC_LIN_KNOCK & 4)  // timing knock-out: no record loads
@@ -616,37 +640,29 @@ __device__ __forceinline__ void lin_surfel_body(const WinParams &wp, const Piece
     for (int i = 0; i < W; ++i) v[i] = rv[i % NF];
     r = rv[1], c = rv[2];
 #else
+    double cc_ = 0.0;  // (a thread's costs of all chunks are added in chunk order)
+    // (the sample blocks' corrections are read again in every chunk: hoisted out of the chunk loop the compiler kept their 24 doubles
+    // in VGPRs across it and spilled ~18 of them - k_lin_fused 87 -> 112 us at C4; the pointer is made opaque per chunk)
+    const double *xq = x;
     if (UNARY)
-      eval_unary(wp, rv, 1, 0, pc.key, x, r, c, v);  // one key per piece: the sample blocks are wave-uniform
+      eval_unary(wp, rv, 1, 0, pc.key, xq, r, cc_, v);  // one key per piece: the sample blocks are wave-uniform
     else
-      eval_binary(wp, rv, 1, 0, pc.key, x, r, c, v);
+      eval_binary(wp, rv, 1, 0, pc.key, xq, r, cc_, v);
+    c += cc_;
 #endif
   }
-  // cost of the piece: fixed shuffle tree per wavefront, the four wavefront sums are added in the tail
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) c += __shfl_down(c, d, 64);
-  if ((tid & 63) == 0) sC[tid >> 6] = c;
 #ifdef WC_PROF_LIN
   lt_[1] = clock64();
   lt_[2] = lt_[1];
 #endif
-  double acc[4][4] = {{0.0}};
-  const int blk = tid % NBLK, slice = tid / NBLK;
-  int bi = 0, remb = blk;
-  while (remb >= NB - bi) {
-    remb -= NB - bi;
-    ++bi;
-  }
-  const int bj = bi + remb;
-  const double *pi = sV + 4 * bi, *pj = sV + 4 * bj;
-  // the rows go through LDS in rounds of RH (the piece's count is uniform over the workgroup: so are the rounds and their barriers)
+  // the rows go through LDS in rounds of RH (the chunk's count is uniform over the workgroup: so are the rounds and their barriers)
 #pragma unroll 1
-  for (int h = 0; h * RH < (int)pc.count; ++h) {
+  for (int h = 0; h * RH < ccount; ++h) {
     if (h) __syncthreads();  // the round before has been read
 #if defined(WC_LIN_KNOCK) && (WC_LIN_KNOCK & 32)  // timing knock-out: no row writes
-    if (tid < (int)pc.count && tid / RH == h && v[0] == 12345.0) {
+    if (tid < ccount && tid / RH == h && v[0] == 12345.0) {
 #else
-    if (tid < (int)pc.count && tid / RH == h) {
+    if (tid < ccount && tid / RH == h) {
 #endif
       const int row = tid - h * RH;
 #pragma unroll
@@ -657,7 +673,7 @@ __device__ __forceinline__ void lin_surfel_body(const WinParams &wp, const Piece
     if (slice < NS) {
       // the slices partition the round's rows [0, cnt); columns past T (last block) belong to the next row (or, for the last
       // row, to unwritten storage): those products land in accumulator entries that are never read
-      const int cnt = min((int)pc.count - h * RH, RH);
+      const int cnt = min(ccount - h * RH, RH);
       const int sl = ((cnt + NS - 1) / NS) | 1;  // odd: the slices that share a wavefront then start on different banks
 #if defined(WC_LIN_KNOCK) && (WC_LIN_KNOCK & 1)  // timing knock-out: no Gram loop
       const int k0 = min(slice * sl, cnt), k1 = min(k0 + 1, cnt);
@@ -679,6 +695,11 @@ __device__ __forceinline__ void lin_surfel_body(const WinParams &wp, const Piece
       }
     }
   }
+  }  // (chunks)
+  // cost of the piece: fixed shuffle tree per wavefront, the four wavefront sums are added in the tail
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) c += __shfl_down(c, d, 64);
+  if ((tid & 63) == 0) sC[tid >> 6] = c;
 #ifdef WC_PROF_LIN
   lt_[3] = clock64();
 #endif
@@ -726,11 +747,11 @@ __device__ __forceinline__ void lin_surfel_body(const WinParams &wp, const Piece
            lt_[4] - lt_[0]);
 #endif
 }
-template <int W, bool UNARY>
+template <int W, bool UNARY, bool MULTI = false>
 __global__ void __launch_bounds__(kPiece) k_lin_surfel(WinParams wp, const Piece *pieces, const double *rec, const uint32_t *keys,
                                                       uint32_t nrec, const double *x, double *partial, uint32_t cost_slot0) {
   __shared__ __attribute__((aligned(16))) double smem[LinSurfelLds<W>::DOUBLES];
-  lin_surfel_body<W, UNARY>(wp, pieces[blockIdx.x], rec, nrec, x, partial, smem, cost_slot0 + blockIdx.x);
+  lin_surfel_body<W, UNARY, MULTI>(wp, pieces[blockIdx.x], rec, nrec, x, partial, smem, cost_slot0 + blockIdx.x);
 }
 
 using f64x4 = __attribute__((ext_vector_type(4))) double;
@@ -2672,10 +2693,10 @@ static int window_build_impl(wc_ctx *ctx, const wc_surfel *d_sld_surf, const wc_
   auto t_b = tnow();
   // pieces + the CSR source lists of the gather
   uint32_t off = 0;
-  auto cut = [&](const std::vector<Seg> &segs, uint32_t T, bool split) {
+  auto cut = [&](const std::vector<Seg> &segs, uint32_t T, bool split, uint32_t piece_max = kPiece) {
     for (const Seg &s : segs) {
-      for (uint32_t b = 0; b < s.count; b += split ? kPiece : s.count) {
-        const uint32_t c = split ? std::min<uint32_t>(kPiece, s.count - b) : s.count;
+      for (uint32_t b = 0; b < s.count; b += split ? piece_max : s.count) {
+        const uint32_t c = split ? std::min<uint32_t>(piece_max, s.count - b) : s.count;
         pieces.push_back({s.start + b, c, s.key, off});
         off += T * (T + 1) / 2;
       }
@@ -2683,12 +2704,12 @@ static int window_build_impl(wc_ctx *ctx, const wc_surfel *d_sld_surf, const wc_
   };
   // (longest pieces first inside a family: workgroups are dispatched in piece order, and a full piece started last would
   // run alone at the end of the launch)
-  auto by_size = [&](size_t first) {  // stable counting sort of pieces[first..) by count, descending (counts are 1..kPiece)
-    std::vector<uint32_t> pos(kPiece + 2, 0);
-    for (size_t i = first; i < pieces.size(); ++i) pos[kPiece - pieces[i].count + 1]++;
-    for (int c = 0; c <= kPiece; ++c) pos[c + 1] += pos[c];
+  auto by_size = [&](size_t first, uint32_t piece_max = kPiece) {  // stable counting sort of pieces[first..) by count, descending (counts are 1..piece_max)
+    std::vector<uint32_t> pos(piece_max + 2, 0);
+    for (size_t i = first; i < pieces.size(); ++i) pos[piece_max - pieces[i].count + 1]++;
+    for (uint32_t c = 0; c <= piece_max; ++c) pos[c + 1] += pos[c];
     std::vector<Piece> out(pieces.size() - first);
-    for (size_t i = first; i < pieces.size(); ++i) out[pos[kPiece - pieces[i].count]++] = pieces[i];
+    for (size_t i = first; i < pieces.size(); ++i) out[pos[piece_max - pieces[i].count]++] = pieces[i];
     std::copy(out.begin(), out.end(), pieces.begin() + first);
   };
   WC_TRY(collect_families(ctx, job, segs_b, segs_u));
@@ -2714,9 +2735,26 @@ static int window_build_impl(wc_ctx *ctx, const wc_surfel *d_sld_surf, const wc_
       for (int q = p; q < nblk; ++q) src_begin[pair_id(blk[p], blk[q]) + 1]++;
     }
   }
-  cut(segs_u, 13, true);
+  // (unary pieces of up to kLinChunksU chunks of kPiece records - lin_surfel_body; development option lin_unary_chunks: 1 = rounds 2 - 5's
+  // pieces of one chunk)
+  // Measured (profiles/dev/ab_lin2.py, device time of one linearisation): C4's 12 299 pieces 0.124 -> 0.110 ms with four chunks (9 329
+  // pieces; two chunks 0.115, eight 0.118: a piece of 2 048 records is the launch's tail), the step-sized window's 3 492 pieces 0.044
+  // either way, a window of 1 336 pieces 0.0230 -> 0.0238: the long pieces are for windows whose launch is several rounds of the chip's
+  // workgroup slots.
+  uint32_t nrec_u = 0;
+  for (const Seg &sg : segs_u) nrec_u += sg.count;
+  const bool many = pieces.size() + nrec_u / kPiece > 6000u;
+  // In the LM loop (x != 0, the solve's kernels between two linearisations) the long pieces LOSE: they only fit the register file as a launch
+  // of their own (k_lin_surfel<12, true, true>; inside k_lin_fused the chunk loop spilled), and k_lin_fused without the unary family +
+  // that launch last 99 us + a boundary against 87 fused - C4 0.406 -> 0.417 ms per LM iteration.  Default: one chunk; the option keeps
+  // the long pieces for A/B runs.
+  (void)many;
+  const int want_ch = ctx->dev.lin_unary_chunks > 0 ? ctx->dev.lin_unary_chunks : 1;
+  const uint32_t upiece = (uint32_t)kPiece * (uint32_t)std::max(1, std::min(kLinChunksU, want_ch));
+  W->unary_multi = upiece > (uint32_t)kPiece;
+  cut(segs_u, 13, true, upiece);
   W->npiece_u = (uint32_t)pieces.size() - W->npiece_b;
-  by_size(W->npiece_b);
+  by_size(W->npiece_b, upiece);
   cut(segs_i, 37, false);
   W->npiece_i = (uint32_t)pieces.size() - W->npiece_b - W->npiece_u;
   W->npart_doubles = off;
@@ -3057,7 +3095,7 @@ int enqueue_linearize(wc_ctx *ctx, wc_window_state *W, const double *d_x, int ma
   // surfel families, fork / join by events: 1 650 LM it/s against 1 790 at C4, odometry-step solve 2.58 against 2.39 ms - the two
   // cross-stream waits cost more than the launch they hide.  One stream.)
   const bool imu_apart = ctx->dev.lin_imu_apart != 0;  // (A/B: the IMU family as a launch of its own)
-  const bool unary_in = ctx->dev.lin_unary_apart == 0;  // (A/B: the unary family as a launch of its own)
+  const bool unary_in = ctx->dev.lin_unary_apart == 0 && !W->unary_multi;  // (A/B: the unary family as a launch of its own; multi-chunk pieces: always)
   const bool fused = W->npiece_b && W->npiece_i && !imu_apart && kPiece == 256;
   const bool fused_u = fused && unary_in && W->npiece_u;
 #ifndef WC_LIN_FEW
@@ -3082,9 +3120,14 @@ int enqueue_linearize(wc_ctx *ctx, wc_window_state *W, const double *d_x, int ma
   else if (W->npiece_b)
     k_lin_surfel<24, false><<<W->npiece_b, kPiece, 0, st>>>(W->wp, pcs, (const double *)W->brec.p, (const uint32_t *)W->bkey.p, W->nb,
                                                           d_x, partial, W->npart_doubles);
-  if (W->npiece_u && !fused_u)
-    k_lin_surfel<12, true><<<W->npiece_u, kPiece, 0, st>>>(W->wp, pcs + W->npiece_b, (const double *)W->urec.p,
-                                                         (const uint32_t *)W->ukey.p, W->nu, d_x, partial, W->npart_doubles + W->npiece_b);
+  if (W->npiece_u && !fused_u) {
+    if (W->unary_multi)
+      k_lin_surfel<12, true, true><<<W->npiece_u, kPiece, 0, st>>>(W->wp, pcs + W->npiece_b, (const double *)W->urec.p,
+                                                                 (const uint32_t *)W->ukey.p, W->nu, d_x, partial, W->npart_doubles + W->npiece_b);
+    else
+      k_lin_surfel<12, true><<<W->npiece_u, kPiece, 0, st>>>(W->wp, pcs + W->npiece_b, (const double *)W->urec.p,
+                                                           (const uint32_t *)W->ukey.p, W->nu, d_x, partial, W->npart_doubles + W->npiece_b);
+  }
   if (W->npiece_i && !fused)
     k_lin_imu<<<W->npiece_i, 256, 0, st>>>(W->wp, pcs + W->npiece_b + W->npiece_u, (const ImuRec *)W->irec.p, d_x,
                                           (const double *)W->times_d.p, partial, W->npart_doubles + W->npiece_b + W->npiece_u);
@@ -3427,15 +3470,19 @@ extern "C" int wc_window_solve(wc_ctx *ctx, double *h_x_inout, wc_solve_summary 
           const PcrDamp damp{radius, ns, diag}, nodamp{0.0, ns, diag};
           for (int s = 1, lev = 0; lev < nlev; s *= 2, ++lev) {  // (ns >= 4: at least one level)
             const bool last = lev == nlev - 1, first = lev == 0;
-            const dim3 grid(M * nch);
+            // (the levels of small stride work on banded right-hand sides: fewer column chunks per row - k_pcr_level; development option
+            // pcr_full_width: every level over all columns, as in rounds 3 - 5)
+            const int band_chunks = (kSB * (4 * s + 1) + 255) / 256;
+            const int limited = (ctx->dev.pcr_full_width == 0 && band_chunks < nch) ? band_chunks : 0;
+            const dim3 grid(M * (limited ? limited : nch));
             if (last && first)
-              k_pcr_level<true, true><<<grid, 256, 0, st>>>(s, M, Dp[cur], Ap[cur], Rp[cur], Dp[cur ^ 1], Ap[cur ^ 1], Rp[cur ^ 1], ldr, fail, damp);
+              k_pcr_level<true, true><<<grid, 256, 0, st>>>(s, M, Dp[cur], Ap[cur], Rp[cur], Dp[cur ^ 1], Ap[cur ^ 1], Rp[cur ^ 1], ldr, fail, damp, npz, limited);
             else if (last)
-              k_pcr_level<true, false><<<grid, 256, 0, st>>>(s, M, Dp[cur], Ap[cur], Rp[cur], Dp[cur ^ 1], Ap[cur ^ 1], Rp[cur ^ 1], ldr, fail, nodamp);
+              k_pcr_level<true, false><<<grid, 256, 0, st>>>(s, M, Dp[cur], Ap[cur], Rp[cur], Dp[cur ^ 1], Ap[cur ^ 1], Rp[cur ^ 1], ldr, fail, nodamp, npz, limited);
             else if (first)
-              k_pcr_level<false, true><<<grid, 256, 0, st>>>(s, M, Dp[cur], Ap[cur], Rp[cur], Dp[cur ^ 1], Ap[cur ^ 1], Rp[cur ^ 1], ldr, fail, damp);
+              k_pcr_level<false, true><<<grid, 256, 0, st>>>(s, M, Dp[cur], Ap[cur], Rp[cur], Dp[cur ^ 1], Ap[cur ^ 1], Rp[cur ^ 1], ldr, fail, damp, npz, limited);
             else
-              k_pcr_level<false, false><<<grid, 256, 0, st>>>(s, M, Dp[cur], Ap[cur], Rp[cur], Dp[cur ^ 1], Ap[cur ^ 1], Rp[cur ^ 1], ldr, fail, nodamp);
+              k_pcr_level<false, false><<<grid, 256, 0, st>>>(s, M, Dp[cur], Ap[cur], Rp[cur], Dp[cur ^ 1], Ap[cur ^ 1], Rp[cur ^ 1], ldr, fail, nodamp, npz, limited);
             cur ^= 1;
           }
           X = Rp[cur];  // the last level wrote X = T^-1 [C | bB] where the others write R'
