@@ -1829,7 +1829,8 @@ __device__ __forceinline__ bool factor_inv32_role(double (*sB)[kNB + 1], double 
 
 // Round 6: the same routine with the wavefront's role (its tile, or the finishing role of wavefront 1) as a compile-time constant: one
 // branch on the wavefront at the top instead of ~25 wave-uniform predicates per block step, which the fully unrolled body kept in SGPRs
-// spilled to VGPR lanes (two v_readlane + wait states per use).
+// spilled to VGPR lanes (two v_readlane + wait states per use).  11.7 k -> 9.6 k shader clocks, the same bits (wc_selftest_factor32, variant 1 against 0).
+// (The block-step loop unrolled by two instead of fully - predicates formed in place, an eighth of the code: 11.1 k.)
 __device__ __forceinline__ bool factor_inv32_roles(double (*sB)[kNB + 1], double (*sXi)[kNB + 1]) {
   switch (threadIdx.x >> 6) {
     case 0: return factor_inv32_role<0>(sB, sXi);
