@@ -11,7 +11,7 @@ for trial in range(3):
     a = b @ b.T + (0.5 if trial else 1e-3) * np.eye(32)
     Lr = np.linalg.cholesky(a)
     Xr = np.linalg.inv(Lr)
-    for v in (0, 1, 2):
+    for v in (0, 1):
         L, X, clk, ok = ctx.selftest_factor32(a, v, 9)
         eL = np.abs(np.tril(L) - Lr).max() / np.abs(Lr).max()
         eX = np.abs(np.tril(X) - Xr).max() / np.abs(Xr).max()
