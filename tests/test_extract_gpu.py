@@ -430,3 +430,59 @@ def test_displaced_root_keeps_its_layer2_nodes(gpu, oracle):
         gpu.set_dev_option("fx_split", -1)
         gpu.params = oracle.default_params()
         gpu.set_params(gpu.params)
+
+
+def test_default_moments_against_extended_precision(gpu, oracle):
+    """which side of the surfel comparison carries the difference?  The surfels of a G2 sweep at epoch-sized
+    stamps and +-20 m coordinates from (a) the default arithmetic (exact integer moments about the voxel centre), (b) exact_sums = 1 (fp64
+    sums in the reference's order) and (c) the CPU oracle (the reference's un-centred fp64 sums, surfel_extraction.cc:36-51), each against
+    the same moments formed in EXTENDED precision (numpy longdouble, centred two-pass).  The default path must be at least as close to
+    that as the reference's own sums are - the 1e-6 (surfels) / 1e-5 (step corrections) between the default path and the oracle is then
+    the oracle's distance from the exact moments, not the default path's."""
+    pts, _ = synth.g2_lattice(600, m=32, seed=synth.SEED + 77)
+    s_def, id_def = gpu.extract_surfels(pts)
+    gpu.set_exact_sums(True)
+    try:
+        s_ex, id_ex = gpu.extract_surfels(pts)
+    finally:
+        gpu.set_exact_sums(False)
+    s_ref, id_ref, _ = oracle.extract_surfels(pts)
+    # extended-precision moments of every (root voxel, layer-1 octant) cell (G2: one surfel per cell, all at layer 1)
+    vs = np.float64(np.float32(0.8))
+    p = np.stack([pts["x"], pts["y"], pts["z"]], 1).astype(np.float64)
+    k = np.floor(p / vs).astype(np.int64)
+    cen = (k + 0.5) * vs
+    octant = (4 * (p[:, 0] > cen[:, 0]) + 2 * (p[:, 1] > cen[:, 1]) + (p[:, 2] > cen[:, 2])).astype(np.int64)
+    key = np.concatenate([k, octant[:, None]], 1)
+    uniq, inv = np.unique(key, axis=0, return_inverse=True)
+    inv = inv.reshape(-1)
+    pl = p.astype(np.longdouble)
+    n = np.bincount(inv).astype(np.longdouble)
+    c = np.stack([np.bincount(inv, weights=None, minlength=len(uniq)) * 0] * 3, 1).astype(np.longdouble)
+    for a in range(3):
+        acc = np.zeros(len(uniq), np.longdouble)
+        np.add.at(acc, inv, pl[:, a])
+        c[:, a] = acc / n
+    d = pl - c[inv]
+    cov = np.zeros((len(uniq), 9), np.longdouble)
+    for a in range(3):
+        for b in range(3):
+            acc = np.zeros(len(uniq), np.longdouble)
+            np.add.at(acc, inv, d[:, a] * d[:, b])
+            cov[:, 3 * a + b] = acc / n
+    truth = {(int(u[0]), int(u[1]), int(u[2]), int(u[3])): i for i, u in enumerate(uniq)}
+
+    def errs(s, ids):
+        assert len(s) == len(uniq)
+        rows = np.array([truth[(int(i["kx"]), int(i["ky"]), int(i["kz"]), int((i["node"] >> 2) & 7))] for i in ids])
+        assert np.all((ids["node"] & 3) == 1)  # layer 1
+        ec = np.abs(s["center"].astype(np.longdouble) - c[rows]).max() / max(float(np.abs(c).max()), 1.0)
+        scale = np.abs(cov[rows]).max(axis=1, keepdims=True)
+        ev = (np.abs(s["cov"].astype(np.longdouble) - cov[rows]) / scale).max()
+        return float(ec), float(ev)
+
+    e_def, e_ex, e_ref = errs(s_def, id_def), errs(s_ex, id_ex), errs(s_ref, id_ref)
+    print("\ncentre / covariance against extended precision: default %.1e / %.1e, exact_sums %.1e / %.1e, oracle %.1e / %.1e" % (e_def + e_ex + e_ref))
+    assert e_def[0] <= 1e-15 and e_def[1] <= 1e-9  # the integer moments are exact: what is left is the final division and the 2^-44 m^2 grid
+    assert e_def[1] <= e_ref[1] * 1.001 and e_def[0] <= e_ref[0] * 1.001 + 1e-16  # never further from the exact moments than the reference's sums
+    assert e_ex[1] <= 10 * e_ref[1] + 1e-12  # (the reference's order on the device: the same kind of noise as the oracle's)
