@@ -65,6 +65,13 @@ int wc_ctx_set_params(wc_ctx *ctx, const wc_params *params);
  *   lin_imu_apart, lin_unary_apart, lin_post_apart   factor families / mailbox of a linearisation as launches of their own
  *   lm_dense, lm_eval_pass, lm_sync, lm_back_chunks   earlier forms of the LM step kept for A/B runs
  *   pcr_ahead (1)                                     0: the bias elimination's level 0 at the start of an iteration (rounds 3 - 4)
+ *   pcr_full_width     bias elimination: every reduction level over all columns of its right-hand sides (rounds 3 - 5) instead of their bands
+ *   lin_unary_chunks   chunks of 256 records per unary assembly piece (0 / 1: one - the default; 2 .. 4: long pieces, a launch of their own)
+ *   lm_one_collective  sharded windows: rounds 3 - 5's ONE all-reduce per linearisation (IMU triples sharded too) instead of the
+ *                      two-collective form (IMU factors replicated; 16-byte cost collective, then the pose corners)
+ *   lm_side_stream (1) two-collective form: the large collective on a side stream beside the bias elimination (1: with the in-library RCCL
+ *                      binding, 0: never, 2: always - the choreography with a communicator of callbacks, for tests)
+ *   dbg_lm             experiment bits of the LM solve's kernels (development sessions; 0 in every measured or tested run)
  *   lm_dense_radius    iterations whose trust-region radius exceeds 10^value take the dense step (default 10; 0 = never)
  * Tests use it to run both forms of a choice on the same data.  Unknown names return WC_ERR_ARG. */
 int wc_ctx_set_dev_option(wc_ctx *ctx, const char *name, int value);

@@ -470,6 +470,10 @@ def test_default_moments_against_extended_precision(gpu, oracle):
             acc = np.zeros(len(uniq), np.longdouble)
             np.add.at(acc, inv, d[:, a] * d[:, b])
             cov[:, 3 * a + b] = acc / n
+    tl = pts["time"].astype(np.longdouble)
+    tacc = np.zeros(len(uniq), np.longdouble)
+    np.add.at(tacc, inv, tl - tl[0])
+    tmean = tl[0] + tacc / n  # (mean of the stamps, formed about the first stamp in extended precision)
     truth = {(int(u[0]), int(u[1]), int(u[2]), int(u[3])): i for i, u in enumerate(uniq)}
 
     def errs(s, ids):
@@ -479,10 +483,15 @@ def test_default_moments_against_extended_precision(gpu, oracle):
         ec = np.abs(s["center"].astype(np.longdouble) - c[rows]).max() / max(float(np.abs(c).max()), 1.0)
         scale = np.abs(cov[rows]).max(axis=1, keepdims=True)
         ev = (np.abs(s["cov"].astype(np.longdouble) - cov[rows]) / scale).max()
-        return float(ec), float(ev)
+        et = np.abs(s["t"].astype(np.longdouble) - tmean[rows]).max()  # seconds
+        return float(ec), float(ev), float(et)
 
     e_def, e_ex, e_ref = errs(s_def, id_def), errs(s_ex, id_ex), errs(s_ref, id_ref)
-    print("\ncentre / covariance against extended precision: default %.1e / %.1e, exact_sums %.1e / %.1e, oracle %.1e / %.1e" % (e_def + e_ex + e_ref))
+    print("\ncentre / covariance / stamp [s] against extended precision: default %.1e / %.1e / %.1e, exact_sums %.1e / %.1e / %.1e, oracle %.1e / %.1e / %.1e"
+          % (e_def + e_ex + e_ref))
+    # the stamps are where the two arithmetics part: the reference adds epoch-sized doubles one by one (surfel_extraction.cc:36-47: ~n ulp of
+    # n x 1.6e9 s), the default path averages integer ticks relative to the sweep's first stamp - the correctly rounded mean
+    assert e_def[2] <= 3e-7 and e_def[2] <= e_ref[2]
     assert e_def[0] <= 1e-15 and e_def[1] <= 1e-9  # the integer moments are exact: what is left is the final division and the 2^-44 m^2 grid
     assert e_def[1] <= e_ref[1] * 1.001 and e_def[0] <= e_ref[0] * 1.001 + 1e-16  # never further from the exact moments than the reference's sums
     assert e_ex[1] <= 10 * e_ref[1] + 1e-12  # (the reference's order on the device: the same kind of noise as the oracle's)

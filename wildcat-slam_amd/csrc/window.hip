@@ -2060,7 +2060,12 @@ __device__ __forceinline__ void chol_extra_tile(double *A, int ld, int k, int nb
 // n_tri: workgroups of the factorisation proper (1 + tiles (tiles + 1) / 2); the grid's remaining workgroups are tiles of the appended
 // identity rows (chol_extra_tile), `tiles` per tile row
 __global__ void __launch_bounds__(256) k_chol_step(double *A, int ld, int k, int nblk, double *Lmat, double *Linv, int *fail, int n_real, int n_tri,
-                                                   int tiles, int dbg = 0, long long *dbgbuf = nullptr) {
+                                                   int tiles, int dbg_in = 0, long long *dbgbuf = nullptr) {
+#ifdef WC_DEV_KNOBS  // (development option dbg_lm: per-workgroup wall-clock stamps (8), phase clocks of one tile (16), knock-outs of the appended tiles (1, 2, 4))
+  const int dbg = dbg_in;
+#else
+  constexpr int dbg = 0;  // (the release kernel carries none of it)
+#endif
   struct Stamp {
     long long *p;
     __device__ Stamp(long long *q) : p(q) {
@@ -3492,7 +3497,9 @@ extern "C" int wc_window_solve(wc_ctx *ctx, double *h_x_inout, wc_solve_summary 
           // (development option lm_back_chunks: rounds 2 - 5's back substitution - chunk solves + products - and k_schur_bias_y / k_lm_step
           // as launches of their own, for A/B runs; default: identity rows appended to the factorisation, k_back_mul, one fused tail)
           const bool back_mul = ctx->dev.lm_back_chunks == 0;
+#ifdef WC_DEV_KNOBS
           if (ctx->dev.dbg_lm & 8) WC_TRY(wc_ensure(ctx, W->reduce, (size_t)nblk2 * 1024 * 8));
+#endif
           for (int k = 0; k + 1 < nblk2; ++k) {
             const int tiles = ((nblk2 - k - 1) * kNB + 63) / 64;
             const int n_tri = 1 + tiles * (tiles + 1) / 2;
@@ -3500,6 +3507,7 @@ extern "C" int wc_window_solve(wc_ctx *ctx, double *h_x_inout, wc_solve_summary 
             k_chol_step<<<n_tri + n_extra, 256, 0, st>>>(A, ld2, k, nblk2, Lmat, (double *)W->Linv.p, fail, npz, n_tri, tiles, ctx->dev.dbg_lm,
                                                          (long long *)W->reduce.p);
           }
+#ifdef WC_DEV_KNOBS
           if (ctx->dev.dbg_lm & 8) {  // (development session: wall-clock stamps of every workgroup of every step, 100 MHz)
             static int calls = 0;
             if (++calls == 3) {
@@ -3520,6 +3528,7 @@ extern "C" int wc_window_solve(wc_ctx *ctx, double *h_x_inout, wc_solve_summary 
               }
             }
           }
+#endif
           const StepArgs sa{x, scale, g, diag, lin_cost(W), xc, mail, h_stage_dev, 0};
           if (back_mul) {
             k_back_mul<<<(npz + 7) / 8, 256, 0, st>>>(A, Lmat, ld2, nblk2, npz, (const double *)W->Linv.p, yred);
