@@ -66,6 +66,7 @@ int wc_ctx_set_params(wc_ctx *ctx, const wc_params *params);
  *   lm_dense, lm_eval_pass, lm_sync, lm_back_chunks   earlier forms of the LM step kept for A/B runs
  *   pcr_ahead (1)                                     0: the bias elimination's level 0 at the start of an iteration (rounds 3 - 4)
  *   pcr_full_width     bias elimination: every reduction level over all columns of its right-hand sides (rounds 3 - 5) instead of their bands
+ *   lin_pair (1)       binary assembly pieces of at most 128 records two to a workgroup (0: one each - rounds 2 - 5; the same bits)
  *   lin_unary_chunks   chunks of 256 records per unary assembly piece (0 / 1: one - the default; 2 .. 4: long pieces, a launch of their own)
  *   lm_one_collective  sharded windows: rounds 3 - 5's ONE all-reduce per linearisation (IMU triples sharded too) instead of the
  *                      two-collective form (IMU factors replicated; 16-byte cost collective, then the pose corners)

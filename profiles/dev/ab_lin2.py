@@ -1,5 +1,5 @@
 """A/B of one linearisation at C4 and at the odometry step's size under development options (round 6): device time per linearisation
-(wc_window_linearize_timed), pieces, max |H - H_first| / max |H|.  python profiles/dev/ab_lin2.py "lin_unary_chunks=1" "" """
+(wc_window_linearize_timed), pieces, max |H - H_first| / max |H|.  python profiles/dev/ab_lin2.py "lin_pair=0" "" """
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", os.environ.get("AB_LM_TREE", "."), "wildcat-slam_amd", "python"))
 import numpy as np
@@ -26,7 +26,7 @@ for name, (scans, patches) in (("C4 20x50000", (20, 50000)), ("10x31248", (10, 3
         ms = min(tms)
         if os.environ.get("AB_VERBOSE"): print(" ".join("%.3f" % t for t in tms))
         for kv in [s for s in spec.split(",") if s]:
-            ctx.set_dev_option(kv.split("=")[0], 0)
+            ctx.set_dev_option(kv.split("=")[0], {"lin_pair": 1}.get(kv.split("=")[0], 0))
         if first is None:
             first = (H, g, cost)
         print("%-12s [%-24s] %.4f ms per linearisation, pieces %d, |dH| %.1e |dg| %.1e |dcost| %.1e" % (

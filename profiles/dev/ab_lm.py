@@ -17,7 +17,7 @@ ctx.warmup() if hasattr(ctx, "warmup") else None
 def apply(spec, on):
     for kv in [s for s in spec.split(",") if s]:
         k, v = kv.split("=")
-        ctx.set_dev_option(k, int(v) if on else 0)
+        ctx.set_dev_option(k, int(v) if on else {"lin_pair": 1, "lm_side_stream": 1, "pcr_ahead": 1, "fx_split": -1, "knn_group": -1}.get(k, 0))
 
 
 def c4_like(scans, patches, seed):

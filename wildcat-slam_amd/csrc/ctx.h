@@ -53,6 +53,7 @@ struct wc_dev_opts {
   int match_pair_swap = 0;   // the sliding-window search on the helper instead of the fixed-window one
   int lin_imu_apart = 0, lin_unary_apart = 0, lin_post_apart = 0;  // the linearisation's families / mailbox as launches of their own
   int lm_dense = 0;          // round 2's LM step: dense Cholesky of all 12 ns unknowns
+  int lin_pair = 1;          // binary assembly pieces of at most 128 records two to a workgroup (0: one each, rounds 2 - 5)
   int lin_unary_chunks = 0;  // chunks of 256 records per unary piece (0: the library's 4; 1: rounds 2 - 5's pieces)
   int pcr_full_width = 0;    // bias elimination: every reduction level over all columns of the right-hand sides (rounds 3 - 5) instead of their bands
   int lm_side_stream = 1;    // two-collective form: the large collective on a side stream (1: with the in-library RCCL binding; 0: never; 2: always - tests)

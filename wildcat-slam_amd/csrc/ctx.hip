@@ -81,6 +81,7 @@ const DevOpt kDevOpts[] = {
     {"lm_side_stream", "WC_LM_SIDE_STREAM", &wc_dev_opts::lm_side_stream, false},
     {"pcr_full_width", "WC_PCR_FULL_WIDTH", &wc_dev_opts::pcr_full_width, true},
     {"lin_unary_chunks", "WC_LIN_UNARY_CHUNKS", &wc_dev_opts::lin_unary_chunks, false},
+    {"lin_pair", "WC_LIN_PAIR", &wc_dev_opts::lin_pair, false},
     {"lm_sync", "WC_LM_SYNC", &wc_dev_opts::lm_sync, true},
     {"lm_eval_pass", "WC_LM_EVAL_PASS", &wc_dev_opts::lm_eval_pass, true},
     {"pcr_ahead", "WC_PCR_AHEAD", &wc_dev_opts::pcr_ahead, true},

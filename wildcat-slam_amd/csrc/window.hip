@@ -104,6 +104,7 @@ struct wc_window_state {
   // offset of block pair pid in the reduction buffer: 144 doubles for a pair of sample blocks at most two apart (IMU factors
   // reach that far, cost_functor.h:264-355), 36 - the pose x pose corner - for the others (surfel factors only, :16-179)
   bool sharded = false;
+  uint32_t npiece_b_big = 0;  // binary pieces of more than kPiece / 2 records (a prefix of the family): the others are paired in k_lin_fused
   bool unary_multi = false;  // unary pieces hold several chunks of kPiece records: the family is a launch of its own (k_lin_surfel<12, true, true>)
   uint32_t lin_count = 0;  // linearisations enqueued in the two-collective form (parity of the late max |g| slot)
   // the large collective + k_expand_corners on a stream of their own, beside the bias elimination (ordered by events; joined in front of
@@ -747,6 +748,110 @@ __device__ __forceinline__ void lin_surfel_body(const WinParams &wp, const Piece
            lt_[4] - lt_[0]);
 #endif
 }
+// Round 6: TWO binary pieces of at most 128 records each in one workgroup.  A binary key of C4 holds ~125 records: as a
+// piece of its own it keeps half a workgroup idle through the evaluation and pays a descriptor round trip and a launch slot for it.  Here
+// wavefronts 0 - 1 evaluate piece A's records and wavefronts 2 - 3 piece B's at the same time (the key is wave-uniform: readfirstlane keeps
+// the sample blocks' corrections in scalar loads); then, piece by piece, exactly what lin_surfel_body does for a piece of <= 128 records:
+// its rows through LDS (one round), the Gram blocks by (block pair, slice), partial blocks, tail, cost = its two wavefronts' sums.  Same
+// slices, same order of every sum: the same bits as two workgroups.  The pieces keep their own output and cost slots: k_gather does not
+// know the difference.
+__device__ __forceinline__ void lin_binary_pair_body(const WinParams &wp, const Piece pcA, const Piece pcB /* count 0: none */, const double *rec,
+                                                     uint32_t nrec, const double *x, double *partial, double *smem, uint32_t cost_slotA,
+                                                     uint32_t cost_slotB) {
+  constexpr int W = 24;
+  using L = LinSurfelLds<W>;
+  constexpr int T = L::T, NB = L::NB, NBLK = L::NBLK, NS = L::NS, TS = L::TS, PB = L::PB, RH = L::RH, NSH = L::NSH;
+  static_assert(RH == kPiece / 2 && kPiece == 256, "a piece of the pair is one round of rows");
+  double *sV = smem, *sC = smem + L::VMAX;
+  const int tid = threadIdx.x;
+  constexpr int NOUT = T * (T + 1) / 2, NTE = (NOUT + kPiece - 1) / kPiece;
+  int toff[NTE];
+#pragma unroll
+  for (int i = 0; i < NTE; ++i) toff[i] = tid + i * kPiece < NOUT ? (int)kLinTail24.off[tid + i * kPiece] : -1;
+  const bool second = tid >= RH;
+  const int row = tid & (RH - 1);
+  const uint32_t my_count = (uint32_t)__builtin_amdgcn_readfirstlane((int)(second ? pcB.count : pcA.count));
+  const uint32_t my_begin = (uint32_t)__builtin_amdgcn_readfirstlane((int)(second ? pcB.begin : pcA.begin));
+  const uint32_t my_key = (uint32_t)__builtin_amdgcn_readfirstlane((int)(second ? pcB.key : pcA.key));
+  double c = 0.0;
+  double v[W], r = 0.0;
+  if (row < (int)my_count) {
+    const uint32_t k = my_begin + (uint32_t)row;
+    double rv[15];
+#pragma unroll
+    for (int f = 0; f < 15; ++f) rv[f] = rec[(size_t)f * nrec + k];
+    eval_binary(wp, rv, 1, 0, my_key, x, r, c, v);
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) c += __shfl_down(c, d, 64);
+  if ((tid & 63) == 0) sC[tid >> 6] = c;
+  const int blk = tid % NBLK, slice = tid / NBLK;
+  int bi = 0, remb = blk;
+  while (remb >= NB - bi) {
+    remb -= NB - bi;
+    ++bi;
+  }
+  const int bj = bi + remb;
+  const double *pi = sV + 4 * bi, *pj = sV + 4 * bj;
+#pragma unroll 1
+  for (int h = 0; h < 2; ++h) {
+    const uint32_t cnt_u = h ? pcB.count : pcA.count, part_off = h ? pcB.part_off : pcA.part_off, cslot = h ? cost_slotB : cost_slotA;
+    if (cnt_u == 0u) break;  // (uniform: no second piece)
+    if (h) __syncthreads();  // the first piece's tail has read its partial blocks
+    if ((tid >= RH) == (h == 1) && row < (int)cnt_u) {
+#pragma unroll
+      for (int i = 0; i < W; ++i) sV[row * TS + i] = v[i];
+      sV[row * TS + W] = r;
+    }
+    __syncthreads();
+    double acc[4][4] = {{0.0}};
+    if (slice < NS) {
+      const int cnt = (int)cnt_u;
+      const int sl = ((cnt + NS - 1) / NS) | 1;
+      const int k0 = min(slice * sl, cnt), k1 = min(k0 + sl, cnt);
+      for (int k = k0; k < k1; ++k) {
+        double a[4], c4[4];
+        {
+          const double2 a01 = *(const double2 *)(pi + k * TS), a23 = *(const double2 *)(pi + k * TS + 2);
+          const double2 c01 = *(const double2 *)(pj + k * TS), c23 = *(const double2 *)(pj + k * TS + 2);
+          a[0] = a01.x, a[1] = a01.y, a[2] = a23.x, a[3] = a23.y;
+          c4[0] = c01.x, c4[1] = c01.y, c4[2] = c23.x, c4[3] = c23.y;
+        }
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) acc[p][q] = fma(a[p], c4[q], acc[p][q]);
+      }
+    }
+#pragma unroll 1
+    for (int base = 0; base < NS; base += NSH) {
+      __syncthreads();
+      if (slice >= base && slice < base + NSH && slice < NS) {
+        double *dst = sV + ((slice - base) * NBLK + blk) * PB;
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) dst[p * 4 + q] = base ? dst[p * 4 + q] + acc[p][q] : acc[p][q];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NTE; ++i) {
+      const int e = tid + i * kPiece, off = toff[i];
+      if (off < 0) continue;
+      double out = 0.0;
+      if (off == 0xFFFF) {
+        out = h ? (sC[2] + sC[3]) + 0.0 : (sC[0] + sC[1]) + 0.0;  // (a piece alone: (its two wavefronts' sums) + (0 + 0) of the idle ones)
+        partial[cslot] = out;
+      } else {
+#pragma unroll
+        for (int sl = 0; sl < NSH; ++sl) out += sV[sl * NBLK * PB + off];
+      }
+      partial[part_off + e] = out;
+    }
+  }
+}
+
 template <int W, bool UNARY, bool MULTI = false>
 __global__ void __launch_bounds__(kPiece) k_lin_surfel(WinParams wp, const Piece *pieces, const double *rec, const uint32_t *keys,
                                                       uint32_t nrec, const double *x, double *partial, uint32_t cost_slot0) {
@@ -871,20 +976,32 @@ __global__ void __launch_bounds__(256) k_lin_imu(WinParams wp, const Piece *piec
 // OCC = workgroups per CU the register budget is cut for: 4 (128 VGPRs - the IMU body, a latency chain of a few hundred workgroups,
 // then spills 47 registers) when the surfel pieces outnumber the chip's workgroup slots, 3 (168 VGPRs, no spills) for the small windows
 // of a real stream, where the IMU chain IS the kernel (facade: 15.7 -> 13.5 us)
+// n_big: binary pieces of more than 128 records (the family is sorted by size, largest first): a workgroup each; the others go two to a
+// workgroup (lin_binary_pair_body).  n_bwg = n_big + ceil((n_b - n_big) / 2) workgroups for the binary family (n_big = n_b: no pairing).
 template <bool WITH_UNARY, int OCC>
 __global__ void __launch_bounds__(256, OCC) k_lin_fused(WinParams wp, const Piece *pieces, uint32_t n_imu, uint32_t n_b, uint32_t n_u, const double *brec,
                                                      uint32_t nb, const double *urec, uint32_t nu, const ImuRec *irec, const double *times,
-                                                     const double *x, double *partial, uint32_t cost_slot0) {
+                                                     const double *x, double *partial, uint32_t cost_slot0, uint32_t n_big, uint32_t n_bwg) {
   constexpr int SZ0 = LinSurfelLds<24>::DOUBLES > kLinImuLds ? LinSurfelLds<24>::DOUBLES : kLinImuLds;
   constexpr int SZ = LinSurfelLds<12>::DOUBLES > SZ0 ? LinSurfelLds<12>::DOUBLES : SZ0;
   __shared__ __attribute__((aligned(16))) double smem[SZ];
   const uint32_t b = blockIdx.x;
-  if (b < n_imu)
+  if (b < n_imu) {
     lin_imu_body(wp, pieces[n_b + n_u + b], irec, x, times, partial, smem, cost_slot0 + n_b + n_u + b);
-  else if (!WITH_UNARY || b < n_imu + n_b)
-    lin_surfel_body<24, false>(wp, pieces[b - n_imu], brec, nb, x, partial, smem, cost_slot0 + b - n_imu);
-  else
-    lin_surfel_body<12, true>(wp, pieces[b - n_imu], urec, nu, x, partial, smem, cost_slot0 + b - n_imu);
+  } else if (b < n_imu + n_bwg) {
+    const uint32_t q = b - n_imu;
+    if (q < n_big) {
+      lin_surfel_body<24, false>(wp, pieces[q], brec, nb, x, partial, smem, cost_slot0 + q);
+    } else {
+      const uint32_t p0 = n_big + 2u * (q - n_big), p1 = p0 + 1u;
+      Piece none = pieces[p0];
+      none.count = 0u;
+      lin_binary_pair_body(wp, pieces[p0], p1 < n_b ? pieces[p1] : none, brec, nb, x, partial, smem, cost_slot0 + p0, cost_slot0 + p1);
+    }
+  } else if (WITH_UNARY) {
+    const uint32_t q = n_b + (b - n_imu - n_bwg);
+    lin_surfel_body<12, true>(wp, pieces[q], urec, nu, x, partial, smem, cost_slot0 + q);
+  }
 }
 
 // Gather of the piece partials into the dense normal equations, g and the cost: ONE launch with four roles by workgroup
@@ -2723,6 +2840,8 @@ static int window_build_impl(wc_ctx *ctx, const wc_surfel *d_sld_surf, const wc_
   cut(segs_b, 25, true);
   W->npiece_b = (uint32_t)pieces.size();
   by_size(0);
+  W->npiece_b_big = 0;  // (sorted by size, largest first: the pieces of more than half a workgroup's records)
+  while (W->npiece_b_big < W->npiece_b && pieces[W->npiece_b_big].count > (uint32_t)kPiece / 2u) ++W->npiece_b_big;
   const uint32_t npairs = (uint32_t)(ns * (ns + 1) / 2);
   W->npairs = npairs;
   src_begin.assign(npairs + 1, 0), gsrc_begin.assign(ns + 1, 0);
@@ -3108,20 +3227,23 @@ int enqueue_linearize(wc_ctx *ctx, wc_window_state *W, const double *d_x, int ma
 #define WC_LIN_FEW (6u * 256u)  // two rounds of the chip's slots at three per CU (facade, 244 linearisations: 13.4 us on average with OCC = 4 throughout, 12.2 with 768, 11.9 - 12.4 with 1 536 / 3 072; the step's 2 989 pieces: 26.8 us with OCC = 4, 29.1 with 3)
 #endif
   const bool few = W->npiece_b + W->npiece_u <= WC_LIN_FEW;
+  // (binary pieces of at most 128 records go two to a workgroup - lin_binary_pair_body; development option lin_pair = 0: one each)
+  const uint32_t n_big = ctx->dev.lin_pair != 0 ? W->npiece_b_big : W->npiece_b;
+  const uint32_t n_bwg = n_big + (W->npiece_b - n_big + 1u) / 2u;
   auto fused_launch = [&](auto kern, uint32_t grid) {
     kern<<<grid, 256, 0, st>>>(W->wp, pcs, W->npiece_i, W->npiece_b, W->npiece_u, (const double *)W->brec.p, W->nb, (const double *)W->urec.p, W->nu,
-                               (const ImuRec *)W->irec.p, (const double *)W->times_d.p, d_x, partial, W->npart_doubles);
+                               (const ImuRec *)W->irec.p, (const double *)W->times_d.p, d_x, partial, W->npart_doubles, n_big, n_bwg);
   };
   if (fused_u) {
     if (few)
-      fused_launch(k_lin_fused<true, 3>, W->npiece_i + W->npiece_b + W->npiece_u);
+      fused_launch(k_lin_fused<true, 3>, W->npiece_i + n_bwg + W->npiece_u);
     else
-      fused_launch(k_lin_fused<true, WC_LIN_WG_PER_CU>, W->npiece_i + W->npiece_b + W->npiece_u);
+      fused_launch(k_lin_fused<true, WC_LIN_WG_PER_CU>, W->npiece_i + n_bwg + W->npiece_u);
   } else if (fused) {
     if (few)
-      fused_launch(k_lin_fused<false, 3>, W->npiece_i + W->npiece_b);
+      fused_launch(k_lin_fused<false, 3>, W->npiece_i + n_bwg);
     else
-      fused_launch(k_lin_fused<false, WC_LIN_WG_PER_CU>, W->npiece_i + W->npiece_b);
+      fused_launch(k_lin_fused<false, WC_LIN_WG_PER_CU>, W->npiece_i + n_bwg);
   }
   else if (W->npiece_b)
     k_lin_surfel<24, false><<<W->npiece_b, kPiece, 0, st>>>(W->wp, pcs, (const double *)W->brec.p, (const uint32_t *)W->bkey.p, W->nb,
