@@ -288,11 +288,13 @@ int wc_window_build(wc_ctx *ctx, const wc_surfel *d_sld_surf, const wc_pose *d_s
                     const double *h_grav, int fix_first_pos);
 /* Multi-GPU form (correspondences and IMU factors sharded, unknowns replicated): a COLLECTIVE of the ctx's
  * communicator.  EVERY rank passes the SAME replicated arguments as it would to wc_window_build; the library takes this rank's
- * contiguous share of both correspondence lists and of the IMU state triples, and one small all-reduce checks that the shares add
- * up to the whole problem (WC_ERR_ARG otherwise).  From then on wc_window_linearize / _evaluate / _solve on this problem are
- * collectives: ONE all-reduce per linearisation of {upper block pairs of H, g, cost} - 144 doubles per pair of sample blocks at
- * most two apart, the 6 x 6 pose corner (36) of the others, which only surfel factors reach: 0.76 MB at 64 sample states, 2.7 MB
- * at 127 - plus one double per candidate cost; every rank takes identical accept / reject decisions on identical numbers.
+ * contiguous share of both correspondence lists - the IMU factors, a few hundred to two thousand, stay on EVERY rank -, and one small
+ * all-reduce checks that the shares add up to the whole problem (WC_ERR_ARG otherwise).  From then on wc_window_linearize / _evaluate /
+ * _solve on this problem are collectives, two per linearisation (round 6): {cost of the surfel factors, spare} - 16 bytes, all the
+ * trust-region decision waits for - and {6 x 6 pose corner of every upper block pair, pose half of g} (surfel factors reach nothing
+ * else: 0.60 MB at 64 sample states, 2.35 MB at 127), which the in-library RCCL binding runs on a side stream beside the bias
+ * elimination; every rank takes identical accept / reject decisions on identical numbers.  (Development option lm_one_collective:
+ * rounds 3 - 5's ONE all-reduce of {upper block pairs of H, g, cost} with the IMU triples sharded too: 0.76 / 2.7 MB.)
  * A problem built with wc_window_build is never a collective, whatever is installed on the ctx (a caller that shards the factors
  * itself opts in with wc_window_set_allreduce).  Without a communicator (or a world of one) this is wc_window_build. */
 int wc_window_build_sharded(wc_ctx *ctx, const wc_surfel *d_sld_surf, const wc_pose *d_sld_pose, const wc_pair *d_pairs_sld,
@@ -300,7 +302,9 @@ int wc_window_build_sharded(wc_ctx *ctx, const wc_surfel *d_sld_surf, const wc_p
                             uint64_t n_pairs_fix, const wc_imu_state *h_imu, uint64_t n_imu, const double *h_sample_times, uint64_t ns,
                             const double *h_grav, int fix_first_pos);
 /* counts[4] = {binary factors, unary factors, imu factors, assembly pieces} (of THIS rank's share for a sharded problem);
- * wc_window_reduce_bytes: bytes one linearisation's all-reduce carries (0: the problem is not sharded) */
+ * wc_window_reduce_bytes: bytes one linearisation's collectives carry (0: the problem is not sharded).  A problem built by
+ * wc_window_build_sharded has two per linearisation since round 6 - {cost of the surfel factors, spare} (16 bytes) and {6 x 6 pose corner of
+ * every upper block pair, pose half of g} -, the IMU factors being replicated; the figure is their sum */
 uint64_t wc_window_reduce_bytes(wc_ctx *ctx);
 int wc_window_counts(wc_ctx *ctx, uint64_t counts[4]);
 /* problem.Evaluate(apply_loss_function = true) (lidar_odometry.cc:62-65): cost = 1/2 sum rho; d_residuals (may be NULL)
