@@ -37,8 +37,8 @@ def _rotate_inv(quat, v):
 
 
 def _setup(gpu, oracle, n_scans=3, patches=300, fixed=120, quirks=1, fix_first=True, with_imu=True, extra_mode2=True, seed=11,
-           one_plane=False):
-    w = synth.surfel_window(n_scans, patches, seed=seed, fixed_patches=fixed)
+           one_plane=False, sample_dt=0.08):
+    w = synth.surfel_window(n_scans, patches, seed=seed, fixed_patches=fixed, sample_dt=sample_dt)
     if one_plane:  # degenerate geometry: every surfel normal is the world z axis (two translations and yaw unobservable by lidar)
         for k_s, k_p in (("surf", "pose"), ("fix_surf", "fix_pose")):
             if len(w[k_s]):
@@ -114,6 +114,20 @@ def test_lm_solve_matches_oracle(gpu, oracle, cfg):
     assert _rel(x, x_ref) <= 1e-6, _rel(x, x_ref)
     if not cfg.get("one_plane"):
         assert s_ref.final_cost < 0.7 * s_ref.initial_cost  # the solve really removed the injected pose error
+
+
+@pytest.mark.parametrize("sample_dt,ns", [(0.34, 4), (0.25, 6), (0.2, 7), (0.15, 8)])
+def test_tiny_windows_match_oracle(gpu, oracle, sample_dt, ns):
+    """four to eight sample states: the pose half of the reduced system is ONE 32 x 32 block (ns = 4, 5: no panel step at all, the back
+    product k_back_mul takes its only block from k_schur_form's factor) or two (the appended identity rows get one step); round 6"""
+    w, W, keep = _setup(gpu, oracle, n_scans=2, patches=150, fixed=60, extra_mode2=False, sample_dt=sample_dt)
+    assert W.ns == ns
+    x0 = np.zeros(12 * W.ns)
+    x_ref, s_ref, first_ref = W.solve(x0)
+    x, s, first = gpu.window_solve(x0)
+    assert s.termination == s_ref.termination and s.iterations == s_ref.iterations and s.successful_steps == s_ref.successful_steps
+    assert abs(s.final_cost - s_ref.final_cost) <= 1e-8 * s_ref.final_cost
+    assert _rel(first, first_ref) <= 1e-6 and _rel(x, x_ref) <= 1e-6, (_rel(first, first_ref), _rel(x, x_ref))
 
 
 def test_far_pairs_stay_zero_across_builds_and_timed_linearisation(gpu, oracle):
