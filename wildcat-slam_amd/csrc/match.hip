@@ -78,7 +78,8 @@ constexpr uint32_t kNone = 0xFFFFFFFFu;
 struct MatchParams {
   double cs, as;        // centre / angular scale
   double time_min, ang_max, dist_max;
-  int k;
+  double cos_acc, plane_acc;  // EARLY walks (match_tree.inc): accept a candidate when cos >= cos_acc and the plane distance <= plane_acc - ...
+  int k, same_set;
 };
 
 __device__ __forceinline__ void feature6(const wc_surfel &s, const wc_pose &p, double cs, double as, double f[6], V3 &cw, V3 &nw) {
@@ -332,7 +333,10 @@ static int match_impl(wc_ctx *ctx, const wc_surfel *d_q_surf, const wc_pose *d_q
   MatchParams M;
   M.cs = P.center_scale, M.as = P.angular_scale;
   M.time_min = P.time_diff_min, M.ang_max = P.angular_scale, M.dist_max = P.surfel_dist_max;
-  M.k = P.knn_k;
+  M.k = P.knn_k, M.same_set = same_set ? 1 : 0;
+  // (margins of the early acceptance: 1e-9 in the angle and relative 1e-9 in the distance, against ~1e-15 between the walk's operands and the gates')
+  M.cos_acc = M.ang_max > 1e-8 ? std::cos(std::min(M.ang_max, 3.141592653589793) - 1e-9) + 1e-12 : 2.0;
+  M.plane_acc = M.dist_max * (1.0 - 1e-9) - 1e-12;
   // 3. exact k-NN + gates.  Queries are processed in the order of the tree's leaves, so that the lanes of a wavefront walk the same
   // nodes: same-set queries through the sorted target permutation, queries of another set (sliding window against fixed window)
   // by the leaf they would be looked for in first (in time order their walks are unrelated and the loads diverge)
@@ -393,13 +397,22 @@ static int match_impl(wc_ctx *ctx, const wc_surfel *d_q_surf, const wc_pose *d_q
   // wavefront slots and its LDS until the slowest of its 32 walks has ended - the next workgroup waits for all of them.  Measured
   // (profiles/dev/time_match.py pair, time_room_match.py): the step-like pair of searches 1.674 -> 1.605 ms, a room search 0.444 -> 0.439.
   constexpr int kGroupNT = 64;
+  // two sets, nobody asked for the neighbour lists: the walk may stop at the nearest gate-passing candidate (match_tree.inc, EARLY)
+  const bool early = !d_knn_idx && ctx->dev.knn_early != 0 && (!same_set || ctx->dev.knn_early != 2);
 #define WC_KNN_LAUNCH(KK)                                                                                                                            \
-  if (nq_mine && group_walk)                                                                                                                         \
-    k_knn_tree_group<KK, kGroupNT><<<(nq_mine + kGroupNT / 8 - 1) / (kGroupNT / 8), kGroupNT, 0, st>>>(                                              \
+  if (nq_mine && group_walk && early)                                                                                                                \
+    k_knn_tree_group<KK, kGroupNT, true><<<(nq_mine + kGroupNT / 8 - 1) / (kGroupNT / 8), kGroupNT, 0, st>>>(                                        \
         d_q_surf, d_q_pose, nq, tree, first3, (const double *)b_world.p, nt, M, (uint32_t *)b_gated.p, d_knn_idx, d_knn_d2, qorder, q_begin, q_end,  \
         gated_shard, stats, status);                                                                                                                 \
+  else if (nq_mine && group_walk)                                                                                                                    \
+    k_knn_tree_group<KK, kGroupNT, false><<<(nq_mine + kGroupNT / 8 - 1) / (kGroupNT / 8), kGroupNT, 0, st>>>(                                       \
+        d_q_surf, d_q_pose, nq, tree, first3, (const double *)b_world.p, nt, M, (uint32_t *)b_gated.p, d_knn_idx, d_knn_d2, qorder, q_begin, q_end,  \
+        gated_shard, stats, status);                                                                                                                 \
+  else if (nq_mine && early)                                                                                                                         \
+    k_knn_tree<KK, true><<<(nq_mine + 63) / 64, 64, (size_t)(kNch + 1 + stack_cap) * 64 * 4, st>>>(d_q_surf, d_q_pose, nq, tree, (const double *)b_world.p, nt, M, (uint32_t *)b_gated.p, d_knn_idx, \
+                                                       d_knn_d2, qorder, q_begin, q_end, gated_shard, stats, status, stack_cap);                     \
   else if (nq_mine)                                                                                                                                  \
-    k_knn_tree<KK><<<(nq_mine + 63) / 64, 64, (size_t)(kNch + 1 + stack_cap) * 64 * 4, st>>>(d_q_surf, d_q_pose, nq, tree, (const double *)b_world.p, nt, M, (uint32_t *)b_gated.p, d_knn_idx, \
+    k_knn_tree<KK, false><<<(nq_mine + 63) / 64, 64, (size_t)(kNch + 1 + stack_cap) * 64 * 4, st>>>(d_q_surf, d_q_pose, nq, tree, (const double *)b_world.p, nt, M, (uint32_t *)b_gated.p, d_knn_idx, \
                                                        d_knn_d2, qorder, q_begin, q_end, gated_shard, stats, status, stack_cap);
   switch (P.knn_k) {  // the reference's k = 10 gets its own instantiation (top-k in 30 registers)
     case 10: WC_KNN_LAUNCH(10); break;
