@@ -354,3 +354,40 @@ def test_both_walks_every_k(gpu, group):
     worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_match_walk_worker.py")
     r = subprocess.run([sys.executable, worker, group], env=dict(os.environ), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
     assert r.returncode == 0 and ("walk %s ok" % group) in r.stdout.decode(), r.stdout.decode()[-3000:]
+
+
+@pytest.mark.parametrize("group", [0, 1], ids=["lane-per-query", "eight-lanes-per-query"])
+def test_early_bound_of_the_walks_changes_no_pair(gpu, oracle, group):
+    """Round 6: a walk is bounded by the nearest candidate that passes the gates as well as by the k-th distance (the reference takes the FIRST
+    gated neighbour, knn_surfel_matcher.cc:24-46; one set: only candidates with a larger index end the scan, cc:35-38).  Gates that reject the
+    nearest neighbours (a long time gate, a narrow angle, a thin plane gate), gates that reject nothing, k of 1 ... 16, both sets, both walks,
+    the development option knn_early off (0), on (1) and for two sets only (2): every pair list is the oracle's."""
+    rng = np.random.default_rng(77)
+    w = synth.surfel_window(5, 220, seed=31, fixed_patches=150)
+    # jitter the normals and centres a little so that the gates cut THROUGH the neighbour lists
+    w["surf"]["normal"] += rng.normal(scale=0.03, size=w["surf"]["normal"].shape)
+    w["surf"]["normal"] /= np.linalg.norm(w["surf"]["normal"], axis=1, keepdims=True)
+    w["surf"]["center"] += rng.normal(scale=0.02, size=w["surf"]["center"].shape)
+    dt = float(np.ptp(w["surf"]["t"]))
+    settings = [dict(), dict(time_diff_min=0.45 * dt), dict(time_diff_min=2.0 * dt), dict(surfel_dist_max=0.004), dict(surfel_dist_max=1e3, time_diff_min=0.0),
+                dict(knn_k=1), dict(knn_k=3, time_diff_min=0.3 * dt), dict(knn_k=16, surfel_dist_max=0.01)]
+    seen_cut = 0
+    try:
+        gpu.set_dev_option("knn_group", group)
+        for kw in settings:
+            params = oracle.default_params()
+            for k_, v in kw.items():
+                setattr(params, k_, v)
+            gpu.set_params(params)
+            ref_s = oracle.match(w["surf"], w["pose"], w["surf"], w["pose"], True, params)
+            ref_f = oracle.match(w["surf"], w["pose"], w["fix_surf"], w["fix_pose"], False, params)
+            seen_cut += int(0 < len(ref_s) < len(w["surf"]))
+            for early in (0, 1, 2):
+                gpu.set_dev_option("knn_early", early)
+                assert np.array_equal(gpu.match(w["surf"], w["pose"], w["surf"], w["pose"], True), ref_s), (kw, early)
+                assert np.array_equal(gpu.match(w["surf"], w["pose"], w["fix_surf"], w["fix_pose"], False), ref_f), (kw, early)
+        assert seen_cut >= 3
+    finally:
+        gpu.set_dev_option("knn_early", 1)
+        gpu.set_dev_option("knn_group", -1)
+        gpu.set_params(oracle.default_params())
