@@ -60,7 +60,9 @@ int wc_ctx_set_params(wc_ctx *ctx, const wc_params *params);
  *   ex_sync            wc_extract_surfels_finish waits for the stream instead of the sweep's completion ticket
  *   kd_leaf            target leaf size of the matcher's kd-tree (0 = 8)
  *   knn_group          matcher walk: 0 one lane per query, 1 eight lanes per query, -1 by the call's sizes
- *   knn_early          1 (default): a search against another set bounds its walks by the nearest gate-passing candidate as well; 0: plain k-NN walks
+ *   knn_early          1 (default): the matcher's walks are bounded by the nearest gate-passing candidate as well as by the k-th distance
+ *                      (same pair lists; not when the neighbour lists themselves are asked for); 0: plain k-NN walks; 2: two-set searches only
+ *   knn_sort           leaf-order sort of a two-set search's queries: 0 never, 1 always, -1 (default) from 40 000 queries
  *   match_pair_serial  wc_match_pair runs its two searches one after the other on the ctx
  *   match_pair_swap    the sliding-window search on the helper context instead of the fixed-window one
  *   lin_imu_apart, lin_unary_apart, lin_post_apart   factor families / mailbox of a linearisation as launches of their own

@@ -49,6 +49,7 @@ struct wc_dev_opts {
   int ex_sync = 0;           // extraction: finish waits for the stream instead of the completion ticket
   int kd_leaf = 0;           // matcher: target leaf size of the kd-tree (0: 8)
   int knn_group = -1;        // matcher walk: 0 one lane per query, 1 eight lanes per query, -1 by size
+  int knn_sort = -1;         // two-set searches order their queries by leaf: 0 never, 1 always, -1 by the rule in match.hip
   int knn_early = 1;         // two-set searches bound their walks by the nearest gate-passing candidate too (0: plain k-NN walks, rounds 4 - 5)
   int match_pair_serial = 0; // wc_match_pair runs its searches one after the other on the ctx
   int match_pair_swap = 0;   // the sliding-window search on the helper instead of the fixed-window one

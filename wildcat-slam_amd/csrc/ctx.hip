@@ -70,6 +70,7 @@ const DevOpt kDevOpts[] = {
     {"kd_leaf", "WC_KD_LEAF", &wc_dev_opts::kd_leaf, false},
     {"knn_group", "WC_KNN_GROUP", &wc_dev_opts::knn_group, false},
     {"knn_early", "WC_KNN_EARLY", &wc_dev_opts::knn_early, false},
+    {"knn_sort", "WC_KNN_SORT", &wc_dev_opts::knn_sort, false},
     {"match_pair_serial", "WC_MATCH_PAIR_SERIAL", &wc_dev_opts::match_pair_serial, true},
     {"match_pair_swap", "WC_MATCH_PAIR_SWAP", &wc_dev_opts::match_pair_swap, true},
     {"lin_imu_apart", "WC_LIN_IMU_APART", &wc_dev_opts::lin_imu_apart, true},

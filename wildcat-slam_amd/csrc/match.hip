@@ -343,7 +343,7 @@ static int match_impl(wc_ctx *ctx, const wc_surfel *d_q_surf, const wc_pose *d_q
   const uint32_t *qorder = tree.sorig;
   // (below ~40 k queries the two passes - locate, radix sort: ~70 us - cost more than the walks gain from them: 16 k queries against 4 k
   // targets 0.38 -> 0.31 ms in query order, 64 k the same, 250 k 1.23 -> 1.36; the rule depends on the call's sizes alone)
-  const bool sort_queries = !same_set && nq >= 40000u;
+  const bool sort_queries = !same_set && (ctx->dev.knn_sort >= 0 ? ctx->dev.knn_sort != 0 : nq >= 40000u);
   if (!same_set && !sort_queries) qorder = nullptr;
   if (sort_queries) {
     uint32_t *k0 = (uint32_t *)ctx->b_keys[0].p, *v0 = (uint32_t *)ctx->b_vals[0].p;
