@@ -829,7 +829,9 @@ def bench_window(ctx, args, world, rank, dev, torch, dist, cpu=False):
         "match_walk_per_query": {"fixed_window": {k_: round(v_, 1) for k_, v_ in st_fix.items()}, "sliding_window": {k_: round(v_, 1) for k_, v_ in st_sld.items()},
                                  "index": "6-D kd-tree with bounding boxes over [centre, normal / 5 deg] (csrc/match_tree.inc); points_per_query = targets looked at, "
                                           "exact_per_query = fp64 distances (the lane-per-query walk, from 750 k queries on, takes a fp32 first look and sums the "
-                                          "survivors; the eight-lanes-per-query walk sums every point of a visited leaf); nodes = node ITEMS (4 / 8 child boxes each)"},
+                                          "survivors; the eight-lanes-per-query walk sums every point of a visited leaf); nodes = node ITEMS (4 / 8 child boxes each).  "
+                                          "Round 6: a walk is bounded by the nearest gate-passing candidate as well as by the k-th distance - what "
+                                          "KnnSurfelMatcher::Match uses of a neighbour list (cc:24-46); the pair lists are unchanged"},
     }
     # the assembly's OTHER roof (the binding one): fp64 vector issue.  Flops per record by a fixed counting rule - the
     # Gram matrix of the record's row [J r] (upper triangle: 325 / 91 multiply-adds for 24 / 12 unknowns + residual) plus ~450 / ~250
@@ -843,8 +845,8 @@ def bench_window(ctx, args, world, rank, dev, torch, dist, cpu=False):
     b_match = 192 * (2 * n_s + n_s + len(w["fix_surf"]))
     out["match_roofline"] = {"bound": "hbm", "achieved": round(b_match / t_match / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": round(b_match / t_match / 1e9 / HBM_PEAK_GBS, 5), "algorithmic_bytes": b_match,
-                             "note": "latency-bound gather work (exact 10-NN in 6-D through a kd-tree), far from the byte roofline by construction: the "
-                                     "window's normals are random, the 10th neighbour lies 2 - 5.7 units away"}
+                             "note": "latency-bound gather work (the first gate-passing of the exact 10 nearest in 6-D, through a kd-tree), far from the byte "
+                                     "roofline by construction: the window's normals are random, the 10th neighbour lies 2 - 5.7 units away"}
     try:  # the matcher on what a real scanner produces (never quoted without it): surfels on the surfaces of a room, many sweeps deep
         out["match_room_stream"] = bench_match_room(ctx)
     except Exception as e:
