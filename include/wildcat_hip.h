@@ -62,7 +62,9 @@ int wc_ctx_set_params(wc_ctx *ctx, const wc_params *params);
  *   knn_group          matcher walk: 0 one lane per query, 1 eight lanes per query, -1 by the call's sizes
  *   knn_early          1 (default): the matcher's walks are bounded by the nearest gate-passing candidate as well as by the k-th distance
  *                      (same pair lists; not when the neighbour lists themselves are asked for); 0: plain k-NN walks; 2: two-set searches only
- *   knn_sort           leaf-order sort of a two-set search's queries: 0 never, 1 always, -1 (default) from 40 000 queries
+ *   knn_sort           leaf-order sort of a two-set search's queries: 0 never, 1 always, -1 (default): from 40 000 queries when the plain
+ *                      k-NN walks run (neighbour lists asked for, knn_early = 0), never with the early bound
+ *   match_pair_hold    1 (default): wc_match_pair holds the fixed-window search's walk back until the other search's tree is built
  *   match_pair_serial  wc_match_pair runs its two searches one after the other on the ctx
  *   match_pair_swap    the sliding-window search on the helper context instead of the fixed-window one
  *   lin_imu_apart, lin_unary_apart, lin_post_apart   factor families / mailbox of a linearisation as launches of their own

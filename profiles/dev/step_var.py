@@ -9,6 +9,9 @@ if len(sys.argv) > 2 and sys.argv[2] == "torch":  # (bench.py imports torch: doe
     import torch
     torch.cuda.init(); _x = torch.zeros(4, device="cuda:0"); torch.cuda.synchronize()
 ctx = lib.Context(0)
+for kv in os.environ.get("STEP_VAR_OPTS", "").split(","):  # development options: STEP_VAR_OPTS="match_pair_hold=0,knn_sort=1"
+    if kv:
+        ctx.set_dev_option(kv.split("=")[0], int(kv.split("=")[1]))
 w = synth.g2_scan_sequence(10, 3906, m=32, seed=synth.SEED + 21)
 sw = StepWindow(ctx, w, rank=0, world=1)
 sw.step(); sw.step()

@@ -53,6 +53,7 @@ struct wc_dev_opts {
   int knn_early = 1;         // two-set searches bound their walks by the nearest gate-passing candidate too (0: plain k-NN walks, rounds 4 - 5)
   int match_pair_serial = 0; // wc_match_pair runs its searches one after the other on the ctx
   int match_pair_swap = 0;   // the sliding-window search on the helper instead of the fixed-window one
+  int match_pair_hold = 1;   // wc_match_pair: the fixed-window search's walk waits for the sliding-window search's tree (match.hip: wc_pair_sync)
   int lin_imu_apart = 0, lin_unary_apart = 0, lin_post_apart = 0;  // the linearisation's families / mailbox as launches of their own
   int lm_dense = 0;          // round 2's LM step: dense Cholesky of all 12 ns unknowns
   int lin_pair = 1;          // binary assembly pieces of at most 128 records two to a workgroup (0: one each, rounds 2 - 5)
@@ -148,8 +149,10 @@ struct wc_ctx {
   wc_window_state *win = nullptr;
   wc_ctx *aux = nullptr;  // helper context of wc_match_pair (second stream + scratch), owned by this ctx
   hipEvent_t ev_aux = nullptr;  // orders the helper's stream behind the ctx stream
+  hipEvent_t ev_pair = nullptr; // wc_match_pair: behind the sliding-window search's tree build (match.hip: wc_pair_sync)
   void *pair_worker = nullptr;  // wc_match_pair's helper thread (match.hip: wc_pair_worker), freed through pair_worker_free
   void (*pair_worker_free)(void *) = nullptr;
+  void *pair_sync = nullptr;  // match.hip: wc_pair_sync of the wc_match_pair call this context's search belongs to (null: a search of its own)
   // optional per-stage HIP events of the extraction pipeline (wc_extract_profile)
   bool ex_prof = false;
   int ex_prof_mode = 0;

@@ -73,6 +73,7 @@ const DevOpt kDevOpts[] = {
     {"knn_sort", "WC_KNN_SORT", &wc_dev_opts::knn_sort, false},
     {"match_pair_serial", "WC_MATCH_PAIR_SERIAL", &wc_dev_opts::match_pair_serial, true},
     {"match_pair_swap", "WC_MATCH_PAIR_SWAP", &wc_dev_opts::match_pair_swap, true},
+    {"match_pair_hold", "WC_MATCH_PAIR_HOLD", &wc_dev_opts::match_pair_hold, false},
     {"lin_imu_apart", "WC_LIN_IMU_APART", &wc_dev_opts::lin_imu_apart, true},
     {"lin_unary_apart", "WC_LIN_UNARY_APART", &wc_dev_opts::lin_unary_apart, true},
     {"lin_post_apart", "WC_LIN_POST_APART", &wc_dev_opts::lin_post_apart, true},
@@ -217,6 +218,7 @@ extern "C" void wc_ctx_destroy(wc_ctx *ctx) {
     ctx->aux = nullptr;
   }
   if (ctx->ev_aux) (void)hipEventDestroy(ctx->ev_aux);
+  if (ctx->ev_pair) (void)hipEventDestroy(ctx->ev_pair);
   for (hipEvent_t e : ctx->ev_knn)
     if (e) (void)hipEventDestroy(e);
   (void)wc_comm_rccl_destroy(ctx);

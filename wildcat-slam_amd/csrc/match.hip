@@ -71,6 +71,30 @@ struct wc_pair_worker {
   }
 };
 
+// wc_match_pair, round 6: the fixed-window search's walk is held back until the sliding-window search's TREE is built.  Without the
+// leaf-order sort the fixed-window search (a small tree, built sooner) reaches its walk while the other search is still building: the
+// walk's one-wavefront workgroups then fill every slot, and the build's large workgroups (1 024 threads, 50 - 100 KB of LDS) wait for
+// a compute unit to drain - room surfels, 55 k queries: the pair 0.73 -> 0.84 ms.  One event, recorded behind the sliding-window
+// search's build and waited for in front of the other's walk; the host side is a flag under a mutex (the waiting thread has enqueued
+// its own build by then).  post() is called on EVERY way out of the sliding-window search (without an event when it failed early).
+struct wc_pair_sync {
+  std::mutex m;
+  std::condition_variable cv;
+  bool posted = false, have_event = false;
+  hipEvent_t ev = nullptr;
+  void post(bool with_event) {
+    std::lock_guard<std::mutex> lk(m);
+    if (posted) return;
+    posted = true, have_event = with_event;
+    cv.notify_all();
+  }
+  bool wait() {
+    std::unique_lock<std::mutex> lk(m);
+    cv.wait(lk, [&] { return posted; });
+    return have_event;
+  }
+};
+
 namespace {
 
 constexpr uint32_t kNone = 0xFFFFFFFFu;
@@ -329,7 +353,15 @@ static int match_impl(wc_ctx *ctx, const wc_surfel *d_q_surf, const wc_pose *d_q
   k_features<<<(nt + 255) / 256, 256, 0, st>>>(d_t_surf, d_t_pose, nt, P.center_scale, P.angular_scale, (double *)b_feat.p, (double *)b_world.p, status);
   const KdPlan plan = kd_plan(nt, ctx->dev.kd_leaf);
   KdTree tree;
+  wc_pair_sync *psync = (wc_pair_sync *)ctx->pair_sync;
+  struct PairPost {  // (every way out of a sliding-window search of a pair releases the other search)
+    wc_pair_sync *s;
+    ~PairPost() {
+      if (s) s->post(false);
+    }
+  } pair_post{same_set ? psync : nullptr};
   WC_TRY(kd_build(ctx, (const double *)b_feat.p, nt, plan, tree));
+  if (psync && same_set && psync->ev && hipEventRecord(psync->ev, st) == hipSuccess) psync->post(true);
   MatchParams M;
   M.cs = P.center_scale, M.as = P.angular_scale;
   M.time_min = P.time_diff_min, M.ang_max = P.angular_scale, M.dist_max = P.surfel_dist_max;
@@ -343,7 +375,11 @@ static int match_impl(wc_ctx *ctx, const wc_surfel *d_q_surf, const wc_pose *d_q
   const uint32_t *qorder = tree.sorig;
   // (below ~40 k queries the two passes - locate, radix sort: ~70 us - cost more than the walks gain from them: 16 k queries against 4 k
   // targets 0.38 -> 0.31 ms in query order, 64 k the same, 250 k 1.23 -> 1.36; the rule depends on the call's sizes alone)
-  const bool sort_queries = !same_set && (ctx->dev.knn_sort >= 0 ? ctx->dev.knn_sort != 0 : nq >= 40000u);
+  // (round 6: NOT with the early bound - its walks are a descent and two or three leaves, and the two passes cost more than coherent
+  // descents save even for queries in RANDOM order: 250 k queries against 62 k targets 0.74 -> 0.69 ms (own order 0.77 -> 0.70), C4's 1 M
+  // against 50 k 1.07 -> 0.98 (0.95), room surfels 0.57 -> 0.56; profiles/dev/ab_sort_random.py, ab_room_match.py)
+  const bool early_walk = !d_knn_idx && ctx->dev.knn_early != 0;
+  const bool sort_queries = !same_set && (ctx->dev.knn_sort >= 0 ? ctx->dev.knn_sort != 0 : (nq >= 40000u && !early_walk));
   if (!same_set && !sort_queries) qorder = nullptr;
   if (sort_queries) {
     uint32_t *k0 = (uint32_t *)ctx->b_keys[0].p, *v0 = (uint32_t *)ctx->b_vals[0].p;
@@ -390,6 +426,7 @@ static int match_impl(wc_ctx *ctx, const wc_surfel *d_q_surf, const wc_pose *d_q
   // 0.62 / 0.94 / 1.77 ms, fixed-window 0.62 / 0.96 / 1.13 / 1.35 / 2.28 against 0.31 / 0.54 / 0.80 / 1.23 / 2.15 ms; at a million
   // queries (C4) 2.06 against 2.02 and 3.50 against 3.96 (profiles/dev/time_match_sizes.py, time_match.py).  The rule depends on the
   // call's sizes and kind alone - no timing, no history.
+  if (psync && !same_set && psync->wait()) WC_HIP(ctx, hipStreamWaitEvent(st, psync->ev, 0));  // (wc_pair_sync: behind the other search's build)
   const int group_opt = ctx->dev.knn_group;  // (development option: 0 / 1 pins the walk)
   const bool group_walk = group_opt >= 0 ? group_opt != 0 : (nq_mine < 750000u || (same_set && nq_mine < 1500000u));
   const int first3 = plan.D % 3 ? plan.D % 3 : 3;
@@ -613,6 +650,14 @@ extern "C" int wc_match_pair(wc_ctx *ctx, const wc_surfel *d_sld_surf, const wc_
   WC_HIP(ctx, hipEventRecord(ctx->ev_aux, ctx->stream));
   WC_HIP(ctx, hipStreamWaitEvent(aux->stream, ctx->ev_aux, 0));
   int rc_fix = WC_OK, rc_sld = WC_OK;
+  wc_pair_sync psync;
+  if (!ctx->ev_pair) WC_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_pair, hipEventDisableTiming));
+  psync.ev = ctx->ev_pair;
+  struct PairScope {  // both searches see the call's wc_pair_sync, and neither a later one
+    wc_ctx *a, *b;
+    PairScope(wc_ctx *a_, wc_ctx *b_, wc_pair_sync *s) : a(a_), b(b_) { a->pair_sync = s, b->pair_sync = s; }
+    ~PairScope() { a->pair_sync = nullptr, b->pair_sync = nullptr; }
+  } pair_scope(ctx, aux, &psync);
   // (A rendezvous of the two searches in front of their walk kernels was tried in round 3 - grid kernels: 2.50 - 2.76 ms against
   // 2.45 - 2.50 - and again in round 4 with the tree: a kernel trace showed the fixed-window search's locate + radix passes waiting
   // for wavefront slots behind the other search's k_knn_tree - one Onesweep pass of 250 k keys took 446 us - and its walk starting
@@ -647,6 +692,7 @@ extern "C" int wc_match_pair(wc_ctx *ctx, const wc_surfel *d_sld_surf, const wc_
       threaded = false;
     }
   }
+  if (!threaded || ctx->dev.match_pair_hold == 0) psync.post(false);  // (one thread, one search after the other: nothing to hold back, and nobody to wait for)
   if (swap)
     guarded(rc_fix, search_fix);
   else
