@@ -428,7 +428,9 @@ static int match_impl(wc_ctx *ctx, const wc_surfel *d_q_surf, const wc_pose *d_q
   // call's sizes and kind alone - no timing, no history.
   if (psync && !same_set && psync->wait()) WC_HIP(ctx, hipStreamWaitEvent(st, psync->ev, 0));  // (wc_pair_sync: behind the other search's build)
   const int group_opt = ctx->dev.knn_group;  // (development option: 0 / 1 pins the walk)
-  const bool group_walk = group_opt >= 0 ? group_opt != 0 : (nq_mine < 750000u || (same_set && nq_mine < 1500000u));
+  // (round 6: with the early bound the group walk at every size - its short walks are a descent and two or three leaves, what the lane
+  // walk's fp32 first look and four-wide steps were built to shorten is gone: C4's fixed-window search, 1 M queries, 0.95 -> 0.80 ms)
+  const bool group_walk = group_opt >= 0 ? group_opt != 0 : (early_walk || nq_mine < 750000u || (same_set && nq_mine < 1500000u));
   const int first3 = plan.D % 3 ? plan.D % 3 : 3;
   // Workgroups of ONE wavefront (eight queries): the groups of a workgroup share nothing, and a 256-thread workgroup holds its four
   // wavefront slots and its LDS until the slowest of its 32 walks has ended - the next workgroup waits for all of them.  Measured
