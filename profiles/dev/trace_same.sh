@@ -1,5 +1,5 @@
 #!/bin/bash
-# kernel trace of ONE same-set search of the step-like window under a development option spec: bash profiles/dev/trace_same.sh "knn_early=0" [ab_var/<tree>]
+# kernel trace of ONE same-set search of the step-like window under a development option spec: bash profiles/dev/trace_same.sh "knn_early=0" [ab_var/<tree> | .] [c4]
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R
@@ -9,7 +9,7 @@ sys.path[:0] = ["$R/${2:-.}/wildcat-slam_amd/python"]
 import numpy as np
 from wildcat_slam_amd import lib, synth
 ctx = lib.Context(0)
-w = synth.surfel_window(8, 31248, seed=synth.SEED + 7, fixed_patches=62496)
+w = synth.surfel_window(*([20, 50000] if "${3:-}" == "c4" else [8, 31248]), seed=synth.SEED + 7, fixed_patches=62496)
 n_s = len(w["surf"])
 d_s, d_p = ctx.to_device(w["surf"]), ctx.to_device(w["pose"])
 d_b = ctx.alloc(8 * n_s)

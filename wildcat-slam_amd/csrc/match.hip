@@ -316,6 +316,13 @@ static int match_impl(wc_ctx *ctx, const wc_surfel *d_q_surf, const wc_pose *d_q
                       uint32_t *d_knn_idx, double *d_knn_d2, bool want_shard) {
   wc_dev_guard dg_(ctx);
   const auto t_entry = std::chrono::steady_clock::now();
+  wc_pair_sync *psync = ctx ? (wc_pair_sync *)ctx->pair_sync : nullptr;
+  struct PairPost {  // (EVERY way out of a sliding-window search of a pair - the argument checks below included - releases the other search)
+    wc_pair_sync *s;
+    ~PairPost() {
+      if (s) s->post(false);
+    }
+  } pair_post{same_set ? psync : nullptr};
   if (!ctx || !h_n_pairs) return wc_fail(ctx, WC_ERR_ARG, "%s: null or out-of-range argument", __func__);
   *h_n_pairs = 0;
   if (nt_ == 0 || nq_ == 0) return WC_OK;  // knn_surfel_matcher.cc:18-20
@@ -353,13 +360,6 @@ static int match_impl(wc_ctx *ctx, const wc_surfel *d_q_surf, const wc_pose *d_q
   k_features<<<(nt + 255) / 256, 256, 0, st>>>(d_t_surf, d_t_pose, nt, P.center_scale, P.angular_scale, (double *)b_feat.p, (double *)b_world.p, status);
   const KdPlan plan = kd_plan(nt, ctx->dev.kd_leaf);
   KdTree tree;
-  wc_pair_sync *psync = (wc_pair_sync *)ctx->pair_sync;
-  struct PairPost {  // (every way out of a sliding-window search of a pair releases the other search)
-    wc_pair_sync *s;
-    ~PairPost() {
-      if (s) s->post(false);
-    }
-  } pair_post{same_set ? psync : nullptr};
   WC_TRY(kd_build(ctx, (const double *)b_feat.p, nt, plan, tree));
   if (psync && same_set && psync->ev && hipEventRecord(psync->ev, st) == hipSuccess) psync->post(true);
   MatchParams M;
