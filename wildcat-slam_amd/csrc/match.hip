@@ -410,7 +410,7 @@ static int match_impl(wc_ctx *ctx, const wc_surfel *d_q_surf, const wc_pose *d_q
   WC_TRY(wc_ensure(ctx, ctx->b_route[3], (size_t)(q_end - q_begin + 1) * P.knn_k * 4));
   // (a search of few queries writes the planes of b_gated straight from the walk - ten scattered 4-byte stores per query, what the
   // transposition below exists to avoid at a million queries, are nothing at 100 k, and two launches of the call's tail go)
-  const bool direct_planes = !sharded && (nq < 131072u || (early_walk && !same_set && ctx->dev.knn_group != 0));  // (the group walk's first_only)
+  const bool direct_planes = !sharded && (nq < 131072u || (early_walk && ctx->dev.knn_group != 0 && (!same_set || ctx->dev.knn_early == 1)));  // (the group walk stores what k_resolve can read, no more)
   uint32_t *gated_shard = sharded ? (uint32_t *)ctx->b_route[3].p : (direct_planes ? nullptr : (uint32_t *)ctx->b_route[2].p);
   const uint32_t nq_mine = q_end - q_begin;
   for (hipEvent_t &e : ctx->ev_knn)
