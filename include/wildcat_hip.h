@@ -233,7 +233,9 @@ int wc_reverse_copy_surfels(wc_ctx *ctx, const wc_surfel *d_src_surf, const wc_p
  *                   (older, newer) indices into that set, at most one per query, in query order
  *   same_set == 0 : fixed-window matcher; pair.first indexes the targets (fixed window), pair.second the queries
  *   d_knn_idx / d_knn_d2 (may be NULL): the raw exact k nearest neighbours per query (k = wc_params.knn_k), the output
- *                   of FLANNKNearestSearch (cc:75-89), for known-answer tests
+ *                   of FLANNKNearestSearch (cc:75-89), for known-answer tests.  With them NULL a walk is bounded by the nearest
+ *                   gate-passing candidate as well as by the k-th distance - Match takes the FIRST of the k neighbours that passes
+ *                   the gates (cc:24-46), so the pair list is the same, byte for byte (development option knn_early = 0: off)
  * Surfels must be in the body frame with poses attached (wc_update_surfel_poses). */
 int wc_match(wc_ctx *ctx, const wc_surfel *d_q_surf, const wc_pose *d_q_pose, uint64_t nq, const wc_surfel *d_t_surf,
              const wc_pose *d_t_pose, uint64_t nt, int same_set, wc_pair *d_pairs, uint64_t cap, uint64_t *h_n_pairs,
